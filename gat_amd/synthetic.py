@@ -1,0 +1,143 @@
+"""Synthetic hg19-shaped inputs for the BASELINE.json configurations.
+
+Pure integer numpy, seedable, identical on every box.  Used by bench.py, the parity tests and
+tests/golden/make_goldens.py.  Shapes follow the reference tutorial data
+(tutorial/TutorialIntervalOverlap/*.bed.gz: short segments, ~10^4..10^5-interval annotation
+tracks, ungapped-contig workspaces) but contain no reference data.
+"""
+import collections
+
+import numpy as np
+
+SEG = np.dtype([("start", "<u4"), ("end", "<u4")])
+
+# hg19 primary assembly (public UCSC chromosome sizes)
+HG19 = collections.OrderedDict([
+    ("chr1", 249250621), ("chr2", 243199373), ("chr3", 198022430), ("chr4", 191154276),
+    ("chr5", 180915260), ("chr6", 171115067), ("chr7", 159138663), ("chr8", 146364022),
+    ("chr9", 141213431), ("chr10", 135534747), ("chr11", 135006516), ("chr12", 133851895),
+    ("chr13", 115169878), ("chr14", 107349540), ("chr15", 102531392), ("chr16", 90354753),
+    ("chr17", 81195210), ("chr18", 78077248), ("chr19", 59128983), ("chr20", 63025520),
+    ("chr21", 48129895), ("chr22", 51304566), ("chrX", 155270560), ("chrY", 59373566),
+])
+CHR22 = collections.OrderedDict([("chr22", 51304566)])
+
+
+def _normalize(start, end):
+    """sort by start, merge overlapping (not adjacent) intervals, drop empties."""
+    keep = end > start
+    start, end = start[keep], end[keep]
+    order = np.argsort(start, kind="stable")
+    start, end = start[order], end[order]
+    if len(start) == 0:
+        return np.empty(0, dtype=SEG)
+    run = np.maximum.accumulate(end)
+    head = np.ones(len(start), dtype=bool)
+    head[1:] = start[1:] >= run[:-1]
+    idx = np.flatnonzero(head)
+    out = np.empty(len(idx), dtype=SEG)
+    out["start"] = start[idx]
+    last = np.append(idx[1:] - 1, len(start) - 1)
+    out["end"] = run[last]
+    return out
+
+
+def random_segments(contigs, n, mean_len, seed):
+    """n intervals placed uniformly over the genome, lengths geometric(1/mean_len), normalized.
+
+    returns OrderedDict contig -> SEG array (contigs without intervals are omitted)."""
+    rs = np.random.RandomState(seed)
+    names = list(contigs.keys())
+    sizes = np.array([contigs[c] for c in names], dtype=np.int64)
+    cum = np.cumsum(sizes)
+    pos = rs.randint(0, cum[-1], size=n).astype(np.int64)
+    length = rs.geometric(1.0 / mean_len, size=n).astype(np.int64)
+    ci = np.searchsorted(cum, pos, side="right")
+    start = pos - (cum[ci] - sizes[ci])
+    end = np.minimum(start + length, sizes[ci])
+    out = collections.OrderedDict()
+    for i, name in enumerate(names):
+        m = ci == i
+        if m.any():
+            segs = _normalize(start[m].astype(np.uint32), end[m].astype(np.uint32))
+            if len(segs):
+                out[name] = segs
+    return out
+
+
+def workspace_contigs(contigs):
+    """one workspace segment per contig, [0, size)."""
+    out = collections.OrderedDict()
+    for name, size in contigs.items():
+        a = np.empty(1, dtype=SEG)
+        a["start"], a["end"] = 0, size
+        out[name] = a
+    return out
+
+
+def workspace_ungapped(contigs, pieces=12, gap=50000):
+    """ungapped-style workspace: each contig in `pieces` blocks separated by assembly gaps
+    (cf. the 282-interval contigs_ungapped.bed.gz of the reference tutorial)."""
+    out = collections.OrderedDict()
+    for name, size in contigs.items():
+        edges = np.linspace(10000, size - 10000, pieces + 1).astype(np.int64)
+        a = np.empty(pieces, dtype=SEG)
+        a["start"] = edges[:-1] + gap // 2
+        a["end"] = edges[1:] - gap // 2
+        out[name] = a
+    return out
+
+
+def isochores_blocks(contigs, nclasses=8, block=1000000):
+    """isochore tracks: class k owns every nclasses-th `block`-sized window of each contig.
+
+    returns OrderedDict class_name -> OrderedDict contig -> SEG array."""
+    out = collections.OrderedDict()
+    for k in range(nclasses):
+        per = collections.OrderedDict()
+        for name, size in contigs.items():
+            starts = np.arange(k * block, size, nclasses * block, dtype=np.int64)
+            if len(starts) == 0:
+                continue
+            a = np.empty(len(starts), dtype=SEG)
+            a["start"] = starts
+            a["end"] = np.minimum(starts + block, size)
+            per[name] = a
+        out["iso%d" % k] = per
+    return out
+
+
+def config(name, scale=1.0):
+    """inputs of a BASELINE.json configuration.
+
+    returns dict(segments=, annotations=[(track, dict)], workspace=, isochores=|None,
+                 num_samples=, counter=)"""
+    def n(x):
+        return max(1, int(round(x * scale)))
+
+    if name == "config1":      # chr22, 1k x 1 x 1k, 1000 samples
+        return dict(segments=random_segments(CHR22, n(1000), 500, 11),
+                    annotations=[("anno0", random_segments(CHR22, n(1000), 2000, 100))],
+                    workspace=workspace_contigs(CHR22), isochores=None,
+                    num_samples=1000, counter="nucleotide-overlap")
+    if name == "config2":      # hg19, 10k x 1 x 10k, 10000 samples
+        return dict(segments=random_segments(HG19, n(10000), 500, 11),
+                    annotations=[("anno0", random_segments(HG19, n(10000), 2000, 100))],
+                    workspace=workspace_contigs(HG19), isochores=None,
+                    num_samples=10000, counter="nucleotide-overlap")
+    if name == "config3":      # hg19 isochore-partitioned, 10k x 100 x 10k, 10000 samples
+        return dict(segments=random_segments(HG19, n(10000), 500, 11),
+                    annotations=[("anno%d" % i, random_segments(HG19, n(10000), 2000, 100 + i)) for i in range(100)],
+                    workspace=workspace_contigs(HG19), isochores=isochores_blocks(HG19),
+                    num_samples=10000, counter="nucleotide-overlap")
+    if name == "config4":      # 100k x 1000 x 10k, 100000 samples (8 GPUs)
+        return dict(segments=random_segments(HG19, n(100000), 500, 11),
+                    annotations=[("anno%d" % i, random_segments(HG19, n(10000), 2000, 100 + i)) for i in range(1000)],
+                    workspace=workspace_contigs(HG19), isochores=None,
+                    num_samples=100000, counter="nucleotide-overlap")
+    if name == "config5":      # density, 1M-interval annotation, ungapped workspace
+        return dict(segments=random_segments(HG19, n(10000), 500, 11),
+                    annotations=[("anno0", random_segments(HG19, n(1000000), 300, 100))],
+                    workspace=workspace_ungapped(HG19), isochores=None,
+                    num_samples=1000000, counter="nucleotide-density")
+    raise ValueError("unknown config %r" % name)
