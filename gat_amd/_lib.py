@@ -1,0 +1,276 @@
+"""ctypes binding of libgat_mi355.so (C ABI: include/gat_mi355.h).
+
+The library is the product's only compute path.  If it is missing, or no gfx950 device is
+usable, everything here raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgat_mi355.so")
+
+SEG = np.dtype([("start", "<u4"), ("end", "<u4")])
+
+COUNTER_IDS = {
+    "nucleotide-overlap": 0,
+    "nucleotide-density": 1,
+    "segment-overlap": 2,
+    "segment-midoverlap": 3,
+    "annotation-overlap": 4,
+    "annotation-midoverlap": 5,
+}
+
+# every symbol include/gat_mi355.h declares
+SYMBOLS = [
+    "gat_ctx_create", "gat_ctx_destroy", "gat_last_error", "gat_version", "gat_ctx_synchronize",
+    "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
+    "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample",
+    "gat_count_lists", "gat_problem_info",
+]
+
+
+class GatError(RuntimeError):
+    pass
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("n_units", C.c_int32),
+        ("segs", C.c_void_p),
+        ("seg_off", C.c_void_p),
+        ("ws", C.c_void_p),
+        ("ws_off", C.c_void_p),
+        ("unit_contig", C.c_void_p),
+        ("n_contigs", C.c_int32),
+        ("merge_contigs", C.c_int32),
+        ("n_tracks", C.c_int32),
+        ("annos", C.c_void_p),
+        ("anno_off", C.c_void_p),
+        ("cws_nseg", C.c_void_p),
+        ("bucket_size", C.c_uint32),
+        ("nbuckets", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("ms_sampler", C.c_float),
+        ("ms_contig", C.c_float),
+        ("ms_count", C.c_float),
+        ("ms_total", C.c_float),
+        ("n_placed", C.c_int64),
+        ("n_draws", C.c_int64),
+        ("n_sampled_segments", C.c_int64),
+        ("n_unsuccessful", C.c_int64),
+        ("n_retried", C.c_int64),
+    ]
+
+    def asdict(self):
+        return dict((f, getattr(self, f)) for f, _ in self._fields_)
+
+
+_LIB = None
+
+
+def lib():
+    """load libgat_mi355.so; raises GatError if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise GatError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); gat_amd has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    L.gat_ctx_create.restype = C.c_int
+    L.gat_ctx_create.argtypes = [C.POINTER(vp), C.c_int, vp]
+    L.gat_ctx_destroy.restype = None
+    L.gat_ctx_destroy.argtypes = [vp]
+    L.gat_last_error.restype = C.c_char_p
+    L.gat_last_error.argtypes = [vp]
+    L.gat_version.restype = C.c_char_p
+    L.gat_version.argtypes = []
+    L.gat_ctx_synchronize.restype = C.c_int
+    L.gat_ctx_synchronize.argtypes = [vp]
+    L.gat_dev_alloc.restype = C.c_int
+    L.gat_dev_alloc.argtypes = [vp, C.POINTER(vp), C.c_size_t]
+    L.gat_dev_free.restype = C.c_int
+    L.gat_dev_free.argtypes = [vp, vp]
+    L.gat_memcpy_d2h.restype = C.c_int
+    L.gat_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.gat_memcpy_h2d.restype = C.c_int
+    L.gat_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.gat_problem_create.restype = C.c_int
+    L.gat_problem_create.argtypes = [vp, C.POINTER(ProblemDesc), C.POINTER(vp)]
+    L.gat_problem_destroy.restype = None
+    L.gat_problem_destroy.argtypes = [vp]
+    L.gat_sample_and_count.restype = C.c_int
+    L.gat_sample_and_count.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp, C.POINTER(Stats)]
+    L.gat_sample.restype = C.c_int
+    L.gat_sample.argtypes = [vp, vp, u32, i64, i64, vp, i64, vp, C.POINTER(Stats)]
+    L.gat_count_lists.restype = C.c_int
+    L.gat_count_lists.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, i32, vp, i32, vp]
+    L.gat_problem_info.restype = C.c_int
+    L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    _LIB = L
+    return L
+
+
+_ERRORS = {-1: ValueError, -2: AssertionError, -3: GatError, -4: MemoryError, -5: GatError, -6: ValueError}
+
+
+def _check(rc, ctx=None):
+    if rc == 0:
+        return
+    msg = lib().gat_last_error(ctx).decode("utf-8", "replace")
+    raise _ERRORS.get(rc, GatError)("gat_mi355 error %d: %s" % (rc, msg))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context(object):
+    """one HIP device + stream (gat_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().gat_ctx_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().gat_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().gat_ctx_synchronize(self._h), self._h)
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().gat_dev_alloc(self._h, C.byref(p), nbytes), self._h)
+        return p.value
+
+    def free(self, ptr):
+        _check(lib().gat_dev_free(self._h, C.c_void_p(ptr)), self._h)
+
+    def d2h(self, host_array, dev_ptr):
+        _check(lib().gat_memcpy_d2h(self._h, _p(host_array), C.c_void_p(dev_ptr), host_array.nbytes), self._h)
+
+    def count_lists(self, counters, lists, list_off, n_lists, annos, anno_off, n_tracks, ws_nseg, n_groups):
+        """Counter*(list, annotation, workspace) for n_lists x n_groups lists (observed counts)."""
+        ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
+        lists = np.ascontiguousarray(lists, dtype=SEG)
+        annos = np.ascontiguousarray(annos, dtype=SEG)
+        list_off = np.ascontiguousarray(list_off, dtype=np.int64)
+        anno_off = np.ascontiguousarray(anno_off, dtype=np.int64)
+        ws_nseg = np.ascontiguousarray(ws_nseg, dtype=np.int64)
+        out = np.zeros((len(ids), n_tracks, n_lists), dtype=np.int64)
+        _check(lib().gat_count_lists(self._h, _p(ids), len(ids), _p(lists), _p(list_off), n_lists, _p(annos),
+                                     _p(anno_off), n_tracks, _p(ws_nseg), n_groups, _p(out)), self._h)
+        return [out[k].view(np.float64).copy() if c == "nucleotide-density" else out[k].copy()
+                for k, c in enumerate(counters)]
+
+
+class Problem(object):
+    """device-resident inputs of one segment track (gat_problem).
+
+    `flat` is a mapping with the fields of gat_problem_desc (numpy arrays / ints)."""
+
+    def __init__(self, ctx, flat):
+        self.ctx = ctx
+        keep = {}
+
+        def arr(name, dtype):
+            keep[name] = np.ascontiguousarray(flat[name], dtype=dtype)
+            return _p(keep[name])
+
+        d = ProblemDesc()
+        d.n_units = int(flat["n_units"])
+        d.segs = arr("segs", SEG)
+        d.seg_off = arr("seg_off", np.int64)
+        d.ws = arr("ws", SEG)
+        d.ws_off = arr("ws_off", np.int64)
+        d.unit_contig = arr("unit_contig", np.int32)
+        d.n_contigs = int(flat["n_contigs"])
+        d.merge_contigs = int(flat["merge_contigs"])
+        d.n_tracks = int(flat["n_tracks"])
+        d.annos = arr("annos", SEG)
+        d.anno_off = arr("anno_off", np.int64)
+        d.cws_nseg = arr("cws_nseg", np.int64)
+        d.bucket_size = int(flat.get("bucket_size", 0))
+        d.nbuckets = int(flat.get("nbuckets", 100000))
+        assert len(keep["seg_off"]) == d.n_units + 1 and len(keep["ws_off"]) == d.n_units + 1
+        assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1 and len(keep["cws_nseg"]) == d.n_contigs
+        self.n_units, self.n_contigs, self.n_tracks = d.n_units, d.n_contigs, d.n_tracks
+        self._h = C.c_void_p()
+        _check(lib().gat_problem_create(ctx._h, C.byref(d), C.byref(self._h)), ctx._h)
+        self.last_stats = None
+
+    def close(self):
+        if self._h:
+            lib().gat_problem_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        v = [C.c_int64() for _ in range(5)]
+        _check(lib().gat_problem_info(self._h, *[C.byref(x) for x in v]))
+        return dict(n_units=v[0].value, n_contigs=v[1].value, n_tracks=v[2].value,
+                    slab_segments_per_sample=v[3].value, algorithmic_bytes_per_sample=v[4].value)
+
+    def sample_and_count_device(self, counters, seed, sample_begin, sample_end, counts_dev_ptr):
+        """the batch seam, results left on the device ([counter][track][sample] 8-byte slots)."""
+        ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
+        st = Stats()
+        _check(lib().gat_sample_and_count(self.ctx._h, self._h, _p(ids), len(ids), int(seed) & 0xFFFFFFFF,
+                                          int(sample_begin), int(sample_end), C.c_void_p(counts_dev_ptr), C.byref(st)),
+               self.ctx._h)
+        self.last_stats = st.asdict()
+        return self.last_stats
+
+    def sample_and_count(self, counters, seed, sample_begin, sample_end):
+        """returns a list (per counter) of [n_tracks, n_samples] arrays (int64 / float64 for density)."""
+        ns = sample_end - sample_begin
+        nslots = max(1, len(counters) * self.n_tracks * ns)
+        dev = self.ctx.alloc(nslots * 8)
+        try:
+            self.sample_and_count_device(counters, seed, sample_begin, sample_end, dev)
+            host = np.zeros((len(counters), self.n_tracks, ns), dtype=np.int64)
+            if host.size:
+                self.ctx.d2h(host, dev)
+        finally:
+            self.ctx.free(dev)
+        return [host[k].view(np.float64).copy() if c == "nucleotide-density" else host[k].copy()
+                for k, c in enumerate(counters)]
+
+    def sample(self, seed, sample_begin, sample_end):
+        """sampled contig-level segment lists: (segments SEG array, offsets[(n_samples*n_contigs)+1])."""
+        ns = sample_end - sample_begin
+        off = np.zeros(ns * self.n_contigs + 1, dtype=np.int64)
+        cap = max(1024, self.info()["slab_segments_per_sample"] * ns // 2)
+        st = Stats()
+        while True:
+            out = np.empty(cap, dtype=SEG)
+            rc = lib().gat_sample(self.ctx._h, self._h, int(seed) & 0xFFFFFFFF, int(sample_begin), int(sample_end),
+                                  _p(out), cap, _p(off), C.byref(st))
+            if rc == -3 and off[-1] > cap:
+                cap = int(off[-1])
+                continue
+            _check(rc, self.ctx._h)
+            break
+        self.last_stats = st.asdict()
+        return out[: off[-1]].copy(), off

@@ -1,0 +1,261 @@
+// gat_device.h -- wave64 device primitives for the GAT hot path on gfx950 (CDNA4).
+//
+// Everything here is written for one 64-lane wavefront that owns one Monte-Carlo work unit
+// (sample, isochore): the MT19937 state and the segment buffer live in that wave's LDS slice,
+// the serial placement chain runs on wave-uniform (scalar) values, and sort / merge /
+// intersect / trim are lane-parallel over the LDS buffer.  No MFMA: this path is integer
+// compare/index work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gat {
+
+constexpr int kWave = 64;
+constexpr int kMtN = 624;
+constexpr int kMtM = 397;
+constexpr int kMtLdsWords = 640;   // 624 state words, padded so the segment buffer stays 16-B aligned
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the
+// compiler has to be kept from reordering; the workgroup is a single wave (launch_bounds 64).
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+// ------------------------------------------------------------------------------------------
+// numpy legacy RandomState == MT19937 (init_genrand seeding) + masked rejection, restated for a
+// wave: the 624-word state sits in LDS, the twist runs 64 lanes wide in place, and tempered
+// outputs are handed out from a lane-distributed register (v_readlane) 64 at a time.
+// Reference call sites: gat/Engine.pyx:299,326,420,433,620 (numpy.random.randint).
+struct WaveRng {
+  uint32_t* mt;     // LDS, kMtN words
+  uint32_t rbuf;    // lane i holds tempered output (pos & ~63) + i
+  int pos;          // next state word to hand out, 0..624 (wave-uniform)
+  uint32_t ndraws;  // raw outputs consumed (wave-uniform)
+};
+
+// init_genrand(seed): mt[0]=seed; mt[i] = 1812433253*(mt[i-1]^(mt[i-1]>>30)) + i.
+// The recurrence is serial; it runs on scalar registers and is scattered to the lanes with
+// v_writelane (lane index as an inline constant), one LDS store per 64 words.
+template <int J>
+struct SeedStep {
+  static __device__ __forceinline__ void run(uint32_t& buf, uint32_t& s, uint32_t base) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(buf) : "s"(s), "n"(J));
+    s = 1812433253u * (s ^ (s >> 30)) + (base + (uint32_t)J + 1u);
+    SeedStep<J + 1>::run(buf, s, base);
+  }
+};
+template <>
+struct SeedStep<kWave> {
+  static __device__ __forceinline__ void run(uint32_t&, uint32_t&, uint32_t) {}
+};
+
+__device__ __forceinline__ void rng_seed(WaveRng& r, uint32_t seed, int lane) {
+  uint32_t s = seed;
+  for (int base = 0; base < kMtN; base += kWave) {
+    uint32_t buf = 0;
+    SeedStep<0>::run(buf, s, (uint32_t)base);
+    if (base + lane < kMtN) r.mt[base + lane] = buf;
+  }
+  r.pos = kMtN;
+  r.rbuf = 0;
+  r.ndraws = 0;
+  wave_sync();
+}
+
+// genrand twist, in place, 64 lanes per step.  Word i needs old[i], old[i+1] and
+// (i < 227 ? old[i+397] : new[i-227]); processing chunks of 64 in increasing i keeps exactly
+// those versions in LDS (a chunk never reads a word it writes except through old[i+1], which
+// is loaded before the store of the same instruction group).
+__device__ __forceinline__ void rng_twist(WaveRng& r, int lane) {
+  for (int base = 0; base < kMtN; base += kWave) {
+    const int i = base + lane;
+    uint32_t v = 0;
+    if (i < kMtN) {
+      const uint32_t a = r.mt[i];
+      const uint32_t b = r.mt[i + 1 == kMtN ? 0 : i + 1];
+      const uint32_t c = r.mt[i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM];
+      const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    wave_sync();
+    if (i < kMtN) r.mt[i] = v;
+    wave_sync();
+  }
+}
+
+__device__ __forceinline__ uint32_t rng_next(WaveRng& r, int lane) {
+  if (r.pos == kMtN) {
+    rng_twist(r, lane);
+    r.pos = 0;
+  }
+  if ((r.pos & (kWave - 1)) == 0) {
+    const int i = r.pos + lane;
+    uint32_t y = r.mt[i < kMtN ? i : kMtN - 1];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    r.rbuf = y;
+  }
+  const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)r.rbuf, r.pos & (kWave - 1));
+  r.pos++;
+  r.ndraws++;
+  return x;
+}
+
+// numpy.random.randint(lo, lo+range+1) - lo for range < 2^32-1:
+// random_bounded_uint64 masked path: range 0 consumes nothing; else reject (next & mask) > range.
+__device__ __forceinline__ uint32_t rng_range(WaveRng& r, uint32_t range, int lane) {
+  if (range == 0) return 0;
+  const uint32_t mask = 0xffffffffu >> __builtin_clz(range);
+  uint32_t v;
+  do {
+    v = rng_next(r, lane) & mask;
+  } while (v > range);
+  return v;
+}
+
+// utils/gat_utils.c:36-60 searchsorted with cmpPosition (gat/Engine.pyx:119): leftmost i with
+// (int)(a[i]-t) >= 0.  All operands wave-uniform: runs on the scalar unit / scalar cache.
+__device__ __forceinline__ int bisect_u32(const uint32_t* __restrict__ a, int n, uint32_t t) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    const uint32_t v = a[mid];
+    if ((int32_t)(v - t) < 0) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave reductions / scans
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ int32_t wave_incl_max_i32(int32_t m, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int32_t o = __shfl_up(m, d);
+    if (lane >= d) m = o > m ? o : m;
+  }
+  return m;
+}
+__device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// SegmentList.sort (gat/SegmentList.pyx:478-486: qsort by start only) as an in-LDS bitonic
+// network in its all-ascending ("flip") form, so indices >= n act as +inf without being stored.
+// Tie order among equal starts is unspecified in the reference too; merge() is independent of it.
+__device__ __forceinline__ void cmpex(uint2* seg, int i, int j) {
+  const uint2 a = seg[i], b = seg[j];
+  if (b.x < a.x) { seg[i] = b; seg[j] = a; }
+}
+__device__ __forceinline__ void wave_sort_by_start(uint2* seg, int n, int lane) {
+  if (n < 2) return;
+  int P = 2;
+  while (P < n) P <<= 1;
+  const int half_total = P >> 1;
+  wave_sync();
+  for (int k = 2; k <= P; k <<= 1) {
+    const int hk = k >> 1;
+    for (int t = lane; t < half_total; t += kWave) {
+      const int blk = t / hk, off = t - blk * hk;
+      const int i = blk * k + off, j = blk * k + (k - 1 - off);
+      if (j < n) cmpex(seg, i, j);
+    }
+    wave_sync();
+    for (int d = k >> 2; d > 0; d >>= 1) {
+      for (int t = lane; t < half_total; t += kWave) {
+        const int blk = t / d, off = t - blk * d;
+        const int i = blk * (d << 1) + off, j = i + d;
+        if (j < n) cmpex(seg, i, j);
+      }
+      wave_sync();
+    }
+  }
+}
+
+// SegmentList.merge(0) (gat/SegmentList.pyx:756-816) on a list already sorted by start (empty
+// segments anywhere are skipped, as the reference skips them): in place, 64 elements per step.
+// head[i] = first non-empty, or int32(start) - 0 > running max end; the previous group's end is
+// the running max seen just before the next head.  Returns the new length.
+__device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
+  int count = 0;
+  int32_t carry = INT32_MIN;
+  bool any = false;
+  wave_sync();
+  for (int base = 0; base < n; base += kWave) {
+    const int i = base + lane;
+    uint32_t s = 0, e = 0;
+    bool valid = false;
+    if (i < n) {
+      const uint2 v = seg[i];
+      s = v.x; e = v.y;
+      valid = (s != e);
+    }
+    int32_t m = wave_incl_max_i32(valid ? (int32_t)e : INT32_MIN, lane);
+    const int32_t incl = m > carry ? m : carry;
+    int32_t excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = carry;
+    const uint64_t vb = __ballot(valid);
+    const bool prev_valid = any || (vb & lanemask_lt(lane)) != 0;
+    const bool head = valid && (!prev_valid || (int32_t)s > excl);
+    const uint64_t hb = __ballot(head);
+    const int pos = count + __popcll(hb & lanemask_lt(lane));
+    wave_sync();
+    if (head) {
+      seg[pos].x = s;
+      if (pos > 0) seg[pos - 1].y = (uint32_t)excl;
+    }
+    count += __popcll(hb);
+    carry = __builtin_amdgcn_readlane(incl, kWave - 1);
+    any = any || (vb != 0);
+    wave_sync();
+  }
+  if (count > 0 && lane == 0) seg[count - 1].y = (uint32_t)carry;
+  wave_sync();
+  return count;
+}
+
+// bases of a normalized list W (starts/ends + cdf[i] = cumlen_i - 1) below position p.
+__device__ __forceinline__ uint32_t cov_below(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                              int nw, uint32_t p) {
+  int lo = 0, hi = nw;                         // k = #segments with start < p
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (w[mid].x < p) lo = mid + 1; else hi = mid;
+  }
+  if (lo == 0) return 0;
+  const uint2 prev = w[lo - 1];
+  const uint32_t before = lo >= 2 ? cdf[lo - 2] + 1u : 0u;
+  return before + (p < prev.y ? p : prev.y) - prev.x;
+}
+
+// overlap in bases of one segment with a normalized list (what intersect().sum() adds up for it,
+// gat/SegmentList.pyx:1469-1549 + :1607)
+__device__ __forceinline__ uint32_t seg_overlap_with(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                                     int nw, uint32_t s, uint32_t e) {
+  if (nw == 1) {
+    const uint2 a = w[0];
+    const uint32_t lo = s > a.x ? s : a.x, hi = e < a.y ? e : a.y;
+    return hi > lo ? hi - lo : 0u;
+  }
+  return cov_below(w, cdf, nw, e) - cov_below(w, cdf, nw, s);
+}
+
+}  // namespace gat

@@ -1,0 +1,466 @@
+// gat_kernels.h -- HIP kernels of the GAT hot path (gfx950).
+//
+//   k_sampler : one wave per (sample, isochore unit): SamplerAnnotator.sample
+//               (gat/Engine.pyx:515-646) with HistogramSampler (:387-435) and
+//               SegmentListSampler (:245-348), consolidation = sort + merge(0) + intersect/sum
+//               (gat/SegmentList.pyx:478, :756, :1469, :1607), overshoot trim (:545-597),
+//               final merge(0) + filter (:1401).
+//   k_contig  : one wave per (sample, contig): IntervalDictionary.fromIsochores
+//               (gat/Engine.pyx:2857-2876): concat the contig's units, sort, merge(0).
+//   k_count_seg / k_count_anno : Counter*.__call__ (gat/Engine.pyx:1417-1472) summed over
+//               contigs as gat/__init__.py:578-587 does.
+#pragma once
+#include "gat_device.h"
+
+namespace gat {
+
+// per isochore unit, everything SamplerAnnotator.sample derives from (segments, workspace) before
+// its loop (gat/Engine.pyx:543-565), hoisted to problem creation.
+struct UnitDev {
+  int32_t n_ws;         // workspace segments of the unit
+  int32_t ws_off;       // offset into ws / ws_cdf
+  int32_t n_hist;       // non-empty histogram buckets
+  int32_t hist_off;     // offset into hist_idx / hist_cdf
+  uint32_t hist_total;  // HistogramSampler.total_size == number of working segments
+  uint32_t bucket;      // bucket size (after the bucket_size==0 rule, gat/SegmentList.pyx:1164)
+  uint32_t ws_total;    // SegmentListSampler.total_size == workspace bases
+  int32_t ltotal;       // bases to reproduce (gat/Engine.pyx:550-552)
+  int32_t slab_off;     // offset of the unit's output region inside a sample's slab
+  int32_t slab_cap;     // capacity of that region == LDS buffer capacity used for the unit
+  int32_t contig;
+  int32_t pad;
+};
+
+enum : int32_t {
+  kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab
+  kStatusAssert = 2,     // reference assert would fire (gat/Engine.pyx:645 sum()>0)
+  kStatusTrimAssert = 4, // gat/SegmentList.pyx:560 sum() > size
+};
+
+struct SamplerArgs {
+  const UnitDev* units;
+  const int32_t* order;       // active unit ids, largest first
+  int32_t n_units;
+  const uint2* ws;
+  const uint32_t* ws_cdf;
+  const uint32_t* hist_idx;
+  const uint32_t* hist_cdf;
+  uint32_t seed;
+  int64_t sample_begin;       // global id of sample 0 of this batch
+  uint2* slab;                // [batch][slab_stride]
+  int64_t slab_stride;
+  int32_t* unit_n;            // [batch][n_units]
+  int32_t* flags;             // OR of kStatus*
+  unsigned long long* stat;   // [0]=placed [1]=draws [2]=unsuccessful rounds [3]=output segments
+};
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* mt = lds;
+  uint2* seg = reinterpret_cast<uint2*>(lds + kMtLdsWords);
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x;
+  const int u = A.order[blockIdx.y];
+  const UnitDev* __restrict__ Up = A.units + u;
+  const int nws = Up->n_ws;
+  const int nhist = Up->n_hist;
+  const uint32_t hist_total = Up->hist_total;
+  const uint32_t bucket = Up->bucket;
+  const uint32_t ws_total = Up->ws_total;
+  const int32_t ltotal = Up->ltotal;
+  const int cap = Up->slab_cap;
+  const uint2* __restrict__ ws = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
+  const uint32_t* __restrict__ hist_idx = A.hist_idx + Up->hist_off;
+  const uint32_t* __restrict__ hist_cdf = A.hist_cdf + Up->hist_off;
+
+  // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
+  const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
+  const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
+  WaveRng rng;
+  rng.mt = mt;
+  rng_seed(rng, seed, lane);
+
+  int nU = 0, nS = 0;   // seg[0..nU): unintersected (merged, sorted); seg[nU..nU+nS): sampled since
+  int32_t remaining = ltotal, true_remaining = ltotal;
+  int nuns = 0, status = 0;
+  uint32_t placed = 0;
+
+  while (true_remaining > 0 && nuns < 20) {                       // gat/Engine.pyx:572
+    // ---- hs.sample() (:413-435)
+    uint32_t r = 1;
+    if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
+    const int hj = bisect_u32(hist_cdf, nhist, r);
+    uint32_t len_u = hist_idx[hj] * bucket;
+    if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
+    const int32_t length = (int32_t)len_u;
+
+    // ---- consolidate (:582-606)
+    if (remaining <= length) {
+      const int n = nU + nS;
+      wave_sort_by_start(seg, n, lane);
+      nU = wave_merge0(seg, n, lane);
+      nS = 0;
+      uint32_t cov = 0;
+      for (int i = lane; i < nU; i += kWave) {
+        const uint2 v = seg[i];
+        cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y);
+      }
+      cov = rfl(wave_sum_u32(cov));
+      remaining = ltotal - (int32_t)cov;
+      if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+    }
+
+    // ---- overshoot: trim (:608-626)
+    if (true_remaining < 0) {
+      // SegmentListSampler(unintersected).sample(1): position draw over the cumulated lengths
+      uint32_t total = 0;
+      for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; total += v.y - v.x; }
+      total = rfl(wave_sum_u32(total));
+      const uint32_t p = rng_range(rng, total - 1u, lane);
+      int k = -1;
+      uint32_t run = 0;
+      for (int base = 0; base < nU; base += kWave) {
+        const int i = base + lane;
+        uint32_t len = 0;
+        if (i < nU) { const uint2 v = seg[i]; len = v.y - v.x; }
+        const uint32_t incl = run + wave_incl_sum_u32(len, lane);
+        // cdf[i] = incl-1; leftmost i with (int)(cdf[i]-p) >= 0
+        const bool ge = (i < nU) && ((int32_t)(incl - 1u - p) >= 0);
+        const uint64_t b = __ballot(ge);
+        if (b != 0) { k = base + (int)__builtin_ctzll(b); break; }
+        run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+      }
+      // unintersected is merged(0): previous.end < chosen.start, so sampling_start == chosen.start
+      const uint2 chosen = seg[k];
+      const uint32_t cs = rfl(chosen.x), ce = rfl(chosen.y);
+      const uint32_t pos = cs + rng_range(rng, ce - 1u - cs, lane);
+      const uint32_t forward = rng_range(rng, 1u, lane);            // numpy.random.randint(0, 2)
+      int32_t s = -true_remaining;
+      if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { status |= kStatusTrimAssert; break; }
+      // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597); _getInsertionPoint(pos,pos+1) == k
+      (void)pos;
+      wave_sync();
+      if (lane == 0) {
+        int idx = k;
+        while (s > 0) {
+          const uint2 v = seg[idx];
+          const int32_t l = (int32_t)v.y - (int32_t)v.x;
+          if (l < s) { seg[idx] = make_uint2(0u, 0u); s -= l; }
+          else {
+            seg[idx] = forward ? make_uint2(v.x + (uint32_t)s, v.y) : make_uint2(v.x, (uint32_t)((int32_t)v.y - s));
+            s = 0;
+          }
+          if (forward) { idx++; if (idx == nU) idx = 0; }
+          else { idx--; if (idx < 0) idx = nU - 1; }
+        }
+      }
+      wave_sync();
+      true_remaining = 1;
+      continue;
+    }
+
+    // ---- sls.sample(length) (:279-343)
+    const uint32_t p = rng_range(rng, ws_total - 1u, lane);
+    const int k = bisect_u32(ws_cdf, nws, p);
+    const uint2 chosen = ws[k];
+    int32_t sampling_start = (int32_t)chosen.x - length + 1;
+    if (k > 0) {
+      const int32_t prev_end = (int32_t)ws[k - 1].y;
+      sampling_start = prev_end > sampling_start ? prev_end : sampling_start;
+    }
+    const uint32_t range = chosen.y - 1u - (uint32_t)sampling_start;
+    const int32_t q = sampling_start + (int32_t)rng_range(rng, range, lane);
+    const uint32_t start = (uint32_t)(q > 0 ? q : 0);
+    const uint32_t end = (uint32_t)(q + length);
+    const int32_t omin = (int32_t)chosen.y < (int32_t)end ? (int32_t)chosen.y : (int32_t)end;
+    const int32_t omax = (int32_t)chosen.x > (int32_t)start ? (int32_t)chosen.x : (int32_t)start;
+    const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+    if (true_remaining > 0) {
+      if (nU + nS >= cap) { status |= kStatusOverflow; break; }
+      if (lane == 0) seg[nU + nS] = make_uint2(start, end);
+      nS++;
+      placed++;
+      remaining -= overlap;
+    }
+  }
+
+  // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
+  int nout = 0;
+  if (status == 0) {
+    nU = wave_merge0(seg, nU, lane);
+    uint2* __restrict__ out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+    uint32_t total = 0;
+    for (int base = 0; base < nU; base += kWave) {
+      const int i = base + lane;
+      bool keep = false;
+      uint2 v = make_uint2(0u, 0u);
+      if (i < nU) {
+        v = seg[i];
+        keep = seg_overlap_with(ws, ws_cdf, nws, v.x, v.y) > 0;
+      }
+      const uint64_t b = __ballot(keep);
+      if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
+      nout += __popcll(b);
+    }
+    total = rfl(wave_sum_u32(total));
+    if (!(total > 0)) status |= kStatusAssert;
+  }
+  if (lane == 0) {
+    A.unit_n[(int64_t)sidx * A.n_units + u] = nout;
+    if (status) atomicOr(A.flags, status);
+    atomicAdd(&A.stat[0], (unsigned long long)placed);
+    atomicAdd(&A.stat[1], (unsigned long long)rng.ndraws);
+    atomicAdd(&A.stat[2], (unsigned long long)nuns);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// fromIsochores (gat/Engine.pyx:2857-2876): new[contig].extend(unit lists) then merge(0).
+struct ContigArgs {
+  const int32_t* contig_unit_off;  // n_contigs+1: range into contig_units
+  const int32_t* contig_units;     // unit ids grouped by contig, reference order
+  const UnitDev* units;
+  const int32_t* contig_slab_off;  // n_contigs: output region of the contig inside a sample slab
+  int32_t n_units, n_contigs;
+  const uint2* slab_in;            // sampler output
+  uint2* slab_out;                 // contig-level lists
+  int64_t slab_stride;
+  const int32_t* unit_n;           // [batch][n_units]
+  int32_t* contig_n;               // [batch][n_contigs]
+  unsigned long long* stat;
+};
+
+__global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint2* seg = reinterpret_cast<uint2*>(lds);
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x;
+  const int c = blockIdx.y;
+  int n = 0;
+  const int u0 = A.contig_unit_off[c], u1 = A.contig_unit_off[c + 1];
+  for (int ui = u0; ui < u1; ++ui) {
+    const int u = A.contig_units[ui];
+    const int cnt = A.unit_n[(int64_t)sidx * A.n_units + u];
+    const uint2* __restrict__ src = A.slab_in + (int64_t)sidx * A.slab_stride + A.units[u].slab_off;
+    for (int i = lane; i < cnt; i += kWave) seg[n + i] = src[i];
+    n += cnt;
+  }
+  wave_sort_by_start(seg, n, lane);
+  n = wave_merge0(seg, n, lane);
+  uint2* __restrict__ out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
+  for (int i = lane; i < n; i += kWave) out[i] = seg[i];
+  if (lane == 0) {
+    A.contig_n[(int64_t)sidx * A.n_contigs + c] = n;
+    atomicAdd(&A.stat[3], (unsigned long long)n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Counters.  Annotation track t, contig c is the normalized list starts/ends[off .. off+m) with
+// cumx[i] = total length of its intervals before i.  For a sample segment x:
+//   overlapWithSegments contribution (gat/SegmentList.pyx:1026-1076) = F(x.end) - F(x.start),
+//     F(p) = annotation bases below p  (both lists normalized => equals the sum over pairs);
+//   intersectionWithSegments (:1078-1146): x is tested against the FIRST annotation interval y
+//     with y.end > x.start (the merge-join's current `other`); hit iff y.start < x.end, and in
+//     midpoint mode additionally y.start <= x.start + (x.end-x.start)/2 < y.end.
+struct CountArgs {
+  // sample lists
+  const uint2* seg;           // list (s, c) = seg[s*seg_stride + c_off[c] ..)
+  int64_t seg_stride;
+  const int32_t* c_off;       // n_contigs
+  const int32_t* n_arr;       // n of list (s, c) = n_arr[s*n_stride + n_index[c]]
+  int32_t n_stride;
+  const int32_t* n_index;
+  // annotations
+  const uint32_t* a_start;
+  const uint32_t* a_end;
+  const uint32_t* a_cumx;
+  const int64_t* a_off;       // [t*n_contigs + c], n_tracks*n_contigs+1
+  const int64_t* cws_nseg;    // n_contigs
+  int32_t n_contigs, n_tracks;
+  int32_t n_samples;          // lists in this launch
+  // outputs: slot(k, t, s) = out[(k*n_tracks + t)*out_stride + out_begin + s]
+  int64_t* out;
+  int64_t out_stride;
+  int64_t out_begin;
+  int32_t counter_slot[GAT_NUM_COUNTERS_DEV];   // output index k of each counter id, or -1
+  int32_t tracks_per_block;
+  int32_t samples_per_block;
+  int32_t lds_entries;        // staging capacity (intervals); 0 => read annotations from global
+};
+
+struct AnnoView {
+  const uint32_t* start;
+  const uint32_t* end;
+  const uint32_t* cumx;
+  int m;
+};
+
+// quantities of one sample segment against one annotation list
+__device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
+                                            uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
+  // k1 = #starts < xs
+  int lo = 0, hi = Y.m;
+  while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (Y.start[mid] < xs) lo = mid + 1; else hi = mid; }
+  const int k1 = lo;
+  // k2 = #starts < xe  (xe > xs; annotation intervals are long compared to the gap: gallop)
+  int k2 = k1;
+  while (k2 < Y.m && Y.start[k2] < xe) ++k2;
+  uint32_t f1 = 0, f2 = 0;
+  uint32_t pe = 0;                  // end of interval k1-1
+  if (k1 > 0) {
+    const uint32_t ps = Y.start[k1 - 1];
+    pe = Y.end[k1 - 1];
+    f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - ps;
+  }
+  if (k2 > 0) {
+    const uint32_t ps = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
+    f2 = Y.cumx[k2 - 1] + (xe < pe2 ? xe : pe2) - ps;
+  }
+  ov = f2 - f1;
+  // first interval with end > xs: k1-1 if its end > xs, else k1
+  int j = (k1 > 0 && pe > xs) ? k1 - 1 : k1;
+  hit = 0; midhit = 0;
+  if (j < Y.m) {
+    const uint32_t ys = Y.start[j], ye = Y.end[j];
+    if (ys < xe) {
+      hit = 1;
+      const uint32_t mid = xs + (xe - xs) / 2u;
+      midhit = (ys <= mid && mid < ye) ? 1u : 0u;
+    }
+  }
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  // LDS: acc[3][samples_per_block][tracks_per_block] as 8-byte slots, tile offsets, then staging
+  const int TT = A.tracks_per_block, SC = A.samples_per_block;
+  double* acc = reinterpret_cast<double*>(lds);            // [q][sl][tl], q: 0 ov(int) 1 density 2 hit 3 midhit
+  int32_t* tile_off = reinterpret_cast<int32_t*>(acc + 4 * SC * TT);   // TT+1
+  uint32_t* stage = reinterpret_cast<uint32_t*>(tile_off + ((TT + 1 + 3) & ~3));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = blockIdx.x * SC, t0 = blockIdx.y * TT;
+  const int nt = min(TT, A.n_tracks - t0), ns = min(SC, A.n_samples - s0);
+  int64_t* acc_i = reinterpret_cast<int64_t*>(acc);
+  for (int i = tid; i < 4 * SC * TT; i += 256) acc_i[i] = 0;
+
+  for (int c = 0; c < A.n_contigs; ++c) {
+    __syncthreads();
+    if (STAGED) {
+      if (tid == 0) {
+        int o = 0;
+        for (int t = 0; t < nt; ++t) {
+          tile_off[t] = o;
+          o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]);
+        }
+        tile_off[nt] = o;
+      }
+      __syncthreads();
+      const int total = tile_off[nt];
+      const int E = A.lds_entries;
+      for (int t = 0; t < nt; ++t) {
+        const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
+        const int o = tile_off[t], m = tile_off[t + 1] - o;
+        for (int i = tid; i < m; i += 256) {
+          stage[o + i] = A.a_start[g + i];
+          stage[E + o + i] = A.a_end[g + i];
+          stage[2 * E + o + i] = A.a_cumx[g + i];
+        }
+      }
+      (void)total;
+      __syncthreads();
+    }
+    const double nseg = (double)(uint32_t)A.cws_nseg[c];
+    for (int sl = wave; sl < ns; sl += 4) {
+      const int s = s0 + sl;
+      const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
+      const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+      for (int t = 0; t < nt; ++t) {
+        AnnoView Y;
+        if (STAGED) {
+          const int o = tile_off[t];
+          Y.start = stage + o; Y.end = stage + A.lds_entries + o; Y.cumx = stage + 2 * A.lds_entries + o;
+          Y.m = tile_off[t + 1] - o;
+        } else {
+          const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
+          Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
+          Y.m = (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - g);
+        }
+        uint32_t ov = 0, hit = 0, mid = 0;
+        if (Y.m > 0) {
+          for (int i = lane; i < n; i += 64) {
+            const uint2 x = X[i];
+            uint32_t o1, h1, m1;
+            seg_vs_anno(Y, x.x, x.y, o1, h1, m1);
+            ov += o1; hit += h1; mid += m1;
+          }
+          ov = wave_sum_u32(ov); hit = wave_sum_u32(hit); mid = wave_sum_u32(mid);
+        }
+        if (lane == 0) {
+          const int a = sl * TT + t;
+          acc_i[a] += (int64_t)ov;                                           // Python int sum
+          if (nseg != 0.0) acc[SC * TT + a] += (double)ov / nseg;            // float(ov)/len(workspace)
+          acc_i[2 * SC * TT + a] += (int64_t)hit;
+          acc_i[3 * SC * TT + a] += (int64_t)mid;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < ns * nt; i += 256) {
+    const int sl = i / nt, t = i - sl * nt;
+    const int a = sl * TT + t;
+    const int64_t col = A.out_begin + s0 + sl;
+    const int k0 = A.counter_slot[0], k1 = A.counter_slot[1], k2 = A.counter_slot[2], k3 = A.counter_slot[3];
+    if (k0 >= 0) A.out[((int64_t)k0 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[a];
+    if (k1 >= 0) A.out[((int64_t)k1 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[SC * TT + a];
+    if (k2 >= 0) A.out[((int64_t)k2 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[2 * SC * TT + a];
+    if (k3 >= 0) A.out[((int64_t)k3 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[3 * SC * TT + a];
+  }
+}
+
+// annotation-overlap / annotation-midoverlap: roles swapped (gat/Engine.pyx:1458-1472):
+// each annotation interval y is tested against the first sample segment x with x.end > y.start.
+// One wave per (sample, track); lanes stride the annotation intervals, bisecting the sample list.
+__global__ __launch_bounds__(256) void k_count_anno(CountArgs A) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+  if (w >= (int64_t)A.n_samples * A.n_tracks) return;
+  const int s = (int)(w / A.n_tracks), t = (int)(w - (int64_t)s * A.n_tracks);
+  int64_t hit_total = 0, mid_total = 0;
+  for (int c = 0; c < A.n_contigs; ++c) {
+    const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
+    const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+    const int64_t g = A.a_off[(int64_t)t * A.n_contigs + c];
+    const int m = (int)(A.a_off[(int64_t)t * A.n_contigs + c + 1] - g);
+    uint32_t hit = 0, mid = 0;
+    if (n > 0) {
+      for (int i = lane; i < m; i += 64) {
+        const uint32_t ys = A.a_start[g + i], ye = A.a_end[g + i];
+        int lo = 0, hi = n;                   // j = #x with x.end <= ys
+        while (lo < hi) { const int md = lo + ((hi - lo) >> 1); if (X[md].y <= ys) lo = md + 1; else hi = md; }
+        if (lo < n) {
+          const uint2 x = X[lo];
+          if (x.x < ye) {
+            hit++;
+            const uint32_t mp = ys + (ye - ys) / 2u;
+            if (x.x <= mp && mp < x.y) mid++;
+          }
+        }
+      }
+    }
+    hit_total += (int64_t)wave_sum_u32(hit);
+    mid_total += (int64_t)wave_sum_u32(mid);
+  }
+  if (lane == 0) {
+    const int64_t col = A.out_begin + s;
+    const int k4 = A.counter_slot[4], k5 = A.counter_slot[5];
+    if (k4 >= 0) A.out[((int64_t)k4 * A.n_tracks + t) * A.out_stride + col] = hit_total;
+    if (k5 >= 0) A.out[((int64_t)k5 * A.n_tracks + t) * A.out_stride + col] = mid_total;
+  }
+}
+
+}  // namespace gat

@@ -1,0 +1,728 @@
+// gat_mi355.hip -- host side of libgat_mi355.so (C ABI in include/gat_mi355.h).
+//
+// Host work is limited to what the reference does once per (segments, workspace) pair before
+// sampling starts (gat/Engine.pyx:543-565, hoisted out of the per-sample loop), buffer management
+// and kernel launches.  Sampling, fromIsochores and counting run only as HIP kernels
+// (gat_kernels.h); there is no CPU path for them in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <climits>
+#include <string>
+#include <vector>
+
+#include "../../include/gat_mi355.h"
+#define GAT_NUM_COUNTERS_DEV 6
+#include "gat_kernels.h"
+
+using gat::UnitDev;
+
+static thread_local std::string g_last_error;
+
+struct gat_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  int max_lds = 65536;
+};
+
+static int set_err(gat_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                          \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return set_err(ctx, GAT_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                     __FILE__, __LINE__);                                                          \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  hipError_t alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess) return e;
+    if (!h.empty()) e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    return e;
+  }
+};
+
+// annotations on the device: SoA starts / ends / exclusive cumulated lengths + CSR offsets
+struct AnnoDev {
+  DevBuf<uint32_t> start, end, cumx;
+  DevBuf<int64_t> off;
+  std::vector<int64_t> h_off;
+  int64_t max_m = 0;
+  int64_t total = 0;
+};
+
+static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (s[i].start >= s[i].end)
+      return set_err(ctx, GAT_ERR_ASSERT, "%s list %lld is not normalized: empty/invalid segment %u-%u", what,
+                     (long long)idx, s[i].start, s[i].end);
+    if (s[i].end >= 0x80000000u)
+      return set_err(ctx, GAT_ERR_ARG, "%s list %lld: coordinate %u >= 2^31 not supported", what, (long long)idx, s[i].end);
+    if (i > 0 && s[i - 1].end > s[i].start)
+      return set_err(ctx, GAT_ERR_ASSERT, "%s list %lld is not normalized: %u-%u overlaps/precedes %u-%u", what,
+                     (long long)idx, s[i - 1].start, s[i - 1].end, s[i].start, s[i].end);
+  }
+  return GAT_OK;
+}
+
+static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists) {
+  const int64_t total = anno_off[n_lists];
+  std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
+  A.h_off.assign(anno_off, anno_off + n_lists + 1);
+  A.max_m = 0;
+  A.total = total;
+  for (int64_t l = 0; l < n_lists; ++l) {
+    const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+    int rc = check_list(ctx, annos + o, m, "annotation", l);
+    if (rc) return rc;
+    A.max_m = std::max(A.max_m, m);
+    uint32_t cum = 0;
+    for (int64_t i = 0; i < m; ++i) {
+      hs[(size_t)(o + i)] = annos[o + i].start;
+      he[(size_t)(o + i)] = annos[o + i].end;
+      hc[(size_t)(o + i)] = cum;
+      cum += annos[o + i].end - annos[o + i].start;
+    }
+  }
+  HIPCHK(ctx, A.start.upload(hs, ctx->stream));
+  HIPCHK(ctx, A.end.upload(he, ctx->stream));
+  HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
+  HIPCHK(ctx, A.off.upload(A.h_off, ctx->stream));
+  return GAT_OK;
+}
+
+struct gat_problem {
+  gat_ctx* ctx = nullptr;
+  int32_t n_units = 0, n_contigs = 0, n_tracks = 0, merge_contigs = 0;
+  std::vector<UnitDev> h_units;
+  std::vector<int32_t> h_order;          // active units, largest first
+  std::vector<int32_t> h_base_cap;       // per unit capacity before scaling
+  std::vector<int32_t> h_contig_unit_off, h_contig_units, h_contig_slab_off, h_count_c_off, h_count_n_index;
+  std::vector<int64_t> h_cws_nseg;
+  int cap_scale = 1;
+  int64_t slab_stride = 0;
+  int32_t max_unit_cap = 0, max_contig_cap = 0;
+  int64_t n_seg_total = 0;               // input segments (for the algorithmic byte count)
+  DevBuf<UnitDev> d_units;
+  DevBuf<int32_t> d_order, d_contig_unit_off, d_contig_units, d_contig_slab_off, d_count_c_off, d_count_n_index;
+  DevBuf<uint2> d_ws;
+  DevBuf<uint32_t> d_ws_cdf, d_hist_idx, d_hist_cdf;
+  DevBuf<int64_t> d_cws_nseg;
+  AnnoDev annos;
+  // per-batch scratch
+  int64_t batch = 0;
+  DevBuf<uint2> d_slab, d_cslab;
+  DevBuf<int32_t> d_unit_n, d_contig_n, d_flags;
+  DevBuf<unsigned long long> d_stat;
+};
+
+// ------------------------------------------------------------------------------------------
+extern "C" const char* gat_version(void) { return "gat_mi355 0.1 (gfx950)"; }
+
+extern "C" const char* gat_last_error(const gat_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
+  if (!out) return set_err(nullptr, GAT_ERR_ARG, "gat_ctx_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return set_err(nullptr, GAT_ERR_DEVICE, "no HIP device available (%s): this library has no CPU path",
+                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) return set_err(nullptr, GAT_ERR_ARG, "device %d out of range (0..%d)", device_id, ndev - 1);
+  gat_ctx* ctx = new gat_ctx();
+  ctx->device = device_id;
+  HIPCHK(ctx, hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    int rc = set_err(nullptr, GAT_ERR_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+    delete ctx;
+    return rc;
+  }
+  ctx->max_lds = (int)prop.sharedMemPerBlock;
+  if (ctx->max_lds < 160 * 1024) ctx->max_lds = 160 * 1024;   // gfx950: 160 KiB per workgroup via the opt-in attribute
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  for (auto& ev : ctx->ev) HIPCHK(ctx, hipEventCreate(&ev));
+  *out = ctx;
+  return GAT_OK;
+}
+
+extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int gat_ctx_synchronize(gat_ctx* ctx) {
+  if (!ctx) return set_err(nullptr, GAT_ERR_ARG, "ctx is NULL");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}
+
+extern "C" int gat_dev_alloc(gat_ctx* ctx, void** out, size_t bytes) {
+  if (!ctx || !out) return set_err(ctx, GAT_ERR_ARG, "gat_dev_alloc: NULL argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 1));
+  return GAT_OK;
+}
+extern "C" int gat_dev_free(gat_ctx* ctx, void* p) {
+  if (!ctx) return set_err(ctx, GAT_ERR_ARG, "gat_dev_free: NULL ctx");
+  HIPCHK(ctx, hipFree(p));
+  return GAT_OK;
+}
+extern "C" int gat_memcpy_d2h(gat_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return set_err(ctx, GAT_ERR_ARG, "NULL ctx");
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}
+extern "C" int gat_memcpy_h2d(gat_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return set_err(ctx, GAT_ERR_ARG, "NULL ctx");
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side hoisted setup of one unit (gat/Engine.pyx:543-565)
+static uint32_t host_overlap(const gat_segment* w, int64_t nw, uint32_t s, uint32_t e) {
+  // bases of [s,e) inside the normalized list w
+  uint32_t ov = 0;
+  const gat_segment* it = std::lower_bound(w, w + nw, s, [](const gat_segment& a, uint32_t v) { return a.end <= v; });
+  for (; it != w + nw && it->start < e; ++it) ov += std::min(e, it->end) - std::max(s, it->start);
+  return ov;
+}
+
+static int32_t cap_for(int64_t n) {
+  int64_t c = n + n / 4 + 96;
+  c = (c + 63) / 64 * 64;
+  return (int32_t)c;
+}
+
+static int layout_slab(gat_problem* P) {
+  // regions in contig-major order so that a contig's units are adjacent (k_contig output region)
+  int64_t off = 0;
+  P->max_unit_cap = 0;
+  P->max_contig_cap = 0;
+  for (int c = 0; c < P->n_contigs; ++c) {
+    P->h_contig_slab_off[c] = (int32_t)off;
+    int64_t ccap = 0;
+    for (int ui = P->h_contig_unit_off[c]; ui < P->h_contig_unit_off[c + 1]; ++ui) {
+      const int u = P->h_contig_units[ui];
+      UnitDev& U = P->h_units[u];
+      const int64_t cap = (int64_t)P->h_base_cap[u] * P->cap_scale;
+      U.slab_off = (int32_t)off;
+      U.slab_cap = (int32_t)cap;
+      off += cap;
+      ccap += cap;
+      P->max_unit_cap = std::max<int32_t>(P->max_unit_cap, (int32_t)cap);
+    }
+    P->max_contig_cap = std::max<int32_t>(P->max_contig_cap, (int32_t)ccap);
+    if (!P->merge_contigs) {
+      const int u = P->h_contig_units[P->h_contig_unit_off[c]];
+      P->h_count_c_off[c] = P->h_units[u].slab_off;
+      P->h_count_n_index[c] = u;
+    } else {
+      P->h_count_c_off[c] = P->h_contig_slab_off[c];
+      P->h_count_n_index[c] = c;
+    }
+  }
+  if (off >= (int64_t)1 << 31) return GAT_ERR_CAPACITY;
+  P->slab_stride = off > 0 ? off : 1;
+  return GAT_OK;
+}
+
+static int upload_layout(gat_ctx* ctx, gat_problem* P) {
+  HIPCHK(ctx, P->d_units.upload(P->h_units, ctx->stream));
+  HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
+  HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
+  HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx->stream));
+  P->batch = 0;   // scratch must be re-sized
+  return GAT_OK;
+}
+
+extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_problem** out) {
+  if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (d->n_units < 0 || d->n_contigs < 0 || d->n_tracks < 0 || d->nbuckets <= 0)
+    return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: negative size / nbuckets <= 0");
+  std::unique_ptr<gat_problem> P(new gat_problem());
+  P->ctx = ctx;
+  P->n_units = d->n_units;
+  P->n_contigs = d->n_contigs;
+  P->n_tracks = d->n_tracks;
+  P->merge_contigs = d->merge_contigs ? 1 : 0;
+  P->h_units.resize((size_t)d->n_units);
+  P->h_base_cap.assign((size_t)d->n_units, 0);
+  P->h_cws_nseg.assign(d->cws_nseg, d->cws_nseg + d->n_contigs);
+
+  std::vector<uint2> h_ws;
+  std::vector<uint32_t> h_ws_cdf, h_hist_idx, h_hist_cdf;
+  std::vector<std::pair<int64_t, int32_t>> work;   // (working segments, unit)
+  std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
+
+  for (int u = 0; u < d->n_units; ++u) {
+    UnitDev& U = P->h_units[u];
+    memset(&U, 0, sizeof(U));
+    const gat_segment* us = d->segs + d->seg_off[u];
+    const int64_t nus = d->seg_off[u + 1] - d->seg_off[u];
+    const gat_segment* uw = d->ws + d->ws_off[u];
+    const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+    const int c = d->unit_contig[u];
+    U.contig = c;
+    P->n_seg_total += nus;
+    const bool skipped = (nus == 0 || nuw == 0);     // gat/__init__.py:536-538
+    if (c >= d->n_contigs || (c < 0 && !skipped))
+      return set_err(ctx, GAT_ERR_ARG, "unit %d: contig index %d invalid (skipped units carry -1)", u, c);
+    if (skipped) continue;
+    if (c < 0) return set_err(ctx, GAT_ERR_ARG, "unit %d is not skipped by computeSample but has contig -1", u);
+    per_contig[(size_t)c].push_back(u);
+    int rc;
+    if ((rc = check_list(ctx, us, nus, "segment", u))) return rc;     // gat/Engine.pyx:535
+    if ((rc = check_list(ctx, uw, nuw, "workspace", u))) return rc;   // gat/Engine.pyx:536
+    // working = segments.filter(workspace); ltotal = working.intersect(workspace).sum()
+    uint32_t ltotal = 0, maxlen = 0;
+    int64_t nwork = 0;
+    std::vector<uint32_t> lens;
+    lens.reserve((size_t)nus);
+    for (int64_t i = 0; i < nus; ++i) {
+      const uint32_t ov = host_overlap(uw, nuw, us[i].start, us[i].end);
+      if (ov == 0) continue;
+      ltotal += ov;
+      const uint32_t l = us[i].end - us[i].start;
+      lens.push_back(l);
+      maxlen = std::max(maxlen, l);
+      nwork++;
+    }
+    if (nwork == 0) continue;          // sample() returns an empty list, no RNG use (gat/Engine.pyx:545-546)
+    // getLengthDistribution (gat/SegmentList.pyx:1148-1184)
+    int64_t bucket = d->bucket_size;
+    if (bucket == 0) bucket = (int64_t)std::ceil((double)(int32_t)maxlen / (double)d->nbuckets);
+    std::map<uint32_t, uint32_t> hist;
+    for (uint32_t l : lens) {
+      const int64_t i = ((int64_t)l + bucket - 1) / bucket;
+      if (i >= d->nbuckets)
+        return set_err(ctx, GAT_ERR_VALUE, "unit %d: segment of length %u too large: increase nbuckets (%d) or bucket_size (%lld)",
+                       u, l, d->nbuckets, (long long)bucket);
+      hist[(uint32_t)i] += 1;
+    }
+    U.n_hist = (int32_t)hist.size();
+    U.hist_off = (int32_t)h_hist_idx.size();
+    uint32_t cum = 0;
+    for (auto& kv : hist) {
+      cum += kv.second;
+      h_hist_idx.push_back(kv.first);
+      h_hist_cdf.push_back(cum);
+    }
+    U.hist_total = cum;
+    U.bucket = (uint32_t)bucket;
+    // SegmentListSampler(workspace) (gat/Engine.pyx:261-277)
+    U.n_ws = (int32_t)nuw;
+    U.ws_off = (int32_t)h_ws.size();
+    uint32_t tot = 0;
+    for (int64_t i = 0; i < nuw; ++i) {
+      tot += uw[i].end - uw[i].start;
+      h_ws.push_back(make_uint2(uw[i].start, uw[i].end));
+      h_ws_cdf.push_back(tot - 1u);
+    }
+    U.ws_total = tot;
+    U.ltotal = (int32_t)ltotal;
+    P->h_base_cap[u] = cap_for(nwork);
+    work.push_back(std::make_pair(nwork, (int32_t)u));
+  }
+  // contig -> units (reference order)
+  P->h_contig_unit_off.assign((size_t)d->n_contigs + 1, 0);
+  for (int c = 0; c < d->n_contigs; ++c) {
+    if (per_contig[(size_t)c].empty())
+      return set_err(ctx, GAT_ERR_ARG, "contig %d has no unit: contigs must be those of the non-skipped units", c);
+    if (!P->merge_contigs && per_contig[(size_t)c].size() != 1)
+      return set_err(ctx, GAT_ERR_ARG, "contig %d has %zu units but keys carry no isochore (merge_contigs=0)", c, per_contig[(size_t)c].size());
+    for (int32_t u : per_contig[(size_t)c]) P->h_contig_units.push_back(u);
+    P->h_contig_unit_off[(size_t)c + 1] = (int32_t)P->h_contig_units.size();
+  }
+  std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) {
+    return a.first != b.first ? a.first > b.first : a.second < b.second;
+  });
+  for (auto& w : work) P->h_order.push_back(w.second);
+  P->h_contig_slab_off.assign((size_t)d->n_contigs, 0);
+  P->h_count_c_off.assign((size_t)d->n_contigs, 0);
+  P->h_count_n_index.assign((size_t)d->n_contigs, 0);
+  if (layout_slab(P.get())) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
+
+  HIPCHK(ctx, P->d_order.upload(P->h_order, ctx->stream));
+  HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx->stream));
+  HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
+  HIPCHK(ctx, P->d_ws.upload(h_ws, ctx->stream));
+  HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx->stream));
+  HIPCHK(ctx, P->d_hist_idx.upload(h_hist_idx, ctx->stream));
+  HIPCHK(ctx, P->d_hist_cdf.upload(h_hist_cdf, ctx->stream));
+  HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
+  int rc = upload_layout(ctx, P.get());
+  if (rc) return rc;
+  rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs);
+  if (rc) return rc;
+  HIPCHK(ctx, P->d_flags.alloc(1));
+  HIPCHK(ctx, P->d_stat.alloc(8));
+  *out = P.release();
+  return GAT_OK;
+}
+
+extern "C" void gat_problem_destroy(gat_problem* p) {
+  if (!p) return;
+  if (p->ctx) (void)hipSetDevice(p->ctx->device);
+  delete p;
+}
+
+extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,
+                                int64_t* slab, int64_t* bytes) {
+  if (!p) return set_err(nullptr, GAT_ERR_ARG, "NULL problem");
+  if (n_units) *n_units = p->n_units;
+  if (n_contigs) *n_contigs = p->n_contigs;
+  if (n_tracks) *n_tracks = p->n_tracks;
+  if (slab) *slab = p->slab_stride;
+  // B_sample = 8*sum n' + 8*sum_a sum_c m + 8*A, with n' ~ n input segments
+  if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->annos.total + 8 * (int64_t)p->n_tracks;
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
+  if (P->batch >= want) return GAT_OK;
+  const char* env = getenv("GAT_SLAB_BYTES");
+  const double budget = env ? atof(env) : 12.0 * 1024 * 1024 * 1024;
+  const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs);
+  int64_t b = (int64_t)(budget / (double)per_sample);
+  b = std::max<int64_t>(1, std::min<int64_t>(b, want));
+  if (P->batch >= b) return GAT_OK;
+  HIPCHK(ctx, P->d_slab.alloc((size_t)(b * P->slab_stride)));
+  if (P->merge_contigs) HIPCHK(ctx, P->d_cslab.alloc((size_t)(b * P->slab_stride)));
+  HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
+  HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
+  P->batch = b;
+  return GAT_OK;
+}
+
+struct Counters {
+  int32_t slot[GAT_NUM_COUNTERS];
+  bool any_seg = false, any_anno = false;
+};
+
+static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) {
+  for (int i = 0; i < GAT_NUM_COUNTERS; ++i) C.slot[i] = -1;
+  for (int k = 0; k < n; ++k) {
+    if (ids[k] < 0 || ids[k] >= GAT_NUM_COUNTERS) return set_err(ctx, GAT_ERR_ARG, "unknown counter id %d", ids[k]);
+    if (C.slot[ids[k]] >= 0) return set_err(ctx, GAT_ERR_ARG, "counter id %d given twice", ids[k]);
+    C.slot[ids[k]] = k;
+    if (ids[k] <= GAT_COUNTER_SEGMENT_MIDOVERLAP) C.any_seg = true; else C.any_anno = true;
+  }
+  return GAT_OK;
+}
+
+// launch the count kernels over n_lists sample lists
+static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A) {
+  for (int i = 0; i < GAT_NUM_COUNTERS; ++i) A.counter_slot[i] = C.slot[i];
+  A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
+  if (A.n_samples <= 0 || A.n_tracks <= 0) return GAT_OK;
+  if (C.any_seg) {
+    const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
+    const int E_max = env_e ? atoi(env_e) : 3072;
+    const char* env_sc = getenv("GAT_COUNT_SAMPLES_PER_BLOCK");
+    int SC = env_sc ? atoi(env_sc) : 16;
+    SC = std::max(4, std::min(SC, 64));
+    int TT;
+    bool staged = annos.max_m > 0 && annos.max_m <= E_max;
+    if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, 16), E_max / annos.max_m);
+    else TT = (int)std::min<int64_t>(A.n_tracks, 16);
+    TT = std::max(1, TT);
+    A.tracks_per_block = TT;
+    A.samples_per_block = SC;
+    A.lds_entries = staged ? (int)std::min<int64_t>((int64_t)E_max, annos.max_m * TT) : 0;
+    const size_t lds = (size_t)4 * SC * TT * 8 + (size_t)((TT + 1 + 3) & ~3) * 4 + (size_t)3 * A.lds_entries * 4;
+    dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT));
+    if (staged) {
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(gat::k_count_seg<true>, grid, dim3(256), lds, ctx->stream, A);
+    } else {
+      hipLaunchKernelGGL(gat::k_count_seg<false>, grid, dim3(256), lds, ctx->stream, A);
+    }
+    HIPCHK(ctx, hipGetLastError());
+  }
+  if (C.any_anno) {
+    const int64_t waves = (int64_t)A.n_samples * A.n_tracks;
+    hipLaunchKernelGGL(gat::k_count_anno, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, A);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  return GAT_OK;
+}
+
+// sampler (+ fromIsochores) for one batch; retries with a larger slab on overflow
+static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
+                             gat_stats* st, bool timed) {
+  for (;;) {
+    int rc = ensure_scratch(ctx, P, nb);
+    if (rc) return rc;
+    if (P->batch < nb) return set_err(ctx, GAT_ERR_MEMORY, "internal: batch %lld > scratch %lld", (long long)nb, (long long)P->batch);
+    HIPCHK(ctx, hipMemsetAsync(P->d_unit_n.p, 0, (size_t)(nb * std::max(1, P->n_units)) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(nb * std::max(1, P->n_contigs)) * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_flags.p, 0, 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 8 * 8, ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if (!P->h_order.empty()) {
+      gat::SamplerArgs A;
+      A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units;
+      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.hist_idx = P->d_hist_idx.p; A.hist_cdf = P->d_hist_cdf.p;
+      A.seed = seed; A.sample_begin = begin;
+      A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
+      A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p;
+      const size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
+      if ((int64_t)lds > ctx->max_lds)
+        return set_err(ctx, GAT_ERR_CAPACITY, "unit needs %zu bytes of LDS (> %d): too many segments in one isochore unit", lds, ctx->max_lds);
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_sampler, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
+      hipLaunchKernelGGL(gat::k_sampler, dim3((unsigned)nb, (unsigned)P->h_order.size()), dim3(64), lds, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (P->merge_contigs && P->n_contigs > 0) {
+      gat::ContigArgs B;
+      B.contig_unit_off = P->d_contig_unit_off.p; B.contig_units = P->d_contig_units.p; B.units = P->d_units.p;
+      B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
+      B.slab_in = P->d_slab.p; B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
+      B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
+      const size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8;
+      if ((int64_t)lds > ctx->max_lds)
+        return set_err(ctx, GAT_ERR_CAPACITY, "contig needs %zu bytes of LDS (> %d)", lds, ctx->max_lds);
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_contig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(gat::k_contig, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    int32_t flags = 0;
+    unsigned long long stat[8];
+    HIPCHK(ctx, hipMemcpyAsync(&flags, P->d_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(stat, P->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (flags & (gat::kStatusAssert | gat::kStatusTrimAssert))
+      return set_err(ctx, GAT_ERR_ASSERT, "sampler assertion failed on device (flags=%d): %s", flags,
+                     (flags & gat::kStatusAssert) ? "sampled list has no overlap with the workspace (gat/Engine.pyx:645)"
+                                                  : "trimming more than the total length (gat/SegmentList.pyx:560)");
+    if (flags & gat::kStatusOverflow) {
+      if (P->cap_scale >= 64) return set_err(ctx, GAT_ERR_CAPACITY, "sampler slab overflow even at 64x capacity");
+      P->cap_scale *= 2;
+      if (layout_slab(P)) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments after growth");
+      if ((rc = upload_layout(ctx, P))) return rc;
+      if (st) st->n_retried += nb * (int64_t)P->h_order.size();
+      continue;
+    }
+    if (st) {
+      st->n_placed += (int64_t)stat[0];
+      st->n_draws += (int64_t)stat[1];
+      st->n_unsuccessful += (int64_t)stat[2];
+      if (P->merge_contigs) st->n_sampled_segments += (int64_t)stat[3];
+      if (timed) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        st->ms_sampler += ms;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+        st->ms_contig += ms;
+      }
+    }
+    return GAT_OK;
+  }
+}
+
+static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
+  A.seg = P->merge_contigs ? P->d_cslab.p : P->d_slab.p;
+  A.seg_stride = P->slab_stride;
+  A.c_off = P->d_count_c_off.p;
+  A.n_arr = P->merge_contigs ? P->d_contig_n.p : P->d_unit_n.p;
+  A.n_stride = P->merge_contigs ? P->n_contigs : P->n_units;
+  A.n_index = P->d_count_n_index.p;
+  A.cws_nseg = P->d_cws_nseg.p;
+  A.n_contigs = P->n_contigs;
+  A.n_tracks = P->n_tracks;
+  A.n_samples = (int32_t)nb;
+}
+
+extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                    uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
+                                    gat_stats* stats) {
+  if (!ctx || !P || !counts_dev || (n_counters > 0 && !counter_ids)) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count: NULL argument");
+  if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Counters C;
+  int rc = parse_counters(ctx, counter_ids, n_counters, C);
+  if (rc) return rc;
+  gat_stats local;
+  memset(&local, 0, sizeof(local));
+  const int64_t S = sample_end - sample_begin;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  int64_t done = 0;
+  while (done < S) {
+    if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
+    const int64_t nb = std::min<int64_t>(P->batch, S - done);
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true))) return rc;
+    gat::CountArgs A;
+    memset(&A, 0, sizeof(A));
+    fill_count_args(P, A, nb);
+    A.out = (int64_t*)counts_dev;
+    A.out_stride = S;
+    A.out_begin = done;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    if ((rc = launch_count(ctx, P->annos, C, A))) return rc;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    local.ms_count += ms;
+    done += nb;
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
+  local.ms_total = ms;
+  if (stats) *stats = local;
+  return GAT_OK;
+}
+
+extern "C" int gat_sample(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sample_begin, int64_t sample_end,
+                          gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats) {
+  if (!ctx || !P || !off_host) return set_err(ctx, GAT_ERR_ARG, "gat_sample: NULL argument");
+  if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  gat_stats local;
+  memset(&local, 0, sizeof(local));
+  const int64_t S = sample_end - sample_begin;
+  const int C = P->n_contigs;
+  int rc;
+  int64_t done = 0, total = 0;
+  bool overflow = false;
+  off_host[0] = 0;
+  std::vector<uint2> h_slab;
+  std::vector<int32_t> h_n;
+  while (done < S) {
+    if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
+    const int64_t nb = std::min<int64_t>(P->batch, S - done);
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true))) return rc;
+    const uint2* src = P->merge_contigs ? P->d_cslab.p : P->d_slab.p;
+    const int32_t* nsrc = P->merge_contigs ? P->d_contig_n.p : P->d_unit_n.p;
+    const int nstride = P->merge_contigs ? P->n_contigs : P->n_units;
+    h_slab.resize((size_t)(nb * P->slab_stride));
+    h_n.resize((size_t)(nb * std::max(1, nstride)));
+    HIPCHK(ctx, hipMemcpyAsync(h_slab.data(), src, h_slab.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_n.data(), nsrc, h_n.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < nb; ++i) {
+      for (int c = 0; c < C; ++c) {
+        const int32_t n = h_n[(size_t)(i * nstride + P->h_count_n_index[c])];
+        if (!overflow && out_host && total + n <= cap)
+          memcpy(out_host + total, h_slab.data() + i * P->slab_stride + P->h_count_c_off[c], (size_t)n * sizeof(uint2));
+        else if (n > 0) overflow = true;
+        total += n;
+        off_host[(done + i) * C + c + 1] = total;
+      }
+    }
+    done += nb;
+  }
+  if (!P->merge_contigs) local.n_sampled_segments = total;
+  if (stats) *stats = local;
+  if (overflow) return set_err(ctx, GAT_ERR_CAPACITY, "gat_sample: output needs %lld segments, cap is %lld", (long long)total, (long long)cap);
+  return GAT_OK;
+}
+
+extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                               const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                               const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
+                               const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
+  if (!ctx || !list_off || !anno_off || !counts_host || (n_groups > 0 && !ws_nseg))
+    return set_err(ctx, GAT_ERR_ARG, "gat_count_lists: NULL argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Counters C;
+  int rc = parse_counters(ctx, counter_ids, n_counters, C);
+  if (rc) return rc;
+  AnnoDev A;
+  if ((rc = build_annos(ctx, A, annos, anno_off, (int64_t)n_tracks * n_groups))) return rc;
+  for (int64_t l = 0; l < n_lists * n_groups; ++l)
+    if ((rc = check_list(ctx, lists + list_off[l], list_off[l + 1] - list_off[l], "segment", l))) return rc;
+  const int64_t total = list_off[n_lists * n_groups];
+  std::vector<uint2> h_seg((size_t)total);
+  for (int64_t i = 0; i < total; ++i) h_seg[(size_t)i] = make_uint2(lists[i].start, lists[i].end);
+  DevBuf<uint2> d_seg;
+  DevBuf<int32_t> d_c_off, d_n, d_index;
+  DevBuf<int64_t> d_nseg, d_out;
+  HIPCHK(ctx, d_seg.upload(h_seg, ctx->stream));
+  std::vector<int64_t> h_nseg(ws_nseg, ws_nseg + n_groups);
+  HIPCHK(ctx, d_nseg.upload(h_nseg, ctx->stream));
+  const size_t nslots = (size_t)n_counters * n_tracks * n_lists;
+  HIPCHK(ctx, d_out.alloc(nslots));
+  HIPCHK(ctx, hipMemsetAsync(d_out.p, 0, std::max<size_t>(1, nslots) * 8, ctx->stream));
+  std::vector<int32_t> h_index((size_t)n_groups);
+  for (int g = 0; g < n_groups; ++g) h_index[(size_t)g] = g;
+  HIPCHK(ctx, d_index.upload(h_index, ctx->stream));
+  for (int64_t l = 0; l < n_lists; ++l) {
+    // one launch per list: group offsets differ from list to list
+    std::vector<int32_t> h_c_off((size_t)n_groups), h_n((size_t)n_groups);
+    const int64_t base = list_off[l * n_groups];
+    for (int g = 0; g < n_groups; ++g) {
+      h_c_off[(size_t)g] = (int32_t)(list_off[l * n_groups + g] - base);
+      h_n[(size_t)g] = (int32_t)(list_off[l * n_groups + g + 1] - list_off[l * n_groups + g]);
+    }
+    HIPCHK(ctx, d_c_off.upload(h_c_off, ctx->stream));
+    HIPCHK(ctx, d_n.upload(h_n, ctx->stream));
+    gat::CountArgs K;
+    memset(&K, 0, sizeof(K));
+    K.seg = d_seg.p + base; K.seg_stride = 0; K.c_off = d_c_off.p;
+    K.n_arr = d_n.p; K.n_stride = 0; K.n_index = d_index.p;
+    K.cws_nseg = d_nseg.p; K.n_contigs = n_groups; K.n_tracks = n_tracks; K.n_samples = 1;
+    K.out = d_out.p; K.out_stride = n_lists; K.out_begin = l;
+    if ((rc = launch_count(ctx, A, C, K))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  HIPCHK(ctx, hipMemcpyAsync(counts_host, d_out.p, nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}

@@ -1,0 +1,130 @@
+"""Flatten host-side interval dictionaries into the CSR arrays of gat_problem_desc
+(include/gat_mi355.h), walking them exactly as gat.computeSample does
+(gat/__init__.py:494-591): unit order = list(segs.keys()), units whose workspace or segment
+list is empty are skipped, contig order = first appearance among the units that are not.
+"""
+import collections
+
+import numpy as np
+
+from . import intervals as iv
+
+SEG = iv.SEG
+
+
+def _cat(lists):
+    lists = [x for x in lists]
+    if not lists:
+        return iv.EMPTY.copy(), np.zeros(1, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+    return (np.concatenate(lists) if off[-1] else iv.EMPTY.copy()), off
+
+
+def split_key(key):
+    """contig of an isochore key, as IntervalDictionary.fromIsochores does (gat/Engine.pyx:2862-2868)."""
+    k = key.strip()
+    if "." in k and k != ".":
+        parts = k.split(".")
+        if len(parts) != 2:
+            raise ValueError("isochore key %r: expected exactly one '.' (gat/Engine.pyx:2864)" % key)
+        return parts[0], True
+    return k, False
+
+
+def from_isochores(d):
+    """IntervalDictionary.fromIsochores (gat/Engine.pyx:2857-2876) on a dict key -> SEG array."""
+    new = collections.OrderedDict()
+    merged = False
+    for key, a in d.items():
+        contig, dotted = split_key(key)
+        if dotted:
+            new[contig] = np.concatenate([new[contig], a]) if contig in new else a.copy()
+            merged = True
+        else:
+            new[contig] = a
+    if merged:
+        for k in list(new.keys()):
+            new[k] = iv.merge(new[k], 0)
+    return new
+
+
+def to_isochores(d, isochores, truncate):
+    """IntervalDictionary.toIsochores (gat/Engine.pyx:2837-2855)."""
+    out = collections.OrderedDict()
+    for contig, a in d.items():
+        for track, per in isochores.items():
+            other = per.get(contig, iv.EMPTY)
+            out["%s.%s" % (contig, track)] = iv.intersect(a, other) if truncate else iv.filter(a, other)
+    return out
+
+
+def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000):
+    """segs / workspace: OrderedDict unit key -> SEG array (isochore level);
+    annotations: list of (track, OrderedDict unit key -> SEG array) (isochore level)."""
+    units = list(segs.keys())
+    contig_annotations = [(t, from_isochores(per)) for t, per in annotations]
+    contig_workspace = from_isochores(workspace)
+    seg_arrays, ws_arrays, unit_contig, contigs = [], [], [], []
+    merge = 0
+    dotted_any, plain_any = False, False
+    for u in units:
+        sa = segs[u]
+        wa = workspace.get(u, iv.EMPTY)
+        seg_arrays.append(sa)
+        ws_arrays.append(wa)
+        contig, dotted = split_key(u)
+        dotted_any |= dotted
+        plain_any |= not dotted
+        if dotted:
+            merge = 1
+        if len(sa) == 0 or len(wa) == 0:          # gat/__init__.py:536-538
+            unit_contig.append(-1)
+            continue
+        if contig not in contigs:
+            contigs.append(contig)
+        unit_contig.append(contigs.index(contig))
+    if dotted_any and plain_any:
+        raise ValueError("mixing keys with and without isochores is not supported")
+    anno_arrays = []
+    for _, per in contig_annotations:
+        for c in contigs:
+            anno_arrays.append(per.get(c, iv.EMPTY))
+    segs_cat, seg_off = _cat(seg_arrays)
+    ws_cat, ws_off = _cat(ws_arrays)
+    annos_cat, anno_off = _cat(anno_arrays)
+    return dict(n_units=len(units), unit_names=list(units), segs=segs_cat, seg_off=seg_off, ws=ws_cat, ws_off=ws_off,
+                unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=len(contigs), contig_names=list(contigs),
+                merge_contigs=merge, n_tracks=len(annotations), track_names=[t for t, _ in annotations],
+                annos=annos_cat, anno_off=anno_off,
+                cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
+                bucket_size=int(bucket_size), nbuckets=int(nbuckets))
+
+
+def apply_isochores(segments, annotations, workspace, isochores=None, truncate_segments=False):
+    """the array form of IO.applyIsochores (gat/IO.py:188-248).
+
+    segments / workspace: OrderedDict contig -> normalized SEG array; annotations: list of
+    (track, OrderedDict contig -> SEG array); isochores: OrderedDict track -> OrderedDict contig ->
+    SEG array, or None.  Returns (segs, annotations, workspace) at isochore level."""
+    if isochores:
+        iso = collections.OrderedDict()
+        for track, per in isochores.items():        # isochores.intersect(workspace), gat/IO.py:176
+            iso[track] = collections.OrderedDict((c, iv.intersect(a, workspace[c])) for c, a in per.items() if c in workspace)
+        ws = to_isochores(workspace, iso, True)
+        annos = [(t, to_isochores(per, iso, True)) for t, per in annotations]
+        segs = to_isochores(segments, iso, truncate_segments)
+        return segs, annos, ws
+    segs = collections.OrderedDict()
+    for c, a in segments.items():                    # segments.filter / intersect (gat/IO.py:243-246)
+        if c in workspace:
+            segs[c] = iv.intersect(a, workspace[c]) if truncate_segments else iv.filter(a, workspace[c])
+    annos = []
+    for t, per in annotations:                       # annotations.intersect (gat/IO.py:248)
+        annos.append((t, collections.OrderedDict((c, iv.intersect(a, workspace[c])) for c, a in per.items() if c in workspace)))
+    return segs, annos, workspace
+
+
+def flatten_arrays(segments, annotations, workspace, isochores=None, bucket_size=0, nbuckets=100000,
+                   truncate_segments=False):
+    segs, annos, ws = apply_isochores(segments, annotations, workspace, isochores, truncate_segments)
+    return flatten_units(segs, ws, annos, bucket_size, nbuckets)

@@ -141,3 +141,18 @@ def config(name, scale=1.0):
                     workspace=workspace_ungapped(HG19), isochores=None,
                     num_samples=1000000, counter="nucleotide-density")
     raise ValueError("unknown config %r" % name)
+
+
+def small_genome():
+    """4 small contigs, gapped workspace, 3 isochore classes, 3 annotation tracks; one (contig, isochore)
+    unit without segments and one contig without annotations in track t1 (golden run_small_*)."""
+    contigs = collections.OrderedDict([("chrA", 400000), ("chrB", 250000), ("chrC", 90000), ("chrD", 50000)])
+    cfg = dict(segments=random_segments(contigs, 300, 120, 3),
+               annotations=[("t%d" % i, random_segments(contigs, 150 + 40 * i, 400 + 150 * i, 50 + i)) for i in range(3)],
+               workspace=workspace_ungapped(contigs, pieces=4, gap=4000),
+               isochores=isochores_blocks(contigs, nclasses=3, block=30000))
+    # make one (contig, isochore) unit segment-free and one contig annotation-free
+    seg = cfg["segments"]
+    seg["chrD"] = seg["chrD"][(seg["chrD"]["start"] // 30000) % 3 != 1]
+    cfg["annotations"][1][1].pop("chrC", None)
+    return contigs, cfg

@@ -1,0 +1,157 @@
+/*
+ * gat_mi355.h -- C ABI of libgat_mi355.so: the MI355X (gfx950) implementation of GAT's
+ * Monte-Carlo sampling + overlap-counting hot path.
+ *
+ * The reference (AndreasHeger/gat 1.3.6) has no FFI; its seams for this path are Python-level
+ * calls into Cython cdef classes.  Each entry point below names the reference
+ * interface it replaces (file:line into the reference tree).  All buffers are caller-owned,
+ * plain pointers and sizes; no Python, torch or C++ types cross the boundary.  Functions
+ * return 0 on success or a negative GAT_ERR_* code; gat_last_error() gives the text.
+ * One gat_ctx per host thread; a ctx is bound to one HIP device and one HIP stream.
+ *
+ * There is NO CPU fallback behind this ABI: every entry point that computes runs HIP kernels
+ * and fails with GAT_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef GAT_MI355_H
+#define GAT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == gat/SegmentList.pxd:31-38  struct Segment { Position start; Position end; }, half-open */
+typedef struct { uint32_t start, end; } gat_segment;
+
+typedef struct gat_ctx gat_ctx;
+typedef struct gat_problem gat_problem;
+
+#define GAT_OK 0
+#define GAT_ERR_VALUE (-1)      /* reference raises ValueError (gat/SegmentList.pyx:1170-1182)      */
+#define GAT_ERR_ASSERT (-2)     /* reference raises AssertionError (gat/Engine.pyx:535-536, :645)   */
+#define GAT_ERR_CAPACITY (-3)   /* a caller buffer or a device slab was too small                  */
+#define GAT_ERR_MEMORY (-4)
+#define GAT_ERR_DEVICE (-5)     /* HIP error / no usable gfx950 device                             */
+#define GAT_ERR_ARG (-6)
+
+/* counter ids == the classes of gat/Engine.pyx:1417-1472 (Counter*.name) */
+#define GAT_COUNTER_NUCLEOTIDE_OVERLAP 0     /* CounterNucleotideOverlap        :1417 */
+#define GAT_COUNTER_NUCLEOTIDE_DENSITY 1     /* CounterNucleotideDensity        :1428 */
+#define GAT_COUNTER_SEGMENT_OVERLAP 2        /* CounterSegmentOverlap           :1443 */
+#define GAT_COUNTER_SEGMENT_MIDOVERLAP 3     /* CounterSegmentMidpointOverlap   :1450 */
+#define GAT_COUNTER_ANNOTATION_OVERLAP 4     /* CounterAnnotationOverlap        :1458 */
+#define GAT_COUNTER_ANNOTATION_MIDOVERLAP 5  /* CounterAnnotationMidpointOverlap :1465 */
+#define GAT_NUM_COUNTERS 6
+
+/*
+ * Flat description of what gat.computeSample (gat/__init__.py:494-591) walks for one segment
+ * track: the isochore units in list(segs.keys()) order (:531), their contig after
+ * IntervalDictionary.fromIsochores (gat/Engine.pyx:2857-2876), and the contig-level
+ * annotations / workspace the counters see (:580-587).  All pointers are HOST pointers and are
+ * only read during gat_problem_create.  Every list must be normalized (sorted, disjoint,
+ * non-empty segments: gat/SegmentList.pyx:697) and all coordinates must be < 2^31 (the
+ * reference's int32 lmin/lmax, gat/SegmentList.pyx:68-77, are order-preserving only there).
+ */
+typedef struct {
+  int32_t n_units;              /* isochore keys, reference order                               */
+  const gat_segment* segs;      /* per-unit segment lists, concatenated                         */
+  const int64_t* seg_off;       /* n_units+1                                                    */
+  const gat_segment* ws;        /* per-unit workspace lists, concatenated                       */
+  const int64_t* ws_off;        /* n_units+1                                                    */
+  const int32_t* unit_contig;   /* n_units: contig index, or -1 for a unit computeSample skips  */
+  int32_t n_contigs;            /* contigs in list(sample.keys()) order after fromIsochores     */
+  int32_t merge_contigs;        /* 1 if keys are "contig.isochore": fromIsochores merges(0)     */
+  int32_t n_tracks;             /* annotation tracks                                            */
+  const gat_segment* annos;     /* [track][contig] lists, concatenated                          */
+  const int64_t* anno_off;      /* n_tracks*n_contigs+1                                         */
+  const int64_t* cws_nseg;      /* n_contigs: len(contig_workspace[contig]) (Engine.pyx:1437)   */
+  uint32_t bucket_size;         /* SamplerAnnotator(bucket_size, nbuckets): gat/Engine.pyx:498  */
+  int32_t nbuckets;
+} gat_problem_desc;
+
+/* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
+ * ctx stream; counts summed over all (sample, unit) work units of the call) */
+typedef struct {
+  float ms_sampler;             /* placement + consolidation kernel                             */
+  float ms_contig;              /* fromIsochores kernel (0 when keys carry no isochore)         */
+  float ms_count;               /* overlap-count kernel(s)                                      */
+  float ms_total;               /* whole call on the stream                                     */
+  int64_t n_placed;             /* segments placed (sls.sample calls kept, gat/Engine.pyx:628)  */
+  int64_t n_draws;              /* raw MT19937 outputs consumed                                 */
+  int64_t n_sampled_segments;   /* contig-level segments handed to the counters                 */
+  int64_t n_unsuccessful;       /* sum of nunsuccessful_rounds (gat/Engine.pyx:570-572)         */
+  int64_t n_retried;            /* work units redone with a larger slab                         */
+} gat_stats;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* device_id: HIP device ordinal.  stream: a hipStream_t to run on (e.g. torch's current
+ * stream) or NULL to create a private one. */
+int gat_ctx_create(gat_ctx** out, int device_id, void* stream);
+void gat_ctx_destroy(gat_ctx* ctx);
+const char* gat_last_error(const gat_ctx* ctx);      /* ctx may be NULL: last error of the thread */
+const char* gat_version(void);
+int gat_ctx_synchronize(gat_ctx* ctx);
+
+/* device memory helpers so a ctypes host needs no other HIP binding */
+int gat_dev_alloc(gat_ctx* ctx, void** out, size_t bytes);
+int gat_dev_free(gat_ctx* ctx, void* p);
+int gat_memcpy_d2h(gat_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int gat_memcpy_h2d(gat_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+
+/* ---- problem ---------------------------------------------------------------------------- */
+/* Uploads the inputs once and hoists what SamplerAnnotator.sample recomputes on every call
+ * (gat/Engine.pyx:543-565: filter, ltotal, getLengthDistribution, both sampler CDFs).
+ * Returns GAT_ERR_VALUE where the reference's first sample() would raise ValueError. */
+int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* desc, gat_problem** out);
+void gat_problem_destroy(gat_problem* p);
+
+/* ---- the batch seam ---------------------------------------------------------------------
+ * Replaces UnconditionalSampler.sample / computeSamples / computeSample
+ * (gat/__init__.py:654-778, :494-591) for samples [sample_begin, sample_end):
+ * per sample, every unit is sampled (SamplerAnnotator.sample, gat/Engine.pyx:515-646),
+ * units are re-combined per contig (fromIsochores) and every counter x annotation track is
+ * evaluated and summed over contigs.
+ *
+ * Random streams ("per-unit" contract): work unit (sample s, unit u) draws from
+ * numpy's legacy RandomState seeded with (seed + s*n_units + u) mod 2^32, i.e. exactly what
+ * numpy.random.seed(that) followed by the reference's sampler.sample() consumes.  Results do
+ * not depend on how samples are split over calls, streams or GPUs.
+ *
+ * counts_dev: DEVICE pointer to n_counters*n_tracks*(sample_end-sample_begin) 8-byte slots laid
+ * out [counter][track][sample]; int64 for the integer counters, IEEE double for
+ * nucleotide-density.  Work is enqueued on the ctx stream; the call returns after the
+ * kernels have completed and per-unit status words have been checked. */
+int gat_sample_and_count(gat_ctx* ctx, gat_problem* p,
+                         const int32_t* counter_ids, int n_counters,
+                         uint32_t seed, int64_t sample_begin, int64_t sample_end,
+                         void* counts_dev, gat_stats* stats /* nullable */);
+
+/* Sampler only: replaces sampler.sample() + sample.fromIsochores() (gat/__init__.py:541, :563)
+ * for a range of samples and returns the contig-level lists to the HOST:
+ * off_host has (sample_end-sample_begin)*n_contigs+1 entries, segments of (sample i, contig c)
+ * are out_host[off[i*n_contigs+c] .. off[i*n_contigs+c+1]).  GAT_ERR_CAPACITY if cap is too
+ * small (off_host[last] then holds the required size). */
+int gat_sample(gat_ctx* ctx, gat_problem* p, uint32_t seed,
+               int64_t sample_begin, int64_t sample_end,
+               gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats);
+
+/* Counters only, on caller-provided lists: replaces Engine.computeCounts
+ * (gat/Engine.pyx:2164-2204; observed counts) and counter(segments, annotations, workspace)
+ * (gat/Engine.pyx:1417-1472).  lists: n_lists*n_groups segment lists (HOST, CSR via list_off),
+ * annotations: n_tracks*n_groups lists (HOST, CSR via anno_off), ws_nseg[n_groups] =
+ * len(workspace[group]).  counts_host: [n_counters][n_tracks][n_lists] 8-byte slots. */
+int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                    const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                    const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
+                    const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
+
+/* queries */
+int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,
+                     int64_t* slab_segments_per_sample, int64_t* algorithmic_bytes_per_sample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

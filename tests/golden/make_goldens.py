@@ -461,17 +461,7 @@ def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100
         numpy.round(counts0.mean(axis=2).ravel()[:4], 2), numpy.round(counts1.mean(axis=2).ravel()[:4], 2)))
 
 
-def small_genome():
-    contigs = collections.OrderedDict([("chrA", 400000), ("chrB", 250000), ("chrC", 90000), ("chrD", 50000)])
-    cfg = dict(segments=synthetic.random_segments(contigs, 300, 120, 3),
-               annotations=[("t%d" % i, synthetic.random_segments(contigs, 150 + 40 * i, 400 + 150 * i, 50 + i)) for i in range(3)],
-               workspace=synthetic.workspace_ungapped(contigs, pieces=4, gap=4000),
-               isochores=synthetic.isochores_blocks(contigs, nclasses=3, block=30000))
-    # make one (contig, isochore) unit segment-free and one contig annotation-free
-    seg = cfg["segments"]
-    seg["chrD"] = seg["chrD"][(seg["chrD"]["start"] // 30000) % 3 != 1]
-    cfg["annotations"][1][1].pop("chrC", None)
-    return contigs, cfg
+small_genome = synthetic.small_genome
 
 
 def g4_runs():

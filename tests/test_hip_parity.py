@@ -1,0 +1,183 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated goldens and the
+CPU oracle on the same seeded inputs.  Bit-exact: integer counts, sampled segment lists, and
+IEEE doubles for the density counter."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gat_amd import _lib, synthetic
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RUNS = ["config1", "small_isochores", "small_contigs", "small_isochores_truncated", "config2_s12",
+        "density_ungapped", "dense", "long_segments"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _flat(z):
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", RUNS)
+def test_golden_counts_and_samples(ctx, name):
+    """count matrix and sampled lists == what the reference produced (per-unit stream contract)."""
+    z = np.load(os.path.join(G, "run_%s.npz" % name))
+    counters = [str(c) for c in z["counters"]]
+    S = int(z["num_samples"])
+    P = _lib.Problem(ctx, _flat(z))
+    counts = P.sample_and_count(counters, int(z["seed"]), 0, S)
+    want = z["counts_mode1"]
+    for k, c in enumerate(counters):
+        if c == "nucleotide-density":
+            assert np.array_equal(counts[k], want[k]), c
+        else:
+            assert np.array_equal(counts[k].astype(np.float64), want[k]), c
+    seg, off = P.sample(int(z["seed"]), 0, S)
+    h = hashlib.sha256()
+    for i in range(len(off) - 1):
+        h.update(seg[off[i]:off[i + 1]].tobytes())
+    assert h.hexdigest() == str(z["samples_sha256_mode1"])
+    if "samples_mode1" in z.files:
+        assert np.array_equal(off, z["samples_off_mode1"])
+        assert np.array_equal(seg, z["samples_mode1"])
+    P.close()
+
+
+def _single_unit_flat(segments, workspace, bucket_size, nbuckets):
+    s, w = O.segs(segments), O.segs(workspace)
+    return dict(n_units=1, segs=s, seg_off=[0, len(s)], ws=w, ws_off=[0, len(w)], unit_contig=[0], n_contigs=1,
+                merge_contigs=0, n_tracks=1, annos=w, anno_off=[0, len(w)], cws_nseg=[len(w)],
+                bucket_size=bucket_size, nbuckets=nbuckets)
+
+
+def test_golden_sampler_kats(ctx):
+    """SamplerAnnotator.sample known answers taken from the reference (tests/golden/sampler.json)."""
+    with open(os.path.join(G, "sampler.json")) as f:
+        cases = json.load(f)
+    nrun = 0
+    for c in cases:
+        flat = _single_unit_flat(c["segments"], c["workspace"], c["bucket_size"], c["nbuckets"])
+        if "error" in c:
+            with pytest.raises(ValueError):
+                _lib.Problem(ctx, flat)
+            continue
+        P = _lib.Problem(ctx, flat)
+        for run in c["runs"]:
+            seg, off = P.sample(run["seed"], 0, 1)       # unit stream seed = seed + 0*1 + 0
+            assert len(seg) == run["n"], (c["name"], run["seed"])
+            assert hashlib.sha256(seg.tobytes()).hexdigest() == run["sha256"], (c["name"], run["seed"])
+            nrun += 1
+        P.close()
+    assert nrun >= 250
+
+
+def _random_problem(rs, n_contigs, n_segs, n_tracks, isochores, dense=False):
+    contigs = dict(("c%d" % i, int(rs.randint(20000, 400000))) for i in range(n_contigs))
+    import collections
+    contigs = collections.OrderedDict(sorted(contigs.items()))
+    segs = synthetic.random_segments(contigs, n_segs, 60 if not dense else 400, int(rs.randint(1 << 30)))
+    annos = [("t%d" % t, synthetic.random_segments(contigs, int(rs.randint(20, 400)), int(rs.randint(50, 2000)),
+                                                   int(rs.randint(1 << 30)))) for t in range(n_tracks)]
+    ws = synthetic.workspace_ungapped(contigs, pieces=int(rs.randint(1, 5)), gap=2000)
+    from gat_amd import problem
+    iso = synthetic.isochores_blocks(contigs, nclasses=int(rs.randint(2, 4)), block=int(rs.randint(5000, 40000))) if isochores else None
+    return problem.flatten_arrays(segs, annos, ws, iso)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_problems_vs_oracle(ctx, seed):
+    rs = np.random.RandomState(seed)
+    flat = _random_problem(rs, n_contigs=int(rs.randint(1, 6)), n_segs=int(rs.randint(20, 600)),
+                           n_tracks=int(rs.randint(1, 5)), isochores=bool(seed % 2), dense=(seed % 3 == 0))
+    counters = list(_lib.COUNTER_IDS.keys())
+    S = 40
+    want, wsamples = O.run_samples(flat, counters, 1000 + seed, 1, 5, 5 + S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 1000 + seed, 5, 5 + S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    seg, off = P.sample(1000 + seed, 5, 5 + S)
+    assert np.array_equal(off, wsamples[1])
+    assert np.array_equal(seg, wsamples[0])
+    P.close()
+
+
+def test_shard_independence(ctx):
+    """any split of the sample range gives the same columns (multi-GPU sharding relies on it)."""
+    z = np.load(os.path.join(G, "run_small_isochores.npz"))
+    P = _lib.Problem(ctx, _flat(z))
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    full = P.sample_and_count(counters, 5, 0, 64)
+    a = P.sample_and_count(counters, 5, 0, 23)
+    b = P.sample_and_count(counters, 5, 23, 64)
+    for k in range(2):
+        assert np.array_equal(np.concatenate([a[k], b[k]], axis=1), full[k])
+    P.close()
+
+
+def test_count_lists_vs_oracle(ctx):
+    rs = np.random.RandomState(9)
+    n_groups, n_tracks, n_lists = 3, 4, 2
+    lists, annos = [], []
+    for _ in range(n_lists * n_groups):
+        lists.append(O.normalize([(int(a), int(a + b)) for a, b in zip(rs.randint(0, 50000, 80), rs.randint(1, 300, 80))]))
+    for _ in range(n_tracks * n_groups):
+        annos.append(O.normalize([(int(a), int(a + b)) for a, b in zip(rs.randint(0, 50000, 60), rs.randint(1, 900, 60))]))
+    off = lambda ls: np.concatenate([[0], np.cumsum([len(x) for x in ls])]).astype(np.int64)  # noqa: E731
+    ws_nseg = [3, 1, 7]
+    counters = list(_lib.COUNTER_IDS.keys())
+    got = ctx.count_lists(counters, np.concatenate(lists), off(lists), n_lists, np.concatenate(annos), off(annos),
+                          n_tracks, ws_nseg, n_groups)
+    for k, c in enumerate(counters):
+        for t in range(n_tracks):
+            for l in range(n_lists):
+                vals = [O.counter(c, lists[l * n_groups + g], annos[t * n_groups + g], ws_nseg[g]) for g in range(n_groups)]
+                if c == "nucleotide-density":
+                    acc = 0.0
+                    for v in vals:
+                        acc += v
+                    assert got[k][t, l] == acc
+                else:
+                    assert got[k][t, l] == int(sum(vals))
+
+
+def test_roundtrip_invariants_full_size(ctx):
+    """BASELINE config-2 size, properties the reference's own benchmark suite states
+    (test/benchmark_gat.py:773-780, :828-837): every sampled list is normalized, lies in the
+    workspace, and covers exactly the observed number of workspace bases."""
+    cfg = synthetic.config("config2")
+    from gat_amd import problem
+    flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], None)
+    P = _lib.Problem(ctx, flat)
+    S = 64
+    seg, off = P.sample(77, 1000, 1000 + S)
+    C = flat["n_contigs"]
+    for c in range(C):
+        u = list(flat["unit_contig"]).index(c)
+        us = flat["segs"][flat["seg_off"][u]:flat["seg_off"][u + 1]]
+        uw = flat["ws"][flat["ws_off"][u]:flat["ws_off"][u + 1]]
+        ltotal = O.total(O.intersect(O.filter(us, uw), uw))
+        for i in range(S):
+            x = seg[off[i * C + c]:off[i * C + c + 1]]
+            assert O.check(x)
+            assert O.total(O.intersect(x, uw)) == ltotal
+            assert len(O.filter(x, uw)) == len(x)
+    counts = P.sample_and_count(["nucleotide-overlap"], 77, 1000, 1000 + S)[0]
+    a = flat["annos"]
+    for i in range(0, S, 9):
+        tot = 0
+        for c in range(C):
+            x = seg[off[i * C + c]:off[i * C + c + 1]]
+            tot += O.overlap_with_segments(x, a[flat["anno_off"][c]:flat["anno_off"][c + 1]])
+        assert counts[0, i] == tot
+    P.close()
