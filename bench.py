@@ -84,7 +84,7 @@ def main():
     info = P.info()
     K, A = len(counters), flat["n_tracks"]
     counts = torch.zeros((K, A, S), dtype=torch.int64, device=dev)
-    gathered = torch.zeros((world, K, A, S), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * K, A, S), dtype=torch.int64, device=dev) if world > 1 else None
 
     def step(i):
         # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather

@@ -1,0 +1,47 @@
+"""Sharding of Monte-Carlo samples over the GPUs of a node and the one collective of the path.
+
+Samples are independent given the per-unit stream contract (include/gat_mi355.h), so rank r of G
+takes the contiguous sample-id range shard_range(S, r, G) with no data-path collective; the only
+exchange is ONE all-gather of the per-sample count matrix at the end (RCCL over xGMI when the
+tensors live on GPUs: torch.distributed backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests).
+This replaces the reference's multiprocessing.Pool + result collation
+(gat/__init__.py:681-700, :770-774).
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """contiguous range [begin, end) of rank; all but the last ranks get ceil(n/world) samples."""
+    per = (n + world - 1) // world
+    begin = min(n, rank * per)
+    return begin, min(n, begin + per)
+
+
+def padded_shard(n, world):
+    return (n + world - 1) // world
+
+
+def allgather_counts(local, n_total, group=None):
+    """local: torch int64 tensor [K, A, padded_shard] holding this rank's columns (zero padded);
+    returns [K, A, n_total] with the columns of all ranks in sample order."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local[..., :n_total]
+    per = local.shape[-1]
+    # concatenated form along dim 0 (accepted by both RCCL and gloo), viewed as [G, K, A, per]
+    gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    gathered = gathered.view((world,) + tuple(local.shape))
+    # [G, K, A, per] -> [K, A, G*per] -> trim the padding of the last rank
+    out = gathered.permute(1, 2, 0, 3).reshape(local.shape[0], local.shape[1], world * per)
+    return out[..., :n_total].contiguous()
+
+
+def gather_numpy(local_np, n_total, group=None):
+    """numpy convenience wrapper (CPU tensors; used by the host API when results are already on
+    the host and by the gloo tests)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(local_np))
+    return allgather_counts(t, n_total, group).numpy()

@@ -1,0 +1,650 @@
+"""Host-side mirror of the reference's operator interface for the hot path (gat/Engine.pyx,
+gat/SegmentList.pyx): same class and method names, argument meaning and error behaviour, so that
+code written against `gat.Engine` / `gat.SegmentList` reads the same against `gat_amd`.
+
+Containers are thin numpy wrappers; everything the hot path computes per sample (placement,
+consolidation, fromIsochores on samples, counters) is done by the HIP kernels behind
+libgat_mi355.so -- see gat_amd/__init__.py:run and gat_amd/_lib.py.  There is no CPU fallback.
+"""
+import collections
+import math
+
+import numpy as np
+
+from . import _lib
+from . import intervals as iv
+from . import problem as _problem
+
+SEG = iv.SEG
+
+_CTX = {}
+
+
+def get_context(device=0, stream=None):
+    """process-wide gat_ctx per (device, stream)."""
+    key = (device, stream)
+    if key not in _CTX:
+        _CTX[key] = _lib.Context(device, stream)
+    return _CTX[key]
+
+
+# ------------------------------------------------------------------------------------------------
+class SegmentList(object):
+    """list of half-open (start, end) uint32 segments (gat/SegmentList.pyx:146).
+
+    "normalized" = sorted by start, non-overlapping, no empty segments."""
+
+    def __init__(self, allocate=0, clone=None, iter=None, normalize=False, array=None):  # noqa: A002
+        self.isNormalized = 1
+        if clone is not None:
+            self._a = clone._a.copy()
+            self.isNormalized = clone.isNormalized
+        elif array is not None:
+            self._a = np.ascontiguousarray(array, dtype=SEG)
+            self.isNormalized = 0
+        elif iter is not None:
+            self._a = iv.as_segments(iter)
+            self.isNormalized = 0 if len(self._a) else 1
+        else:
+            self._a = iv.EMPTY.copy()
+        if normalize:
+            self.normalize()
+
+    # --- container protocol
+    def __len__(self):
+        return len(self._a)
+
+    def __iter__(self):
+        for s, e in zip(self._a["start"].tolist(), self._a["end"].tolist()):
+            yield (s, e)
+
+    def __getitem__(self, i):
+        return (int(self._a["start"][i]), int(self._a["end"][i]))
+
+    def __eq__(self, other):
+        return isinstance(other, SegmentList) and np.array_equal(self._a, other._a)
+
+    def __str__(self):
+        return str(self.asList())
+
+    @property
+    def isEmpty(self):
+        return len(self._a) == 0
+
+    def asList(self):
+        return list(self)
+
+    def asArray(self):
+        return self._a
+
+    def asLengths(self):
+        return (self._a["end"].astype(np.int64) - self._a["start"]).tolist()
+
+    # --- construction
+    def add(self, start, end):
+        assert start <= end, "attempting to add invalid segment %i-%i" % (start, end)
+        if start < 0 or end >= (1 << 32):
+            raise OverflowError("can't convert negative value to unsigned int")
+        self._a = np.concatenate([self._a, iv.make([start], [end])])
+        self.isNormalized = 0
+
+    def extend(self, other):
+        self._a = np.concatenate([self._a, other._a])
+        self.isNormalized = 0
+        return self
+
+    def clear(self):
+        self._a = iv.EMPTY.copy()
+        self.isNormalized = 1
+
+    def clone(self):
+        return SegmentList(clone=self)
+
+    # --- algebra (gat/SegmentList.pyx:697, :756, :1401, :1469)
+    def sort(self):
+        self._a = self._a[np.argsort(self._a["start"], kind="stable")]
+
+    def normalize(self):
+        self._a = iv.normalize(self._a)
+        self.isNormalized = 1
+
+    def merge(self, distance):
+        self._a = iv.merge(self._a, distance)
+        self.isNormalized = 1
+
+    def check(self):
+        self.isNormalized = 1 if iv.is_normalized(self._a) else 0
+        if not self.isNormalized:
+            raise ValueError("segment list is not normalized")
+        return self.isNormalized
+
+    def filter(self, other):  # noqa: A003
+        if other is self:
+            self.clear()
+            return
+        self._a = iv.filter(self._a, other._a)
+
+    def intersect(self, other):
+        assert self.isNormalized, "intersection of a non-normalized list"
+        assert other.isNormalized, "intersection with non-normalized list"
+        if other is self:
+            return
+        self._a = iv.intersect(self._a, other._a)
+
+    def sum(self):  # noqa: A003
+        return iv.total(self._a)
+
+    def max(self):  # noqa: A003
+        assert self.isNormalized, "maximum from non-normalized list"
+        return int(self._a["end"][-1]) if len(self._a) else 0
+
+    def min(self):  # noqa: A003
+        assert self.isNormalized, "minimum from non-normalized list"
+        return int(self._a["start"][0]) if len(self._a) else 0
+
+    def largest(self):
+        if len(self._a) == 0:
+            raise ValueError("largest segment from empty list")
+        lengths = self._a["end"].astype(np.int64) - self._a["start"]
+        i = int(np.argmax(lengths))
+        return self[i]
+
+    def getLengthDistribution(self, bucket_size=0, nbuckets=100000):
+        """gat/SegmentList.pyx:1148-1184."""
+        assert bucket_size >= 0, "bucket_size is 0"
+        assert nbuckets > 0, "nbuckets is 0"
+        lengths = self._a["end"].astype(np.int64) - self._a["start"]
+        if bucket_size == 0:
+            s, e = self.largest()
+            bucket_size = int(math.ceil((e - s) / float(nbuckets)))
+        idx = (lengths + bucket_size - 1) // bucket_size
+        if len(idx) and idx.max() >= nbuckets:
+            bad = int(np.argmax(idx >= nbuckets))
+            raise ValueError("segment %i-%i too large: increase nbuckets (%i) or bucket_size (%i)" %
+                             (self._a["start"][bad], self._a["end"][bad], nbuckets, bucket_size))
+        return np.bincount(idx, minlength=nbuckets).astype(np.int64), bucket_size
+
+    # --- counters' primitives (device)
+    def overlapWithSegments(self, other):
+        """gat/SegmentList.pyx:1026-1076, on the GPU."""
+        assert self.isNormalized and other.isNormalized, "intersection from non-normalized list"
+        if other is self:
+            return self.sum()
+        return int(_count_pair("nucleotide-overlap", other, self))
+
+    def intersectionWithSegments(self, other, mode="base"):
+        """gat/SegmentList.pyx:1078-1146, on the GPU."""
+        assert self.isNormalized and other.isNormalized, "intersection from non-normalized list"
+        if other is self:
+            return self.sum()
+        return int(_count_pair("segment-midoverlap" if mode == "midpoint" else "segment-overlap", self, other))
+
+
+def _count_pair(counter, segments, annotations, ws_nseg=1):
+    ctx = get_context()
+    a, b = segments._a, annotations._a
+    r = ctx.count_lists([counter], a, [0, len(a)], 1, b, [0, len(b)], 1, [ws_nseg], 1)
+    return r[0][0, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+class IntervalDictionary(object):
+    """key (contig or contig.isochore) -> SegmentList (gat/Engine.pyx:2741)."""
+
+    def __init__(self, name=None):
+        self.intervals = collections.defaultdict(SegmentList)
+        self.name = name
+
+    def __len__(self):
+        return len(self.intervals)
+
+    def __getitem__(self, key):
+        return self.intervals[key]
+
+    def __setitem__(self, key, val):
+        self.intervals[key] = val
+
+    def __delitem__(self, key):
+        del self.intervals[key]
+
+    def __contains__(self, key):
+        return key in self.intervals
+
+    def keys(self):
+        return self.intervals.keys()
+
+    def items(self):
+        return self.intervals.items()
+
+    def add(self, contig, segmentlist):
+        self.intervals[contig] = segmentlist
+
+    def sum(self):  # noqa: A003
+        return sum(x.sum() for x in self.intervals.values())
+
+    def counts(self):
+        return sum(len(x) for x in self.intervals.values())
+
+    def clone(self):
+        r = IntervalDictionary(self.name)
+        for k, v in self.intervals.items():
+            r[k] = v.clone()
+        return r
+
+    def normalize(self):
+        for k in [k for k, v in self.intervals.items() if len(v) == 0]:
+            del self.intervals[k]
+        for v in self.intervals.values():
+            v.normalize()
+
+    def _pairwise(self, other, op):
+        for contig in list(self.intervals.keys()):
+            if contig in other:
+                op(self.intervals[contig], other[contig])
+            else:
+                del self.intervals[contig]
+
+    def intersect(self, other):
+        self._pairwise(other, lambda a, b: a.intersect(b))
+
+    def filter(self, other):  # noqa: A003
+        self._pairwise(other, lambda a, b: a.filter(b))
+
+    def toIsochores(self, isochores, truncate=False):
+        """gat/Engine.pyx:2837-2855."""
+        for contig in list(self.intervals.keys()):
+            segmentlist = self.intervals[contig]
+            for other_track, other_vv in isochores.items():
+                newlist = segmentlist.clone()
+                if truncate:
+                    newlist.intersect(other_vv[contig])
+                else:
+                    newlist.filter(other_vv[contig])
+                self.intervals["%s.%s" % (contig, other_track)] = newlist
+            del self.intervals[contig]
+
+    def fromIsochores(self):
+        """gat/Engine.pyx:2857-2876."""
+        new = collections.defaultdict(SegmentList)
+        normalize = False
+        for isochore, segmentlist in self.intervals.items():
+            isochore = isochore.strip()
+            if "." in isochore and isochore != ".":
+                contig, _ = isochore.split(".")
+                new[contig].extend(segmentlist)
+                normalize = True
+            else:
+                new[isochore] = segmentlist
+        if normalize:
+            for x in new.values():
+                x.merge(0)
+        self.intervals = new
+
+    def asArrays(self):
+        return collections.OrderedDict((k, v.asArray()) for k, v in self.intervals.items())
+
+
+class IntervalCollection(object):
+    """track -> IntervalDictionary (gat/Engine.pyx:2887)."""
+
+    def __init__(self, name=None):
+        self.intervals = collections.defaultdict(IntervalDictionary)
+        self.name = name
+
+    def setName(self, name):
+        self.name = name
+
+    def getName(self):
+        return self.name
+
+    @property
+    def tracks(self):
+        return self.intervals.keys()
+
+    def keys(self):
+        return self.intervals.keys()
+
+    def items(self):
+        return self.intervals.items()
+
+    def __len__(self):
+        return len(self.intervals)
+
+    def __getitem__(self, key):
+        return self.intervals[key]
+
+    def __delitem__(self, key):
+        del self.intervals[key]
+
+    def __contains__(self, key):
+        return key in self.intervals
+
+    def add(self, track, contig, segmentlist):
+        self.intervals[track][contig] = segmentlist
+
+    def sum(self):  # noqa: A003
+        return sum(v.sum() for v in self.intervals.values())
+
+    def counts(self):
+        return sum(v.counts() for v in self.intervals.values())
+
+    def clone(self):
+        new = IntervalCollection(self.name)
+        for track, v in self.intervals.items():
+            for contig, segmentlist in v.items():
+                new.add(track, contig, segmentlist.clone())
+        return new
+
+    def normalize(self):
+        for vv in self.intervals.values():
+            vv.normalize()
+
+    def sort(self):
+        for vv in self.intervals.values():
+            for s in vv.intervals.values():
+                s.sort()
+
+    def check(self):
+        for vv in self.intervals.values():
+            for s in vv.intervals.values():
+                s.check()
+
+    def merge(self, delete=False):
+        merged = IntervalDictionary()
+        for track in list(self.intervals.keys()):
+            for contig, segmentlist in self.intervals[track].items():
+                merged[contig].extend(segmentlist)
+            if delete:
+                del self.intervals[track]
+        self.intervals["merged"] = merged
+
+    def collapse(self):
+        """gat/Engine.pyx:3014-3038: intersection of all tracks -> track 'collapsed'."""
+        result = IntervalDictionary()
+        contigs = collections.defaultdict(int)
+        for vv in self.intervals.values():
+            for contig in vv.keys():
+                contigs[contig] += 1
+        ntracks = len(self.intervals)
+        shared = set(x for x, y in contigs.items() if y == ntracks)
+        for vv in list(self.intervals.values()):
+            for contig, segmentlist in vv.items():
+                if contig not in shared:
+                    continue
+                if contig not in result:
+                    result[contig] = segmentlist.clone()
+                else:
+                    result[contig].intersect(segmentlist)
+        self.intervals["collapsed"] = result
+
+    def restrict(self, restrict):
+        keep = set([restrict]) if not isinstance(restrict, (list, tuple, set)) else set(restrict)
+        for track in [t for t in self.intervals.keys() if t not in keep]:
+            del self.intervals[track]
+
+    def intersect(self, other):
+        for vv in self.intervals.values():
+            vv.intersect(other)
+
+    def filter(self, other):  # noqa: A003
+        for vv in self.intervals.values():
+            vv.filter(other)
+
+    def toIsochores(self, isochores, truncate=False):
+        for vv in self.intervals.values():
+            vv.toIsochores(isochores, truncate)
+
+    def fromIsochores(self):
+        for vv in self.intervals.values():
+            vv.fromIsochores()
+
+    def save(self, outfile, prefix="", **kwargs):
+        for track, vv in self.intervals.items():
+            outfile.write("track name=%s%s %s\n" % (prefix, track, " ".join("%s=%s" % kv for kv in kwargs.items())))
+            for contig, segmentlist in vv.items():
+                for start, end in segmentlist:
+                    outfile.write("%s\t%i\t%i\n" % (contig, start, end))
+
+
+# ------------------------------------------------------------------------------------------------
+class Sampler(object):
+    pass
+
+
+class SamplerAnnotator(Sampler):
+    """gat/Engine.pyx:445: the default Monte-Carlo sampler, on the GPU.
+
+    sample() places one pseudo-sample.  The reference draws from numpy's process-global legacy
+    RandomState; here each call is one work unit of the per-unit stream contract
+    (include/gat_mi355.h): it draws from RandomState(seed), with `seed` taken from the
+    argument or, if None, from numpy.random.randint(0, 2**32) (so numpy.random.seed() still makes
+    a script reproducible)."""
+
+    def __init__(self, bucket_size=1, nbuckets=100000, nunsuccessful_rounds=0):
+        self.bucket_size = bucket_size
+        self.nbuckets = nbuckets
+        self.nunsuccessful_rounds = nunsuccessful_rounds
+
+    def sample(self, segments, workspace, seed=None):
+        assert segments.isNormalized, "segment list is not normalized"
+        assert workspace.isNormalized, "workspace is not normalized"
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 32))
+        if len(segments) == 0 or len(workspace) == 0 or len(iv.filter(segments.asArray(), workspace.asArray())) == 0:
+            return SegmentList()
+        s, w = segments.asArray(), workspace.asArray()
+        flat = dict(n_units=1, segs=s, seg_off=[0, len(s)], ws=w, ws_off=[0, len(w)], unit_contig=[0], n_contigs=1,
+                    merge_contigs=0, n_tracks=0, annos=iv.EMPTY, anno_off=[0], cws_nseg=[len(w)],
+                    bucket_size=self.bucket_size, nbuckets=self.nbuckets)
+        P = _lib.Problem(get_context(), flat)
+        try:
+            seg, _ = P.sample(seed, 0, 1)
+            self.nunsuccessful_rounds = P.last_stats["n_unsuccessful"]
+        finally:
+            P.close()
+        r = SegmentList(array=seg)
+        r.isNormalized = 1
+        return r
+
+
+class Counter(object):
+    name = None
+
+    def __call__(self, segments, annotations, workspace=None):
+        n = len(workspace) if workspace is not None else 1
+        v = _count_pair(self.name, segments, annotations, n)
+        return float(v) if self.name == "nucleotide-density" else int(v)
+
+
+class CounterNucleotideOverlap(Counter):
+    name = "nucleotide-overlap"           # gat/Engine.pyx:1417
+
+
+class CounterNucleotideDensity(Counter):
+    name = "nucleotide-density"           # gat/Engine.pyx:1428
+
+
+class CounterSegmentOverlap(Counter):
+    name = "segment-overlap"              # gat/Engine.pyx:1443
+
+
+class CounterSegmentMidpointOverlap(Counter):
+    name = "segment-midoverlap"           # gat/Engine.pyx:1450
+
+
+class CounterAnnotationOverlap(Counter):
+    name = "annotation-overlap"           # gat/Engine.pyx:1458
+
+
+class CounterAnnotationMidpointOverlap(Counter):
+    name = "annotation-midoverlap"        # gat/Engine.pyx:1465
+
+
+class UnconditionalWorkspace(object):
+    """gat/Engine.pyx:2061."""
+    is_conditional = False
+
+    def __call__(self, segments, annotations, workspace):
+        return segments, annotations, workspace
+
+
+def computeCounts(counter, aggregator, segments, annotations, workspace, workspace_generator, append=False):
+    """observed counts for all track x annotation pairs (gat/Engine.pyx:2164-2204): one device
+    launch per segment track over all (annotation, isochore) lists."""
+    counts = collections.defaultdict(lambda: collections.defaultdict(float))
+    isochores = list(workspace.keys())
+    ctx = get_context()
+    tracks = list(annotations.tracks)
+    for track in segments.tracks:
+        segs = segments[track]
+        lists = [segs[i].asArray() for i in isochores]
+        annos = [annotations[a][i].asArray() for a in tracks for i in isochores]
+        lcat, loff = _problem._cat(lists)
+        acat, aoff = _problem._cat(annos)
+        ws_nseg = [len(workspace[i]) for i in isochores]
+        if aggregator is not sum:
+            raise NotImplementedError("only aggregator=sum is supported")
+        r = ctx.count_lists([counter.name], lcat, loff, 1, acat, aoff, len(tracks), ws_nseg, len(isochores))[0]
+        for a, annotation in enumerate(tracks):
+            v = r[a, 0]
+            counts[track][annotation] = float(v) if counter.name == "nucleotide-density" else int(v)
+    return counts
+
+
+# ------------------------------------------------------------------------------------------------
+def getTwoSidedPValue(sorted_samples, expected, val):
+    """gat/Engine.pyx:1543-1576 on the sorted sample values."""
+    l = len(sorted_samples)  # noqa: E741
+    idx = int(np.searchsorted(sorted_samples, val, side="left"))
+    min_pval = 1.0 / l
+    if idx == l:
+        idx = 1
+    elif val > expected:
+        while idx > 0 and sorted_samples[idx] == val:
+            idx -= 1
+        idx = l - (idx + 1)
+    else:
+        while idx < l and sorted_samples[idx] == val:
+            idx += 1
+    return max(min_pval, float(idx) / l)
+
+
+class AnnotatorResult(object):
+    """gat/Engine.pyx:1725 / makeEnrichmentStatistics :1635-1718 (numpy on the host; identical
+    IEEE arithmetic: numpy.mean/std, sorted-value lookups)."""
+
+    format_observed = "%i"
+    format_expected = "%6.4f"
+    format_fold = "%6.4f"
+    format_pvalue = "%6.4e"
+    format_counts = "%i"
+    format_density = "%6.4e"
+    headers = ["track", "annotation", "observed", "expected", "CI95low", "CI95high", "stddev", "fold", "l2fold",
+               "pvalue", "qvalue"]
+
+    def __init__(self, track, annotation, counter, observed, samples, reference=None, pseudo_count=1.0):
+        self.track, self.annotation, self.counter = track, annotation, counter
+        samples = [float(x) for x in samples]
+        l = len(samples)  # noqa: E741
+        if l < 1:
+            raise ValueError("no samples")
+        self._samples = np.array(samples, dtype=np.float64)
+        self.observed = float(observed)
+        self.nsamples = l
+        srt = np.sort(self._samples)
+        self._sorted = srt
+        self.expected = float(np.mean(samples))
+        if reference is not None:
+            self.expected *= reference.fold
+        if self.expected != 0:
+            self.fold = (self.observed + pseudo_count) / (self.expected + pseudo_count)
+        else:
+            self.fold = 1.0
+        self.stddev = float(np.std(samples))
+        offset = int(0.05 * l)
+        if offset > 0:
+            self.lower95 = float(srt[min(offset, l - 1)])
+            self.upper95 = float(srt[max(l - offset, 0)])
+        else:
+            self.lower95 = float(srt[0])
+            self.upper95 = float(srt[l - 1])
+        if reference is None:
+            self.pvalue = getTwoSidedPValue(srt, self.expected, self.observed)
+        else:
+            if reference.fold > 0:
+                self.pvalue = getTwoSidedPValue(srt, self.expected, self.observed / reference.fold)
+            else:
+                raise ValueError("0 fold change not applicable")
+            self.lower95 *= reference.fold
+            self.upper95 *= reference.fold
+        self.qvalue = 1.0
+
+    @property
+    def samples(self):
+        return self._samples.copy()
+
+    def getSample(self, sample_id):
+        return float(self._samples[sample_id])
+
+    def getEmpiricalPValue(self, value):
+        return getTwoSidedPValue(self._sorted, self.expected, value)
+
+    def _base_columns(self):
+        logfold = self.format_fold % math.log(self.fold, 2) if self.fold > 0 else "-inf"
+        return (self.track, self.annotation, self.format_observed % self.observed,
+                self.format_expected % self.expected, self.format_expected % self.lower95,
+                self.format_expected % self.upper95, self.format_expected % self.stddev,
+                self.format_fold % self.fold, logfold, self.format_pvalue % self.pvalue,
+                self.format_pvalue % self.qvalue)
+
+    def __str__(self):
+        return "\t".join(self._base_columns())
+
+
+class AnnotatorResultExtended(AnnotatorResult):
+    """gat/Engine.pyx:1854-1974: adds sizes/densities of track, annotation and overlap."""
+
+    headers = AnnotatorResult.headers + [
+        "track_nsegments", "track_size", "track_density", "annotation_nsegments", "annotation_size",
+        "annotation_density", "overlap_nsegments", "overlap_size", "overlap_density",
+        "percent_overlap_nsegments_track", "percent_overlap_size_track",
+        "percent_overlap_nsegments_annotation", "percent_overlap_size_annotation"]
+
+    def __init__(self, track, annotation, counter, observed, samples, track_segments, annotation_segments,
+                 workspace, reference=None, pseudo_count=1.0):
+        AnnotatorResult.__init__(self, track, annotation, counter, observed, samples, reference=reference,
+                                 pseudo_count=pseudo_count)
+        self.track_nsegments = track_segments.counts()
+        self.track_size = track_segments.sum()
+        self.annotation_nsegments = annotation_segments.counts()
+        self.annotation_size = annotation_segments.sum()
+        overlap = track_segments.clone()
+        overlap.intersect(annotation_segments)
+        self.overlap_nsegments = overlap.counts()
+        self.overlap_size = overlap.sum()
+        self.workspace_size = workspace.sum()
+
+    def __str__(self):
+        def _toFold(a, b):
+            return self.format_fold % (100.0 * float(a) / b) if b > 0 else "na"
+
+        def _toDensity(a, b):
+            return self.format_density % (100.0 * float(a) / b) if b > 0 else "na"
+
+        return "\t".join(self._base_columns() + (
+            self.format_counts % self.track_nsegments, self.format_counts % self.track_size,
+            _toDensity(self.track_size, self.workspace_size),
+            self.format_counts % self.annotation_nsegments, self.format_counts % self.annotation_size,
+            _toDensity(self.annotation_size, self.workspace_size),
+            self.format_counts % self.overlap_nsegments, self.format_counts % self.overlap_size,
+            _toDensity(self.overlap_size, self.workspace_size),
+            _toFold(self.overlap_nsegments, self.track_nsegments), _toFold(self.overlap_size, self.track_size),
+            _toFold(self.overlap_nsegments, self.annotation_nsegments), _toFold(self.overlap_size, self.annotation_size)))
+
+
+def updatePValues(annotator_results, method="empirical"):
+    """gat/Engine.pyx:2001-2023 (empirical only)."""
+    if method != "empirical":
+        raise ValueError("only the empirical method is implemented (got %r)" % method)
+    for r in annotator_results:
+        r.pvalue = r.getEmpiricalPValue(r.observed)

@@ -447,7 +447,17 @@ def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100
             if keep_lists:
                 lists.append(a)
                 list_off.append(list_off[-1] + len(a))
+    # the reference's result rows (24 columns, gat/Engine.pyx:1950-1974) for the mode-1 count matrix
+    rows1 = []
+    for k, cname in enumerate(counters):
+        for a, t in enumerate(tracks):
+            r = Engine.AnnotatorResultExtended(track="merged", annotation=t, counter=cname, observed=observed[k, a],
+                                               samples=list(counts1[k, a]), track_segments=segments["merged"],
+                                               annotation_segments=annotations[t], workspace=workspace,
+                                               reference=None, pseudo_count=1.0)
+            rows1.append(str(r))
     out = dict(flat)
+    out.update(rows_mode1=numpy.array(rows1))
     out.update(seed=seed, num_samples=num_samples, counters=numpy.array(counters),
                counts_mode0=counts0, counts_mode1=counts1, observed=observed,
                stats_mode0=numpy.array(stats, dtype=numpy.float64), rows_mode0=numpy.array(rows),

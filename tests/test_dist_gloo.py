@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: two gloo ranks each compute their contiguous sample shard (the CPU oracle
+stands in for the GPU here -- tests may use it) and one all-gather reassembles the count matrix;
+it must equal the single-process matrix column for column."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, S, path):
+    import torch.distributed as dist
+    from gat_amd import distributed
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(G, "run_small_isochores.npz"))
+    flat = {k: z[k] for k in z.files}
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    begin, end = distributed.shard_range(S, rank, world)
+    local, _ = O.run_samples(flat, counters, 11, 1, begin, end)
+    per = distributed.padded_shard(S, world)
+    stack = np.zeros((2, flat["n_tracks"], per), dtype=np.int64)
+    for k in range(2):
+        stack[k, :, :end - begin] = local[k].view(np.int64)
+    full = distributed.gather_numpy(stack, S)
+    np.save(os.path.join(path, "rank%d.npy" % rank), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_allgather(tmp_path):
+    from oracle import oracle as O
+    S = 37                       # odd on purpose: ragged last shard
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, S, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(G, "run_small_isochores.npz"))
+    flat = {k: z[k] for k in z.files}
+    want, _ = O.run_samples(flat, ["nucleotide-overlap", "nucleotide-density"], 11, 1, 0, S)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got[0], want[0])
+        assert np.array_equal(got[1].view(np.float64), want[1])
+    # and the goldens: same columns as the reference produced for these sample ids
+    assert np.array_equal(want[0].astype(np.float64), z["counts_mode1"][0][:, :S])
+
+
+def test_shard_ranges_cover_everything():
+    from gat_amd import distributed
+    for n in (0, 1, 7, 8, 9, 10000):
+        for w in (1, 2, 3, 8):
+            r = [distributed.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+            assert all(e - b <= distributed.padded_shard(n, w) for b, e in r)

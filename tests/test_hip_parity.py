@@ -181,3 +181,41 @@ def test_roundtrip_invariants_full_size(ctx):
             tot += O.overlap_with_segments(x, a[flat["anno_off"][c]:flat["anno_off"][c + 1]])
         assert counts[0, i] == tot
     P.close()
+
+
+def test_run_api_rows_match_reference(ctx):
+    """gat_amd.run() end to end (observed counts, sampled counts, statistics, 24-column rows)
+    against the rows the reference's AnnotatorResultExtended printed for the same count matrix."""
+    import gat_amd
+    z = np.load(os.path.join(G, "run_small_isochores.npz"))
+    _, cfg = synthetic.small_genome()
+
+    def coll(tracks):
+        c = gat_amd.IntervalCollection()
+        for t, per in tracks:
+            for contig, a in per.items():
+                s = gat_amd.SegmentList(array=a)
+                s.isNormalized = 1
+                c.add(t, contig, s)
+        return c
+
+    segments = coll([("merged", cfg["segments"])])
+    annotations = coll(cfg["annotations"])
+    workspaces = coll([("ws", cfg["workspace"])])
+    workspaces.collapse()
+    workspaces.restrict("collapsed")
+    isochores = coll(list(cfg["isochores"].items()))
+    isochores.intersect(workspaces["collapsed"])
+    workspaces.toIsochores(isochores, truncate=True)
+    annotations.toIsochores(isochores, truncate=True)
+    segments.toIsochores(isochores, truncate=False)
+    counters = [gat_amd.COUNTERS[str(c)]() for c in z["counters"]]
+    results = gat_amd.run(segments, annotations, workspaces["collapsed"], gat_amd.SamplerAnnotator(bucket_size=0),
+                          counters, gat_amd.UnconditionalWorkspace(), num_samples=int(z["num_samples"]),
+                          random_seed=int(z["seed"]))
+    rows = [str(r) for r in results]
+    assert rows == [str(x) for x in z["rows_mode1"]]
+    for r in results:
+        k = [str(c) for c in z["counters"]].index(r.counter)
+        a = [str(t) for t in z["track_names"]].index(r.annotation)
+        assert r.observed == z["observed"][k, a]

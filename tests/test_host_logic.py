@@ -1,0 +1,162 @@
+"""Host-side logic (numpy interval algebra, problem flattening, statistics) against the
+reference-generated goldens and the oracle.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gat_amd import engine, intervals as iv, problem, synthetic
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _pairs(a):
+    return [tuple(x) for x in a]
+
+
+def _lst(a):
+    return [(int(s), int(e)) for s, e in zip(a["start"], a["end"])]
+
+
+@pytest.fixture(scope="module")
+def algebra():
+    with open(os.path.join(G, "algebra.json")) as f:
+        return json.load(f)
+
+
+def test_intervals_against_reference_goldens(algebra):
+    n = 0
+    for c in algebra:
+        if c["op"] == "normalize":
+            assert _lst(iv.normalize(iv.as_segments(c["a"]))) == _pairs(c["expect"])
+        elif c["op"] == "merge":
+            assert _lst(iv.merge(iv.as_segments(c["a"]), c["distance"])) == _pairs(c["expect"]), c
+        elif c["op"] == "pair":
+            a, b = iv.as_segments(c["a"]), iv.as_segments(c["b"])
+            assert _lst(iv.filter(a, b)) == _pairs(c["filter"])
+            assert _lst(iv.intersect(a, b)) == _pairs(c["intersect"])
+            assert iv.total(a) == c["sum_a"]
+            assert iv.overlap(a, b) == c["overlap"]
+        elif c["op"] == "length_distribution":
+            s = engine.SegmentList(iter=c["a"], normalize=True)
+            if "error" in c:
+                with pytest.raises(ValueError):
+                    s.getLengthDistribution(c["bucket_size"], c["nbuckets"])
+            else:
+                h, b = s.getLengthDistribution(c["bucket_size"], c["nbuckets"])
+                assert b == c["bucket_size_out"]
+                nz = np.flatnonzero(h)
+                assert [int(i) for i in nz] == c["nonzero"] and [int(h[i]) for i in nz] == c["counts"]
+        else:
+            continue
+        n += 1
+    assert n > 800
+
+
+def test_segmentlist_api():
+    s = engine.SegmentList()
+    assert len(s) == 0 and s.isNormalized
+    s.add(0, 100)
+    assert len(s) == 1
+    s.clear()
+    assert len(s) == 0
+    with pytest.raises(OverflowError):          # test/test_SegmentList.py:353-355
+        engine.SegmentList(iter=[(-100, 5)])
+    a = engine.SegmentList(iter=[(x, x + 10) for x in range(0, 1000, 100)], normalize=True)
+    b = engine.SegmentList(iter=[(0, 1000)], normalize=True)
+    b.intersect(a)
+    assert b.asList() == a.asList()
+    c = engine.SegmentList(iter=[(x, x + 5) for x in range(500, 2000, 100)], normalize=True)
+    c.filter(a)
+    assert c.asList() == [(500, 505), (600, 605), (700, 705), (800, 805), (900, 905)]
+    s1 = engine.SegmentList(iter=[(x, x + 100) for x in range(0, 1000, 100)])
+    s2 = engine.SegmentList(iter=[(x, x + 100) for x in range(2000, 3000, 100)])
+    s1.extend(s2)
+    assert s1.sum() == 2 * s2.sum() and len(s1) == 2 * len(s2)
+
+
+def test_isochore_roundtrip():
+    """test/test_gat.py:87-114: toIsochores / fromIsochores round trip."""
+    d = engine.IntervalDictionary()
+    for contig in ("contig1", "contig2"):
+        d.add(contig, engine.SegmentList(iter=[(x, x + 10) for x in range(0, 1000, 100)], normalize=True))
+    iso = engine.IntervalCollection()
+    iso.add("highGC", "contig1", engine.SegmentList(iter=[(0, 500)], normalize=True))
+    iso.add("lowGC", "contig1", engine.SegmentList(iter=[(500, 1000)], normalize=True))
+    iso.add("highGC", "contig2", engine.SegmentList(iter=[(0, 250)], normalize=True))
+    iso.add("lowGC", "contig2", engine.SegmentList(iter=[(250, 1000)], normalize=True))
+    orig = d.clone()
+    d.toIsochores(iso)
+    assert sorted(d.keys()) == sorted(["contig2.highGC", "contig1.highGC", "contig2.lowGC", "contig1.lowGC"])
+    d.fromIsochores()
+    assert sorted(d.keys()) == ["contig1", "contig2"]
+    for k in d.keys():
+        assert d[k].asList() == orig[k].asList()
+
+
+@pytest.mark.parametrize("name,iso,trunc", [("small_isochores", True, False), ("small_contigs", False, False),
+                                            ("small_isochores_truncated", True, True)])
+def test_flatten_matches_reference_walk(name, iso, trunc):
+    z = np.load(os.path.join(G, "run_%s.npz" % name))
+    _, cfg = synthetic.small_genome()
+    f = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"] if iso else None,
+                               truncate_segments=trunc)
+    for k in ("segs", "seg_off", "ws", "ws_off", "unit_contig", "annos", "anno_off", "cws_nseg"):
+        assert np.array_equal(f[k], z[k]), k
+    assert f["merge_contigs"] == int(z["merge_contigs"]) and list(f["unit_names"]) == [str(x) for x in z["unit_names"]]
+    assert list(f["contig_names"]) == [str(x) for x in z["contig_names"]]
+
+
+def test_flatten_via_collections_matches_arrays():
+    """the class-based route (IntervalCollection.toIsochores ...) == the array route."""
+    _, cfg = synthetic.small_genome()
+    want = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
+
+    def coll(tracks):
+        c = engine.IntervalCollection()
+        for t, per in tracks:
+            for contig, a in per.items():
+                s = engine.SegmentList(array=a)
+                s.isNormalized = 1
+                c.add(t, contig, s)
+        return c
+
+    segments = coll([("merged", cfg["segments"])])
+    annotations = coll(cfg["annotations"])
+    workspaces = coll([("ws", cfg["workspace"])])
+    workspaces.collapse()
+    workspaces.restrict("collapsed")
+    isochores = coll(list(cfg["isochores"].items()))
+    isochores.intersect(workspaces["collapsed"])
+    workspaces.toIsochores(isochores, truncate=True)
+    annotations.toIsochores(isochores, truncate=True)
+    segments.toIsochores(isochores, truncate=False)
+    f = problem.flatten_units(segments["merged"].asArrays(), workspaces["collapsed"].asArrays(),
+                              [(t, annotations[t].asArrays()) for t in annotations.tracks])
+    for k in ("segs", "seg_off", "ws", "ws_off", "unit_contig", "annos", "anno_off", "cws_nseg"):
+        assert np.array_equal(f[k], want[k]), k
+
+
+def test_enrichment_statistics_against_reference():
+    with open(os.path.join(G, "stats.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        r = engine.AnnotatorResult("track", "annotation", "counter", c["observed"], c["samples"],
+                                   pseudo_count=c["pseudo_count"])
+        assert r.expected == c["expected"] and r.stddev == c["stddev"] and r.fold == c["fold"]
+        assert r.pvalue == c["pvalue"]
+        assert str(r).split("\t")[2:] == c["row"]
+    # the reference's own known answers (test/test_gat.py:120-129 is float data, :272-284 ties)
+    samples = [0] * 66 + [1] * 2 + [2] * 20 + [3] * 1 + [4] * 6 + [6] * 2 + [8] * 2 + [16] * 1
+    assert engine.AnnotatorResult("t", "a", "c", 16, samples).pvalue == 0.01
+
+
+def test_pvalue_matches_oracle_restatement():
+    rs = np.random.RandomState(4)
+    for _ in range(200):
+        s = np.sort(rs.poisson(rs.choice([1, 20, 400]), size=int(rs.choice([1, 7, 100]))).astype(np.float64))
+        v = float(rs.choice(s)) if rs.rand() < 0.7 else float(rs.randint(0, 500))
+        e = float(np.mean(s))
+        assert engine.getTwoSidedPValue(s, e, v) == O.two_sided_pvalue(s, e, v)
