@@ -167,22 +167,23 @@ __device__ __forceinline__ void cmpex(uint2* seg, int i, int j) {
 }
 __device__ __forceinline__ void wave_sort_by_start(uint2* seg, int n, int lane) {
   if (n < 2) return;
-  int P = 2;
-  while (P < n) P <<= 1;
-  const int half_total = P >> 1;
+  int lP = 1;
+  while ((1 << lP) < n) ++lP;
+  const int half_total = 1 << (lP - 1);
   wave_sync();
-  for (int k = 2; k <= P; k <<= 1) {
-    const int hk = k >> 1;
+  for (int lk = 1; lk <= lP; ++lk) {
+    // flip step: i and its mirror image inside blocks of k = 2^lk
+    const int hmask = (1 << (lk - 1)) - 1;
     for (int t = lane; t < half_total; t += kWave) {
-      const int blk = t / hk, off = t - blk * hk;
-      const int i = blk * k + off, j = blk * k + (k - 1 - off);
+      const int base = (t >> (lk - 1)) << lk, off = t & hmask;
+      const int i = base + off, j = base + ((1 << lk) - 1 - off);
       if (j < n) cmpex(seg, i, j);
     }
     wave_sync();
-    for (int d = k >> 2; d > 0; d >>= 1) {
+    for (int ld = lk - 2; ld >= 0; --ld) {
+      const int dmask = (1 << ld) - 1;
       for (int t = lane; t < half_total; t += kWave) {
-        const int blk = t / d, off = t - blk * d;
-        const int i = blk * (d << 1) + off, j = i + d;
+        const int i = ((t >> ld) << (ld + 1)) + (t & dmask), j = i + (1 << ld);
         if (j < n) cmpex(seg, i, j);
       }
       wave_sync();
@@ -232,6 +233,51 @@ __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
   return count;
 }
 
+// Insert nS <= 64 unsorted segments seg[nU..nU+nS) into the sorted list seg[0..nU) (the same
+// result as re-sorting everything; equal starts may end up in a different order than qsort would
+// leave them, which merge() does not see).  Every element's final index is its own index plus
+// the number of elements of the other list that sort before it; the old list is shifted in
+// place from its last 64-row backwards (shifts are monotone and <= nS, so nothing unread is
+// overwritten) and rows in front of the first insertion point are not touched.
+__device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, int lane) {
+  wave_sync();
+  uint2 nv = make_uint2(0xffffffffu, 0xffffffffu);
+  if (lane < nS) nv = seg[nU + lane];
+  int nrank = 0;
+  for (int j = 0; j < nS; ++j) {
+    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)nv.x, j);
+    nrank += (sj < nv.x || (sj == nv.x && j < lane)) ? 1 : 0;
+  }
+  int cu = 0;
+  if (lane < nS) {
+    int lo = 0, hi = nU;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (seg[mid].x <= nv.x) lo = mid + 1; else hi = mid;
+    }
+    cu = lo;
+  }
+  const int newpos = cu + nrank;
+  for (int base = ((nU - 1) >> 6) << 6; base >= 0; base -= kWave) {
+    const int i = base + lane;
+    const bool ok = i < nU;
+    uint2 v = make_uint2(0u, 0u);
+    if (ok) v = seg[i];
+    int sh = 0;
+    for (int j = 0; j < nS; ++j) {
+      const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)nv.x, j);
+      sh += (ok && sj < v.x) ? 1 : 0;
+    }
+    const uint64_t moved = __ballot(sh > 0);
+    wave_sync();
+    if (sh > 0) seg[i + sh] = v;
+    wave_sync();
+    if (moved == 0) break;
+  }
+  if (lane < nS) seg[newpos] = nv;
+  wave_sync();
+}
+
 // bases of a normalized list W (starts/ends + cdf[i] = cumlen_i - 1) below position p.
 __device__ __forceinline__ uint32_t cov_below(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
                                               int nw, uint32_t p) {
@@ -256,6 +302,33 @@ __device__ __forceinline__ uint32_t seg_overlap_with(const uint2* __restrict__ w
     return hi > lo ? hi - lo : 0u;
   }
   return cov_below(w, cdf, nw, e) - cov_below(w, cdf, nw, s);
+}
+
+// A unit's workspace held in registers (lane i = workspace segment i), for units with <= 64
+// workspace segments: SegmentListSampler's CDF lookup becomes one v_cmp + ballot and the chosen
+// segment is fetched with v_readlane -- no memory access in the placement loop.
+struct WsRegs {
+  uint32_t start, end, cdf;   // lane i: segment i (lanes >= n: start=end=0xffffffff)
+  int n;
+};
+__device__ __forceinline__ WsRegs ws_load(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf, int n, int lane) {
+  WsRegs r;
+  r.n = n;
+  r.start = 0xffffffffu; r.end = 0xffffffffu; r.cdf = 0xffffffffu;
+  if (lane < n) { const uint2 v = w[lane]; r.start = v.x; r.end = v.y; r.cdf = cdf[lane]; }
+  return r;
+}
+// bases of [s,e) inside a register-resident workspace: sum over its segments (wave-uniform loop,
+// each segment broadcast with v_readlane); exact for normalized lists.
+__device__ __forceinline__ uint32_t ws_overlap_regs(const WsRegs& W, uint32_t s, uint32_t e) {
+  uint32_t ov = 0;
+  for (int j = 0; j < W.n; ++j) {
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_readlane((int)W.start, j);
+    const uint32_t we = (uint32_t)__builtin_amdgcn_readlane((int)W.end, j);
+    const uint32_t lo = s > ws ? s : ws, hi = e < we ? e : we;
+    ov += hi > lo ? hi - lo : 0u;
+  }
+  return ov;
 }
 
 }  // namespace gat

@@ -28,7 +28,7 @@ struct UnitDev {
   int32_t slab_off;     // offset of the unit's output region inside a sample's slab
   int32_t slab_cap;     // capacity of that region == LDS buffer capacity used for the unit
   int32_t contig;
-  int32_t pad;
+  int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
 };
 
 enum : int32_t {
@@ -45,6 +45,7 @@ struct SamplerArgs {
   const uint32_t* ws_cdf;
   const uint32_t* hist_idx;
   const uint32_t* hist_cdf;
+  const uint32_t* rank_len;
   uint32_t seed;
   int64_t sample_begin;       // global id of sample 0 of this batch
   uint2* slab;                // [batch][slab_stride]
@@ -64,7 +65,6 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   const int u = A.order[blockIdx.y];
   const UnitDev* __restrict__ Up = A.units + u;
   const int nws = Up->n_ws;
-  const int nhist = Up->n_hist;
   const uint32_t hist_total = Up->hist_total;
   const uint32_t bucket = Up->bucket;
   const uint32_t ws_total = Up->ws_total;
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   const int cap = Up->slab_cap;
   const uint2* __restrict__ ws = A.ws + Up->ws_off;
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
-  const uint32_t* __restrict__ hist_idx = A.hist_idx + Up->hist_off;
-  const uint32_t* __restrict__ hist_cdf = A.hist_cdf + Up->hist_off;
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  constexpr int kWsRegMax = 64, kWsLoopMax = 32;
+  const bool ws_in_regs = nws <= kWsRegMax;
+  const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
 
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
@@ -91,21 +93,22 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
     // ---- hs.sample() (:413-435)
     uint32_t r = 1;
     if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
-    const int hj = bisect_u32(hist_cdf, nhist, r);
-    uint32_t len_u = hist_idx[hj] * bucket;
+    uint32_t len_u = rank_len[r] * bucket;       // == cdf bisect (utils/gat_utils.c:36), tabulated per rank
     if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
     const int32_t length = (int32_t)len_u;
 
     // ---- consolidate (:582-606)
     if (remaining <= length) {
       const int n = nU + nS;
-      wave_sort_by_start(seg, n, lane);
+      if (nU == 0 || nS > kWave) wave_sort_by_start(seg, n, lane);     // SegmentList.sort of everything
+      else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
       nU = wave_merge0(seg, n, lane);
       nS = 0;
       uint32_t cov = 0;
-      for (int i = lane; i < nU; i += kWave) {
-        const uint2 v = seg[i];
-        cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y);
+      if (nws <= kWsLoopMax) {
+        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
+      } else {
+        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
       }
       cov = rfl(wave_sum_u32(cov));
       remaining = ltotal - (int32_t)cov;
@@ -163,13 +166,23 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
 
     // ---- sls.sample(length) (:279-343)
     const uint32_t p = rng_range(rng, ws_total - 1u, lane);
-    const int k = bisect_u32(ws_cdf, nws, p);
-    const uint2 chosen = ws[k];
-    int32_t sampling_start = (int32_t)chosen.x - length + 1;
-    if (k > 0) {
-      const int32_t prev_end = (int32_t)ws[k - 1].y;
-      sampling_start = prev_end > sampling_start ? prev_end : sampling_start;
+    int k;
+    uint2 chosen;
+    int32_t prev_end = 0;
+    if (ws_in_regs) {
+      // leftmost i with (int)(cdf[i]-p) >= 0 (utils/gat_utils.c:36 + cmpPosition), one compare per lane
+      const uint64_t b = __ballot(lane < nws && (int32_t)(W.cdf - p) >= 0);
+      k = (int)__builtin_ctzll(b);
+      chosen.x = (uint32_t)__builtin_amdgcn_readlane((int)W.start, k);
+      chosen.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k);
+      if (k > 0) prev_end = __builtin_amdgcn_readlane((int)W.end, k - 1);
+    } else {
+      k = bisect_u32(ws_cdf, nws, p);
+      chosen = ws[k];
+      if (k > 0) prev_end = (int32_t)ws[k - 1].y;
     }
+    int32_t sampling_start = (int32_t)chosen.x - length + 1;
+    if (k > 0) sampling_start = prev_end > sampling_start ? prev_end : sampling_start;
     const uint32_t range = chosen.y - 1u - (uint32_t)sampling_start;
     const int32_t q = sampling_start + (int32_t)rng_range(rng, range, lane);
     const uint32_t start = (uint32_t)(q > 0 ? q : 0);
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
       uint2 v = make_uint2(0u, 0u);
       if (i < nU) {
         v = seg[i];
-        keep = seg_overlap_with(ws, ws_cdf, nws, v.x, v.y) > 0;
+        keep = (nws <= kWsLoopMax ? ws_overlap_regs(W, v.x, v.y) : seg_overlap_with(ws, ws_cdf, nws, v.x, v.y)) > 0;
       }
       const uint64_t b = __ballot(keep);
       if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }

@@ -140,7 +140,7 @@ struct gat_problem {
   DevBuf<UnitDev> d_units;
   DevBuf<int32_t> d_order, d_contig_unit_off, d_contig_units, d_contig_slab_off, d_count_c_off, d_count_n_index;
   DevBuf<uint2> d_ws;
-  DevBuf<uint32_t> d_ws_cdf, d_hist_idx, d_hist_cdf;
+  DevBuf<uint32_t> d_ws_cdf, d_hist_idx, d_hist_cdf, d_rank_len;
   DevBuf<int64_t> d_cws_nseg;
   AnnoDev annos;
   // per-batch scratch
@@ -300,7 +300,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   P->h_cws_nseg.assign(d->cws_nseg, d->cws_nseg + d->n_contigs);
 
   std::vector<uint2> h_ws;
-  std::vector<uint32_t> h_ws_cdf, h_hist_idx, h_hist_cdf;
+  std::vector<uint32_t> h_ws_cdf, h_hist_idx, h_hist_cdf, h_rank_len;
   std::vector<std::pair<int64_t, int32_t>> work;   // (working segments, unit)
   std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
 
@@ -352,10 +352,13 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     U.n_hist = (int32_t)hist.size();
     U.hist_off = (int32_t)h_hist_idx.size();
     uint32_t cum = 0;
+    U.rank_off = (int32_t)h_rank_len.size();
+    h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
     for (auto& kv : hist) {
       cum += kv.second;
       h_hist_idx.push_back(kv.first);
       h_hist_cdf.push_back(cum);
+      for (uint32_t q = 0; q < kv.second; ++q) h_rank_len.push_back(kv.first);   // ranks (cum-count, cum]
     }
     U.hist_total = cum;
     U.bucket = (uint32_t)bucket;
@@ -399,6 +402,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx->stream));
   HIPCHK(ctx, P->d_hist_idx.upload(h_hist_idx, ctx->stream));
   HIPCHK(ctx, P->d_hist_cdf.upload(h_hist_cdf, ctx->stream));
+  HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx->stream));
   HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
   int rc = upload_layout(ctx, P.get());
   if (rc) return rc;
@@ -513,7 +517,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
       A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units;
-      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.hist_idx = P->d_hist_idx.p; A.hist_cdf = P->d_hist_cdf.p;
+      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.hist_idx = P->d_hist_idx.p; A.hist_cdf = P->d_hist_cdf.p; A.rank_len = P->d_rank_len.p;
       A.seed = seed; A.sample_begin = begin;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p;
