@@ -65,6 +65,7 @@ class Stats(C.Structure):
         ("n_sampled_segments", C.c_int64),
         ("n_unsuccessful", C.c_int64),
         ("n_retried", C.c_int64),
+        ("n_full_units", C.c_int64),
     ]
 
     def asdict(self):

@@ -37,6 +37,12 @@ struct WaveRng {
   uint32_t rbuf;    // lane i holds tempered output (pos & ~63) + i
   int pos;          // next state word to hand out, 0..624 (wave-uniform)
   uint32_t ndraws;  // raw outputs consumed (wave-uniform)
+  // pre-generated source (k_rng rows): output j of this stream is pre[j*64]; exhausted is set (and
+  // zeros are returned, which every rejection loop accepts) when the rows run out, so that the
+  // caller can redo the unit from its seed with the in-LDS generator
+  const uint32_t* pre;
+  uint32_t pre_j, pre_rows;
+  bool use_pre, exhausted;
 };
 
 // init_genrand(seed): mt[0]=seed; mt[i] = 1812433253*(mt[i-1]^(mt[i-1]>>30)) + i.
@@ -65,6 +71,8 @@ __device__ __forceinline__ void rng_seed(WaveRng& r, uint32_t seed, int lane) {
   r.pos = kMtN;
   r.rbuf = 0;
   r.ndraws = 0;
+  r.use_pre = false;
+  r.exhausted = false;
   wave_sync();
 }
 
@@ -90,6 +98,13 @@ __device__ __forceinline__ void rng_twist(WaveRng& r, int lane) {
 }
 
 __device__ __forceinline__ uint32_t rng_next(WaveRng& r, int lane) {
+  if (r.use_pre) {
+    if (r.pre_j >= r.pre_rows) { r.exhausted = true; return 0u; }
+    const uint32_t x = rfl(r.pre[(size_t)r.pre_j * kWave]);
+    r.pre_j++;
+    r.ndraws++;
+    return x;
+  }
   if (r.pos == kMtN) {
     rng_twist(r, lane);
     r.pos = 0;

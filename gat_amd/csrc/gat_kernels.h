@@ -41,10 +41,9 @@ struct SamplerArgs {
   const UnitDev* units;
   const int32_t* order;       // active unit ids, largest first
   int32_t n_units;
+  int32_t batch;              // samples in this batch
   const uint2* ws;
   const uint32_t* ws_cdf;
-  const uint32_t* hist_idx;
-  const uint32_t* hist_cdf;
   const uint32_t* rank_len;
   uint32_t seed;
   int64_t sample_begin;       // global id of sample 0 of this batch
@@ -52,17 +51,222 @@ struct SamplerArgs {
   int64_t slab_stride;
   int32_t* unit_n;            // [batch][n_units]
   int32_t* flags;             // OR of kStatus*
-  unsigned long long* stat;   // [0]=placed [1]=draws [2]=unsuccessful rounds [3]=output segments
+  unsigned long long* stat;   // [0]=placed [1]=draws [2]=unsuccessful rounds [3]=output segments [4]=full-mode units
+  // lane-parallel front end (k_rng + k_place); all null/0 when the sampler runs stand-alone
+  const int64_t* rng_off;     // per active index: word offset of the unit's first tile in rng_out
+  const int32_t* rng_rows;    // per active index: rows (raw outputs per stream) generated
+  uint32_t* rng_out;          // tile (active a, sample block sb): rng_out[rng_off[a] + (sb*rows + j)*64 + lane]
+  int32_t* st_n;              // [batch][n_units] hand-off: segments placed before the first consolidation
+  int32_t* st_remaining;      //                   `remaining` at that point
+  int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
+  uint32_t* st_draws;         //                   raw outputs consumed so far
 };
 
+constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
 // ------------------------------------------------------------------------------------------
+// k_rng: one MT19937 stream per LANE (64 streams of one unit = one tile per wave).  The state of
+// lane l is mt[i*64 + l] (bank-conflict free); seeding and the twist are the serial reference
+// loops, run by all 64 lanes at once.  Tempered outputs go to HBM as rows of 64 (one coalesced
+// 256-B store per output index), which is the order k_place consumes them in.
+__global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* mt = lds + threadIdx.x;                 // lane column, stride 64
+  const int lane = threadIdx.x;
+  const int sb = blockIdx.x, a = blockIdx.y;
+  const int u = A.order[a];
+  const int rows = A.rng_rows[a];
+  const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
+  uint32_t x = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
+  for (int i = 0; i < kMtN; ++i) {                  // init_genrand
+    mt[i * kWave] = x;
+    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
+  }
+  uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
+  for (int blk = 0; blk < rows / kMtN; ++blk) {
+    uint32_t cur = mt[0];
+    uint32_t first_new = 0;
+#pragma unroll 4
+    for (int i = 0; i < kMtN - kMtM; ++i) {         // 0..226: partner i+397 (old)
+      const uint32_t nxt = mt[(i + 1) * kWave];
+      const uint32_t far = mt[(i + kMtM) * kWave];
+      const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
+      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+      mt[i * kWave] = v;
+      if (i == 0) first_new = v;
+      out[(int64_t)i * kWave] = mt_temper(v);
+      cur = nxt;
+    }
+#pragma unroll 4
+    for (int i = kMtN - kMtM; i < kMtN - 1; ++i) {  // 227..622: partner i-227 (new)
+      const uint32_t nxt = mt[(i + 1) * kWave];
+      const uint32_t far = mt[(i + kMtM - kMtN) * kWave];
+      const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
+      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+      mt[i * kWave] = v;
+      out[(int64_t)i * kWave] = mt_temper(v);
+      cur = nxt;
+    }
+    {                                               // 623: wraps to the new word 0
+      const uint32_t far = mt[(kMtM - 1) * kWave];
+      const uint32_t y = (cur & kMtUpper) | (first_new & kMtLower);
+      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+      mt[(kMtN - 1) * kWave] = v;
+      out[(int64_t)(kMtN - 1) * kWave] = mt_temper(v);
+    }
+    out += (int64_t)kMtN * kWave;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_place: the placement loop of SamplerAnnotator.sample (gat/Engine.pyx:572-635) up to the first
+// consolidation, ONE STREAM PER LANE.  Every lane consumes exactly one raw MT19937 output per
+// iteration (row j of its tile), so the loads are coalesced and data independent; what a lane
+// does with the output depends on its state: L (length rank draw, :419-422), B (bucket offset,
+// :432-433), P (workspace position, :299), O (offset inside the chosen segment, :326).  Rejected
+// outputs (masked value > range) leave the state unchanged -- exactly numpy's masked rejection.
+// A lane halts when `remaining <= length` (:582): the pending length, the number of outputs
+// consumed and `remaining` are handed to k_sampler, which consolidates and finishes the unit.
+constexpr int kPlaceWsLds = 512;      // workspace segments kept in LDS (12 B each)
+
+__global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
+  __shared__ uint32_t l_ws_start[kPlaceWsLds], l_ws_end[kPlaceWsLds], l_ws_cdf[kPlaceWsLds];
+  const int lane = threadIdx.x;
+  const int sb = blockIdx.x, a = blockIdx.y;
+  const int u = A.order[a];
+  const UnitDev* __restrict__ Up = A.units + u;
+  const int nws = Up->n_ws;
+  const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
+  const int cap = Up->slab_cap;
+  const uint2* __restrict__ ws = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  const int rows = A.rng_rows[a];
+  const int sidx = sb * kWave + lane;
+  const bool live = sidx < A.batch;
+  const bool ws_lds = nws <= kPlaceWsLds;
+  if (ws_lds) {
+    for (int i = lane; i < nws; i += kWave) { const uint2 v = ws[i]; l_ws_start[i] = v.x; l_ws_end[i] = v.y; l_ws_cdf[i] = ws_cdf[i]; }
+  }
+  __syncthreads();
+  const uint32_t* __restrict__ rng = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
+  uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
+
+  // wave-uniform draw parameters
+  const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; 0 consumes nothing
+  const uint32_t rangeL = drawL ? hist_total - 2u : 0u, maskL = drawL ? 0xffffffffu >> __builtin_clz(rangeL) : 0u;
+  const bool drawB = bucket > 1;
+  const uint32_t rangeB = bucket - 1u, maskB = drawB ? 0xffffffffu >> __builtin_clz(rangeB) : 0u;
+  const bool drawP = ws_total > 1;
+  const uint32_t rangeP = ws_total - 1u, maskP = drawP ? 0xffffffffu >> __builtin_clz(rangeP) : 0u;
+  const uint2 ws0 = ws[0];
+
+  enum { S_L = 0, S_B = 1, S_P = 2, S_O = 3, S_HALT = 4 };
+  enum { T_NONE = 0, T_RANK = 1, T_LEN = 2, T_POS = 3, T_PLACE = 4 };
+  int st = live ? S_L : S_HALT;
+  int32_t rem = Up->ltotal;
+  int nS = 0;
+  uint32_t len = 0, r = 1, p = 0, range3 = 0, mask3 = 0, cs = 0, ce = 0;
+  int32_t sstart = 0, q = 0;
+  int32_t pend = -1;           // pending length at the trigger; -1 = not (yet) triggered
+  uint32_t used = 0;           // raw outputs consumed by this lane
+  int flag = 0;
+
+  // transitions that need no further draw; returns with st set
+  auto resolve = [&](int t) {
+    for (;;) {
+      if (t == T_RANK) {
+        len = rank_len[r] * bucket;
+        if (drawB) { st = S_B; return; }
+        t = T_LEN;
+      }
+      if (t == T_LEN) {
+        if (rem <= (int32_t)len) { pend = (int32_t)len; st = S_HALT; return; }      // :582 trigger
+        if (drawP) { st = S_P; return; }
+        p = 0; t = T_POS;
+      }
+      if (t == T_POS) {
+        // searchsorted(cdf, p) (utils/gat_utils.c:36, cmpPosition): leftmost k with (int)(cdf[k]-p) >= 0
+        int k = 0;
+        int32_t prev_end = 0;
+        if (nws == 1) { cs = ws0.x; ce = ws0.y; }
+        else {
+          int lo = 0, hi = nws;
+          if (ws_lds) {
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws_cdf[mid] - p) < 0) lo = mid + 1; else hi = mid; }
+            k = lo; cs = l_ws_start[k]; ce = l_ws_end[k];
+            if (k > 0) prev_end = (int32_t)l_ws_end[k - 1];
+          } else {
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(ws_cdf[mid] - p) < 0) lo = mid + 1; else hi = mid; }
+            k = lo; const uint2 c = ws[k]; cs = c.x; ce = c.y;
+            if (k > 0) prev_end = (int32_t)ws[k - 1].y;
+          }
+        }
+        sstart = (int32_t)cs - (int32_t)len + 1;
+        if (k > 0) sstart = prev_end > sstart ? prev_end : sstart;
+        range3 = ce - 1u - (uint32_t)sstart;
+        if (range3 != 0) { mask3 = 0xffffffffu >> __builtin_clz(range3); st = S_O; return; }
+        q = sstart; t = T_PLACE;
+      }
+      if (t == T_PLACE) {
+        const uint32_t start = (uint32_t)(q > 0 ? q : 0);
+        const uint32_t end = (uint32_t)(q + (int32_t)len);
+        const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;
+        const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;
+        const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+        if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; return; }
+        out[nS] = make_uint2(start, end);
+        nS++;
+        rem -= overlap;
+        if (drawL) { st = S_L; return; }
+        r = 1; t = T_RANK;
+      }
+    }
+  };
+
+  if (live && !drawL) { r = 1; resolve(T_RANK); }     // first length needs no draw
+  for (int j = 0; j < rows; ++j) {
+    if (__ballot(st != S_HALT) == 0) break;
+    const uint32_t y = rng[(int64_t)j * kWave];
+    if (st == S_HALT) continue;
+    used++;
+    int t = T_NONE;
+    if (st == S_L) { const uint32_t v = y & maskL; if (v <= rangeL) { r = 1u + v; t = T_RANK; } }
+    else if (st == S_B) { const uint32_t v = y & maskB; if (v <= rangeB) { len += v; t = T_LEN; } }
+    else if (st == S_P) { const uint32_t v = y & maskP; if (v <= rangeP) { p = v; t = T_POS; } }
+    else { const uint32_t v = y & mask3; if (v <= range3) { q = sstart + (int32_t)v; t = T_PLACE; } }
+    if (t != T_NONE) resolve(t);
+  }
+  if (live) {
+    const int64_t o = (int64_t)sidx * A.n_units + u;
+    A.st_n[o] = nS;
+    A.st_remaining[o] = rem;
+    A.st_length[o] = (st == S_HALT && pend >= 0 && flag == 0) ? pend : -1;   // rows ran out / overflow: full mode
+    A.st_draws[o] = used;
+    if (flag) atomicOr(A.flags, flag);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sampler: one wave per (sample, unit).  Stand-alone it runs the whole of
+// SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
+// placed segments, `remaining`, the pending length and the position in the stream handed over.
 __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
   uint2* seg = reinterpret_cast<uint2*>(lds + kMtLdsWords);
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
-  const int u = A.order[blockIdx.y];
+  const int a = blockIdx.y;
+  const int u = A.order[a];
   const UnitDev* __restrict__ Up = A.units + u;
   const int nws = Up->n_ws;
   const uint32_t hist_total = Up->hist_total;
@@ -76,156 +280,188 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   constexpr int kWsRegMax = 64, kWsLoopMax = 32;
   const bool ws_in_regs = nws <= kWsRegMax;
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
+  uint2* __restrict__ out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const int64_t so = (int64_t)sidx * A.n_units + u;
 
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
   const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
-  WaveRng rng;
-  rng.mt = mt;
-  rng_seed(rng, seed, lane);
+  const bool have_pre = A.st_length != nullptr;
+  const int32_t pre_len = have_pre ? A.st_length[so] : -1;
 
-  int nU = 0, nS = 0;   // seg[0..nU): unintersected (merged, sorted); seg[nU..nU+nS): sampled since
-  int32_t remaining = ltotal, true_remaining = ltotal;
-  int nuns = 0, status = 0;
-  uint32_t placed = 0;
-
-  while (true_remaining > 0 && nuns < 20) {                       // gat/Engine.pyx:572
-    // ---- hs.sample() (:413-435)
-    uint32_t r = 1;
-    if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
-    uint32_t len_u = rank_len[r] * bucket;       // == cdf bisect (utils/gat_utils.c:36), tabulated per rank
-    if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
-    const int32_t length = (int32_t)len_u;
-
-    // ---- consolidate (:582-606)
-    if (remaining <= length) {
-      const int n = nU + nS;
-      if (nU == 0 || nS > kWave) wave_sort_by_start(seg, n, lane);     // SegmentList.sort of everything
-      else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
-      nU = wave_merge0(seg, n, lane);
-      nS = 0;
-      uint32_t cov = 0;
-      if (nws <= kWsLoopMax) {
-        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
-      } else {
-        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
-      }
-      cov = rfl(wave_sum_u32(cov));
-      remaining = ltotal - (int32_t)cov;
-      if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+  int nout = 0, status = 0, nuns = 0;
+  uint32_t placed = 0, ndraws = 0, full_units = 0;
+  for (int attempt = (pre_len >= 0 ? 0 : 1); attempt < 2; ++attempt) {
+    const bool resume = attempt == 0;
+    WaveRng rng;
+    rng.mt = mt;
+    int nU = 0, nS = 0;   // seg[0..nU): unintersected (merged, sorted); seg[nU..nU+nS): sampled since
+    int32_t remaining = ltotal, true_remaining = ltotal;
+    int32_t pending = -1;
+    nuns = 0; status = 0; placed = 0;
+    if (resume) {
+      nS = A.st_n[so];
+      for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
+      remaining = A.st_remaining[so];
+      pending = pre_len;
+      rng.use_pre = true; rng.exhausted = false; rng.ndraws = A.st_draws[so]; rng.pos = 0; rng.rbuf = 0;
+      rng.pre_rows = (uint32_t)A.rng_rows[a];
+      rng.pre_j = rng.ndraws;
+      rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
+      placed = (uint32_t)nS;
+      wave_sync();
+    } else {
+      rng_seed(rng, seed, lane);
+      rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0;
+      full_units = 1;
     }
 
-    // ---- overshoot: trim (:608-626)
-    if (true_remaining < 0) {
-      // SegmentListSampler(unintersected).sample(1): position draw over the cumulated lengths
+    while (true_remaining > 0 && nuns < 20) {                       // gat/Engine.pyx:572
+      // ---- hs.sample() (:413-435)
+      int32_t length;
+      if (pending >= 0) { length = pending; pending = -1; }
+      else {
+        uint32_t r = 1;
+        if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
+        uint32_t len_u = rank_len[r] * bucket;     // == cdf bisect (utils/gat_utils.c:36), tabulated per rank
+        if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
+        length = (int32_t)len_u;
+      }
+
+      // ---- consolidate (:582-606)
+      if (remaining <= length) {
+        const int n = nU + nS;
+        if (nU == 0 || nS > kWave) wave_sort_by_start(seg, n, lane);     // SegmentList.sort of everything
+        else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
+        nU = wave_merge0(seg, n, lane);
+        nS = 0;
+        uint32_t cov = 0;
+        if (nws <= kWsLoopMax) {
+          for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
+        } else {
+          for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
+        }
+        cov = rfl(wave_sum_u32(cov));
+        remaining = ltotal - (int32_t)cov;
+        if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+      }
+
+      // ---- overshoot: trim (:608-626)
+      if (true_remaining < 0) {
+        // SegmentListSampler(unintersected).sample(1): position draw over the cumulated lengths
+        uint32_t total = 0;
+        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; total += v.y - v.x; }
+        total = rfl(wave_sum_u32(total));
+        const uint32_t p = rng_range(rng, total - 1u, lane);
+        int k = 0;
+        uint32_t run = 0;
+        for (int base = 0; base < nU; base += kWave) {
+          const int i = base + lane;
+          uint32_t len = 0;
+          if (i < nU) { const uint2 v = seg[i]; len = v.y - v.x; }
+          const uint32_t incl = run + wave_incl_sum_u32(len, lane);
+          // cdf[i] = incl-1; leftmost i with (int)(cdf[i]-p) >= 0
+          const bool ge = (i < nU) && ((int32_t)(incl - 1u - p) >= 0);
+          const uint64_t b = __ballot(ge);
+          if (b != 0) { k = base + (int)__builtin_ctzll(b); break; }
+          run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        }
+        // unintersected is merged(0): previous.end < chosen.start, so sampling_start == chosen.start
+        const uint2 chosen = seg[k];
+        const uint32_t cs = rfl(chosen.x), ce = rfl(chosen.y);
+        (void)rng_range(rng, ce - 1u - cs, lane);                       // position inside the segment: only its index k matters
+        const uint32_t forward = rng_range(rng, 1u, lane);            // numpy.random.randint(0, 2)
+        int32_t s = -true_remaining;
+        if (rng.exhausted) break;
+        if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { status |= kStatusTrimAssert; break; }
+        // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597); _getInsertionPoint(pos,pos+1) == k
+        wave_sync();
+        if (lane == 0) {
+          int idx = k;
+          while (s > 0) {
+            const uint2 v = seg[idx];
+            const int32_t l = (int32_t)v.y - (int32_t)v.x;
+            if (l < s) { seg[idx] = make_uint2(0u, 0u); s -= l; }
+            else {
+              seg[idx] = forward ? make_uint2(v.x + (uint32_t)s, v.y) : make_uint2(v.x, (uint32_t)((int32_t)v.y - s));
+              s = 0;
+            }
+            if (forward) { idx++; if (idx == nU) idx = 0; }
+            else { idx--; if (idx < 0) idx = nU - 1; }
+          }
+        }
+        wave_sync();
+        true_remaining = 1;
+        continue;
+      }
+
+      // ---- sls.sample(length) (:279-343)
+      const uint32_t p = rng_range(rng, ws_total - 1u, lane);
+      int k;
+      uint2 chosen;
+      int32_t prev_end = 0;
+      if (ws_in_regs) {
+        // leftmost i with (int)(cdf[i]-p) >= 0 (utils/gat_utils.c:36 + cmpPosition), one compare per lane
+        const uint64_t b = __ballot(lane < nws && (int32_t)(W.cdf - p) >= 0);
+        k = (int)__builtin_ctzll(b);
+        chosen.x = (uint32_t)__builtin_amdgcn_readlane((int)W.start, k);
+        chosen.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k);
+        if (k > 0) prev_end = __builtin_amdgcn_readlane((int)W.end, k - 1);
+      } else {
+        k = bisect_u32(ws_cdf, nws, p);
+        chosen = ws[k];
+        if (k > 0) prev_end = (int32_t)ws[k - 1].y;
+      }
+      int32_t sampling_start = (int32_t)chosen.x - length + 1;
+      if (k > 0) sampling_start = prev_end > sampling_start ? prev_end : sampling_start;
+      const uint32_t range = chosen.y - 1u - (uint32_t)sampling_start;
+      const int32_t q = sampling_start + (int32_t)rng_range(rng, range, lane);
+      if (rng.exhausted) break;
+      const uint32_t start = (uint32_t)(q > 0 ? q : 0);
+      const uint32_t end = (uint32_t)(q + length);
+      const int32_t omin = (int32_t)chosen.y < (int32_t)end ? (int32_t)chosen.y : (int32_t)end;
+      const int32_t omax = (int32_t)chosen.x > (int32_t)start ? (int32_t)chosen.x : (int32_t)start;
+      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+      if (true_remaining > 0) {
+        if (nU + nS >= cap) { status |= kStatusOverflow; break; }
+        if (lane == 0) seg[nU + nS] = make_uint2(start, end);
+        nS++;
+        placed++;
+        remaining -= overlap;
+      }
+    }
+    ndraws = rng.ndraws;
+    if (rng.use_pre && rng.exhausted) continue;       // rows ran out: redo this unit from its seed
+
+    // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
+    nout = 0;
+    if (status == 0) {
+      nU = wave_merge0(seg, nU, lane);
       uint32_t total = 0;
-      for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; total += v.y - v.x; }
-      total = rfl(wave_sum_u32(total));
-      const uint32_t p = rng_range(rng, total - 1u, lane);
-      int k = -1;
-      uint32_t run = 0;
       for (int base = 0; base < nU; base += kWave) {
         const int i = base + lane;
-        uint32_t len = 0;
-        if (i < nU) { const uint2 v = seg[i]; len = v.y - v.x; }
-        const uint32_t incl = run + wave_incl_sum_u32(len, lane);
-        // cdf[i] = incl-1; leftmost i with (int)(cdf[i]-p) >= 0
-        const bool ge = (i < nU) && ((int32_t)(incl - 1u - p) >= 0);
-        const uint64_t b = __ballot(ge);
-        if (b != 0) { k = base + (int)__builtin_ctzll(b); break; }
-        run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-      }
-      // unintersected is merged(0): previous.end < chosen.start, so sampling_start == chosen.start
-      const uint2 chosen = seg[k];
-      const uint32_t cs = rfl(chosen.x), ce = rfl(chosen.y);
-      const uint32_t pos = cs + rng_range(rng, ce - 1u - cs, lane);
-      const uint32_t forward = rng_range(rng, 1u, lane);            // numpy.random.randint(0, 2)
-      int32_t s = -true_remaining;
-      if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { status |= kStatusTrimAssert; break; }
-      // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597); _getInsertionPoint(pos,pos+1) == k
-      (void)pos;
-      wave_sync();
-      if (lane == 0) {
-        int idx = k;
-        while (s > 0) {
-          const uint2 v = seg[idx];
-          const int32_t l = (int32_t)v.y - (int32_t)v.x;
-          if (l < s) { seg[idx] = make_uint2(0u, 0u); s -= l; }
-          else {
-            seg[idx] = forward ? make_uint2(v.x + (uint32_t)s, v.y) : make_uint2(v.x, (uint32_t)((int32_t)v.y - s));
-            s = 0;
-          }
-          if (forward) { idx++; if (idx == nU) idx = 0; }
-          else { idx--; if (idx < 0) idx = nU - 1; }
+        bool keep = false;
+        uint2 v = make_uint2(0u, 0u);
+        if (i < nU) {
+          v = seg[i];
+          keep = (nws <= kWsLoopMax ? ws_overlap_regs(W, v.x, v.y) : seg_overlap_with(ws, ws_cdf, nws, v.x, v.y)) > 0;
         }
+        const uint64_t b = __ballot(keep);
+        if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
+        nout += __popcll(b);
       }
-      wave_sync();
-      true_remaining = 1;
-      continue;
+      total = rfl(wave_sum_u32(total));
+      if (!(total > 0)) status |= kStatusAssert;
     }
-
-    // ---- sls.sample(length) (:279-343)
-    const uint32_t p = rng_range(rng, ws_total - 1u, lane);
-    int k;
-    uint2 chosen;
-    int32_t prev_end = 0;
-    if (ws_in_regs) {
-      // leftmost i with (int)(cdf[i]-p) >= 0 (utils/gat_utils.c:36 + cmpPosition), one compare per lane
-      const uint64_t b = __ballot(lane < nws && (int32_t)(W.cdf - p) >= 0);
-      k = (int)__builtin_ctzll(b);
-      chosen.x = (uint32_t)__builtin_amdgcn_readlane((int)W.start, k);
-      chosen.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k);
-      if (k > 0) prev_end = __builtin_amdgcn_readlane((int)W.end, k - 1);
-    } else {
-      k = bisect_u32(ws_cdf, nws, p);
-      chosen = ws[k];
-      if (k > 0) prev_end = (int32_t)ws[k - 1].y;
-    }
-    int32_t sampling_start = (int32_t)chosen.x - length + 1;
-    if (k > 0) sampling_start = prev_end > sampling_start ? prev_end : sampling_start;
-    const uint32_t range = chosen.y - 1u - (uint32_t)sampling_start;
-    const int32_t q = sampling_start + (int32_t)rng_range(rng, range, lane);
-    const uint32_t start = (uint32_t)(q > 0 ? q : 0);
-    const uint32_t end = (uint32_t)(q + length);
-    const int32_t omin = (int32_t)chosen.y < (int32_t)end ? (int32_t)chosen.y : (int32_t)end;
-    const int32_t omax = (int32_t)chosen.x > (int32_t)start ? (int32_t)chosen.x : (int32_t)start;
-    const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
-    if (true_remaining > 0) {
-      if (nU + nS >= cap) { status |= kStatusOverflow; break; }
-      if (lane == 0) seg[nU + nS] = make_uint2(start, end);
-      nS++;
-      placed++;
-      remaining -= overlap;
-    }
-  }
-
-  // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
-  int nout = 0;
-  if (status == 0) {
-    nU = wave_merge0(seg, nU, lane);
-    uint2* __restrict__ out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
-    uint32_t total = 0;
-    for (int base = 0; base < nU; base += kWave) {
-      const int i = base + lane;
-      bool keep = false;
-      uint2 v = make_uint2(0u, 0u);
-      if (i < nU) {
-        v = seg[i];
-        keep = (nws <= kWsLoopMax ? ws_overlap_regs(W, v.x, v.y) : seg_overlap_with(ws, ws_cdf, nws, v.x, v.y)) > 0;
-      }
-      const uint64_t b = __ballot(keep);
-      if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
-      nout += __popcll(b);
-    }
-    total = rfl(wave_sum_u32(total));
-    if (!(total > 0)) status |= kStatusAssert;
+    break;
   }
   if (lane == 0) {
-    A.unit_n[(int64_t)sidx * A.n_units + u] = nout;
+    A.unit_n[so] = nout;
     if (status) atomicOr(A.flags, status);
     atomicAdd(&A.stat[0], (unsigned long long)placed);
-    atomicAdd(&A.stat[1], (unsigned long long)rng.ndraws);
+    atomicAdd(&A.stat[1], (unsigned long long)ndraws);
     atomicAdd(&A.stat[2], (unsigned long long)nuns);
+    if (full_units) atomicAdd(&A.stat[4], (unsigned long long)full_units);
   }
 }
 

@@ -148,6 +148,14 @@ struct gat_problem {
   DevBuf<uint2> d_slab, d_cslab;
   DevBuf<int32_t> d_unit_n, d_contig_n, d_flags;
   DevBuf<unsigned long long> d_stat;
+  // lane-parallel front end (k_rng + k_place)
+  std::vector<int32_t> h_rng_rows;       // per active index: raw outputs generated per stream
+  std::vector<int64_t> h_rng_off;
+  int64_t rng_rows_total = 0;            // sum of h_rng_rows
+  DevBuf<int32_t> d_rng_rows, d_st_n, d_st_remaining, d_st_length;
+  DevBuf<int64_t> d_rng_off;
+  DevBuf<uint32_t> d_rng_out, d_st_draws;
+  int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
 };
 
 // ------------------------------------------------------------------------------------------
@@ -390,12 +398,37 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     return a.first != b.first ? a.first > b.first : a.second < b.second;
   });
   for (auto& w : work) P->h_order.push_back(w.second);
+  // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
+  // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
+  // are redone by k_sampler from their seed.
+  {
+    const char* env = getenv("GAT_SAMPLER_MODE");
+    if (env && !strcmp(env, "wave")) P->sampler_mode = 0;
+    auto expect = [](uint64_t range) {
+      if (range == 0) return 0.0;
+      uint64_t m = range; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; m |= m >> 32;
+      return (double)(m + 1) / (double)(range + 1);
+    };
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[u];
+      double e = 1.6;                                                      // offset draw: range varies per placement
+      if (U.hist_total > 2) e += expect((uint64_t)U.hist_total - 2);
+      if (U.bucket > 1) e += expect((uint64_t)U.bucket - 1);
+      if (U.ws_total > 1) e += expect((uint64_t)U.ws_total - 1);
+      const double need = e * (double)U.hist_total * 1.12 + 160.0;
+      int64_t rows = ((int64_t)std::ceil(need / gat::kMtN)) * gat::kMtN;
+      rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
+      P->h_rng_rows.push_back((int32_t)rows);
+      P->rng_rows_total += rows;
+    }
+  }
   P->h_contig_slab_off.assign((size_t)d->n_contigs, 0);
   P->h_count_c_off.assign((size_t)d->n_contigs, 0);
   P->h_count_n_index.assign((size_t)d->n_contigs, 0);
   if (layout_slab(P.get())) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
 
   HIPCHK(ctx, P->d_order.upload(P->h_order, ctx->stream));
+  HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx->stream));
   HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx->stream));
   HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
   HIPCHK(ctx, P->d_ws.upload(h_ws, ctx->stream));
@@ -437,7 +470,8 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->batch >= want) return GAT_OK;
   const char* env = getenv("GAT_SLAB_BYTES");
   const double budget = env ? atof(env) : 12.0 * 1024 * 1024 * 1024;
-  const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs);
+  const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
+                             (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0);
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
@@ -445,6 +479,18 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->merge_contigs) HIPCHK(ctx, P->d_cslab.alloc((size_t)(b * P->slab_stride)));
   HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
   HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
+  if (P->sampler_mode) {
+    const int64_t nsb = (b + 63) / 64;
+    P->h_rng_off.assign(P->h_order.size() + 1, 0);
+    for (size_t a = 0; a < P->h_order.size(); ++a) P->h_rng_off[a + 1] = P->h_rng_off[a] + nsb * (int64_t)P->h_rng_rows[a] * 64;
+    HIPCHK(ctx, P->d_rng_off.upload(P->h_rng_off, ctx->stream));
+    HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
+    const size_t ns = (size_t)(b * std::max(1, P->n_units));
+    HIPCHK(ctx, P->d_st_n.alloc(ns));
+    HIPCHK(ctx, P->d_st_remaining.alloc(ns));
+    HIPCHK(ctx, P->d_st_length.alloc(ns));
+    HIPCHK(ctx, P->d_st_draws.alloc(ns));
+  }
   P->batch = b;
   return GAT_OK;
 }
@@ -516,16 +562,31 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
-      A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units;
-      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.hist_idx = P->d_hist_idx.p; A.hist_cdf = P->d_hist_cdf.p; A.rank_len = P->d_rank_len.p;
+      memset(&A, 0, sizeof(A));
+      A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
+      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p;
       A.seed = seed; A.sample_begin = begin;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p;
+      if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
+      if (P->sampler_mode) {
+        // lane-parallel front end: the scratch was sized for P->batch samples, tiles are laid out for that
+        const int64_t nsb_alloc = (P->batch + 63) / 64;
+        const unsigned nsb = (unsigned)((nb + 63) / 64);
+        (void)nsb_alloc;
+        A.rng_off = P->d_rng_off.p; A.rng_rows = P->d_rng_rows.p; A.rng_out = P->d_rng_out.p;
+        A.st_n = P->d_st_n.p; A.st_remaining = P->d_st_remaining.p; A.st_length = P->d_st_length.p; A.st_draws = P->d_st_draws.p;
+        const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
+        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), lds_rng, ctx->stream, A);
+        HIPCHK(ctx, hipGetLastError());
+        hipLaunchKernelGGL(gat::k_place, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
+        HIPCHK(ctx, hipGetLastError());
+      }
       const size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
       if ((int64_t)lds > ctx->max_lds)
         return set_err(ctx, GAT_ERR_CAPACITY, "unit needs %zu bytes of LDS (> %d): too many segments in one isochore unit", lds, ctx->max_lds);
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_sampler, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
       hipLaunchKernelGGL(gat::k_sampler, dim3((unsigned)nb, (unsigned)P->h_order.size()), dim3(64), lds, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
     }
@@ -566,6 +627,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       st->n_draws += (int64_t)stat[1];
       st->n_unsuccessful += (int64_t)stat[2];
       if (P->merge_contigs) st->n_sampled_segments += (int64_t)stat[3];
+      st->n_full_units += (int64_t)stat[4];
       if (timed) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -83,6 +83,7 @@ typedef struct {
   int64_t n_sampled_segments;   /* contig-level segments handed to the counters                 */
   int64_t n_unsuccessful;       /* sum of nunsuccessful_rounds (gat/Engine.pyx:570-572)         */
   int64_t n_retried;            /* work units redone with a larger slab                         */
+  int64_t n_full_units;         /* work units run without the lane-parallel front end           */
 } gat_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
