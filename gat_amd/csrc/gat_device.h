@@ -42,6 +42,7 @@ struct WaveRng {
   // caller can redo the unit from its seed with the in-LDS generator
   const uint32_t* pre;
   uint32_t pre_j, pre_rows;
+  uint32_t pre_base;   // rbuf holds outputs [pre_base, pre_base+64) of the stream (one vector load per 64 draws)
   bool use_pre, exhausted;
 };
 
@@ -100,7 +101,12 @@ __device__ __forceinline__ void rng_twist(WaveRng& r, int lane) {
 __device__ __forceinline__ uint32_t rng_next(WaveRng& r, int lane) {
   if (r.use_pre) {
     if (r.pre_j >= r.pre_rows) { r.exhausted = true; return 0u; }
-    const uint32_t x = rfl(r.pre[(size_t)r.pre_j * kWave]);
+    if (r.pre_j - r.pre_base >= (uint32_t)kWave) {
+      r.pre_base = r.pre_j;
+      const uint32_t row = r.pre_base + (uint32_t)lane;
+      r.rbuf = row < r.pre_rows ? r.pre[(size_t)row * kWave] : 0u;
+    }
+    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)r.rbuf, (int)(r.pre_j - r.pre_base));
     r.pre_j++;
     r.ndraws++;
     return x;

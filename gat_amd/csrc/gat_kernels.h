@@ -52,6 +52,8 @@ struct SamplerArgs {
   int32_t* unit_n;            // [batch][n_units]
   int32_t* flags;             // OR of kStatus*
   unsigned long long* stat;   // [0]=placed [1]=draws [2]=unsuccessful rounds [3]=output segments [4]=full-mode units
+  uint32_t* ws_stat;          // [batch][n_units][4]: the same per work unit (summed by k_reduce_stats; one
+                              // atomic per work unit on a single line costs more than the sampling itself)
   // lane-parallel front end (k_rng + k_place); all null/0 when the sampler runs stand-alone
   const int64_t* rng_off;     // per active index: word offset of the unit's first tile in rng_out
   const int32_t* rng_rows;    // per active index: rows (raw outputs per stream) generated
@@ -60,6 +62,7 @@ struct SamplerArgs {
   int32_t* st_remaining;      //                   `remaining` at that point
   int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
   uint32_t* st_draws;         //                   raw outputs consumed so far
+  int32_t debug;              // timing experiments only (GAT_DEBUG_SKIP): results are wrong when non-zero
 };
 
 constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   const int32_t pre_len = have_pre ? A.st_length[so] : -1;
 
   int nout = 0, status = 0, nuns = 0;
+  if (A.debug & 8) return;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
   for (int attempt = (pre_len >= 0 ? 0 : 1); attempt < 2; ++attempt) {
     const bool resume = attempt == 0;
@@ -298,6 +302,7 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
     int nU = 0, nS = 0;   // seg[0..nU): unintersected (merged, sorted); seg[nU..nU+nS): sampled since
     int32_t remaining = ltotal, true_remaining = ltotal;
     int32_t pending = -1;
+    bool dirty = false;          // unintersected holds trim placeholders not yet merged away
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = A.st_n[so];
@@ -307,18 +312,21 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
       rng.use_pre = true; rng.exhausted = false; rng.ndraws = A.st_draws[so]; rng.pos = 0; rng.rbuf = 0;
       rng.pre_rows = (uint32_t)A.rng_rows[a];
       rng.pre_j = rng.ndraws;
+      rng.pre_base = rng.pre_j - (uint32_t)kWave;     // forces the first prefetch
       rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
       placed = (uint32_t)nS;
       wave_sync();
     } else {
       rng_seed(rng, seed, lane);
-      rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0;
+      rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
       full_units = 1;
     }
 
+    if (A.debug & 16) return;
     while (true_remaining > 0 && nuns < 20) {                       // gat/Engine.pyx:572
       // ---- hs.sample() (:413-435)
       int32_t length;
+      if (A.debug & 32) return;
       if (pending >= 0) { length = pending; pending = -1; }
       else {
         uint32_t r = 1;
@@ -331,10 +339,13 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
       // ---- consolidate (:582-606)
       if (remaining <= length) {
         const int n = nU + nS;
+        if (A.debug & 1) {} else
         if (nU == 0 || nS > kWave) wave_sort_by_start(seg, n, lane);     // SegmentList.sort of everything
         else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
+        if (A.debug & 64) return;
         nU = wave_merge0(seg, n, lane);
         nS = 0;
+        if (A.debug & 128) return;
         uint32_t cov = 0;
         if (nws <= kWsLoopMax) {
           for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
@@ -344,6 +355,11 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
         cov = rfl(wave_sum_u32(cov));
         remaining = ltotal - (int32_t)cov;
         if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+        dirty = false;
+        if (A.debug & 2) break;
+        // the reference still draws a position here (:628) before its loop test fails; the draws and
+        // the segment are discarded and the unit's stream ends, so nothing observable depends on them
+        if (!(true_remaining != 0 && nuns < 20)) break;
       }
 
       // ---- overshoot: trim (:608-626)
@@ -391,6 +407,7 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
           }
         }
         wave_sync();
+        dirty = true;
         true_remaining = 1;
         continue;
       }
@@ -435,8 +452,8 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
 
     // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
     nout = 0;
-    if (status == 0) {
-      nU = wave_merge0(seg, nU, lane);
+    if (status == 0 && !(A.debug & 4)) {
+      if (dirty) nU = wave_merge0(seg, nU, lane);     // otherwise already merged by the last consolidation
       uint32_t total = 0;
       for (int base = 0; base < nU; base += kWave) {
         const int i = base + lane;
@@ -458,10 +475,29 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
   if (lane == 0) {
     A.unit_n[so] = nout;
     if (status) atomicOr(A.flags, status);
-    atomicAdd(&A.stat[0], (unsigned long long)placed);
-    atomicAdd(&A.stat[1], (unsigned long long)ndraws);
-    atomicAdd(&A.stat[2], (unsigned long long)nuns);
-    if (full_units) atomicAdd(&A.stat[4], (unsigned long long)full_units);
+    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(placed, ndraws, (uint32_t)nuns, full_units);
+  }
+}
+
+// sums the per-work-unit statistics: one atomic per block instead of one per work unit
+__global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict__ ws_stat, int64_t n,
+                                                      unsigned long long* __restrict__ stat) {
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a4 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4*>(ws_stat + i * 4);
+    a0 += v.x; a1 += v.y; a2 += v.z; a4 += v.w;
+  }
+  __shared__ unsigned long long red[4][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); a4 += __shfl_xor(a4, d);
+  }
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a4; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    atomicAdd(&stat[threadIdx.x == 3 ? 4 : threadIdx.x], t);
   }
 }
 
@@ -502,7 +538,6 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   for (int i = lane; i < n; i += kWave) out[i] = seg[i];
   if (lane == 0) {
     A.contig_n[(int64_t)sidx * A.n_contigs + c] = n;
-    atomicAdd(&A.stat[3], (unsigned long long)n);
   }
 }
 

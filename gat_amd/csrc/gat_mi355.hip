@@ -154,7 +154,7 @@ struct gat_problem {
   int64_t rng_rows_total = 0;            // sum of h_rng_rows
   DevBuf<int32_t> d_rng_rows, d_st_n, d_st_remaining, d_st_length;
   DevBuf<int64_t> d_rng_off;
-  DevBuf<uint32_t> d_rng_out, d_st_draws;
+  DevBuf<uint32_t> d_rng_out, d_st_draws, d_ws_stat;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
 };
 
@@ -479,6 +479,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->merge_contigs) HIPCHK(ctx, P->d_cslab.alloc((size_t)(b * P->slab_stride)));
   HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
   HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
+  HIPCHK(ctx, P->d_ws_stat.alloc((size_t)(b * std::max(1, P->n_units)) * 4));
   if (P->sampler_mode) {
     const int64_t nsb = (b + 63) / 64;
     P->h_rng_off.assign(P->h_order.size() + 1, 0);
@@ -559,6 +560,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(nb * std::max(1, P->n_contigs)) * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(P->d_flags.p, 0, 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 8 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_ws_stat.p, 0, (size_t)(nb * std::max(1, P->n_units)) * 16, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
@@ -567,7 +569,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p;
       A.seed = seed; A.sample_begin = begin;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
-      A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p;
+      A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
+      { const char* dbg = getenv("GAT_DEBUG_SKIP"); A.debug = dbg ? atoi(dbg) : 0; }
       if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
       if (P->sampler_mode) {
         // lane-parallel front end: the scratch was sized for P->batch samples, tiles are laid out for that
@@ -588,6 +591,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         return set_err(ctx, GAT_ERR_CAPACITY, "unit needs %zu bytes of LDS (> %d): too many segments in one isochore unit", lds, ctx->max_lds);
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_sampler, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(gat::k_sampler, dim3((unsigned)nb, (unsigned)P->h_order.size()), dim3(64), lds, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+      hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
+                         (int64_t)nb * P->n_units, P->d_stat.p);
       HIPCHK(ctx, hipGetLastError());
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -626,7 +632,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       st->n_placed += (int64_t)stat[0];
       st->n_draws += (int64_t)stat[1];
       st->n_unsuccessful += (int64_t)stat[2];
-      if (P->merge_contigs) st->n_sampled_segments += (int64_t)stat[3];
+      (void)stat[3];
       st->n_full_units += (int64_t)stat[4];
       if (timed) {
         float ms = 0;
@@ -734,7 +740,7 @@ extern "C" int gat_sample(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t s
     }
     done += nb;
   }
-  if (!P->merge_contigs) local.n_sampled_segments = total;
+  local.n_sampled_segments = total;
   if (stats) *stats = local;
   if (overflow) return set_err(ctx, GAT_ERR_CAPACITY, "gat_sample: output needs %lld segments, cap is %lld", (long long)total, (long long)cap);
   return GAT_OK;

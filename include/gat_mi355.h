@@ -80,7 +80,7 @@ typedef struct {
   float ms_total;               /* whole call on the stream                                     */
   int64_t n_placed;             /* segments placed (sls.sample calls kept, gat/Engine.pyx:628)  */
   int64_t n_draws;              /* raw MT19937 outputs consumed                                 */
-  int64_t n_sampled_segments;   /* contig-level segments handed to the counters                 */
+  int64_t n_sampled_segments;   /* contig-level segments returned (gat_sample only)               */
   int64_t n_unsuccessful;       /* sum of nunsuccessful_rounds (gat/Engine.pyx:570-572)         */
   int64_t n_retried;            /* work units redone with a larger slab                         */
   int64_t n_full_units;         /* work units run without the lane-parallel front end           */
