@@ -138,10 +138,13 @@ __global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
 // outputs (masked value > range) leave the state unchanged -- exactly numpy's masked rejection.
 // A lane halts when `remaining <= length` (:582): the pending length, the number of outputs
 // consumed and `remaining` are handed to k_sampler, which consolidates and finishes the unit.
-constexpr int kPlaceWsLds = 512;      // workspace segments kept in LDS (12 B each)
+constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (12 B each)
+constexpr int kPlaceRankLds = 2048;   // length-rank table entries kept in LDS
+constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   __shared__ uint32_t l_ws_start[kPlaceWsLds], l_ws_end[kPlaceWsLds], l_ws_cdf[kPlaceWsLds];
+  __shared__ uint32_t l_rank[kPlaceRankLds];
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = blockIdx.y;
   const int u = A.order[a];
@@ -155,105 +158,118 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const int rows = A.rng_rows[a];
   const int sidx = sb * kWave + lane;
   const bool live = sidx < A.batch;
-  const bool ws_lds = nws <= kPlaceWsLds;
-  if (ws_lds) {
-    for (int i = lane; i < nws; i += kWave) { const uint2 v = ws[i]; l_ws_start[i] = v.x; l_ws_end[i] = v.y; l_ws_cdf[i] = ws_cdf[i]; }
-  }
-  __syncthreads();
-  const uint32_t* __restrict__ rng = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
-  uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
+  const int64_t so = (int64_t)sidx * A.n_units + u;
 
-  // wave-uniform draw parameters
-  const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; 0 consumes nothing
-  const uint32_t rangeL = drawL ? hist_total - 2u : 0u, maskL = drawL ? 0xffffffffu >> __builtin_clz(rangeL) : 0u;
+  // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
+  const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; range 0 consumes nothing
+  const bool drawP = ws_total > 1;
+  if (!drawL || !drawP) {                            // degenerate unit (<= 2 segments / 1-base workspace):
+    if (live) { A.st_n[so] = 0; A.st_remaining[so] = Up->ltotal; A.st_length[so] = -1; A.st_draws[so] = 0; }
+    return;                                          // k_sampler runs it from its seed
+  }
+  const uint32_t rangeL = hist_total - 2u, maskL = 0xffffffffu >> __builtin_clz(rangeL);
   const bool drawB = bucket > 1;
   const uint32_t rangeB = bucket - 1u, maskB = drawB ? 0xffffffffu >> __builtin_clz(rangeB) : 0u;
-  const bool drawP = ws_total > 1;
-  const uint32_t rangeP = ws_total - 1u, maskP = drawP ? 0xffffffffu >> __builtin_clz(rangeP) : 0u;
+  const uint32_t rangeP = ws_total - 1u, maskP = 0xffffffffu >> __builtin_clz(rangeP);
+
+  const bool ws_lds = nws <= kPlaceWsLds;
+  const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
+  if (ws_lds)
+    for (int i = lane; i < nws; i += kWave) { const uint2 v = ws[i]; l_ws_start[i] = v.x; l_ws_end[i] = v.y; l_ws_cdf[i] = ws_cdf[i]; }
+  if (rank_lds)
+    for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
+  __syncthreads();
   const uint2 ws0 = ws[0];
+  const uint32_t* __restrict__ rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
+  uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
 
   enum { S_L = 0, S_B = 1, S_P = 2, S_O = 3, S_HALT = 4 };
-  enum { T_NONE = 0, T_RANK = 1, T_LEN = 2, T_POS = 3, T_PLACE = 4 };
   int st = live ? S_L : S_HALT;
+  uint32_t curmask = maskL, currange = rangeL;
   int32_t rem = Up->ltotal;
   int nS = 0;
-  uint32_t len = 0, r = 1, p = 0, range3 = 0, mask3 = 0, cs = 0, ce = 0;
-  int32_t sstart = 0, q = 0;
-  int32_t pend = -1;           // pending length at the trigger; -1 = not (yet) triggered
-  uint32_t used = 0;           // raw outputs consumed by this lane
+  uint32_t len = 0, cs = 0, ce = 0;
+  int32_t sstart = 0;
+  int32_t pend = -1;           // pending length at the trigger; -1 = not triggered
+  uint32_t used = 0;           // raw outputs consumed by this lane when it halted
   int flag = 0;
 
-  // transitions that need no further draw; returns with st set
-  auto resolve = [&](int t) {
-    for (;;) {
-      if (t == T_RANK) {
-        len = rank_len[r] * bucket;
-        if (drawB) { st = S_B; return; }
-        t = T_LEN;
-      }
-      if (t == T_LEN) {
-        if (rem <= (int32_t)len) { pend = (int32_t)len; st = S_HALT; return; }      // :582 trigger
-        if (drawP) { st = S_P; return; }
-        p = 0; t = T_POS;
-      }
-      if (t == T_POS) {
-        // searchsorted(cdf, p) (utils/gat_utils.c:36, cmpPosition): leftmost k with (int)(cdf[k]-p) >= 0
+  auto step = [&](uint32_t y, uint32_t jj) {
+    const uint32_t v = y & curmask;
+    const bool acc = st != S_HALT && v <= currange;
+    if (!__any(acc)) return;
+    bool place = false;
+    int32_t q = 0;
+    if (acc) {
+      const int st0 = st;
+      bool have_len = false;
+      if (st0 == S_L) {                                              // hs.sample(): rank -> length (:419-431)
+        const uint32_t r = 1u + v;
+        len = (rank_lds ? l_rank[r] : rank_len[r]) * bucket;
+        if (drawB) { st = S_B; curmask = maskB; currange = rangeB; } else have_len = true;
+      } else if (st0 == S_B) {                                       // + randint(0, bucket) (:432-433)
+        len += v;
+        have_len = true;
+      } else if (st0 == S_P) {                                       // sls.sample(): workspace position (:299-306)
         int k = 0;
         int32_t prev_end = 0;
         if (nws == 1) { cs = ws0.x; ce = ws0.y; }
         else {
-          int lo = 0, hi = nws;
+          int lo = 0, hi = nws;                                      // leftmost k with (int)(cdf[k]-p) >= 0
           if (ws_lds) {
-            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws_cdf[mid] - p) < 0) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws_cdf[mid] - v) < 0) lo = mid + 1; else hi = mid; }
             k = lo; cs = l_ws_start[k]; ce = l_ws_end[k];
             if (k > 0) prev_end = (int32_t)l_ws_end[k - 1];
           } else {
-            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(ws_cdf[mid] - p) < 0) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(ws_cdf[mid] - v) < 0) lo = mid + 1; else hi = mid; }
             k = lo; const uint2 c = ws[k]; cs = c.x; ce = c.y;
             if (k > 0) prev_end = (int32_t)ws[k - 1].y;
           }
         }
-        sstart = (int32_t)cs - (int32_t)len + 1;
+        sstart = (int32_t)cs - (int32_t)len + 1;                     // :318-325
         if (k > 0) sstart = prev_end > sstart ? prev_end : sstart;
-        range3 = ce - 1u - (uint32_t)sstart;
-        if (range3 != 0) { mask3 = 0xffffffffu >> __builtin_clz(range3); st = S_O; return; }
-        q = sstart; t = T_PLACE;
+        const uint32_t range3 = ce - 1u - (uint32_t)sstart;
+        if (range3 != 0) { st = S_O; curmask = 0xffffffffu >> __builtin_clz(range3); currange = range3; }
+        else { q = sstart; place = true; }                           // range 0: randint consumes nothing
+      } else {                                                       // offset inside the segment (:326-328)
+        q = sstart + (int32_t)v;
+        place = true;
       }
-      if (t == T_PLACE) {
-        const uint32_t start = (uint32_t)(q > 0 ? q : 0);
-        const uint32_t end = (uint32_t)(q + (int32_t)len);
-        const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;
-        const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;
-        const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
-        if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; return; }
+      if (have_len) {
+        if (rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }   // :582 -> consolidate
+        else { st = S_P; curmask = maskP; currange = rangeP; }
+      }
+    }
+    if (place) {                                                     // :331-343, :630-635
+      const uint32_t start = (uint32_t)(q > 0 ? q : 0);
+      const uint32_t end = (uint32_t)(q + (int32_t)len);
+      const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;
+      const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;
+      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+      if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
+      else {
         out[nS] = make_uint2(start, end);
         nS++;
         rem -= overlap;
-        if (drawL) { st = S_L; return; }
-        r = 1; t = T_RANK;
+        st = S_L; curmask = maskL; currange = rangeL;
       }
     }
   };
 
-  if (live && !drawL) { r = 1; resolve(T_RANK); }     // first length needs no draw
-  for (int j = 0; j < rows; ++j) {
+  for (int j = 0; j < rows; j += kPlaceChunk) {
     if (__ballot(st != S_HALT) == 0) break;
-    const uint32_t y = rng[(int64_t)j * kWave];
-    if (st == S_HALT) continue;
-    used++;
-    int t = T_NONE;
-    if (st == S_L) { const uint32_t v = y & maskL; if (v <= rangeL) { r = 1u + v; t = T_RANK; } }
-    else if (st == S_B) { const uint32_t v = y & maskB; if (v <= rangeB) { len += v; t = T_LEN; } }
-    else if (st == S_P) { const uint32_t v = y & maskP; if (v <= rangeP) { p = v; t = T_POS; } }
-    else { const uint32_t v = y & mask3; if (v <= range3) { q = sstart + (int32_t)v; t = T_PLACE; } }
-    if (t != T_NONE) resolve(t);
+    uint32_t y[kPlaceChunk];
+#pragma unroll
+    for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
+    rp += kPlaceChunk * kWave;
+#pragma unroll
+    for (int c = 0; c < kPlaceChunk; ++c) step(y[c], (uint32_t)(j + c));
   }
   if (live) {
-    const int64_t o = (int64_t)sidx * A.n_units + u;
-    A.st_n[o] = nS;
-    A.st_remaining[o] = rem;
-    A.st_length[o] = (st == S_HALT && pend >= 0 && flag == 0) ? pend : -1;   // rows ran out / overflow: full mode
-    A.st_draws[o] = used;
+    A.st_n[so] = nS;
+    A.st_remaining[so] = rem;
+    A.st_length[so] = (st == S_HALT && pend >= 0 && flag == 0) ? pend : -1;   // rows ran out / overflow: full mode
+    A.st_draws[so] = used;
     if (flag) atomicOr(A.flags, flag);
   }
 }
