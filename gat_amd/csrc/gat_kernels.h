@@ -573,11 +573,15 @@ struct CountArgs {
   const int32_t* n_arr;       // n of list (s, c) = n_arr[s*n_stride + n_index[c]]
   int32_t n_stride;
   const int32_t* n_index;
-  // annotations
+  // annotations: list (t, c) = start/end/cumx[a_off[t*C+c] ..), grid[g_off[t*C+c] .. +cells[c]+1)
   const uint32_t* a_start;
   const uint32_t* a_end;
-  const uint32_t* a_cumx;
-  const int64_t* a_off;       // [t*n_contigs + c], n_tracks*n_contigs+1
+  const uint32_t* a_cumx;     // bases of the list's intervals before interval i
+  const uint32_t* a_grid;     // grid[g] = #starts < (g << shift[c]); grid[cells[c]] = m
+  const int64_t* a_off;       // n_tracks*n_contigs+1
+  const int64_t* g_off;       // n_tracks*n_contigs+1
+  const int32_t* c_shift;     // n_contigs
+  const int32_t* c_cells;     // n_contigs
   const int64_t* cws_nseg;    // n_contigs
   int32_t n_contigs, n_tracks;
   int32_t n_samples;          // lists in this launch
@@ -589,24 +593,33 @@ struct CountArgs {
   int32_t tracks_per_block;
   int32_t samples_per_block;
   int32_t lds_entries;        // staging capacity (intervals); 0 => read annotations from global
+  int32_t lds_grid;           // staging capacity (grid words)
+  uint32_t* part;             // [n_contigs][3][n_tracks][n_samples] per-contig partial counts
 };
 
 struct AnnoView {
   const uint32_t* start;
   const uint32_t* end;
   const uint32_t* cumx;
-  int m;
+  const uint32_t* grid;
+  int m, shift, cells;
 };
+
+// number of interval starts < p: the cell index gives the range, cells hold about one start
+__device__ __forceinline__ int starts_below(const AnnoView& Y, uint32_t p) {
+  uint32_t g = p >> Y.shift;
+  g = g < (uint32_t)(Y.cells - 1) ? g : (uint32_t)(Y.cells - 1);
+  int k = (int)Y.grid[g];
+  const int hi = (int)Y.grid[g + 1];
+  while (k < hi && Y.start[k] < p) ++k;
+  return k;
+}
 
 // quantities of one sample segment against one annotation list
 __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
                                             uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
-  // k1 = #starts < xs
-  int lo = 0, hi = Y.m;
-  while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (Y.start[mid] < xs) lo = mid + 1; else hi = mid; }
-  const int k1 = lo;
-  // k2 = #starts < xe  (xe > xs; annotation intervals are long compared to the gap: gallop)
-  int k2 = k1;
+  const int k1 = starts_below(Y, xs);                     // #starts < xs
+  int k2 = k1;                                            // #starts < xe: gallop from k1
   while (k2 < Y.m && Y.start[k2] < xe) ++k2;
   uint32_t f1 = 0, f2 = 0;
   uint32_t pe = 0;                  // end of interval k1-1
@@ -621,7 +634,7 @@ __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint
   }
   ov = f2 - f1;
   // first interval with end > xs: k1-1 if its end > xs, else k1
-  int j = (k1 > 0 && pe > xs) ? k1 - 1 : k1;
+  const int j = (k1 > 0 && pe > xs) ? k1 - 1 : k1;
   hit = 0; midhit = 0;
   if (j < Y.m) {
     const uint32_t ys = Y.start[j], ye = Y.end[j];
@@ -633,93 +646,129 @@ __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint
   }
 }
 
+constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per wave)
+
+// One block per (sample chunk, track tile, contig): the tile's annotation slices of that contig
+// (starts / ends / cumulated lengths + position grid) are staged into LDS once and every wave
+// streams its samples' segment lists against them.  Per (sample, track, contig) the block leaves
+// three uint32 partials (overlap bases, segments hit, midpoint hits) in `part`; k_count_finish
+// adds them up over the contigs in reference order.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  // LDS: acc[3][samples_per_block][tracks_per_block] as 8-byte slots, tile offsets, then staging
   const int TT = A.tracks_per_block, SC = A.samples_per_block;
-  double* acc = reinterpret_cast<double*>(lds);            // [q][sl][tl], q: 0 ov(int) 1 density 2 hit 3 midhit
-  int32_t* tile_off = reinterpret_cast<int32_t*>(acc + 4 * SC * TT);   // TT+1
+  uint32_t* res = lds;                                                // [3][SC][TT]
+  int32_t* tile_off = reinterpret_cast<int32_t*>(res + 3 * SC * TT);  // TT+1
   uint32_t* stage = reinterpret_cast<uint32_t*>(tile_off + ((TT + 1 + 3) & ~3));
+  const int E = A.lds_entries;
+  uint32_t* st_grid = stage + 3 * E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s0 = blockIdx.x * SC, t0 = blockIdx.y * TT;
+  const int s0 = blockIdx.x * SC, t0 = blockIdx.y * TT, c = blockIdx.z;
   const int nt = min(TT, A.n_tracks - t0), ns = min(SC, A.n_samples - s0);
-  int64_t* acc_i = reinterpret_cast<int64_t*>(acc);
-  for (int i = tid; i < 4 * SC * TT; i += 256) acc_i[i] = 0;
-
-  for (int c = 0; c < A.n_contigs; ++c) {
-    __syncthreads();
-    if (STAGED) {
-      if (tid == 0) {
-        int o = 0;
-        for (int t = 0; t < nt; ++t) {
-          tile_off[t] = o;
-          o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]);
-        }
-        tile_off[nt] = o;
-      }
-      __syncthreads();
-      const int total = tile_off[nt];
-      const int E = A.lds_entries;
+  const int shift = A.c_shift[c], cells = A.c_cells[c];
+  for (int i = tid; i < 3 * SC * TT; i += 256) res[i] = 0;
+  if (STAGED) {
+    if (tid == 0) {
+      int o = 0;
       for (int t = 0; t < nt; ++t) {
-        const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
-        const int o = tile_off[t], m = tile_off[t + 1] - o;
-        for (int i = tid; i < m; i += 256) {
-          stage[o + i] = A.a_start[g + i];
-          stage[E + o + i] = A.a_end[g + i];
-          stage[2 * E + o + i] = A.a_cumx[g + i];
-        }
+        tile_off[t] = o;
+        o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]);
       }
-      (void)total;
-      __syncthreads();
+      tile_off[nt] = o;
     }
-    const double nseg = (double)(uint32_t)A.cws_nseg[c];
-    for (int sl = wave; sl < ns; sl += 4) {
-      const int s = s0 + sl;
-      const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
-      const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
+      const int o = tile_off[t], m = tile_off[t + 1] - o;
+      for (int i = tid; i < m; i += 256) {
+        stage[o + i] = A.a_start[g + i];
+        stage[E + o + i] = A.a_end[g + i];
+        stage[2 * E + o + i] = A.a_cumx[g + i];
+      }
+      const int64_t gg = A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
+      for (int i = tid; i <= cells; i += 256) st_grid[t * (cells + 1) + i] = A.a_grid[gg + i];
+    }
+  }
+  __syncthreads();
+  for (int sl = wave; sl < ns; sl += 4) {
+    const int s = s0 + sl;
+    const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
+    const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+    for (int base = 0; base < n; base += kWave * kCountXR) {
+      uint2 x[kCountXR];
+#pragma unroll
+      for (int r = 0; r < kCountXR; ++r) {
+        const int i = base + r * kWave + lane;
+        x[r] = i < n ? X[i] : make_uint2(0u, 0u);          // empty segment: contributes nothing
+      }
       for (int t = 0; t < nt; ++t) {
         AnnoView Y;
+        Y.shift = shift; Y.cells = cells;
         if (STAGED) {
           const int o = tile_off[t];
-          Y.start = stage + o; Y.end = stage + A.lds_entries + o; Y.cumx = stage + 2 * A.lds_entries + o;
+          Y.start = stage + o; Y.end = stage + E + o; Y.cumx = stage + 2 * E + o;
+          Y.grid = st_grid + t * (cells + 1);
           Y.m = tile_off[t + 1] - o;
         } else {
           const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
           Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
+          Y.grid = A.a_grid + A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
           Y.m = (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - g);
         }
+        if (Y.m == 0) continue;
         uint32_t ov = 0, hit = 0, mid = 0;
-        if (Y.m > 0) {
-          for (int i = lane; i < n; i += 64) {
-            const uint2 x = X[i];
+#pragma unroll
+        for (int r = 0; r < kCountXR; ++r) {
+          if (x[r].x != x[r].y) {
             uint32_t o1, h1, m1;
-            seg_vs_anno(Y, x.x, x.y, o1, h1, m1);
+            seg_vs_anno(Y, x[r].x, x[r].y, o1, h1, m1);
             ov += o1; hit += h1; mid += m1;
           }
-          ov = wave_sum_u32(ov); hit = wave_sum_u32(hit); mid = wave_sum_u32(mid);
         }
+        ov = wave_sum_u32(ov); hit = wave_sum_u32(hit); mid = wave_sum_u32(mid);
         if (lane == 0) {
           const int a = sl * TT + t;
-          acc_i[a] += (int64_t)ov;                                           // Python int sum
-          if (nseg != 0.0) acc[SC * TT + a] += (double)ov / nseg;            // float(ov)/len(workspace)
-          acc_i[2 * SC * TT + a] += (int64_t)hit;
-          acc_i[3 * SC * TT + a] += (int64_t)mid;
+          res[a] += ov;                                     // uint32 accumulate within the contig (:1034)
+          res[SC * TT + a] += hit;
+          res[2 * SC * TT + a] += mid;
         }
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < ns * nt; i += 256) {
-    const int sl = i / nt, t = i - sl * nt;
-    const int a = sl * TT + t;
-    const int64_t col = A.out_begin + s0 + sl;
-    const int k0 = A.counter_slot[0], k1 = A.counter_slot[1], k2 = A.counter_slot[2], k3 = A.counter_slot[3];
-    if (k0 >= 0) A.out[((int64_t)k0 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[a];
-    if (k1 >= 0) A.out[((int64_t)k1 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[SC * TT + a];
-    if (k2 >= 0) A.out[((int64_t)k2 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[2 * SC * TT + a];
-    if (k3 >= 0) A.out[((int64_t)k3 * A.n_tracks + t0 + t) * A.out_stride + col] = acc_i[3 * SC * TT + a];
+  // part[((c*3 + q)*n_tracks + t)*n_samples + s]
+  for (int i = tid; i < 3 * nt * ns; i += 256) {
+    const int q = i / (nt * ns), rem = i - q * nt * ns;
+    const int t = rem / ns, sl = rem - t * ns;
+    A.part[(((int64_t)c * 3 + q) * A.n_tracks + t0 + t) * A.n_samples + s0 + sl] = res[q * SC * TT + sl * TT + t];
   }
+}
+
+// sum([...]) over the contigs in list(sample.keys()) order (gat/__init__.py:578-587): Python ints
+// for the integer counters, left-to-right IEEE doubles of float(overlap)/len(workspace) for
+// nucleotide-density (gat/Engine.pyx:1437-1441).  One thread per (track, sample).
+__global__ __launch_bounds__(256) void k_count_finish(CountArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)A.n_tracks * A.n_samples) return;
+  const int t = (int)(i / A.n_samples), s = (int)(i - (int64_t)t * A.n_samples);
+  int64_t ov = 0, hit = 0, mid = 0;
+  double dens = 0.0;
+  for (int c = 0; c < A.n_contigs; ++c) {
+    const int64_t b = (((int64_t)c * 3) * A.n_tracks + t) * A.n_samples + s;
+    const int64_t q = (int64_t)A.n_tracks * A.n_samples;
+    const uint32_t o = A.part[b];
+    ov += (int64_t)o;
+    hit += (int64_t)A.part[b + q];
+    mid += (int64_t)A.part[b + 2 * q];
+    const double nseg = (double)(uint32_t)A.cws_nseg[c];
+    if (nseg != 0.0) dens += (double)o / nseg;
+  }
+  const int64_t col = A.out_begin + s;
+  const int k0 = A.counter_slot[0], k1 = A.counter_slot[1], k2 = A.counter_slot[2], k3 = A.counter_slot[3];
+  if (k0 >= 0) A.out[((int64_t)k0 * A.n_tracks + t) * A.out_stride + col] = ov;
+  if (k1 >= 0) A.out[((int64_t)k1 * A.n_tracks + t) * A.out_stride + col] = __double_as_longlong(dens);
+  if (k2 >= 0) A.out[((int64_t)k2 * A.n_tracks + t) * A.out_stride + col] = hit;
+  if (k3 >= 0) A.out[((int64_t)k3 * A.n_tracks + t) * A.out_stride + col] = mid;
 }
 
 // annotation-overlap / annotation-midoverlap: roles swapped (gat/Engine.pyx:1458-1472):

@@ -78,10 +78,12 @@ struct DevBuf {
 
 // annotations on the device: SoA starts / ends / exclusive cumulated lengths + CSR offsets
 struct AnnoDev {
-  DevBuf<uint32_t> start, end, cumx;
-  DevBuf<int64_t> off;
+  DevBuf<uint32_t> start, end, cumx, grid;
+  DevBuf<int64_t> off, goff;
+  DevBuf<int32_t> shift, cells;
   std::vector<int64_t> h_off;
   int64_t max_m = 0;
+  int64_t max_cells = 0;
   int64_t total = 0;
 };
 
@@ -99,7 +101,8 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
   return GAT_OK;
 }
 
-static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists) {
+static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists,
+                       int32_t n_groups) {
   const int64_t total = anno_off[n_lists];
   std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
   A.h_off.assign(anno_off, anno_off + n_lists + 1);
@@ -118,6 +121,46 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
       cum += annos[o + i].end - annos[o + i].start;
     }
   }
+  // per group (contig) a uniform grid over the start coordinates, about one start per cell:
+  // grid[g] = #starts < (g << shift); the count kernels look a position up instead of bisecting
+  const int64_t n_tracks = n_groups > 0 ? n_lists / n_groups : 0;
+  std::vector<int32_t> h_shift((size_t)std::max(1, n_groups), 0), h_cells((size_t)std::max(1, n_groups), 1);
+  std::vector<int64_t> h_goff((size_t)n_lists + 1, 0);
+  A.max_cells = 1;
+  for (int c = 0; c < n_groups; ++c) {
+    uint32_t max_start = 0;
+    int64_t mc = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c, o = anno_off[l], m = anno_off[l + 1] - o;
+      mc = std::max(mc, m);
+      if (m > 0) max_start = std::max(max_start, annos[o + m - 1].start);
+    }
+    int64_t target = 16;
+    while (target < mc) target <<= 1;
+    int sh = 0;
+    while (((int64_t)max_start >> sh) + 1 > target) ++sh;
+    h_shift[(size_t)c] = sh;
+    h_cells[(size_t)c] = (int32_t)(((int64_t)max_start >> sh) + 1);
+    A.max_cells = std::max<int64_t>(A.max_cells, h_cells[(size_t)c]);
+  }
+  for (int64_t l = 0; l < n_lists; ++l) h_goff[(size_t)l + 1] = h_goff[(size_t)l] + h_cells[(size_t)(l % n_groups)] + 1;
+  std::vector<uint32_t> hg((size_t)h_goff[(size_t)n_lists]);
+  for (int64_t l = 0; l < n_lists; ++l) {
+    const int c = (int)(l % n_groups);
+    const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+    const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
+    uint32_t* g = hg.data() + h_goff[(size_t)l];
+    int64_t k = 0;
+    for (int cell = 0; cell <= cells; ++cell) {
+      const uint64_t bound = (uint64_t)cell << sh;
+      while (k < m && (uint64_t)annos[o + k].start < bound) ++k;
+      g[cell] = (uint32_t)(cell == cells ? m : k);
+    }
+  }
+  HIPCHK(ctx, A.grid.upload(hg, ctx->stream));
+  HIPCHK(ctx, A.goff.upload(h_goff, ctx->stream));
+  HIPCHK(ctx, A.shift.upload(h_shift, ctx->stream));
+  HIPCHK(ctx, A.cells.upload(h_cells, ctx->stream));
   HIPCHK(ctx, A.start.upload(hs, ctx->stream));
   HIPCHK(ctx, A.end.upload(he, ctx->stream));
   HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
@@ -154,7 +197,7 @@ struct gat_problem {
   int64_t rng_rows_total = 0;            // sum of h_rng_rows
   DevBuf<int32_t> d_rng_rows, d_st_n, d_st_remaining, d_st_length;
   DevBuf<int64_t> d_rng_off;
-  DevBuf<uint32_t> d_rng_out, d_st_draws, d_ws_stat;
+  DevBuf<uint32_t> d_rng_out, d_st_draws, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
 };
 
@@ -439,7 +482,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
   int rc = upload_layout(ctx, P.get());
   if (rc) return rc;
-  rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs);
+  rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs);
   if (rc) return rc;
   HIPCHK(ctx, P->d_flags.alloc(1));
   HIPCHK(ctx, P->d_stat.alloc(8));
@@ -513,32 +556,47 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
 }
 
 // launch the count kernels over n_lists sample lists
-static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A) {
+static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part) {
   for (int i = 0; i < GAT_NUM_COUNTERS; ++i) A.counter_slot[i] = C.slot[i];
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
+  A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
   if (A.n_samples <= 0 || A.n_tracks <= 0) return GAT_OK;
   if (C.any_seg) {
     const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
-    const int E_max = env_e ? atoi(env_e) : 3072;
+    const int E_max = env_e ? atoi(env_e) : 1024;
     const char* env_sc = getenv("GAT_COUNT_SAMPLES_PER_BLOCK");
-    int SC = env_sc ? atoi(env_sc) : 16;
-    SC = std::max(4, std::min(SC, 64));
+    int SC = env_sc ? atoi(env_sc) : 32;
+    SC = std::max(4, std::min(SC, 256));
+    const char* env_tt = getenv("GAT_COUNT_TRACKS_PER_BLOCK");
+    const int TT_max = env_tt ? atoi(env_tt) : 16;
     int TT;
-    bool staged = annos.max_m > 0 && annos.max_m <= E_max;
-    if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, 16), E_max / annos.max_m);
-    else TT = (int)std::min<int64_t>(A.n_tracks, 16);
+    const char* env_st = getenv("GAT_COUNT_STAGED");
+    bool staged = annos.max_m > 0 && annos.max_m <= E_max && !(env_st && atoi(env_st) == 0);
+    if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, TT_max), E_max / annos.max_m);
+    else TT = (int)std::min<int64_t>(A.n_tracks, TT_max);
     TT = std::max(1, TT);
     A.tracks_per_block = TT;
     A.samples_per_block = SC;
     A.lds_entries = staged ? (int)std::min<int64_t>((int64_t)E_max, annos.max_m * TT) : 0;
-    const size_t lds = (size_t)4 * SC * TT * 8 + (size_t)((TT + 1 + 3) & ~3) * 4 + (size_t)3 * A.lds_entries * 4;
-    dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT));
+    A.lds_grid = staged ? (int)((annos.max_cells + 1) * TT) : 0;
+    const size_t lds = (size_t)3 * SC * TT * 4 + (size_t)((TT + 1 + 3) & ~3) * 4 +
+                       (size_t)3 * A.lds_entries * 4 + (size_t)A.lds_grid * 4;
+    const size_t need = (size_t)A.n_contigs * 3 * (size_t)A.n_tracks * (size_t)A.n_samples;
+    if (part.n < need) HIPCHK(ctx, part.alloc(need));
+    A.part = part.p;
+    if (A.n_contigs > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 contigs");
+    dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT), (unsigned)std::max(1, A.n_contigs));
+    if (A.n_contigs > 0) {
     if (staged) {
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(gat::k_count_seg<true>, grid, dim3(256), lds, ctx->stream, A);
     } else {
       hipLaunchKernelGGL(gat::k_count_seg<false>, grid, dim3(256), lds, ctx->stream, A);
     }
+    HIPCHK(ctx, hipGetLastError());
+    }
+    const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
+    hipLaunchKernelGGL(gat::k_count_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, A);
     HIPCHK(ctx, hipGetLastError());
   }
   if (C.any_anno) {
@@ -684,7 +742,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     A.out_stride = S;
     A.out_begin = done;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if ((rc = launch_count(ctx, P->annos, C, A))) return rc;
+    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -757,7 +815,7 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
   int rc = parse_counters(ctx, counter_ids, n_counters, C);
   if (rc) return rc;
   AnnoDev A;
-  if ((rc = build_annos(ctx, A, annos, anno_off, (int64_t)n_tracks * n_groups))) return rc;
+  if ((rc = build_annos(ctx, A, annos, anno_off, (int64_t)n_tracks * n_groups, n_groups))) return rc;
   for (int64_t l = 0; l < n_lists * n_groups; ++l)
     if ((rc = check_list(ctx, lists + list_off[l], list_off[l + 1] - list_off[l], "segment", l))) return rc;
   const int64_t total = list_off[n_lists * n_groups];
@@ -766,6 +824,7 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
   DevBuf<uint2> d_seg;
   DevBuf<int32_t> d_c_off, d_n, d_index;
   DevBuf<int64_t> d_nseg, d_out;
+  DevBuf<uint32_t> d_part;
   HIPCHK(ctx, d_seg.upload(h_seg, ctx->stream));
   std::vector<int64_t> h_nseg(ws_nseg, ws_nseg + n_groups);
   HIPCHK(ctx, d_nseg.upload(h_nseg, ctx->stream));
@@ -791,7 +850,7 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
     K.n_arr = d_n.p; K.n_stride = 0; K.n_index = d_index.p;
     K.cws_nseg = d_nseg.p; K.n_contigs = n_groups; K.n_tracks = n_tracks; K.n_samples = 1;
     K.out = d_out.p; K.out_stride = n_lists; K.out_begin = l;
-    if ((rc = launch_count(ctx, A, C, K))) return rc;
+    if ((rc = launch_count(ctx, A, C, K, d_part))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   HIPCHK(ctx, hipMemcpyAsync(counts_host, d_out.p, nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
