@@ -605,44 +605,46 @@ struct AnnoView {
   int m, shift, cells;
 };
 
-// number of interval starts < p: the cell index gives the range, cells hold about one start
-__device__ __forceinline__ int starts_below(const AnnoView& Y, uint32_t p) {
-  uint32_t g = p >> Y.shift;
+// quantities of one sample segment x = [xs, xe) against one annotation list Y.
+//   k1 = #starts < xs comes from the position grid (about one start per cell) plus a short scan;
+//   the scan leaves sk = start[k1], the first start >= xs.  A sample segment is far shorter than
+//   the gaps between annotation intervals, so almost always sk >= xe: x then meets only interval
+//   k1-1 and overlap = min(xe, end[k1-1]) - xs if that interval reaches past xs.  Otherwise the
+//   general form F(xe) - F(xs), F(p) = cumx[k-1] + min(p, end[k-1]) - start[k-1], is used.
+template <bool WANT_HITS>
+__device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
+                                            uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
+  uint32_t g = xs >> Y.shift;
   g = g < (uint32_t)(Y.cells - 1) ? g : (uint32_t)(Y.cells - 1);
   int k = (int)Y.grid[g];
   const int hi = (int)Y.grid[g + 1];
-  while (k < hi && Y.start[k] < p) ++k;
-  return k;
-}
-
-// quantities of one sample segment against one annotation list
-__device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
-                                            uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
-  const int k1 = starts_below(Y, xs);                     // #starts < xs
-  int k2 = k1;                                            // #starts < xe: gallop from k1
-  while (k2 < Y.m && Y.start[k2] < xe) ++k2;
-  uint32_t f1 = 0, f2 = 0;
-  uint32_t pe = 0;                  // end of interval k1-1
-  if (k1 > 0) {
-    const uint32_t ps = Y.start[k1 - 1];
-    pe = Y.end[k1 - 1];
-    f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - ps;
-  }
-  if (k2 > 0) {
-    const uint32_t ps = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
-    f2 = Y.cumx[k2 - 1] + (xe < pe2 ? xe : pe2) - ps;
-  }
-  ov = f2 - f1;
-  // first interval with end > xs: k1-1 if its end > xs, else k1
-  const int j = (k1 > 0 && pe > xs) ? k1 - 1 : k1;
+  uint32_t sk = k < Y.m ? Y.start[k] : 0xffffffffu;
+  while (k < hi && sk < xs) { ++k; sk = k < Y.m ? Y.start[k] : 0xffffffffu; }
+  const int k1 = k;
+  const uint32_t pe = k1 > 0 ? Y.end[k1 - 1] : 0u;       // end of the last interval starting before xs
   hit = 0; midhit = 0;
-  if (j < Y.m) {
-    const uint32_t ys = Y.start[j], ye = Y.end[j];
-    if (ys < xe) {
+  if (!(sk < xe)) {                                       // no interval starts inside x
+    ov = pe > xs ? (xe < pe ? xe : pe) - xs : 0u;
+    if (WANT_HITS && pe > xs) {                           // first interval with end > xs is k1-1 and it starts before xs
       hit = 1;
       const uint32_t mid = xs + (xe - xs) / 2u;
-      midhit = (ys <= mid && mid < ye) ? 1u : 0u;
+      midhit = mid < pe ? 1u : 0u;                        // start[k1-1] < xs <= mid
     }
+    return;
+  }
+  int k2 = k1 + 1;                                        // #starts < xe
+  while (k2 < Y.m && Y.start[k2] < xe) ++k2;
+  uint32_t f1 = 0;
+  if (k1 > 0) f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - Y.start[k1 - 1];
+  const uint32_t ps2 = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
+  const uint32_t f2 = Y.cumx[k2 - 1] + (xe < pe2 ? xe : pe2) - ps2;
+  ov = f2 - f1;
+  if (WANT_HITS) {
+    // first interval with end > xs: k1-1 if it reaches past xs, else k1 (which starts inside x)
+    hit = 1;
+    const uint32_t mid = xs + (xe - xs) / 2u;
+    if (pe > xs) midhit = mid < pe ? 1u : 0u;
+    else midhit = (sk <= mid && mid < Y.end[k1]) ? 1u : 0u;
   }
 }
 
@@ -653,7 +655,7 @@ constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per
 // streams its samples' segment lists against them.  Per (sample, track, contig) the block leaves
 // three uint32 partials (overlap bases, segments hit, midpoint hits) in `part`; k_count_finish
 // adds them up over the contigs in reference order.
-template <bool STAGED>
+template <bool STAGED, bool WANT_HITS>
 __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int TT = A.tracks_per_block, SC = A.samples_per_block;
@@ -721,16 +723,16 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
         for (int r = 0; r < kCountXR; ++r) {
           if (x[r].x != x[r].y) {
             uint32_t o1, h1, m1;
-            seg_vs_anno(Y, x[r].x, x[r].y, o1, h1, m1);
+            seg_vs_anno<WANT_HITS>(Y, x[r].x, x[r].y, o1, h1, m1);
             ov += o1; hit += h1; mid += m1;
           }
         }
-        ov = wave_sum_u32(ov); hit = wave_sum_u32(hit); mid = wave_sum_u32(mid);
+        ov = wave_sum_u32(ov);
+        if (WANT_HITS) { hit = wave_sum_u32(hit); mid = wave_sum_u32(mid); }
         if (lane == 0) {
           const int a = sl * TT + t;
           res[a] += ov;                                     // uint32 accumulate within the contig (:1034)
-          res[SC * TT + a] += hit;
-          res[2 * SC * TT + a] += mid;
+          if (WANT_HITS) { res[SC * TT + a] += hit; res[2 * SC * TT + a] += mid; }
         }
       }
     }

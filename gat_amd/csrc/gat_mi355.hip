@@ -566,7 +566,12 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     const int E_max = env_e ? atoi(env_e) : 1024;
     const char* env_sc = getenv("GAT_COUNT_SAMPLES_PER_BLOCK");
     int SC = env_sc ? atoi(env_sc) : 32;
-    SC = std::max(4, std::min(SC, 256));
+    if (!env_sc) {   // enough blocks to fill 256 CUs several times over, large enough to amortise the staging
+      const int64_t tiles0 = (A.n_tracks + 0) , work = (int64_t)A.n_samples * tiles0 * std::max(1, A.n_contigs) / 8192;
+      SC = 8;
+      while (SC < 128 && SC * 2 <= work) SC *= 2;
+    }
+    SC = std::max(1, std::min(SC, 256));
     const char* env_tt = getenv("GAT_COUNT_TRACKS_PER_BLOCK");
     const int TT_max = env_tt ? atoi(env_tt) : 16;
     int TT;
@@ -587,11 +592,15 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     if (A.n_contigs > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 contigs");
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT), (unsigned)std::max(1, A.n_contigs));
     if (A.n_contigs > 0) {
+    const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
     if (staged) {
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_seg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gat::k_count_seg<true>, grid, dim3(256), lds, ctx->stream, A);
+      const void* fn = hits ? (const void*)gat::k_count_seg<true, true> : (const void*)gat::k_count_seg<true, false>;
+      HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (hits) hipLaunchKernelGGL((gat::k_count_seg<true, true>), grid, dim3(256), lds, ctx->stream, A);
+      else hipLaunchKernelGGL((gat::k_count_seg<true, false>), grid, dim3(256), lds, ctx->stream, A);
     } else {
-      hipLaunchKernelGGL(gat::k_count_seg<false>, grid, dim3(256), lds, ctx->stream, A);
+      if (hits) hipLaunchKernelGGL((gat::k_count_seg<false, true>), grid, dim3(256), lds, ctx->stream, A);
+      else hipLaunchKernelGGL((gat::k_count_seg<false, false>), grid, dim3(256), lds, ctx->stream, A);
     }
     HIPCHK(ctx, hipGetLastError());
     }
