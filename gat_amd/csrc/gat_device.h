@@ -212,6 +212,200 @@ __device__ __forceinline__ void wave_sort_by_start(uint2* seg, int n, int lane) 
   }
 }
 
+// The same sort with the elements held in registers (E per lane, element r*64+lane in register r).
+// Partners at a distance below 64 are fetched with a cross-lane shuffle, larger
+// distances are register-to-register; no LDS round trip or barrier per stage.
+template <int E>
+__device__ __forceinline__ void sort_stage_lanes(uint32_t (&ks)[E], uint32_t (&ke)[E], int ml, int hb, int lane) {
+  const int src = (lane ^ ml) << 2;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const uint32_t ps = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ks[r]);
+    const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ke[r]);
+    const bool lower = (((r << 6) | lane) & (1 << hb)) == 0;
+    const bool take = lower ? (ps < ks[r]) : (ps > ks[r]);      // equal starts: neither side moves
+    ks[r] = take ? ps : ks[r];
+    ke[r] = take ? pe : ke[r];
+  }
+}
+// partner differs in register index (RMASK) and, for the flip steps, mirrors the lane (xor 63)
+template <int E, int RMASK, bool MIRROR>
+__device__ __forceinline__ void sort_stage_regs(uint32_t (&ks)[E], uint32_t (&ke)[E], int lane) {
+  uint32_t ns[E], ne[E];
+  const int src = (lane ^ 63) << 2;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    uint32_t ps = ks[r ^ RMASK], pe = ke[r ^ RMASK];
+    if (MIRROR) {
+      ps = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ps);
+      pe = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pe);
+    }
+    // the highest bit of the mask is the top bit of RMASK: lower element iff that bit of r is clear
+    constexpr int top = RMASK >= 16 ? 16 : RMASK >= 8 ? 8 : RMASK >= 4 ? 4 : RMASK >= 2 ? 2 : 1;
+    const bool lower = (r & top) == 0;
+    const bool take = lower ? (ps < ks[r]) : (ps > ks[r]);
+    ns[r] = take ? ps : ks[r];
+    ne[r] = take ? pe : ke[r];
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) { ks[r] = ns[r]; ke[r] = ne[r]; }
+}
+template <int E>
+__device__ __forceinline__ void sort_disperse_below64(uint32_t (&ks)[E], uint32_t (&ke)[E], int ld_from, int lane) {
+  for (int ld = ld_from; ld >= 0; --ld) sort_stage_lanes<E>(ks, ke, 1 << ld, ld, lane);
+}
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(uint2* seg, int n, int lane) {
+  uint32_t ks[E], ke[E];
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    uint2 x = make_uint2(0xffffffffu, 0xffffffffu);
+    if (i < n) x = seg[i];
+    ks[r] = x.x; ke[r] = x.y;
+  }
+  for (int lk = 1; lk <= 6; ++lk) {                             // blocks of 2..64: lane-only stages
+    sort_stage_lanes<E>(ks, ke, (1 << lk) - 1, lk - 1, lane);   // flip
+    sort_disperse_below64<E>(ks, ke, lk - 2, lane);
+  }
+  if (E >= 2) {                                                 // k = 128
+    sort_stage_regs<E, 1, true>(ks, ke, lane);
+    sort_disperse_below64<E>(ks, ke, 5, lane);
+  }
+  if (E >= 4) {                                                 // k = 256
+    sort_stage_regs<E, (E >= 4 ? 3 : 0), true>(ks, ke, lane);
+    sort_stage_regs<E, 1, false>(ks, ke, lane);
+    sort_disperse_below64<E>(ks, ke, 5, lane);
+  }
+  if (E >= 8) {                                                 // k = 512
+    sort_stage_regs<E, (E >= 8 ? 7 : 0), true>(ks, ke, lane);
+    sort_stage_regs<E, (E >= 4 ? 2 : 0), false>(ks, ke, lane);
+    sort_stage_regs<E, 1, false>(ks, ke, lane);
+    sort_disperse_below64<E>(ks, ke, 5, lane);
+  }
+  if (E >= 16) {                                                // k = 1024
+    sort_stage_regs<E, (E >= 16 ? 15 : 0), true>(ks, ke, lane);
+    sort_stage_regs<E, (E >= 8 ? 4 : 0), false>(ks, ke, lane);
+    sort_stage_regs<E, (E >= 4 ? 2 : 0), false>(ks, ke, lane);
+    sort_stage_regs<E, 1, false>(ks, ke, lane);
+    sort_disperse_below64<E>(ks, ke, 5, lane);
+  }
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    if (i < n) seg[i] = make_uint2(ks[r], ke[r]);
+  }
+  wave_sync();
+}
+// dispatch on the list length; beyond 1024 elements the in-LDS network is used
+__device__ __forceinline__ void wave_sort_auto(uint2* seg, int n, int lane) {
+  if (n < 2) return;
+  if (n <= 64) wave_sort_regs<1>(seg, n, lane);
+  else if (n <= 128) wave_sort_regs<2>(seg, n, lane);
+  else if (n <= 256) wave_sort_regs<4>(seg, n, lane);
+  else if (n <= 512) wave_sort_regs<8>(seg, n, lane);
+  else if (n <= 1024) wave_sort_regs<16>(seg, n, lane);
+  else wave_sort_by_start(seg, n, lane);
+}
+
+// Sort by start for keys that are spread over a range (placed segments are): 512 buckets by
+// position (about one element per bucket), LDS atomics give every element a slot in its bucket, a
+// prefix sum the bucket offsets, and a rank among the few members of its own bucket the final
+// index.  ~10x fewer instructions than the sorting network.  Returns false (nothing written) when
+// the keys are too clustered (a bucket with more than 16 members, or all starts equal); the caller
+// then uses the network.  scratch: 513 words of LDS.
+template <int E>
+__device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* scratch, int lane) {
+  constexpr int NB = 512, PER = NB / kWave;
+  uint32_t ks[E], ke[E];
+  wave_sync();
+  uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    ks[r] = 0; ke[r] = 0;
+    if (i < n) { const uint2 x = seg[i]; ks[r] = x.x; ke[r] = x.y; lo = x.x < lo ? x.x : lo; hi = x.x > hi ? x.x : hi; }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d), oh = (uint32_t)__shfl_xor((int)hi, d);
+    lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+  }
+  lo = rfl(lo); hi = rfl(hi);
+  const uint32_t span = hi - lo;
+  if (span == 0) return false;
+  const bool direct = span < (uint32_t)NB;                       // fewer positions than buckets
+  const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)NB << 32) / ((uint64_t)span + 1u));
+  for (int i = lane; i <= NB; i += kWave) scratch[i] = 0;
+  wave_sync();
+  uint32_t bk[E], slot[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    bk[r] = 0; slot[r] = 0;
+    if (i < n) {
+      const uint32_t d = ks[r] - lo;
+      bk[r] = direct ? d : __umulhi(d, scale);
+      slot[r] = atomicAdd(&scratch[bk[r]], 1u);
+    }
+  }
+  wave_sync();
+  // exclusive prefix over the bucket counts: lane owns PER consecutive buckets
+  uint32_t c[PER], sum = 0, maxc = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { c[q] = scratch[lane * PER + q]; sum += c[q]; maxc = c[q] > maxc ? c[q] : maxc; }
+  uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxc, d); maxc = o > maxc ? o : maxc; }
+  maxc = rfl(maxc);
+  if (maxc > 16u) return false;
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < PER; ++q) { scratch[lane * PER + q] = run; run += c[q]; }
+  if (lane == kWave - 1) scratch[NB] = run;
+  wave_sync();
+  uint32_t base[E], cnt[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    base[r] = 0; cnt[r] = 0;
+    if (i < n) { base[r] = scratch[bk[r]]; cnt[r] = scratch[bk[r] + 1] - base[r]; seg[base[r] + slot[r]] = make_uint2(ks[r], ke[r]); }
+  }
+  wave_sync();
+  uint32_t rank[E];
+#pragma unroll
+  for (int r = 0; r < E; ++r) rank[r] = 0;
+  for (uint32_t m = 0; m < maxc; ++m) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+      if (m < cnt[r]) {
+        const uint32_t s2 = seg[base[r] + m].x;
+        rank[r] += (s2 < ks[r] || (s2 == ks[r] && m < slot[r])) ? 1u : 0u;
+      }
+    }
+  }
+  wave_sync();
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    const int i = r * kWave + lane;
+    if (i < n) seg[base[r] + rank[r]] = make_uint2(ks[r], ke[r]);
+  }
+  wave_sync();
+  return true;
+}
+// bucket sort when possible (scratch available, list short enough), else the sorting network
+__device__ __forceinline__ void wave_sort_fast(uint2* seg, int n, uint32_t* scratch, int lane) {
+  if (n < 2) return;
+  bool done = false;
+  if (scratch != nullptr && n > 64) {
+    if (n <= 256) done = wave_sort_bucket<4>(seg, n, scratch, lane);
+    else if (n <= 512) done = wave_sort_bucket<8>(seg, n, scratch, lane);
+    else if (n <= 1024) done = wave_sort_bucket<16>(seg, n, scratch, lane);
+  }
+  if (!done) wave_sort_auto(seg, n, lane);
+}
+
 // SegmentList.merge(0) (gat/SegmentList.pyx:756-816) on a list already sorted by start (empty
 // segments anywhere are skipped, as the reference skips them): in place, 64 elements per step.
 // head[i] = first non-empty, or int32(start) - 0 > running max end; the previous group's end is

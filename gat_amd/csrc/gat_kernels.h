@@ -356,7 +356,8 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
       if (remaining <= length) {
         const int n = nU + nS;
         if (A.debug & 1) {} else
-        if (nU == 0 || nS > kWave) wave_sort_by_start(seg, n, lane);     // SegmentList.sort of everything
+        if (nU == 0 || nS > kWave) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
+                                        // (the MT19937 words are idle scratch while the stream comes from k_rng)
         else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
         if (A.debug & 64) return;
         nU = wave_merge0(seg, n, lane);
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     for (int i = lane; i < cnt; i += kWave) seg[n + i] = src[i];
     n += cnt;
   }
-  wave_sort_by_start(seg, n, lane);
+  wave_sort_auto(seg, n, lane);
   n = wave_merge0(seg, n, lane);
   uint2* __restrict__ out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
   for (int i = lane; i < n; i += kWave) out[i] = seg[i];
