@@ -101,7 +101,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    acc = dict(ms_sampler=0.0, ms_contig=0.0, ms_count=0.0, n_placed=0, n_draws=0, n_sampled_segments=0, n_retried=0)
+    acc = dict(ms_sampler=0.0, ms_contig=0.0, ms_count=0.0, n_placed=0, n_draws=0, n_sampled_segments=0, n_retried=0,
+               n_full_units=0)
     for i in range(args.steps):
         st = step(args.warmup + i)
         for k in acc:
@@ -151,7 +152,8 @@ def main():
                         "mt19937_draws_per_s": acc["n_draws"] / samp_s if samp_s else 0.0,
                         "kernel_samples_per_s": S * args.steps / samp_s if samp_s else 0.0,
                         "contig_kernel_avg_ms": acc["ms_contig"] / args.steps,
-                        "units_retried": acc["n_retried"]},
+                        "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
+                        "work_units": S * args.steps * flat["n_units"]},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, counters, args.seed, args.cpu_seconds)

@@ -94,11 +94,15 @@ __global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
     x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
   }
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
-  for (int blk = 0; blk < rows / kMtN; ++blk) {
+  for (int done = 0; done < rows; done += kMtN) {
+    // the last block is generated only as far as rows are wanted (rows is a multiple of 8)
+    const int want = rows - done < kMtN ? rows - done : kMtN;
+    const int n1 = want < kMtN - kMtM ? want : kMtN - kMtM;
+    const int n2 = want < kMtN - 1 ? want : kMtN - 1;
     uint32_t cur = mt[0];
     uint32_t first_new = 0;
 #pragma unroll 4
-    for (int i = 0; i < kMtN - kMtM; ++i) {         // 0..226: partner i+397 (old)
+    for (int i = 0; i < n1; ++i) {                  // 0..226: partner i+397 (old)
       const uint32_t nxt = mt[(i + 1) * kWave];
       const uint32_t far = mt[(i + kMtM) * kWave];
       const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
       cur = nxt;
     }
 #pragma unroll 4
-    for (int i = kMtN - kMtM; i < kMtN - 1; ++i) {  // 227..622: partner i-227 (new)
+    for (int i = kMtN - kMtM; i < n2; ++i) {        // 227..622: partner i-227 (new)
       const uint32_t nxt = mt[(i + 1) * kWave];
       const uint32_t far = mt[(i + kMtM - kMtN) * kWave];
       const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
       out[(int64_t)i * kWave] = mt_temper(v);
       cur = nxt;
     }
-    {                                               // 623: wraps to the new word 0
+    if (want == kMtN) {                             // 623: wraps to the new word 0
       const uint32_t far = mt[(kMtM - 1) * kWave];
       const uint32_t y = (cur & kMtUpper) | (first_new & kMtLower);
       const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);

@@ -454,12 +454,27 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     };
     for (int32_t u : P->h_order) {
       const UnitDev& U = P->h_units[u];
-      double e = 1.6;                                                      // offset draw: range varies per placement
-      if (U.hist_total > 2) e += expect((uint64_t)U.hist_total - 2);
-      if (U.bucket > 1) e += expect((uint64_t)U.bucket - 1);
-      if (U.ws_total > 1) e += expect((uint64_t)U.ws_total - 1);
-      const double need = e * (double)U.hist_total * 1.12 + 160.0;
-      int64_t rows = ((int64_t)std::ceil(need / gat::kMtN)) * gat::kMtN;
+      // offset draw: range = chosen workspace segment + sampled length - 2, weighted by how often a segment
+      // is chosen (its share of the workspace) and taken at the mean working-segment length
+      const gat_segment* uw = d->ws + d->ws_off[u];
+      const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+      const double mean_len = U.hist_total ? (double)(uint32_t)U.ltotal / (double)U.hist_total : 1.0;
+      double e = 0.0, v = 0.0;
+      for (int64_t k = 0; k < nuw; ++k) {
+        const double wl = (double)(uw[k].end - uw[k].start);
+        const double p = expect((uint64_t)(wl + mean_len)) ;
+        e += wl / (double)U.ws_total * p;
+      }
+      auto addvar = [&](double ex) { if (ex > 0) v += (ex - 1.0) * ex; };   // geometric: var = (1-p)/p^2 = ex(ex-1)
+      addvar(e);
+      if (U.hist_total > 2) { const double x = expect((uint64_t)U.hist_total - 2); e += x; addvar(x); }
+      if (U.bucket > 1) { const double x = expect((uint64_t)U.bucket - 1); e += x; addvar(x); }
+      if (U.ws_total > 1) { const double x = expect((uint64_t)U.ws_total - 1); e += x; addvar(x); }
+      const char* env_sl = getenv("GAT_RNG_SLACK");
+      const double slack = env_sl ? atof(env_sl) : 1.06;
+      // spread of the raw-output count: ~sqrt(placements) x (std per placement ~1.3), 6 sigma
+      const double need = e * (double)U.hist_total * slack + 6.0 * std::sqrt((double)U.hist_total * (v + 0.5)) + 64.0;
+      int64_t rows = ((int64_t)std::ceil(need / 8.0)) * 8;          // whole k_place chunks
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
       P->rng_rows_total += rows;
