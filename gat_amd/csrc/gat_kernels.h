@@ -76,60 +76,57 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rng: one MT19937 stream per LANE (64 streams of one unit = one tile per wave).  The state of
-// lane l is mt[i*64 + l] (bank-conflict free); seeding and the twist are the serial reference
-// loops, run by all 64 lanes at once.  Tempered outputs go to HBM as rows of 64 (one coalesced
-// 256-B store per output index), which is the order k_place consumes them in.
-__global__ __launch_bounds__(64) void k_rng(SamplerArgs A) {
+// k_rng: one MT19937 stream per LANE (64 streams of one unit = one tile per workgroup).  The
+// state of lane l is mt[i*64 + l] (bank-conflict free, 156 KB: one workgroup per CU).  Seeding and
+// the twist are the serial reference loops run by all 64 lanes at once.  The workgroup has two
+// waves on two SIMDs: wave 0 twists chunk t in place while wave 1 tempers chunk t-1 and stores it
+// to HBM as rows of 64 (one coalesced 256-B store per output index, the order k_place consumes),
+// one barrier per chunk; the twist of word i only reads words i, i+1 and i+397 / i-227, never a
+// word of the chunk being tempered.
+constexpr int kRngChunk = 52;      // 624 = 12 * 52
+
+__global__ __launch_bounds__(128) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* mt = lds + threadIdx.x;                 // lane column, stride 64
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t* mt = lds + lane;                        // lane column, stride 64
   const int sb = blockIdx.x, a = blockIdx.y;
   const int u = A.order[a];
   const int rows = A.rng_rows[a];
-  const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
-  uint32_t x = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
-  for (int i = 0; i < kMtN; ++i) {                  // init_genrand
-    mt[i * kWave] = x;
-    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
+  if (wv == 0) {
+    const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
+    uint32_t x = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
+    for (int i = 0; i < kMtN; ++i) {                // init_genrand
+      mt[i * kWave] = x;
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
+    }
   }
+  __syncthreads();
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
-  for (int done = 0; done < rows; done += kMtN) {
-    // the last block is generated only as far as rows are wanted (rows is a multiple of 8)
-    const int want = rows - done < kMtN ? rows - done : kMtN;
-    const int n1 = want < kMtN - kMtM ? want : kMtN - kMtM;
-    const int n2 = want < kMtN - 1 ? want : kMtN - 1;
-    uint32_t cur = mt[0];
-    uint32_t first_new = 0;
+  const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
+  for (int t = 0; t <= nchunks; ++t) {
+    if (wv == 0) {
+      if (t < nchunks) {
+        const int e0 = t * kRngChunk;
+        const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
+        const int i0 = (t % (kMtN / kRngChunk)) * kRngChunk;
 #pragma unroll 4
-    for (int i = 0; i < n1; ++i) {                  // 0..226: partner i+397 (old)
-      const uint32_t nxt = mt[(i + 1) * kWave];
-      const uint32_t far = mt[(i + kMtM) * kWave];
-      const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
-      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
-      mt[i * kWave] = v;
-      if (i == 0) first_new = v;
-      out[(int64_t)i * kWave] = mt_temper(v);
-      cur = nxt;
-    }
+        for (int k = 0; k < cnt; ++k) {
+          const int i = i0 + k;
+          const int in = i + 1 == kMtN ? 0 : i + 1;                  // word 623 pairs with the NEW word 0
+          const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;   // i < 227: old word i+397, else new word i-227
+          const uint32_t cur = mt[i * kWave], nxt = mt[in * kWave], far = mt[jf * kWave];
+          const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
+          mt[i * kWave] = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+        }
+      }
+    } else if (t >= 1) {
+      const int e0 = (t - 1) * kRngChunk;
+      const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
+      const int i0 = ((t - 1) % (kMtN / kRngChunk)) * kRngChunk;
 #pragma unroll 4
-    for (int i = kMtN - kMtM; i < n2; ++i) {        // 227..622: partner i-227 (new)
-      const uint32_t nxt = mt[(i + 1) * kWave];
-      const uint32_t far = mt[(i + kMtM - kMtN) * kWave];
-      const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
-      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
-      mt[i * kWave] = v;
-      out[(int64_t)i * kWave] = mt_temper(v);
-      cur = nxt;
+      for (int k = 0; k < cnt; ++k) out[(int64_t)(e0 + k) * kWave] = mt_temper(mt[(i0 + k) * kWave]);
     }
-    if (want == kMtN) {                             // 623: wraps to the new word 0
-      const uint32_t far = mt[(kMtM - 1) * kWave];
-      const uint32_t y = (cur & kMtUpper) | (first_new & kMtLower);
-      const uint32_t v = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
-      mt[(kMtN - 1) * kWave] = v;
-      out[(int64_t)(kMtN - 1) * kWave] = mt_temper(v);
-    }
-    out += (int64_t)kMtN * kWave;
+    __syncthreads();
   }
 }
 
