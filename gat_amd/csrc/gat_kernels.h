@@ -78,14 +78,16 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // ------------------------------------------------------------------------------------------
 // k_rng: one MT19937 stream per LANE (64 streams of one unit = one tile per workgroup).  The
 // state of lane l is mt[i*64 + l] (bank-conflict free, 156 KB: one workgroup per CU).  Seeding and
-// the twist are the serial reference loops run by all 64 lanes at once.  The workgroup has two
-// waves on two SIMDs: wave 0 twists chunk t in place while wave 1 tempers chunk t-1 and stores it
-// to HBM as rows of 64 (one coalesced 256-B store per output index, the order k_place consumes),
-// one barrier per chunk; the twist of word i only reads words i, i+1 and i+397 / i-227, never a
-// word of the chunk being tempered.
+// the twist are the serial reference recurrences run by all 64 lanes at once.  The workgroup has
+// four waves, one per SIMD: in step s waves 0/1 twist chunks 2s / 2s+1 in place while waves 2/3
+// temper chunks 2s-2 / 2s-1 and store them to HBM as rows of 64 (one coalesced 256-B store per
+// output index, the order k_place consumes), one barrier per step.  The twist of word i reads
+// words i, i+1 and i+397 (old) or i-227 (new, written >= 4 chunks earlier); the only word another
+// wave changes in the same step is the old word that follows chunk 2s, which wave 0 reads one step
+// ahead.
 constexpr int kRngChunk = 52;      // 624 = 12 * 52
 
-__global__ __launch_bounds__(128) void k_rng(SamplerArgs A) {
+__global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint32_t* mt = lds + lane;                        // lane column, stride 64
@@ -103,28 +105,40 @@ __global__ __launch_bounds__(128) void k_rng(SamplerArgs A) {
   __syncthreads();
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
-  for (int t = 0; t <= nchunks; ++t) {
-    if (wv == 0) {
+  constexpr int kPerBlock = kMtN / kRngChunk;       // 12 chunks per 624-word block
+  uint32_t next_old = mt[kRngChunk * kWave];         // old first word of chunk 1 (for wave 0, step 0)
+  for (int s = 0; 2 * s - 2 < nchunks; ++s) {
+    if (wv < 2) {
+      const int t = 2 * s + wv;
       if (t < nchunks) {
         const int e0 = t * kRngChunk;
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
-        const int i0 = (t % (kMtN / kRngChunk)) * kRngChunk;
+        const int i0 = (t % kPerBlock) * kRngChunk;
 #pragma unroll 4
         for (int k = 0; k < cnt; ++k) {
           const int i = i0 + k;
-          const int in = i + 1 == kMtN ? 0 : i + 1;                  // word 623 pairs with the NEW word 0
-          const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;   // i < 227: old word i+397, else new word i-227
-          const uint32_t cur = mt[i * kWave], nxt = mt[in * kWave], far = mt[jf * kWave];
+          const int in = i + 1 == kMtN ? 0 : i + 1;                        // word 623 pairs with the NEW word 0
+          const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;    // i < 227: old word i+397, else new word i-227
+          const uint32_t cur = mt[i * kWave], far = mt[jf * kWave];
+          uint32_t nxt = mt[in * kWave];
+          if (wv == 0 && k == kRngChunk - 1) nxt = next_old;               // wave 1 is rewriting that word right now
           const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
           mt[i * kWave] = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
         }
       }
-    } else if (t >= 1) {
-      const int e0 = (t - 1) * kRngChunk;
-      const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
-      const int i0 = ((t - 1) % (kMtN / kRngChunk)) * kRngChunk;
+      if (wv == 0) {                                 // first word of chunk 2(s+1)+1: untouched until the next step
+        const int tn = 2 * (s + 1) + 1;
+        next_old = mt[((tn % kPerBlock) * kRngChunk) * kWave];
+      }
+    } else {
+      const int t = 2 * s - 4 + wv;                  // waves 2, 3: chunks 2s-2, 2s-1
+      if (t >= 0 && t < nchunks) {
+        const int e0 = t * kRngChunk;
+        const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
+        const int i0 = (t % kPerBlock) * kRngChunk;
 #pragma unroll 4
-      for (int k = 0; k < cnt; ++k) out[(int64_t)(e0 + k) * kWave] = mt_temper(mt[(i0 + k) * kWave]);
+        for (int k = 0; k < cnt; ++k) out[(int64_t)(e0 + k) * kWave] = mt_temper(mt[(i0 + k) * kWave]);
+      }
     }
     __syncthreads();
   }

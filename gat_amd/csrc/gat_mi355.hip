@@ -663,7 +663,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         A.st_n = P->d_st_n.p; A.st_remaining = P->d_st_remaining.p; A.st_length = P->d_st_length.p; A.st_draws = P->d_st_draws.p;
         const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
-        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(128), lds_rng, ctx->stream, A);
+        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(256), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
         hipLaunchKernelGGL(gat::k_place, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
