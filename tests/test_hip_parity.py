@@ -219,3 +219,46 @@ def test_run_api_rows_match_reference(ctx):
         k = [str(c) for c in z["counters"]].index(r.counter)
         a = [str(t) for t in z["track_names"]].index(r.annotation)
         assert r.observed == z["observed"][k, a]
+
+
+def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
+    import collections
+    from gat_amd import problem
+    contigs = collections.OrderedDict(("k%d" % i, 3000000 + 500000 * i) for i in range(n_contigs))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    annos = [("t0", synthetic.random_segments(contigs, 500, 1500, int(rs.randint(1 << 30))))]
+    ws = synthetic.workspace_ungapped(contigs, pieces=ws_pieces, gap=600)
+    return problem.flatten_arrays(segs, annos, ws, None)
+
+
+@pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "rows_run_out", "slab_overflow_retry"])
+def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
+    """code paths the BASELINE shapes do not reach: workspace lists beyond the register / LDS tables,
+    units beyond the register sort, streams that run out of pre-generated rows (redone from the seed),
+    and slab overflow (batch redone with doubled capacity).  All must stay bit-exact."""
+    rs = np.random.RandomState(hash(case) % 1000)
+    if case == "many_workspace_segments":
+        flat = _big_problem(rs, 900, 400)
+    elif case == "large_units":
+        flat = _big_problem(rs, 6000, 3)
+    elif case == "rows_run_out":
+        monkeypatch.setenv("GAT_RNG_SLACK", "0.6")
+        flat = _big_problem(rs, 700, 5)
+    else:
+        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+        flat = _big_problem(rs, 700, 5)
+    counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    S = 24
+    want, wsamples = O.run_samples(flat, counters, 99, 1, 3, 3 + S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 99, 3, 3 + S)
+    st = P.last_stats
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), (case, c)
+    seg, off = P.sample(99, 3, 3 + S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    if case == "rows_run_out":
+        assert st["n_full_units"] > 0
+    if case == "slab_overflow_retry":
+        assert st["n_retried"] > 0
+    P.close()
