@@ -118,6 +118,14 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
+        # HBM bytes of the count kernel per launch from the committed rocprofv3 PMC passes of this same
+        # command (tools/collect_profiles.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 FETCH correction
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_count_kernel_traffic.json")
+        if os.path.exists(tf) and args.scale == 1.0:
+            rec = json.load(open(tf)).get("%s:%d" % (args.config, S))
+            if rec:
+                traffic = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
         total_samples = S * args.steps * world
         bytes_per_sample = info["algorithmic_bytes_per_sample"]
         count_s = acc["ms_count"] / 1e3
@@ -143,7 +151,8 @@ def main():
                        "samples_per_step_per_gpu": S, "sharding": "samples, contiguous ranges per rank; one RCCL all-gather"},
             "roofline": {"bound": "hbm", "kernel": "k_count_seg (overlap counters)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None,
+                         "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_per_sample * S,
                          "algorithmic_bytes_per_sample": bytes_per_sample,
                          "avg_launch_ms": acc["ms_count"] / args.steps,
                          "share_of_gpu_time": acc["ms_count"] / max(1e-9, acc["ms_count"] + acc["ms_sampler"] + acc["ms_contig"])},
