@@ -8,6 +8,8 @@ import re
 import numpy as np
 
 from . import intervals, problem, synthetic            # noqa: F401
+from . import io as IO                                   # noqa: F401
+from . import stats as Stats                             # noqa: F401
 from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator,   # noqa: F401
                      Counter, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
@@ -134,3 +136,89 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                     outfile.write("%s\t%s\t%i\t%s\n" % (o.track, o.annotation, o.observed,
                                                       ",".join("%i" % x for x in o.samples)))
     return annotator_results
+
+
+def buildParser(usage=None):
+    """gat command line parser: the options of the reference's buildParser (gat/__init__.py:54-429)
+    that concern the accelerated path, with the same names, destinations and defaults."""
+    import optparse
+    parser = optparse.OptionParser(version="%prog (gat_amd " + __version__ + ")", usage=usage)
+    g = optparse.OptionGroup(parser, "Input options")
+    g.add_option("-a", "--annotation-bed-file", "--annotations", "--annotation-file", dest="annotation_files",
+                 type="string", action="append", help="filename with annotations")
+    g.add_option("-s", "--segment-bed-file", "--segments", "--segment-file", dest="segment_files", type="string",
+                 action="append", help="filename with segments")
+    g.add_option("-w", "--workspace-bed-file", "--workspace", "--workspace-file", dest="workspace_files",
+                 type="string", action="append", help="filename with workspace segments")
+    g.add_option("-i", "--isochore-bed-file", "--isochores", "--isochore-file", dest="isochore_files", type="string",
+                 action="append", help="filename with isochore segments")
+    g.add_option("--ignore-segment-tracks", dest="ignore_segment_tracks", action="store_true",
+                 help="all segments belong to one track called 'merged' [default]")
+    g.add_option("--with-segment-tracks", dest="ignore_segment_tracks", action="store_false",
+                 help="the segments file is arranged in tracks")
+    g.add_option("--enable-split-tracks", dest="enable_split_tracks", action="store_true")
+    g.add_option("--annotations-label", dest="annotations_label", type="string")
+    parser.add_option_group(g)
+    g = optparse.OptionGroup(parser, "Output options")
+    g.add_option("-o", "--order", dest="output_order", type="choice",
+                 choices=("track", "annotation", "fold", "pvalue", "qvalue", "observed"))
+    g.add_option("--output-tables-pattern", dest="output_tables_pattern", type="string")
+    g.add_option("--output-counts-pattern", dest="output_counts_pattern", type="string")
+    g.add_option("--output-samples-pattern", dest="output_samples_pattern", type="string")
+    parser.add_option_group(g)
+    g = optparse.OptionGroup(parser, "Sampling algorithm options")
+    g.add_option("-c", "--counter", dest="counters", type="choice", action="append", choices=tuple(COUNTERS.keys()))
+    g.add_option("-m", "--sampler", dest="sampler", type="choice", choices=("annotator",))
+    g.add_option("-n", "--num-samples", dest="num_samples", type="int")
+    g.add_option("--bucket-size", dest="bucket_size", type="int")
+    g.add_option("--nbuckets", dest="nbuckets", type="int")
+    parser.add_option_group(g)
+    g = optparse.OptionGroup(parser, "Statistics options")
+    g.add_option("-p", "--pvalue-method", dest="pvalue_method", type="choice", choices=("empirical",))
+    g.add_option("-q", "--qvalue-method", dest="qvalue_method", type="choice",
+                 choices=("BH", "bonferroni", "holm", "hochberg", "BY", "none"))
+    g.add_option("--pseudo-count", dest="pseudo_count", type="float")
+    parser.add_option_group(g)
+    g = optparse.OptionGroup(parser, "Processing options")
+    g.add_option("-t", "--num-threads", dest="num_threads", type="int", help="accepted and ignored: the GPU replaces the pool")
+    g.add_option("--random-seed", dest="random_seed", type="int")
+    g.add_option("--truncate-segments-to-workspace", dest="truncate_segments_to_workspace", action="store_true")
+    g.add_option("--truncate-workspace-to-annotations", dest="truncate_workspace_to_annotations", action="store_true")
+    g.add_option("--restrict-workspace", dest="restrict_workspace", action="store_true")
+    g.add_option("--device", dest="device", type="int", help="HIP device ordinal [default=%default]")
+    parser.add_option_group(g)
+    g = optparse.OptionGroup(parser, "Common options")
+    g.add_option("-v", "--verbose", dest="loglevel", type="int")
+    g.add_option("-S", "--stdout", dest="stdout", type="string", metavar="FILE")
+    g.add_option("-L", "--log", dest="stdlog", type="string", metavar="FILE")
+    parser.add_option_group(g)
+    parser.set_defaults(annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
+                        counters=[], enable_split_tracks=False, ignore_segment_tracks=True, isochore_files=[],
+                        nbuckets=100000, num_samples=1000, num_threads=0, output_counts_pattern=None,
+                        output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",
+                        overlapping_annotations=False, pseudo_count=1.0, pvalue_method="empirical", qvalue_method="BH",
+                        random_seed=None, restrict_workspace=False, sampler="annotator", segment_files=[],
+                        truncate_segments_to_workspace=False, truncate_workspace_to_annotations=False,
+                        workspace_files=[], device=0, loglevel=1, stdout=None, stdlog=None)
+    return parser
+
+
+def fromSegments(options, args=None):
+    """run an analysis from BED files: scripts/gat-run.py:77-220 of the reference."""
+    segments, annotations, workspaces, isochores = IO.buildSegments(options)
+    workspace = IO.applyIsochores(segments, annotations, workspaces, options, isochores,
+                                  truncate_segments_to_workspace=options.truncate_segments_to_workspace,
+                                  truncate_workspace_to_annotations=options.truncate_workspace_to_annotations,
+                                  restrict_workspace=options.restrict_workspace)
+    if options.sampler != "annotator":
+        raise ValueError("only the annotator sampler runs on the GPU path")
+    sampler = SamplerAnnotator(bucket_size=options.bucket_size, nbuckets=options.nbuckets)
+    counters = []
+    for counter in options.counters:
+        if counter not in COUNTERS:
+            raise ValueError("unknown counter '%s'" % counter)
+        counters.append(COUNTERS[counter]())
+    return run(segments, annotations, workspace, sampler, counters, workspace_generator=UnconditionalWorkspace(),
+               num_samples=options.num_samples, output_counts_pattern=options.output_counts_pattern,
+               output_samples_pattern=options.output_samples_pattern, pseudo_count=options.pseudo_count,
+               num_threads=options.num_threads, random_seed=options.random_seed)

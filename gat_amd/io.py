@@ -1,0 +1,198 @@
+"""Input/output around the hot path, mirroring gat/IO.py and the BED reader of gat/Engine.pyx:
+BED tracks -> IntervalCollection (readFromBed, gat/Engine.pyx:2480-2556), buildSegments /
+applyIsochores (gat/IO.py:88-293) and the result table (outputResults, gat/IO.py:457-539)."""
+import collections
+import glob
+import gzip
+import os
+import re
+
+import numpy as np
+
+from . import engine, stats
+from . import intervals as iv
+
+_TRACK_RE = re.compile(r'([^\s=]+) *= *("[^"]*"|[^ ]*)')
+
+
+def openFile(filename, mode="r"):
+    if filename.endswith(".gz"):
+        return gzip.open(filename, mode + "t")
+    return open(filename, mode)
+
+
+def readFromBed(filenames, allow_multiple=False, ignore_tracks=False):
+    """gat/Engine.pyx:2480-2556: track -> IntervalDictionary.  Track name = `track name=...` line,
+    else column 4, else the file's base name; ignore_tracks puts everything into 'merged'."""
+    if isinstance(filenames, str):
+        filenames = [filenames]
+    acc = collections.OrderedDict()        # track -> contig -> [starts, ends]
+    tracks = {}
+    for filename in filenames:
+        default_name = os.path.basename(filename)
+        track = None
+        with openFile(filename, "r") as infile:
+            for line in infile:
+                if line.startswith("#") or line.startswith("\n"):
+                    continue
+                if line.startswith("track"):
+                    track = dict((k, v[1:-1] if v[:1] == '"' else v) for k, v in _TRACK_RE.findall(line[:-1]))
+                    continue
+                fields = line.rstrip("\n").split("\t")
+                if len(fields) < 3:
+                    raise IOError("malformatted entry in %s: %r" % (filename, line))
+                if ignore_tracks:
+                    name = "merged"
+                elif track is not None:
+                    if "name" not in track:
+                        raise KeyError("track without field 'name' in file '%s'" % filename)
+                    name = track["name"]
+                elif len(fields) >= 4 and fields[3]:
+                    name = fields[3]
+                else:
+                    name = default_name
+                if name in tracks:
+                    if tracks[name] != filename:
+                        if not allow_multiple:
+                            raise ValueError("track '%s' in multiple filenames: %s and %s" % (name, tracks[name], filename))
+                        tracks[name] = filename
+                else:
+                    tracks[name] = filename
+                per = acc.setdefault(name, collections.OrderedDict())
+                se = per.setdefault(fields[0], ([], []))
+                start, end = int(fields[1]), int(fields[2])
+                assert start <= end, "attempting to add invalid segment %i-%i" % (start, end)
+                se[0].append(start)
+                se[1].append(end)
+    out = collections.defaultdict(engine.IntervalDictionary)
+    for name, per in acc.items():
+        d = engine.IntervalDictionary()
+        for contig, (s, e) in per.items():
+            d.add(contig, engine.SegmentList(array=iv.make(np.array(s, dtype=np.int64), np.array(e, dtype=np.int64))))
+        out[name] = d
+    return out
+
+
+def readSegmentList(label, filenames, enable_split_tracks=False, ignore_tracks=False):
+    """gat/IO.py:36-64."""
+    results = engine.IntervalCollection(name=label)
+    results.intervals = readFromBed(filenames, allow_multiple=enable_split_tracks, ignore_tracks=ignore_tracks)
+    return results
+
+
+def expandGlobs(infiles):
+    out = []
+    for x in infiles:
+        out.extend(glob.glob(x))
+    return out
+
+
+def buildSegments(options):
+    """gat/IO.py:88-185: load and normalize segments, annotations, workspace (collapsed), isochores."""
+    options.segment_files = expandGlobs(options.segment_files)
+    options.annotation_files = expandGlobs(options.annotation_files)
+    options.workspace_files = expandGlobs(options.workspace_files)
+    if not options.segment_files:
+        raise ValueError("please specify at least one segment file")
+    if not options.annotation_files:
+        raise ValueError("please specify at least one annotation file")
+    if not options.workspace_files:
+        raise ValueError("please specify at least one workspace file")
+    segments = readSegmentList("segments", options.segment_files, ignore_tracks=options.ignore_segment_tracks)
+    segments.normalize()
+    if segments.sum() == 0:
+        raise ValueError("segments file is empty - run aborted")
+    if len(segments) > 1000:
+        raise ValueError("too many (%i) segment files - use track definitions or --ignore-segment-tracks" % len(segments))
+    annotations = readSegmentList("annotations", options.annotation_files, enable_split_tracks=options.enable_split_tracks,
+                                  ignore_tracks=options.annotations_label is not None)
+    if options.annotations_label is not None:
+        annotations.setName(options.annotations_label)
+    if getattr(options, "annotations_to_points", None):
+        raise NotImplementedError("--annotations-to-points is outside the accelerated path")
+    if getattr(options, "overlapping_annotations", False):
+        raise NotImplementedError("--overlapping-annotations is outside the accelerated path (counters need normalized lists)")
+    annotations.normalize()
+    workspaces = readSegmentList("workspaces", options.workspace_files, options.enable_split_tracks)
+    workspaces.normalize()
+    workspaces.collapse()
+    workspaces.restrict("collapsed")
+    isochores = None
+    if options.isochore_files:
+        isochores = engine.IntervalCollection(name="isochores")
+        isochores.intervals = readFromBed(expandGlobs(options.isochore_files))
+        isochores.sort()
+        isochores.check()
+        isochores.normalize()
+        isochores.intersect(workspaces["collapsed"])
+    return segments, annotations, workspaces, isochores
+
+
+def applyIsochores(segments, annotations, workspaces, options, isochores=None, truncate_segments_to_workspace=False,
+                   truncate_workspace_to_annotations=False, restrict_workspace=False):
+    """gat/IO.py:188-293."""
+    if isochores:
+        workspaces.toIsochores(isochores, truncate=True)
+        annotations.toIsochores(isochores, truncate=True)
+        segments.toIsochores(isochores, truncate=options.truncate_segments_to_workspace)
+        if workspaces.sum() == 0:
+            raise ValueError("isochores and workspaces do not overlap")
+        if annotations.sum() == 0:
+            raise ValueError("isochores and annotations do not overlap")
+        if segments.sum() == 0:
+            raise ValueError("isochores and segments do not overlap")
+    else:
+        if options.truncate_segments_to_workspace:
+            segments.intersect(workspaces["collapsed"])
+        else:
+            segments.filter(workspaces["collapsed"])
+        annotations.intersect(workspaces["collapsed"])
+    workspace = workspaces["collapsed"]
+    if restrict_workspace:
+        for _ in (segments, annotations):
+            if "merged" in segments:
+                workspace.filter(segments["merged"])
+            else:
+                segments.merge()
+                workspace.filter(segments["merged"])
+                del segments["merged"]
+    if truncate_workspace_to_annotations:
+        annotations.merge()
+        annotations["merged"].normalize()
+        workspace.intersect(annotations["merged"])
+        del annotations["merged"]
+    return workspace
+
+
+def outputResults(results, options, header, description_header=(), description_width=0, descriptions=None,
+                  format_observed="%i"):
+    """gat/IO.py:457-539: q-values, one table per counter, rows ordered by --order."""
+    pvalues = [x.pvalue for x in results]
+    qvalues = stats.getQValues(pvalues, method=options.qvalue_method)
+    for x, qvalue in zip(results, qvalues):
+        x.qvalue = qvalue
+        x.format_observed = format_observed
+    counters = []
+    for x in results:
+        if x.counter not in counters:
+            counters.append(x.counter)
+    for counter in counters:
+        if len(counters) == 1:
+            outfile, output = options.stdout, list(results)
+        else:
+            outfile = openFile(re.sub("%s", counter, options.output_tables_pattern), "w")
+            output = [x for x in results if x.counter == counter]
+        outfile.write("\t".join(list(header) + list(description_header)) + "\n")
+        keys = {"track": lambda x: (x.track, x.annotation), "observed": lambda x: x.observed,
+                "annotation": lambda x: (x.annotation, x.track), "fold": lambda x: x.fold,
+                "pvalue": lambda x: x.pvalue, "qvalue": lambda x: x.qvalue}
+        if options.output_order not in keys:
+            raise ValueError("unknown sort order %s" % options.output_order)
+        output.sort(key=keys[options.output_order])
+        for result in output:
+            outfile.write(str(result))
+            if descriptions:
+                outfile.write("\t" + "\t".join(descriptions.get(result.annotation, [""] * description_width)))
+            outfile.write("\n")
+        if outfile is not options.stdout:
+            outfile.close()

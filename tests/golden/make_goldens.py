@@ -547,8 +547,85 @@ def g6_stats():
     print("G6 stats: %d cases" % len(cases))
 
 
+# ------------------------------------------------------------------------------------------
+# G5 the command line tool end to end: the reference's scripts/gat-run.py (option parsing, BED
+# reading, isochores, gat.run, BH q-values, table output) with the per-unit re-seeding patched into
+# gat.computeSample, so that its table is the one the GPU build has to print byte for byte.
+def write_bed(path, tracks, with_track_lines=True):
+    with open(path, "w") as f:
+        for name, per in tracks:
+            if with_track_lines:
+                f.write("track name=%s\n" % name)
+            for contig, a in per.items():
+                for s, e in pairs(a):
+                    f.write("%s\t%i\t%i\n" % (contig, s, e))
+
+
+def g5_cli():
+    import importlib.util
+    cli_dir = os.path.join(HERE, "cli")
+    os.makedirs(cli_dir, exist_ok=True)
+    contigs, cfg = synthetic.small_genome()
+    seg2 = synthetic.random_segments(contigs, 120, 200, 77)
+    write_bed(os.path.join(cli_dir, "segments.bed"), [("segA", cfg["segments"]), ("segB", seg2)])
+    write_bed(os.path.join(cli_dir, "annotations.bed"), cfg["annotations"])
+    write_bed(os.path.join(cli_dir, "workspace.bed"), [("ws", cfg["workspace"])], with_track_lines=False)
+    write_bed(os.path.join(cli_dir, "isochores.bed"), list(cfg["isochores"].items()))
+    spec = importlib.util.spec_from_file_location("gat_run_ref", os.path.join(os.path.dirname(gat.__file__), "..", "scripts", "gat-run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    original = gat.computeSample
+    state = dict(track=None, base=0, n_units=0, sampler=None)
+
+    def patched(args):
+        w = args[0]
+        if state["track"] != w.track:                      # next segment track: disjoint unit streams
+            if state["track"] is not None:
+                state["base"] = (state["base"] + state["num_samples"] * state["n_units"]) & 0xFFFFFFFF
+            state["track"] = w.track
+            state["sampler"] = ReseedingSampler(w.sampler, w.segments, state["base"])
+            state["n_units"] = state["sampler"].n_units
+        rs = state["sampler"]
+        rs.base_seed = state["base"]
+        rs.sample_id = int(w.sample_id)
+        rs.records = []
+        return original((w._replace(sampler=rs),) + tuple(args[1:]))
+
+    cases = collections.OrderedDict([
+        ("default", ["--num-samples=100", "--random-seed=5"]),
+        ("isochores_track_order", ["--num-samples=80", "--random-seed=6", "--isochores=%s" % os.path.join(cli_dir, "isochores.bed"),
+                                   "--order=track", "--counter=segment-overlap"]),
+        ("segment_tracks", ["--num-samples=60", "--random-seed=7", "--with-segment-tracks", "--order=annotation",
+                            "--qvalue-method=holm"]),
+        ("density_truncated", ["--num-samples=50", "--random-seed=8", "--counter=nucleotide-density",
+                               "--truncate-segments-to-workspace", "--order=pvalue", "--pseudo-count=0.5"]),
+    ])
+    gat.computeSample = patched
+    try:
+        for name, extra in cases.items():
+            out = os.path.join(cli_dir, "expected_%s.tsv" % name)
+            argv = ["gat-run.py", "--segments=%s" % os.path.join(cli_dir, "segments.bed"),
+                    "--annotations=%s" % os.path.join(cli_dir, "annotations.bed"),
+                    "--workspace=%s" % os.path.join(cli_dir, "workspace.bed"),
+                    "--stdout=%s" % out, "--log=%s" % os.path.join(cli_dir, "ref.log")] + extra
+            seed = int([x for x in extra if x.startswith("--random-seed")][0].split("=")[1])
+            ns = int([x for x in extra if x.startswith("--num-samples")][0].split("=")[1])
+            state.update(track=None, base=seed, n_units=0, sampler=None, num_samples=ns)
+            mod.main(argv)
+            lines = [l for l in open(out) if not l.startswith("#")]
+            with open(out, "w") as f:
+                f.writelines(lines)
+            print("G5 cli %s: %d rows" % (name, len(lines) - 1))
+    finally:
+        gat.computeSample = original
+    if os.path.exists(os.path.join(cli_dir, "ref.log")):
+        os.remove(os.path.join(cli_dir, "ref.log"))
+    with open(os.path.join(cli_dir, "cases.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
     if "g1" in which:
         g1_algebra()
     if "g2" in which:
@@ -557,5 +634,7 @@ if __name__ == "__main__":
         g3_sampler()
     if "g4" in which:
         g4_runs()
+    if "g5" in which:
+        g5_cli()
     if "g6" in which:
         g6_stats()

@@ -262,3 +262,27 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     if case == "slab_overflow_retry":
         assert st["n_retried"] > 0
     P.close()
+
+
+def test_cli_table_matches_reference(ctx, tmp_path):
+    """scripts/gat-run.py end to end against the table the reference's gat-run.py printed for the same
+    BED files and seed (per-unit stream contract patched into the reference, tests/golden/make_goldens.py)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gat_run_amd", os.path.join(root, "scripts", "gat-run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cli = os.path.join(G, "cli")
+    with open(os.path.join(cli, "cases.json")) as f:
+        cases = json.load(f)
+    for name, extra in cases.items():
+        extra = [x if not x.startswith("--isochores=") else "--isochores=%s" % os.path.join(cli, "isochores.bed") for x in extra]
+        out = str(tmp_path / ("%s.tsv" % name))
+        argv = ["gat-run.py", "--segments=%s" % os.path.join(cli, "segments.bed"),
+                "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+                "--workspace=%s" % os.path.join(cli, "workspace.bed"), "--stdout=%s" % out,
+                "--log=%s" % str(tmp_path / "log")] + extra
+        assert mod.main(argv) == 0
+        got = [l for l in open(out) if not l.startswith("#")]
+        want = [l for l in open(os.path.join(cli, "expected_%s.tsv" % name)) if not l.startswith("#")]
+        assert got == want, name
