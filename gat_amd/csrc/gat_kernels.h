@@ -279,14 +279,65 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     }
   };
 
-  for (int j = 0; j < rows; j += kPlaceChunk) {
-    if (__ballot(st != S_HALT) == 0) break;
-    uint32_t y[kPlaceChunk];
+  // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
+  // LDS -- needs no workspace search, no bucket draw and never an immediate placement
+  const bool simple = nws == 1 && !drawB && rank_lds && ws0.y - ws0.x > 1u;
+  auto step_simple = [&](uint32_t y, uint32_t jj) {
+    const uint32_t v = y & curmask;
+    const bool acc = st != S_HALT && v <= currange;
+    if (!__any(acc)) return;
+    if (acc) {
+      if (st == S_L) {
+        len = l_rank[1u + v];
+        if (rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }
+        else { st = S_P; curmask = maskP; currange = rangeP; }
+      } else if (st == S_P) {
+        sstart = (int32_t)ws0.x - (int32_t)len + 1;
+        const uint32_t range3 = ws0.y - 1u - (uint32_t)sstart;
+        st = S_O; curmask = 0xffffffffu >> __builtin_clz(range3); currange = range3;
+      } else {
+        const int32_t q = sstart + (int32_t)v;
+        const uint32_t start = (uint32_t)(q > 0 ? q : 0);
+        const uint32_t end = (uint32_t)(q + (int32_t)len);
+        const int32_t omin = (int32_t)ws0.y < (int32_t)end ? (int32_t)ws0.y : (int32_t)end;
+        const int32_t omax = (int32_t)ws0.x > (int32_t)start ? (int32_t)ws0.x : (int32_t)start;
+        const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+        if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
+        else {
+          reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 3][lane])[nS & 1] = make_uint2(start, end);
+          nS++;
+          if ((nS & 7) == 0) {
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nS - 8);
 #pragma unroll
-    for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
-    rp += kPlaceChunk * kWave;
+            for (int w = 0; w < 4; ++w) dst[w] = l_out[w][lane];
+          }
+          rem -= overlap;
+          st = S_L; curmask = maskL; currange = rangeL;
+        }
+      }
+    }
+  };
+
+  if (simple) {
+    for (int j = 0; j < rows; j += kPlaceChunk) {
+      if (__ballot(st != S_HALT) == 0) break;
+      uint32_t y[kPlaceChunk];
 #pragma unroll
-    for (int c = 0; c < kPlaceChunk; ++c) step(y[c], (uint32_t)(j + c));
+      for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
+      rp += kPlaceChunk * kWave;
+#pragma unroll
+      for (int c = 0; c < kPlaceChunk; ++c) step_simple(y[c], (uint32_t)(j + c));
+    }
+  } else {
+    for (int j = 0; j < rows; j += kPlaceChunk) {
+      if (__ballot(st != S_HALT) == 0) break;
+      uint32_t y[kPlaceChunk];
+#pragma unroll
+      for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
+      rp += kPlaceChunk * kWave;
+#pragma unroll
+      for (int c = 0; c < kPlaceChunk; ++c) step(y[c], (uint32_t)(j + c));
+    }
   }
   if (live) {
     for (int i = nS & ~7; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 3][lane])[i & 1];   // partial last line
