@@ -353,7 +353,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 // k_sampler: one wave per (sample, unit).  Stand-alone it runs the whole of
 // SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
 // placed segments, `remaining`, the pending length and the position in the stream handed over.
-__global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
+__global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
   uint2* seg = reinterpret_cast<uint2*>(lds + kMtLdsWords);
@@ -394,6 +394,8 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
     int32_t remaining = ltotal, true_remaining = ltotal;
     int32_t pending = -1;
     bool dirty = false;          // unintersected holds trim placeholders not yet merged away
+    bool cov_valid = false;      // cov_known = workspace coverage of unintersected as it stands
+    uint32_t cov_known = 0;
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = A.st_n[so];
@@ -429,25 +431,34 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
 
       // ---- consolidate (:582-606)
       if (remaining <= length) {
-        const int n = nU + nS;
-        if (A.debug & 1) {} else
-        if (nU == 0 || nS > kWave) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
-                                        // (the MT19937 words are idle scratch while the stream comes from k_rng)
-        else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
-        if (A.debug & 64) return;
-        nU = wave_merge0(seg, n, lane);
-        nS = 0;
-        if (A.debug & 128) return;
-        uint32_t cov = 0;
-        if (nws <= kWsLoopMax) {
-          for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
+        uint32_t cov;
+        if (nS == 0 && cov_valid) {
+          // nothing was placed since the last consolidation, only trimmed: merge(0) would just drop the
+          // placeholders (left for the final pass) and the coverage is the old one minus what the trim removed
+          cov = cov_known;
         } else {
-          for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
+          const int n = nU + nS;
+          if (A.debug & 1) {} else
+          if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
+                                        // (the MT19937 words are idle scratch while the stream comes from k_rng)
+          else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
+          if (A.debug & 64) return;
+          nU = wave_merge0(seg, n, lane);
+          nS = 0;
+          dirty = false;
+          if (A.debug & 128) return;
+          cov = 0;
+          if (nws <= kWsLoopMax) {
+            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
+          } else {
+            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
+          }
+          cov = rfl(wave_sum_u32(cov));
         }
-        cov = rfl(wave_sum_u32(cov));
+        cov_known = cov;
+        cov_valid = true;
         remaining = ltotal - (int32_t)cov;
         if (true_remaining == remaining) nuns++; else true_remaining = remaining;
-        dirty = false;
         if (A.debug & 2) break;
         // the reference still draws a position here (:628) before its loop test fails; the draws and
         // the segment are discarded and the unit's stream ends, so nothing observable depends on them
@@ -484,20 +495,25 @@ __global__ __launch_bounds__(64) void k_sampler(SamplerArgs A) {
         if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { status |= kStatusTrimAssert; break; }
         // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597); _getInsertionPoint(pos,pos+1) == k
         wave_sync();
+        uint32_t removed = 0;                      // workspace bases taken away by the trim (lane 0)
         if (lane == 0) {
           int idx = k;
           while (s > 0) {
             const uint2 v = seg[idx];
             const int32_t l = (int32_t)v.y - (int32_t)v.x;
-            if (l < s) { seg[idx] = make_uint2(0u, 0u); s -= l; }
+            uint32_t ra, rb;                       // removed range
+            if (l < s) { seg[idx] = make_uint2(0u, 0u); s -= l; ra = v.x; rb = v.y; }
             else {
-              seg[idx] = forward ? make_uint2(v.x + (uint32_t)s, v.y) : make_uint2(v.x, (uint32_t)((int32_t)v.y - s));
+              if (forward) { seg[idx] = make_uint2(v.x + (uint32_t)s, v.y); ra = v.x; rb = v.x + (uint32_t)s; }
+              else { seg[idx] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
               s = 0;
             }
+            if (rb > ra) removed += nws <= kWsLoopMax ? ws_overlap_regs(W, ra, rb) : seg_overlap_with(ws, ws_cdf, nws, ra, rb);
             if (forward) { idx++; if (idx == nU) idx = 0; }
             else { idx--; if (idx < 0) idx = nU - 1; }
           }
         }
+        cov_known -= rfl(removed);
         wave_sync();
         dirty = true;
         true_remaining = 1;
