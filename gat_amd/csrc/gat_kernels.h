@@ -627,7 +627,8 @@ struct ContigArgs {
 
 __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint2* seg = reinterpret_cast<uint2*>(lds);
+  uint32_t* scratch = lds;                               // 513 words for the bucket sort
+  uint2* seg = reinterpret_cast<uint2*>(lds + 520);
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
   const int c = blockIdx.y;
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     for (int i = lane; i < cnt; i += kWave) seg[n + i] = src[i];
     n += cnt;
   }
-  wave_sort_auto(seg, n, lane);
+  wave_sort_fast(seg, n, scratch, lane);
   n = wave_merge0(seg, n, lane);
   uint2* __restrict__ out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
   for (int i = lane; i < n; i += kWave) out[i] = seg[i];

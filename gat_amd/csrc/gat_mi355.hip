@@ -686,7 +686,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
       B.slab_in = P->d_slab.p; B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
-      const size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8;
+      const size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
       if ((int64_t)lds > ctx->max_lds)
         return set_err(ctx, GAT_ERR_CAPACITY, "contig needs %zu bytes of LDS (> %d)", lds, ctx->max_lds);
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_contig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
