@@ -161,6 +161,18 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
+// wave total on the VALU data-parallel-primitive path (no LDS crossbar): quad swaps, row mirrors,
+// then the two row broadcasts; the total lands in lane 63
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);    // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);    // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);   // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);   // row_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
 __device__ __forceinline__ int32_t wave_incl_max_i32(int32_t m, int lane) {
 #pragma unroll
   for (int d = 1; d < kWave; d <<= 1) {

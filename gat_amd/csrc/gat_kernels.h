@@ -698,12 +698,14 @@ struct AnnoView {
   int m, shift, cells;
 };
 
-// quantities of one sample segment x = [xs, xe) against one annotation list Y.
+// quantities of one sample segment x = [xs, xe) against one annotation list Y (Y.m >= 1).
 //   k1 = #starts < xs comes from the position grid (about one start per cell) plus a short scan;
 //   the scan leaves sk = start[k1], the first start >= xs.  A sample segment is far shorter than
 //   the gaps between annotation intervals, so almost always sk >= xe: x then meets only interval
 //   k1-1 and overlap = min(xe, end[k1-1]) - xs if that interval reaches past xs.  Otherwise the
-//   general form F(xe) - F(xs), F(p) = cumx[k-1] + min(p, end[k-1]) - start[k-1], is used.
+//   general form F(xe) - F(xs), F(p) = cumx[k-1] + min(p, end[k-1]) - start[k-1], is used (behind a
+//   wave-uniform __any test).  Measured alternatives that were slower: predicated fixed-count scans
+//   (+7 %), eight lookups advanced in lock step (+37 %).
 template <bool WANT_HITS>
 __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
                                             uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
@@ -714,30 +716,33 @@ __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint
   uint32_t sk = k < Y.m ? Y.start[k] : 0xffffffffu;
   while (k < hi && sk < xs) { ++k; sk = k < Y.m ? Y.start[k] : 0xffffffffu; }
   const int k1 = k;
-  const uint32_t pe = k1 > 0 ? Y.end[k1 - 1] : 0u;       // end of the last interval starting before xs
+  const uint32_t pe_raw = Y.end[k1 > 0 ? k1 - 1 : 0];
+  const bool reach = k1 > 0 && pe_raw > xs;                // the last interval starting before xs reaches past it
+  ov = reach ? (xe < pe_raw ? xe : pe_raw) - xs : 0u;
   hit = 0; midhit = 0;
-  if (!(sk < xe)) {                                       // no interval starts inside x
-    ov = pe > xs ? (xe < pe ? xe : pe) - xs : 0u;
-    if (WANT_HITS && pe > xs) {                           // first interval with end > xs is k1-1 and it starts before xs
-      hit = 1;
-      const uint32_t mid = xs + (xe - xs) / 2u;
-      midhit = mid < pe ? 1u : 0u;                        // start[k1-1] < xs <= mid
-    }
-    return;
-  }
-  int k2 = k1 + 1;                                        // #starts < xe
-  while (k2 < Y.m && Y.start[k2] < xe) ++k2;
-  uint32_t f1 = 0;
-  if (k1 > 0) f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - Y.start[k1 - 1];
-  const uint32_t ps2 = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
-  const uint32_t f2 = Y.cumx[k2 - 1] + (xe < pe2 ? xe : pe2) - ps2;
-  ov = f2 - f1;
   if (WANT_HITS) {
-    // first interval with end > xs: k1-1 if it reaches past xs, else k1 (which starts inside x)
-    hit = 1;
     const uint32_t mid = xs + (xe - xs) / 2u;
-    if (pe > xs) midhit = mid < pe ? 1u : 0u;
-    else midhit = (sk <= mid && mid < Y.end[k1]) ? 1u : 0u;
+    hit = reach ? 1u : 0u;                                 // first interval with end > xs is k1-1 and starts before xs
+    midhit = (reach && mid < pe_raw) ? 1u : 0u;
+  }
+  const bool slow = sk < xe;                               // an interval starts inside x
+  if (__any(slow)) {
+    if (slow) {
+      const uint32_t pe = k1 > 0 ? pe_raw : 0u;
+      int k2 = k1 + 1;                                     // #starts < xe
+      while (k2 < Y.m && Y.start[k2] < xe) ++k2;
+      uint32_t f1 = 0;
+      if (k1 > 0) f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - Y.start[k1 - 1];
+      const uint32_t ps2 = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
+      ov = Y.cumx[k2 - 1] + (xe < pe2 ? xe : pe2) - ps2 - f1;
+      if (WANT_HITS) {
+        // first interval with end > xs: k1-1 if it reaches past xs, else k1 (which starts inside x)
+        hit = 1;
+        const uint32_t mid = xs + (xe - xs) / 2u;
+        if (pe > xs) midhit = mid < pe ? 1u : 0u;
+        else midhit = (sk <= mid && mid < Y.end[k1]) ? 1u : 0u;
+      }
+    }
   }
 }
 
@@ -745,15 +750,14 @@ constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per
 
 // One block per (sample chunk, track tile, contig): the tile's annotation slices of that contig
 // (starts / ends / cumulated lengths + position grid) are staged into LDS once and every wave
-// streams its samples' segment lists against them.  Per (sample, track, contig) the block leaves
+// streams its samples' segment lists against them.  Per (sample, track, contig) the wave leaves
 // three uint32 partials (overlap bases, segments hit, midpoint hits) in `part`; k_count_finish
 // adds them up over the contigs in reference order.
 template <bool STAGED, bool WANT_HITS>
 __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int TT = A.tracks_per_block, SC = A.samples_per_block;
-  uint32_t* res = lds;                                                // [3][SC][TT]
-  int32_t* tile_off = reinterpret_cast<int32_t*>(res + 3 * SC * TT);  // TT+1
+  int32_t* tile_off = reinterpret_cast<int32_t*>(lds);                // TT+1
   uint32_t* stage = reinterpret_cast<uint32_t*>(tile_off + ((TT + 1 + 3) & ~3));
   const int E = A.lds_entries;
   uint32_t* st_grid = stage + 3 * E;
@@ -761,7 +765,6 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   const int s0 = blockIdx.x * SC, t0 = blockIdx.y * TT, c = blockIdx.z;
   const int nt = min(TT, A.n_tracks - t0), ns = min(SC, A.n_samples - s0);
   const int shift = A.c_shift[c], cells = A.c_cells[c];
-  for (int i = tid; i < 3 * SC * TT; i += 256) res[i] = 0;
   if (STAGED) {
     if (tid == 0) {
       int o = 0;
@@ -785,57 +788,61 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
     }
   }
   __syncthreads();
+  const int64_t qstride = (int64_t)A.n_tracks * A.n_samples;
   for (int sl = wave; sl < ns; sl += 4) {
     const int s = s0 + sl;
     const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
     const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
-    for (int base = 0; base < n; base += kWave * kCountXR) {
-      uint2 x[kCountXR];
+    const bool one_pass = n <= kWave * kCountXR;
+    uint2 x[kCountXR];
+    if (one_pass) {
 #pragma unroll
       for (int r = 0; r < kCountXR; ++r) {
-        const int i = base + r * kWave + lane;
-        x[r] = i < n ? X[i] : make_uint2(0u, 0u);          // empty segment: contributes nothing
+        const int i = r * kWave + lane;
+        x[r] = i < n ? X[i] : make_uint2(0xffffffffu, 0xffffffffu);   // padding: beyond every interval, adds 0
       }
-      for (int t = 0; t < nt; ++t) {
-        AnnoView Y;
-        Y.shift = shift; Y.cells = cells;
-        if (STAGED) {
-          const int o = tile_off[t];
-          Y.start = stage + o; Y.end = stage + E + o; Y.cumx = stage + 2 * E + o;
-          Y.grid = st_grid + t * (cells + 1);
-          Y.m = tile_off[t + 1] - o;
-        } else {
-          const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
-          Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
-          Y.grid = A.a_grid + A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
-          Y.m = (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - g);
-        }
-        if (Y.m == 0) continue;
-        uint32_t ov = 0, hit = 0, mid = 0;
+    }
+    for (int t = 0; t < nt; ++t) {
+      AnnoView Y;
+      Y.shift = shift; Y.cells = cells;
+      if (STAGED) {
+        const int o = tile_off[t];
+        Y.start = stage + o; Y.end = stage + E + o; Y.cumx = stage + 2 * E + o;
+        Y.grid = st_grid + t * (cells + 1);
+        Y.m = tile_off[t + 1] - o;
+      } else {
+        const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
+        Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
+        Y.grid = A.a_grid + A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
+        Y.m = (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - g);
+      }
+      uint32_t ov = 0, hit = 0, mid = 0;
+      if (Y.m > 0) {
+        for (int base = 0; base < n; base += kWave * kCountXR) {
+          if (!one_pass) {
 #pragma unroll
-        for (int r = 0; r < kCountXR; ++r) {
-          if (x[r].x != x[r].y) {
+            for (int r = 0; r < kCountXR; ++r) {
+              const int i = base + r * kWave + lane;
+              x[r] = i < n ? X[i] : make_uint2(0xffffffffu, 0xffffffffu);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < kCountXR; ++r) {
             uint32_t o1, h1, m1;
             seg_vs_anno<WANT_HITS>(Y, x[r].x, x[r].y, o1, h1, m1);
             ov += o1; hit += h1; mid += m1;
           }
         }
-        ov = wave_sum_u32(ov);
-        if (WANT_HITS) { hit = wave_sum_u32(hit); mid = wave_sum_u32(mid); }
-        if (lane == 0) {
-          const int a = sl * TT + t;
-          res[a] += ov;                                     // uint32 accumulate within the contig (:1034)
-          if (WANT_HITS) { res[SC * TT + a] += hit; res[2 * SC * TT + a] += mid; }
-        }
+        ov = wave_total_u32(ov);                            // uint32 accumulate within the contig (:1034)
+        if (WANT_HITS) { hit = wave_total_u32(hit); mid = wave_total_u32(mid); }
+      }
+      if (lane == 0) {
+        // part[((c*3 + q)*n_tracks + t)*n_samples + s]
+        const int64_t b = (((int64_t)c * 3) * A.n_tracks + t0 + t) * A.n_samples + s;
+        A.part[b] = ov;
+        if (WANT_HITS) { A.part[b + qstride] = hit; A.part[b + 2 * qstride] = mid; }
       }
     }
-  }
-  __syncthreads();
-  // part[((c*3 + q)*n_tracks + t)*n_samples + s]
-  for (int i = tid; i < 3 * nt * ns; i += 256) {
-    const int q = i / (nt * ns), rem = i - q * nt * ns;
-    const int t = rem / ns, sl = rem - t * ns;
-    A.part[(((int64_t)c * 3 + q) * A.n_tracks + t0 + t) * A.n_samples + s0 + sl] = res[q * SC * TT + sl * TT + t];
   }
 }
 

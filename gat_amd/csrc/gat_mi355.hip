@@ -600,8 +600,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     A.samples_per_block = SC;
     A.lds_entries = staged ? (int)std::min<int64_t>((int64_t)E_max, annos.max_m * TT) : 0;
     A.lds_grid = staged ? (int)((annos.max_cells + 1) * TT) : 0;
-    const size_t lds = (size_t)3 * SC * TT * 4 + (size_t)((TT + 1 + 3) & ~3) * 4 +
-                       (size_t)3 * A.lds_entries * 4 + (size_t)A.lds_grid * 4;
+    const size_t lds = (size_t)((TT + 1 + 3) & ~3) * 4 + (size_t)3 * A.lds_entries * 4 + (size_t)A.lds_grid * 4;
     const size_t need = (size_t)A.n_contigs * 3 * (size_t)A.n_tracks * (size_t)A.n_samples;
     if (part.n < need) HIPCHK(ctx, part.alloc(need));
     A.part = part.p;
