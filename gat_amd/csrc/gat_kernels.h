@@ -395,7 +395,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     int32_t pending = -1;
     bool dirty = false;          // unintersected holds trim placeholders not yet merged away
     bool cov_valid = false;      // cov_known = workspace coverage of unintersected as it stands
-    uint32_t cov_known = 0;
+    uint32_t cov_known = 0, total_known = 0;
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = A.st_n[so];
@@ -432,11 +432,35 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
       // ---- consolidate (:582-606)
       if (remaining <= length) {
         uint32_t cov;
+        bool handled = false;
         if (nS == 0 && cov_valid) {
           // nothing was placed since the last consolidation, only trimmed: merge(0) would just drop the
           // placeholders (left for the final pass) and the coverage is the old one minus what the trim removed
           cov = cov_known;
-        } else {
+          handled = true;
+        } else if (nS == 1 && cov_valid && !dirty && nU > 0) {
+          // one new segment and a clean merged list: if it neither overlaps nor touches its neighbours
+          // (merge(0) joins at start <= previous max end) the merged list is the old one plus this segment
+          const uint2 xv = seg[nU];
+          const uint32_t xs = rfl(xv.x), xe = rfl(xv.y);
+          int pcount = 0;                                   // #U with start <= xs
+          for (int base = 0; base < nU; base += kWave) {
+            const int i = base + lane;
+            pcount += __popcll(__ballot(i < nU && seg[i].x <= xs));
+          }
+          const uint2 pv = seg[pcount > 0 ? pcount - 1 : 0], nv = seg[pcount < nU ? pcount : nU - 1];
+          const bool touch_prev = pcount > 0 && (int32_t)xs <= (int32_t)rfl(pv.y);
+          const bool touch_next = pcount < nU && (int32_t)rfl(nv.x) <= (int32_t)xe;
+          if (xs != xe && !touch_prev && !touch_next) {
+            wave_insert_sorted(seg, nU, 1, lane);
+            nU += 1;
+            nS = 0;
+            cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : seg_overlap_with(ws, ws_cdf, nws, xs, xe));
+            total_known += xe - xs;
+            handled = true;
+          }
+        }
+        if (!handled) {
           const int n = nU + nS;
           if (A.debug & 1) {} else
           if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
@@ -448,12 +472,14 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           dirty = false;
           if (A.debug & 128) return;
           cov = 0;
+          uint32_t tot = 0;
           if (nws <= kWsLoopMax) {
-            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); }
+            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); tot += v.y - v.x; }
           } else {
-            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); }
+            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); tot += v.y - v.x; }
           }
           cov = rfl(wave_sum_u32(cov));
+          total_known = rfl(wave_sum_u32(tot));             // sum() of the merged list, for the trim's position draw
         }
         cov_known = cov;
         cov_valid = true;
@@ -468,9 +494,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
       // ---- overshoot: trim (:608-626)
       if (true_remaining < 0) {
         // SegmentListSampler(unintersected).sample(1): position draw over the cumulated lengths
-        uint32_t total = 0;
-        for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; total += v.y - v.x; }
-        total = rfl(wave_sum_u32(total));
+        const uint32_t total = total_known;           // kept by the consolidation / earlier trims
         const uint32_t p = rng_range(rng, total - 1u, lane);
         int k = 0;
         uint32_t run = 0;
@@ -514,6 +538,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           }
         }
         cov_known -= rfl(removed);
+        total_known -= (uint32_t)(-true_remaining);      // trim_ends removes exactly that many bases
         wave_sync();
         dirty = true;
         true_remaining = 1;
