@@ -600,8 +600,23 @@ def g5_cli():
         ("density_truncated", ["--num-samples=50", "--random-seed=8", "--counter=nucleotide-density",
                                "--truncate-segments-to-workspace", "--order=pvalue", "--pseudo-count=0.5"]),
     ])
+    # the reference's own integration-test data (test/data/*.bed.gz, test/check_run.py): real mouse ChIP-seq
+    # intervals, 279 844 workspace segments; copied as data fixtures into tests/golden/refdata/
+    refdata = os.path.join(HERE, "refdata")
+    ref_case = ["--num-samples=60", "--random-seed=9", "--with-segment-tracks", "--order=track"]
     gat.computeSample = patched
     try:
+        out = os.path.join(refdata, "expected_mode1_s60.tsv")
+        argv = ["gat-run.py", "--segments=%s" % os.path.join(refdata, "segments_single.bed.gz"),
+                "--annotations=%s" % os.path.join(refdata, "annotations.bed.gz"),
+                "--workspace=%s" % os.path.join(refdata, "workspace.bed.gz"),
+                "--stdout=%s" % out, "--log=%s" % os.path.join(cli_dir, "ref.log")] + ref_case
+        state.update(track=None, base=9, n_units=0, sampler=None, num_samples=60)
+        mod.main(argv)
+        lines = [l for l in open(out) if not l.startswith("#")]
+        with open(out, "w") as f:
+            f.writelines(lines)
+        print("G5 refdata: %d rows" % (len(lines) - 1))
         for name, extra in cases.items():
             out = os.path.join(cli_dir, "expected_%s.tsv" % name)
             argv = ["gat-run.py", "--segments=%s" % os.path.join(cli_dir, "segments.bed"),

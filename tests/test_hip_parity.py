@@ -286,3 +286,56 @@ def test_cli_table_matches_reference(ctx, tmp_path):
         got = [l for l in open(out) if not l.startswith("#")]
         want = [l for l in open(os.path.join(cli, "expected_%s.tsv" % name)) if not l.startswith("#")]
         assert got == want, name
+
+
+def _run_cli(tmp_path, name, args):
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gat_run_amd", os.path.join(root, "scripts", "gat-run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / ("%s.tsv" % name))
+    assert mod.main(["gat-run.py", "--stdout=%s" % out, "--log=%s" % str(tmp_path / "log")] + args) == 0
+    return [l for l in open(out) if not l.startswith("#")]
+
+
+def test_reference_dataset_bit_exact(ctx, tmp_path):
+    """the reference's own integration-test data (test/data/*.bed.gz: mouse ChIP-seq peaks, 279 844 workspace
+    segments, 4 segment tracks x 7 annotation tracks): table == what the reference's gat-run.py prints under
+    the per-unit stream contract (tests/golden/refdata/expected_mode1_s60.tsv)."""
+    d = os.path.join(G, "refdata")
+    got = _run_cli(tmp_path, "refdata", ["--segments=%s" % os.path.join(d, "segments_single.bed.gz"),
+                                         "--annotations=%s" % os.path.join(d, "annotations.bed.gz"),
+                                         "--workspace=%s" % os.path.join(d, "workspace.bed.gz"),
+                                         "--num-samples=60", "--random-seed=9", "--with-segment-tracks", "--order=track"])
+    want = [l for l in open(os.path.join(d, "expected_mode1_s60.tsv")) if not l.startswith("#")]
+    assert got == want
+
+
+def test_reference_dataset_check_run(ctx, tmp_path):
+    """test/check_run.py of the reference, re-expressed: 1000 samples on the same data; `observed` must equal the
+    reference's 2013 output (test/data/output_single.tsv) exactly (:109-112), expected / fold / pvalue within its
+    tolerances of 10 % max and 5 % mean difference (:33-34, :87-106)."""
+    d = os.path.join(G, "refdata")
+    got = _run_cli(tmp_path, "check_run", ["--segments=%s" % os.path.join(d, "segments_single.bed.gz"),
+                                           "--annotations=%s" % os.path.join(d, "annotations.bed.gz"),
+                                           "--workspace=%s" % os.path.join(d, "workspace.bed.gz"),
+                                           "--num-samples=1000", "--random-seed=1", "--with-segment-tracks"])
+
+    def table(lines):
+        hdr = lines[0].rstrip("\n").split("\t")
+        return dict(((f[0], f[1]), dict(zip(hdr, f))) for f in (l.rstrip("\n").split("\t") for l in lines[1:]))
+
+    ref = table([l for l in open(os.path.join(d, "output_single.tsv")) if not l.startswith("#")])
+    mine = table(got)
+    assert set(ref.keys()) == set(mine.keys()) and len(ref) == 28
+    for col in ("observed", "track_nsegments", "track_size", "annotation_nsegments", "annotation_size",
+                "overlap_nsegments", "overlap_size"):
+        for k in ref:
+            assert mine[k][col] == ref[k][col], (k, col)
+    for col in ("expected", "fold", "pvalue"):
+        diffs = []
+        for k in ref:
+            a, b = float(mine[k][col]), float(ref[k][col])
+            diffs.append(0.0 if a == b else 100.0 * abs(a - b) / max(abs(a), abs(b)))
+        assert max(diffs) < 10.0 and sum(diffs) / len(diffs) < 5.0, (col, max(diffs))
