@@ -164,7 +164,7 @@ def main():
                         "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
                         "work_units": S * args.steps * flat["n_units"]},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(flat, counters, args.seed, args.cpu_seconds)
         print(json.dumps(out))
     P.close()
