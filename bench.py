@@ -29,8 +29,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="config2")
     ap.add_argument("--samples", type=int, default=0, help="samples per GPU per step (default: the config's)")
     ap.add_argument("--seed", type=int, default=12345)
