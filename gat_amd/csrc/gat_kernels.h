@@ -62,7 +62,6 @@ struct SamplerArgs {
   int32_t* st_remaining;      //                   `remaining` at that point
   int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
   uint32_t* st_draws;         //                   raw outputs consumed so far
-  int32_t debug;              // timing experiments only (GAT_DEBUG_SKIP): results are wrong when non-zero
 };
 
 constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
@@ -384,7 +383,6 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   const int32_t pre_len = have_pre ? A.st_length[so] : -1;
 
   int nout = 0, status = 0, nuns = 0;
-  if (A.debug & 8) return;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
   for (int attempt = (pre_len >= 0 ? 0 : 1); attempt < 2; ++attempt) {
     const bool resume = attempt == 0;
@@ -415,11 +413,9 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
       full_units = 1;
     }
 
-    if (A.debug & 16) return;
     while (true_remaining > 0 && nuns < 20) {                       // gat/Engine.pyx:572
       // ---- hs.sample() (:413-435)
       int32_t length;
-      if (A.debug & 32) return;
       if (pending >= 0) { length = pending; pending = -1; }
       else {
         uint32_t r = 1;
@@ -462,15 +458,12 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         }
         if (!handled) {
           const int n = nU + nS;
-          if (A.debug & 1) {} else
           if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)
           else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
-          if (A.debug & 64) return;
           nU = wave_merge0(seg, n, lane);
           nS = 0;
           dirty = false;
-          if (A.debug & 128) return;
           cov = 0;
           uint32_t tot = 0;
           if (nws <= kWsLoopMax) {
@@ -485,7 +478,6 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         cov_valid = true;
         remaining = ltotal - (int32_t)cov;
         if (true_remaining == remaining) nuns++; else true_remaining = remaining;
-        if (A.debug & 2) break;
         // the reference still draws a position here (:628) before its loop test fails; the draws and
         // the segment are discarded and the unit's stream ends, so nothing observable depends on them
         if (!(true_remaining != 0 && nuns < 20)) break;
@@ -585,7 +577,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
 
     // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
     nout = 0;
-    if (status == 0 && !(A.debug & 4)) {
+    if (status == 0) {
       if (dirty) nU = wave_merge0(seg, nU, lane);     // otherwise already merged by the last consolidation
       uint32_t total = 0;
       for (int base = 0; base < nU; base += kWave) {

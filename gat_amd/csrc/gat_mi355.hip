@@ -652,7 +652,6 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.seed = seed; A.sample_begin = begin;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
-      { const char* dbg = getenv("GAT_DEBUG_SKIP"); A.debug = dbg ? atoi(dbg) : 0; }
       if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
       if (P->sampler_mode) {
         // lane-parallel front end: the scratch was sized for P->batch samples, tiles are laid out for that
