@@ -10,7 +10,7 @@ import numpy as np
 from . import intervals, problem, synthetic            # noqa: F401
 from . import io as IO                                   # noqa: F401
 from . import stats as Stats                             # noqa: F401
-from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator,   # noqa: F401
+from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator, SamplerSegments,  # noqa: F401
                      Counter, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
                      UnconditionalWorkspace, computeCounts, AnnotatorResult, AnnotatorResultExtended,
@@ -41,6 +41,7 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
     flat = problem.flatten_units(segs.asArrays(), workspace.asArrays(),
                                  [(t, annotations[t].asArrays()) for t in tracks],
                                  getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000))
+    flat["sampler"] = getattr(sampler, "kind", 0)
     names = [c.name for c in counters]
     rank, world = 0, 1
     try:
@@ -94,8 +95,8 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
         seed = int(np.random.randint(0, 2 ** 32))
     if getattr(workspace_generator, "is_conditional", False):
         raise NotImplementedError("conditional workspaces are outside the accelerated path")
-    if not isinstance(sampler, SamplerAnnotator):
-        raise NotImplementedError("only SamplerAnnotator runs on the GPU path")
+    if not isinstance(sampler, (SamplerAnnotator, SamplerSegments)):
+        raise NotImplementedError("only SamplerAnnotator and SamplerSegments run on the GPU path")
 
     observed_counts = [computeCounts(counter=c, aggregator=sum, segments=segments, annotations=annotations,
                                      workspace=workspace, workspace_generator=workspace_generator) for c in counters]
@@ -168,7 +169,7 @@ def buildParser(usage=None):
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Sampling algorithm options")
     g.add_option("-c", "--counter", dest="counters", type="choice", action="append", choices=tuple(COUNTERS.keys()))
-    g.add_option("-m", "--sampler", dest="sampler", type="choice", choices=("annotator",))
+    g.add_option("-m", "--sampler", dest="sampler", type="choice", choices=("annotator", "segments"))
     g.add_option("-n", "--num-samples", dest="num_samples", type="int")
     g.add_option("--bucket-size", dest="bucket_size", type="int")
     g.add_option("--nbuckets", dest="nbuckets", type="int")
@@ -210,9 +211,12 @@ def fromSegments(options, args=None):
                                   truncate_segments_to_workspace=options.truncate_segments_to_workspace,
                                   truncate_workspace_to_annotations=options.truncate_workspace_to_annotations,
                                   restrict_workspace=options.restrict_workspace)
-    if options.sampler != "annotator":
-        raise ValueError("only the annotator sampler runs on the GPU path")
-    sampler = SamplerAnnotator(bucket_size=options.bucket_size, nbuckets=options.nbuckets)
+    if options.sampler == "annotator":
+        sampler = SamplerAnnotator(bucket_size=options.bucket_size, nbuckets=options.nbuckets)
+    elif options.sampler == "segments":
+        sampler = SamplerSegments()                      # scripts/gat-run.py:133 passes no bucket arguments
+    else:
+        raise ValueError("sampler '%s' is outside the accelerated path" % options.sampler)
     counters = []
     for counter in options.counters:
         if counter not in COUNTERS:

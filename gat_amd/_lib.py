@@ -51,6 +51,7 @@ class ProblemDesc(C.Structure):
         ("cws_nseg", C.c_void_p),
         ("bucket_size", C.c_uint32),
         ("nbuckets", C.c_int32),
+        ("sampler", C.c_int32),
     ]
 
 
@@ -209,6 +210,7 @@ class Problem(object):
         d.cws_nseg = arr("cws_nseg", np.int64)
         d.bucket_size = int(flat.get("bucket_size", 0))
         d.nbuckets = int(flat.get("nbuckets", 100000))
+        d.sampler = int(flat.get("sampler", 0))
         assert len(keep["seg_off"]) == d.n_units + 1 and len(keep["ws_off"]) == d.n_units + 1
         assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1 and len(keep["cws_nseg"]) == d.n_contigs
         self.n_units, self.n_contigs, self.n_tracks = d.n_units, d.n_contigs, d.n_tracks

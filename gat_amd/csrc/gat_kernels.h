@@ -29,6 +29,8 @@ struct UnitDev {
   int32_t slab_cap;     // capacity of that region == LDS buffer capacity used for the unit
   int32_t contig;
   int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
+  int32_t n_target;     // SamplerSegments: len(segments) placements (gat/Engine.pyx:726)
+  int32_t pad;
 };
 
 enum : int32_t {
@@ -62,6 +64,7 @@ struct SamplerArgs {
   int32_t* st_remaining;      //                   `remaining` at that point
   int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
   uint32_t* st_draws;         //                   raw outputs consumed so far
+  int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
 };
 
 constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const int64_t so = (int64_t)sidx * A.n_units + u;
 
   // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
+  const bool kind1 = A.sampler_kind == 1;
+  const int target = Up->n_target;
   const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; range 0 consumes nothing
   const bool drawP = ws_total > 1;
   if (!drawL || !drawP) {                            // degenerate unit (<= 2 segments / 1-base workspace):
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   int nS = 0;
   uint32_t len = 0, cs = 0, ce = 0;
   int32_t sstart = 0;
-  int32_t pend = -1;           // pending length at the trigger; -1 = not triggered
+  int32_t pend = -1;           // pending length at the trigger; -1 = not triggered; -2 = SamplerSegments complete
   uint32_t used = 0;           // raw outputs consumed by this lane when it halted
   int flag = 0;
 
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
         place = true;
       }
       if (have_len) {
-        if (rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }   // :582 -> consolidate
+        if (!kind1 && rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }   // :582 -> consolidate
         else { st = S_P; curmask = maskP; currange = rangeP; }
       }
     }
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
         }
         rem -= overlap;
         st = S_L; curmask = maskL; currange = rangeL;
+        if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }       // SamplerSegments: n placements
       }
     }
   };
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     if (acc) {
       if (st == S_L) {
         len = l_rank[1u + v];
-        if (rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }
+        if (!kind1 && rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }
         else { st = S_P; curmask = maskP; currange = rangeP; }
       } else if (st == S_P) {
         sstart = (int32_t)ws0.x - (int32_t)len + 1;
@@ -312,6 +318,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
           }
           rem -= overlap;
           st = S_L; curmask = maskL; currange = rangeL;
+          if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }
         }
       }
     }
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     for (int i = nS & ~7; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 3][lane])[i & 1];   // partial last line
     A.st_n[so] = nS;
     A.st_remaining[so] = rem;
-    A.st_length[so] = (st == S_HALT && pend >= 0 && flag == 0) ? pend : -1;   // rows ran out / overflow: full mode
+    A.st_length[so] = (st == S_HALT && pend != -1 && flag == 0) ? pend : -1;  // rows ran out / overflow: full mode
     A.st_draws[so] = used;
     if (flag) atomicOr(A.flags, flag);
   }
@@ -384,6 +391,47 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
 
   int nout = 0, status = 0, nuns = 0;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
+  if (A.sampler_kind == 1) {
+    // SamplerSegments.sample (gat/Engine.pyx:695-737): len(segments) placements, no consolidation.  Normally
+    // k_place has done all of it (st_length == -2); otherwise the unit is run here from its seed.
+    if (pre_len == -2) {
+      nout = A.st_n[so];
+      placed = (uint32_t)nout;
+      ndraws = A.st_draws[so];
+    } else {
+      WaveRng rng;
+      rng.mt = mt;
+      rng_seed(rng, seed, lane);
+      rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
+      full_units = 1;
+      const int target = Up->n_target;
+      for (int x = 0; x < target; ++x) {
+        uint32_t r = 1;
+        if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
+        uint32_t len_u = rank_len[r] * bucket;
+        if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
+        const int32_t length = (int32_t)len_u;
+        const uint32_t p = rng_range(rng, ws_total - 1u, lane);
+        const int k = bisect_u32(ws_cdf, nws, p);
+        const uint2 chosen = ws[k];
+        int32_t sampling_start = (int32_t)chosen.x - length + 1;
+        if (k > 0) { const int32_t pe = (int32_t)ws[k - 1].y; sampling_start = pe > sampling_start ? pe : sampling_start; }
+        const uint32_t range = chosen.y - 1u - (uint32_t)sampling_start;
+        const int32_t q = sampling_start + (int32_t)rng_range(rng, range, lane);
+        if (nout >= cap) { status |= kStatusOverflow; break; }
+        if (lane == 0) out[nout] = make_uint2((uint32_t)(q > 0 ? q : 0), (uint32_t)(q + length));
+        nout++;
+      }
+      placed = (uint32_t)nout;
+      ndraws = rng.ndraws;
+    }
+    if (lane == 0) {
+      A.unit_n[so] = status ? 0 : nout;
+      if (status) atomicOr(A.flags, status);
+      *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(placed, ndraws, 0u, full_units);
+    }
+    return;
+  }
   for (int attempt = (pre_len >= 0 ? 0 : 1); attempt < 2; ++attempt) {
     const bool resume = attempt == 0;
     WaveRng rng;

@@ -170,7 +170,7 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
 
 struct gat_problem {
   gat_ctx* ctx = nullptr;
-  int32_t n_units = 0, n_contigs = 0, n_tracks = 0, merge_contigs = 0;
+  int32_t n_units = 0, n_contigs = 0, n_tracks = 0, merge_contigs = 0, sampler = 0;
   std::vector<UnitDev> h_units;
   std::vector<int32_t> h_order;          // active units, largest first
   std::vector<int32_t> h_base_cap;       // per unit capacity before scaling
@@ -347,6 +347,9 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   P->n_contigs = d->n_contigs;
   P->n_tracks = d->n_tracks;
   P->merge_contigs = d->merge_contigs ? 1 : 0;
+  if (d->sampler != GAT_SAMPLER_ANNOTATOR && d->sampler != GAT_SAMPLER_SEGMENTS)
+    return set_err(ctx, GAT_ERR_ARG, "unknown sampler %d", d->sampler);
+  P->sampler = d->sampler;
   P->h_units.resize((size_t)d->n_units);
   P->h_base_cap.assign((size_t)d->n_units, 0);
   P->h_cws_nseg.assign(d->cws_nseg, d->cws_nseg + d->n_contigs);
@@ -425,7 +428,8 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     }
     U.ws_total = tot;
     U.ltotal = (int32_t)ltotal;
-    P->h_base_cap[u] = cap_for(nwork);
+    U.n_target = (int32_t)nus;                       // SamplerSegments places len(segments) segments
+    P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(nwork, nus) : nwork);
     work.push_back(std::make_pair(nwork, (int32_t)u));
   }
   // contig -> units (reference order)
@@ -474,7 +478,8 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       const char* env_sl = getenv("GAT_RNG_SLACK");
       const double slack = env_sl ? atof(env_sl) : 1.06;
       // spread of the raw-output count: ~sqrt(placements) x (std per placement ~1.3), 6 sigma
-      const double need = e * (double)U.hist_total * slack + 6.0 * std::sqrt((double)U.hist_total * (v + 0.5)) + 64.0;
+      const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
+      const double need = e * nplace * slack + 6.0 * std::sqrt(nplace * (v + 0.5)) + 64.0;
       int64_t rows = ((int64_t)std::ceil(need / 8.0)) * 8;          // whole k_place chunks
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
@@ -649,7 +654,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       memset(&A, 0, sizeof(A));
       A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p;
-      A.seed = seed; A.sample_begin = begin;
+      A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
       if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
@@ -749,6 +754,9 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   Counters C;
   int rc = parse_counters(ctx, counter_ids, n_counters, C);
   if (rc) return rc;
+  if (P->sampler == GAT_SAMPLER_SEGMENTS && !P->merge_contigs && n_counters > 0)
+    return set_err(ctx, GAT_ERR_ASSERT, "SamplerSegments output is not normalized unless fromIsochores merges it "
+                   "(keys without isochores): the counters assert (gat/SegmentList.pyx:1031)");
   gat_stats local;
   memset(&local, 0, sizeof(local));
   const int64_t S = sample_end - sample_begin;

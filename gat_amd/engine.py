@@ -420,6 +420,8 @@ class SamplerAnnotator(Sampler):
     argument or, if None, from numpy.random.randint(0, 2**32) (so numpy.random.seed() still makes
     a script reproducible)."""
 
+    kind = 0
+
     def __init__(self, bucket_size=1, nbuckets=100000, nunsuccessful_rounds=0):
         self.bucket_size = bucket_size
         self.nbuckets = nbuckets
@@ -445,6 +447,35 @@ class SamplerAnnotator(Sampler):
         r = SegmentList(array=seg)
         r.isNormalized = 1
         return r
+
+
+class SamplerSegments(Sampler):
+    """gat/Engine.pyx:653: places len(segments) segments drawn from the length distribution; sampled
+    segments may overlap and the list is returned in placement order (not normalized), exactly as the
+    reference does.  Same per-unit stream convention as SamplerAnnotator.sample."""
+
+    kind = 1
+
+    def __init__(self, bucket_size=1, nbuckets=100000):
+        self.bucket_size = bucket_size
+        self.nbuckets = nbuckets
+
+    def sample(self, segments, workspace, seed=None):
+        assert workspace.isNormalized, "workspace is not normalized"
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 32))
+        if len(segments) == 0 or len(workspace) == 0 or len(iv.filter(segments.asArray(), workspace.asArray())) == 0:
+            return SegmentList()
+        s, w = segments.asArray(), workspace.asArray()
+        flat = dict(n_units=1, segs=s, seg_off=[0, len(s)], ws=w, ws_off=[0, len(w)], unit_contig=[0], n_contigs=1,
+                    merge_contigs=0, n_tracks=0, annos=iv.EMPTY, anno_off=[0], cws_nseg=[len(w)],
+                    bucket_size=self.bucket_size, nbuckets=self.nbuckets, sampler=1)
+        P = _lib.Problem(get_context(), flat)
+        try:
+            seg, _ = P.sample(seed, 0, 1)
+        finally:
+            P.close()
+        return SegmentList(array=seg)
 
 
 class Counter(object):

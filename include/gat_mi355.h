@@ -45,6 +45,11 @@ typedef struct gat_problem gat_problem;
 #define GAT_COUNTER_ANNOTATION_MIDOVERLAP 5  /* CounterAnnotationMidpointOverlap :1465 */
 #define GAT_NUM_COUNTERS 6
 
+/* samplers */
+#define GAT_SAMPLER_ANNOTATOR 0   /* SamplerAnnotator: place until the workspace overlap matches (default)   */
+#define GAT_SAMPLER_SEGMENTS 1    /* SamplerSegments: len(segments) placements, no consolidation; the lists are */
+                                  /* normalized only by fromIsochores, so counters need isochore keys           */
+
 /*
  * Flat description of what gat.computeSample (gat/__init__.py:494-591) walks for one segment
  * track: the isochore units in list(segs.keys()) order (:531), their contig after
@@ -69,6 +74,7 @@ typedef struct {
   const int64_t* cws_nseg;      /* n_contigs: len(contig_workspace[contig]) (Engine.pyx:1437)   */
   uint32_t bucket_size;         /* SamplerAnnotator(bucket_size, nbuckets): gat/Engine.pyx:498  */
   int32_t nbuckets;
+  int32_t sampler;              /* GAT_SAMPLER_ANNOTATOR (gat/Engine.pyx:445) or GAT_SAMPLER_SEGMENTS (:653) */
 } gat_problem_desc;
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the

@@ -577,6 +577,41 @@ done:
   return rc;
 }
 
+/* gat/Engine.pyx:695-737 SamplerSegments.sample */
+int gato_sampler_segments(gato_rng* rng, const gato_segment* segs, size_t nsegs,
+                          const gato_segment* ws, size_t nws, uint32_t bucket_size_cfg, int nbuckets,
+                          gato_segment* out, size_t out_cap, size_t* nout) {
+  Segment* working = NULL;
+  size_t nworking, x;
+  int64_t* histogram = NULL;
+  hist_sampler hs = {0, 0, 0, 0};
+  sl_sampler sls = {0, 0, 0, 0};
+  Position bucket_size = 0, start, end;
+  PositionDifference overlap;
+  int rc = GATO_OK;
+  *nout = 0;
+  if (!gato_check(ws, nws)) return GATO_ERR_ASSERT;            /* :706 */
+  working = (Segment*)malloc((nsegs ? nsegs : 1) * sizeof(Segment));
+  memcpy(working, segs, nsegs * sizeof(Segment));
+  nworking = gato_filter(working, nsegs, ws, nws);              /* :711-712 */
+  if (nworking == 0) { free(working); return GATO_OK; }
+  histogram = (int64_t*)malloc(sizeof(int64_t) * (size_t)nbuckets);
+  if ((rc = gato_length_distribution(working, nworking, bucket_size_cfg, nbuckets, histogram, &bucket_size))) goto done;
+  if ((rc = hist_sampler_init(&hs, histogram, nbuckets, bucket_size))) goto done;
+  if ((rc = sl_sampler_init(&sls, ws, nws))) goto done;
+  if (nsegs > out_cap) { rc = GATO_ERR_CAPACITY; goto done; }
+  for (x = 0; x < nsegs; x++) {                                 /* :726 for x in xrange(len(segments)) */
+    Position length = hist_sampler_sample(&hs, rng);
+    if (!(length > 0)) { rc = GATO_ERR_ASSERT; goto done; }
+    if ((rc = sl_sampler_sample(&sls, rng, length, &start, &end, &overlap))) goto done;
+    out[x].start = start; out[x].end = end;
+  }
+  *nout = nsegs;
+done:
+  free(working); free(histogram); free(hs.cdf); free(sls.cdf);
+  return rc;
+}
+
 /* gat/Engine.pyx:1417-1472 Counter*.__call__ for one contig */
 double gato_counter(int counter_id, const gato_segment* segs, size_t nsegs,
                     const gato_segment* annos, size_t nannos, int64_t ws_nseg) {
@@ -638,7 +673,8 @@ static int run_samples_rng(const gato_problem* p, const int32_t* counter_ids, in
         gato_rng_seed(rng, (uint32_t)(((uint64_t)seed + (uint64_t)s * (uint64_t)p->n_units + (uint64_t)u) & 0xffffffffull));
       for (;;) {
         gato_rng save = *rng;
-        rc = gato_sampler_annotator(rng, us, nus, uw, nuw, p->bucket_size, p->nbuckets, unit_out, cap, &nout, NULL);
+        if (p->sampler == 1) rc = gato_sampler_segments(rng, us, nus, uw, nuw, p->bucket_size, p->nbuckets, unit_out, cap, &nout);
+        else rc = gato_sampler_annotator(rng, us, nus, uw, nuw, p->bucket_size, p->nbuckets, unit_out, cap, &nout, NULL);
         if (rc == GATO_ERR_CAPACITY) {               /* grow and redo this unit from the saved stream */
           *rng = save;
           cap *= 2;
@@ -668,6 +704,9 @@ static int run_samples_rng(const gato_problem* p, const int32_t* counter_ids, in
       }
     }
 
+    /* counters assert isNormalized (gat/SegmentList.pyx:1031): raw SamplerSegments output is not, unless
+     * fromIsochores merged it */
+    if (n_counters > 0 && p->sampler == 1 && !p->merge_contigs) { rc = GATO_ERR_ASSERT; goto done; }
     /* gat/__init__.py:578-587: sum([...]) over contigs, Python ints exact / floats left-to-right */
     for (k = 0; k < n_counters; k++) {
       int cid = counter_ids[k];

@@ -78,6 +78,14 @@ int gato_sampler_annotator(gato_rng* rng,
                            gato_segment* out, size_t out_cap, size_t* nout,
                            int* nunsuccessful_rounds);
 
+/* SamplerSegments.sample (gat/Engine.pyx:695-737): len(segments) placements, no consolidation; the
+ * result is in placement order (unsorted, may overlap). */
+int gato_sampler_segments(gato_rng* rng,
+                          const gato_segment* segs, size_t nsegs,
+                          const gato_segment* ws, size_t nws,
+                          uint32_t bucket_size, int nbuckets,
+                          gato_segment* out, size_t out_cap, size_t* nout);
+
 /* ---- batch seam: gat/__init__.py:494-591 computeSample over a sample range ------------
  * Flat (CSR) problem description, shared with the product's C ABI (include/gat_mi355.h). */
 typedef struct {
@@ -95,6 +103,7 @@ typedef struct {
   const int64_t* cws_nseg;       /* n_contigs: len(contig_workspace[contig]) (Engine.pyx:1437) */
   uint32_t bucket_size;          /* SamplerAnnotator(bucket_size, nbuckets) */
   int32_t nbuckets;
+  int32_t sampler;               /* 0: SamplerAnnotator, 1: SamplerSegments (gat/Engine.pyx:653) */
 } gato_problem;
 
 /* counter ids (gat/Engine.pyx:1417-1472) */

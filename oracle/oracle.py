@@ -44,6 +44,7 @@ class Problem(C.Structure):
         ("cws_nseg", C.c_void_p),
         ("bucket_size", C.c_uint32),
         ("nbuckets", C.c_int32),
+        ("sampler", C.c_int32),
     ]
 
 
@@ -98,6 +99,8 @@ def lib():
         L.gato_sampler_annotator.restype = C.c_int
         L.gato_sampler_annotator.argtypes = [C.POINTER(RNG), vp, sz, vp, sz, u32, C.c_int, vp, sz,
                                              C.POINTER(sz), C.POINTER(C.c_int)]
+        L.gato_sampler_segments.restype = C.c_int
+        L.gato_sampler_segments.argtypes = [C.POINTER(RNG), vp, sz, vp, sz, u32, C.c_int, vp, sz, C.POINTER(sz)]
         L.gato_counter.restype = C.c_double
         L.gato_counter.argtypes = [C.c_int, vp, sz, vp, sz, i64]
         L.gato_run_samples.restype = C.c_int
@@ -240,6 +243,20 @@ def sampler_annotator(rng, segments, workspace, bucket_size=0, nbuckets=100000):
     return out[: n.value].copy(), nun.value
 
 
+def sampler_segments(rng, segments, workspace, bucket_size=0, nbuckets=100000):
+    """SamplerSegments(bucket_size, nbuckets).sample(segments, workspace) on `rng`."""
+    a, w = segs(segments), segs(workspace)
+    out = np.empty(len(a) + 1, dtype=SEG)
+    n = C.c_size_t(0)
+    rc = lib().gato_sampler_segments(C.byref(rng.state), _p(a), len(a), _p(w), len(w), bucket_size, nbuckets,
+                                     _p(out), len(out), C.byref(n))
+    if rc == -1:
+        raise ValueError("oracle sampler: ValueError")
+    if rc:
+        raise AssertionError("oracle sampler rc=%d" % rc)
+    return out[: n.value].copy()
+
+
 def counter(name, segments, annotations, ws_nseg=1):
     a, b = segs(segments), segs(annotations)
     return float(lib().gato_counter(COUNTER_IDS[name], _p(a), len(a), _p(b), len(b), ws_nseg))
@@ -273,6 +290,7 @@ def run_samples(flat, counters, seed, stream_mode, sample_begin, sample_end, wan
     p.cws_nseg = arr("cws_nseg", np.int64)
     p.bucket_size = int(flat.get("bucket_size", 0))
     p.nbuckets = int(flat.get("nbuckets", 100000))
+    p.sampler = int(flat.get("sampler", 0))
     ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
     ns = sample_end - sample_begin
     counts = np.zeros((len(ids), p.n_tracks, ns), dtype=np.int64)

@@ -397,7 +397,7 @@ def build_reference_inputs(cfg, truncate_segments=False):
 
 
 def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100000, keep_lists=True,
-             truncate_segments=False):
+             truncate_segments=False, sampler_class=None):
     segments, annotations, workspace = build_reference_inputs(cfg, truncate_segments)
     counter_objs = [COUNTERS[c]() for c in counters]
     wsgen = Engine.UnconditionalWorkspace()
@@ -406,7 +406,8 @@ def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100
 
     # ---- mode 0: the reference's own gat.run on one global stream
     numpy.random.seed(seed)
-    sampler = Engine.SamplerAnnotator(bucket_size=bucket_size, nbuckets=nbuckets)
+    sampler_class = sampler_class or Engine.SamplerAnnotator
+    sampler = sampler_class(bucket_size=bucket_size, nbuckets=nbuckets)
     results = gat.run(segments, annotations, workspace, sampler, counter_objs, wsgen,
                       num_samples=num_samples, pseudo_count=1.0)
     counts0 = numpy.zeros((len(counters), len(tracks), num_samples), dtype=numpy.float64)
@@ -426,7 +427,7 @@ def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100
     contig_annotations.fromIsochores()
     contig_workspace = workspace.clone()
     contig_workspace.fromIsochores()
-    rsampler = ReseedingSampler(Engine.SamplerAnnotator(bucket_size=bucket_size, nbuckets=nbuckets), segs, seed)
+    rsampler = ReseedingSampler(sampler_class(bucket_size=bucket_size, nbuckets=nbuckets), segs, seed)
     counts1 = numpy.zeros((len(counters), len(tracks), num_samples), dtype=numpy.float64)
     lists, list_off, sha = [], [0], hashlib.sha256()
     for x in range(num_samples):
@@ -457,7 +458,7 @@ def run_case(name, cfg, counters, num_samples, seed, bucket_size=0, nbuckets=100
                                                reference=None, pseudo_count=1.0)
             rows1.append(str(r))
     out = dict(flat)
-    out.update(rows_mode1=numpy.array(rows1))
+    out.update(rows_mode1=numpy.array(rows1), sampler=(1 if sampler_class is Engine.SamplerSegments else 0))
     out.update(seed=seed, num_samples=num_samples, counters=numpy.array(counters),
                counts_mode0=counts0, counts_mode1=counts1, observed=observed,
                stats_mode0=numpy.array(stats, dtype=numpy.float64), rows_mode0=numpy.array(rows),
@@ -488,6 +489,8 @@ def g4_runs():
     run_case("small_contigs", cfg2, all6, 60, 12)
     # P2c: truncate segments to the workspace (--truncate-segments-to-workspace)
     run_case("small_isochores_truncated", cfg, ["nucleotide-overlap", "segment-overlap"], 30, 13, truncate_segments=True)
+    # P2d: SamplerSegments (gat/Engine.pyx:653): fixed number of placements, merged by fromIsochores
+    run_case("small_isochores_sampler_segments", cfg, all6, 40, 14, sampler_class=Engine.SamplerSegments)
     # P3: BASELINE config 2 shape (hg19, 10k x 2 x 10k), 12 samples
     cfg = synthetic.config("config2")
     cfg["annotations"].append(("anno1", synthetic.random_segments(synthetic.HG19, 10000, 2000, 101)))

@@ -14,7 +14,7 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RUNS = ["config1", "small_isochores", "small_contigs", "small_isochores_truncated", "config2_s12",
-        "density_ungapped", "dense", "long_segments"]
+        "density_ungapped", "dense", "long_segments", "small_isochores_sampler_segments"]
 
 
 @pytest.fixture(scope="module")
@@ -339,3 +339,36 @@ def test_reference_dataset_check_run(ctx, tmp_path):
             a, b = float(mine[k][col]), float(ref[k][col])
             diffs.append(0.0 if a == b else 100.0 * abs(a - b) / max(abs(a), abs(b)))
         assert max(diffs) < 10.0 and sum(diffs) / len(diffs) < 5.0, (col, max(diffs))
+
+
+def test_sampler_segments_vs_oracle(ctx, monkeypatch):
+    """SamplerSegments (gat/Engine.pyx:653): raw placement-order lists without isochores, merged lists and all
+    counters with isochores; counters on un-merged lists raise like the reference's asserts; row exhaustion and
+    degenerate units take the wave-per-unit fallback."""
+    rs = np.random.RandomState(21)
+    for iso in (False, True):
+        flat = _random_problem(rs, n_contigs=3, n_segs=250, n_tracks=2, isochores=iso)
+        flat["sampler"] = 1
+        want_c, wsamples = (None, None)
+        counters = list(_lib.COUNTER_IDS.keys()) if iso else []
+        want_c, wsamples = O.run_samples(flat, counters, 77, 1, 2, 34, want_samples=True)
+        P = _lib.Problem(ctx, flat)
+        seg, off = P.sample(77, 2, 34)
+        assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+        if iso:
+            got = P.sample_and_count(counters, 77, 2, 34)
+            for k, c in enumerate(counters):
+                assert np.array_equal(got[k], want_c[k]), c
+        else:
+            with pytest.raises(AssertionError):
+                P.sample_and_count(["nucleotide-overlap"], 77, 2, 34)
+        P.close()
+    monkeypatch.setenv("GAT_RNG_SLACK", "0.5")
+    flat = _random_problem(rs, n_contigs=2, n_segs=300, n_tracks=1, isochores=False)
+    flat["sampler"] = 1
+    _, wsamples = O.run_samples(flat, [], 5, 1, 0, 20, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    seg, off = P.sample(5, 0, 20)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    assert P.last_stats["n_full_units"] > 0
+    P.close()
