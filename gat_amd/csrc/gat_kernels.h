@@ -911,6 +911,75 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   }
 }
 
+// Roles swapped for long sample lists (overlap is symmetric): one block per (sample, contig) builds
+// the same lookup structure (starts / ends / cumulated lengths / position grid) over the SAMPLE list
+// in LDS and every wave streams whole annotation tracks against it, lanes over the track's
+// intervals.  With n' sample segments and m << n' annotation intervals per contig this does m
+// lookups per (sample, track, contig) instead of n'.  nucleotide-overlap / nucleotide-density only.
+constexpr int kSwapThreads = 1024;   // 16 waves share one indexed sample list: the lookups are latency bound
+
+__global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int capx = A.lds_entries, lcells = A.lds_grid;       // list capacity, log2 of the grid size
+  uint32_t* xs = lds;
+  uint32_t* xe = xs + capx;
+  uint32_t* xcum = xe + capx;
+  uint32_t* grid = xcum + capx;                               // (1 << lcells) + 1
+  __shared__ uint32_t wsum[kSwapThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, c = blockIdx.y;
+  const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
+  const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+  const int64_t pbase = (((int64_t)c * 3) * A.n_tracks) * A.n_samples + s;
+  if (n == 0 || n > capx) {                                   // n > capx cannot happen (capx = slab capacity)
+    for (int t = tid; t < A.n_tracks; t += kSwapThreads) A.part[pbase + (int64_t)t * A.n_samples] = 0;
+    return;
+  }
+  // 1. list into LDS; exclusive prefix sum of the lengths (thread owns a contiguous chunk)
+  const int per = (n + kSwapThreads - 1) / kSwapThreads;
+  const int i0 = tid * per, i1 = min(n, i0 + per);
+  uint32_t local = 0;
+  for (int i = i0; i < i1; ++i) { const uint2 v = X[i]; xs[i] = v.x; xe[i] = v.y; local += v.y - v.x; }
+  uint32_t incl = wave_incl_sum_u32(local, lane);
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint32_t base = incl - local;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int i = i0; i < i1; ++i) { xcum[i] = base; base += xe[i] - xs[i]; }
+  __syncthreads();
+  // 2. position grid over the starts: grid[g] = #starts < (g << shift)
+  const uint32_t maxstart = xs[n - 1];
+  const int bits = maxstart ? 32 - __builtin_clz(maxstart) : 1;
+  const int shift = bits > lcells ? bits - lcells : 0;
+  const int cells = (int)(maxstart >> shift) + 1;
+  for (int g = tid; g <= cells; g += kSwapThreads) {
+    uint32_t k = (uint32_t)n;
+    if (g < cells) {
+      const uint32_t bound = (uint32_t)g << shift;
+      int lo = 0, hi = n;
+      while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (xs[mid] < bound) lo = mid + 1; else hi = mid; }
+      k = (uint32_t)lo;
+    }
+    grid[g] = k;
+  }
+  __syncthreads();
+  AnnoView V;
+  V.start = xs; V.end = xe; V.cumx = xcum; V.grid = grid; V.m = n; V.shift = shift; V.cells = cells;
+  // 3. annotation tracks against the list
+  for (int t = wave; t < A.n_tracks; t += kSwapThreads / kWave) {
+    const int64_t g = A.a_off[(int64_t)t * A.n_contigs + c];
+    const int m = (int)(A.a_off[(int64_t)t * A.n_contigs + c + 1] - g);
+    uint32_t ov = 0;
+    for (int i = lane; i < m; i += kWave) {
+      uint32_t o1, h1, m1;
+      seg_vs_anno<false>(V, A.a_start[g + i], A.a_end[g + i], o1, h1, m1);
+      ov += o1;
+    }
+    ov = wave_total_u32(ov);
+    if (lane == 0) A.part[pbase + (int64_t)t * A.n_samples] = ov;
+  }
+}
+
 // sum([...]) over the contigs in list(sample.keys()) order (gat/__init__.py:578-587): Python ints
 // for the integer counters, left-to-right IEEE doubles of float(overlap)/len(workspace) for
 // nucleotide-density (gat/Engine.pyx:1437-1441).  One thread per (track, sample).

@@ -199,6 +199,7 @@ struct gat_problem {
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_st_draws, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
+  int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
 };
 
 // ------------------------------------------------------------------------------------------
@@ -505,6 +506,15 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   if (rc) return rc;
   rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs);
   if (rc) return rc;
+  {
+    // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
+    const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
+    const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->annos.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
+    const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
+    const size_t lds_need = (size_t)3 * capx * 4 + (8192 + 1) * 4;
+    (void)lds_need; (void)capx;
+    if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
+  }
   HIPCHK(ctx, P->d_flags.alloc(1));
   HIPCHK(ctx, P->d_stat.alloc(8));
   *out = P.release();
@@ -577,7 +587,8 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
 }
 
 // launch the count kernels over n_lists sample lists
-static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part) {
+static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part,
+                        int swap_capx = 0) {
   for (int i = 0; i < GAT_NUM_COUNTERS; ++i) A.counter_slot[i] = C.slot[i];
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
   A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
@@ -611,6 +622,19 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     A.part = part.p;
     if (A.n_contigs > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 contigs");
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT), (unsigned)std::max(1, A.n_contigs));
+    const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
+    if (A.n_contigs > 0 && swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) {
+      // long sample lists against short annotation lists: index the sample list, stream the tracks
+      gat::CountArgs B = A;
+      int lcells = 4;
+      while ((1 << lcells) < swap_capx && lcells < 13) ++lcells;
+      B.lds_entries = swap_capx;
+      B.lds_grid = lcells;
+      const size_t lds_swap = (size_t)3 * swap_capx * 4 + ((size_t)(1 << lcells) + 1) * 4;
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_swap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_swap));
+      hipLaunchKernelGGL(gat::k_count_swap, dim3((unsigned)A.n_samples, (unsigned)A.n_contigs), dim3(gat::kSwapThreads), lds_swap, ctx->stream, B);
+      HIPCHK(ctx, hipGetLastError());
+    } else
     if (A.n_contigs > 0) {
     const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
     if (staged) {
@@ -773,7 +797,12 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     A.out_stride = S;
     A.out_begin = done;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part))) return rc;
+    int swap_capx = 0;
+    if (P->swap_capx) {
+      const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
+      if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
+    }
+    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;

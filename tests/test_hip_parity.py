@@ -231,7 +231,8 @@ def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
     return problem.flatten_arrays(segs, annos, ws, None)
 
 
-@pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "rows_run_out", "slab_overflow_retry"])
+@pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "large_units_swapped_count", "rows_run_out",
+                                  "slab_overflow_retry"])
 def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     """code paths the BASELINE shapes do not reach: workspace lists beyond the register / LDS tables,
     units beyond the register sort, streams that run out of pre-generated rows (redone from the seed),
@@ -239,7 +240,7 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     rs = np.random.RandomState(hash(case) % 1000)
     if case == "many_workspace_segments":
         flat = _big_problem(rs, 900, 400)
-    elif case == "large_units":
+    elif case in ("large_units", "large_units_swapped_count"):
         flat = _big_problem(rs, 6000, 3)
     elif case == "rows_run_out":
         monkeypatch.setenv("GAT_RNG_SLACK", "0.6")
@@ -248,6 +249,8 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
         monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
         flat = _big_problem(rs, 700, 5)
     counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    if case == "large_units_swapped_count":        # overlap counters only: sample lists indexed, tracks streamed
+        counters = ["nucleotide-density", "nucleotide-overlap"]
     S = 24
     want, wsamples = O.run_samples(flat, counters, 99, 1, 3, 3 + S, want_samples=True)
     P = _lib.Problem(ctx, flat)
