@@ -406,6 +406,64 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
   wave_sync();
   return true;
 }
+// Counting sort by position bucket for long lists whose unsorted source is still in global memory
+// (the slab k_place wrote): histogram pass, exclusive prefix, scatter pass into the LDS list
+// (atomic cursor per bucket), then every lane insertion-sorts whole buckets (about one element
+// each).  nb buckets (power of two >= n), scratch = nb + 1 words of LDS.  Returns false (dst not
+// written) when the keys are too clustered for that to be cheap.
+__device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2* __restrict__ src, int n,
+                                                        uint32_t* scratch, int nb, int lane) {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  for (int i = lane; i < n; i += kWave) { const uint32_t x = src[i].x; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d), oh = (uint32_t)__shfl_xor((int)hi, d);
+    lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+  }
+  lo = rfl(lo); hi = rfl(hi);
+  const uint32_t span = hi - lo;
+  if (span == 0) return false;
+  const bool direct = span < (uint32_t)nb;
+  const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)nb << 32) / ((uint64_t)span + 1u));
+  wave_sync();
+  for (int i = lane; i <= nb; i += kWave) scratch[i] = 0;
+  wave_sync();
+  for (int i = lane; i < n; i += kWave) {
+    const uint32_t d = src[i].x - lo;
+    atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u);
+  }
+  wave_sync();
+  // exclusive prefix: lane owns nb/64 consecutive buckets
+  const int per = nb / kWave;
+  uint32_t sum = 0, maxc = 0;
+  for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
+  uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxc, d); maxc = o > maxc ? o : maxc; }
+  if (rfl(maxc) > 48u) return false;
+  for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; scratch[lane * per + q] = run; run += c; }
+  wave_sync();
+  for (int i = lane; i < n; i += kWave) {
+    const uint2 v = src[i];
+    const uint32_t d = v.x - lo;
+    const uint32_t pos = atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u);
+    dst[pos] = v;
+  }
+  wave_sync();
+  // scratch[b] is now the END of bucket b; lane sorts the buckets lane, lane+64, ...
+  for (int b = lane; b < nb; b += kWave) {
+    const int e = (int)scratch[b], s0 = b ? (int)scratch[b - 1] : 0;
+    for (int i = s0 + 1; i < e; ++i) {
+      const uint2 v = dst[i];
+      int j = i - 1;
+      while (j >= s0 && dst[j].x > v.x) { dst[j + 1] = dst[j]; --j; }
+      dst[j + 1] = v;
+    }
+  }
+  wave_sync();
+  return true;
+}
+
 // bucket sort when possible (scratch available, list short enough), else the sorting network
 __device__ __forceinline__ void wave_sort_fast(uint2* seg, int n, uint32_t* scratch, int lane) {
   if (n < 2) return;

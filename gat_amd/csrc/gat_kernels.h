@@ -65,6 +65,8 @@ struct SamplerArgs {
   int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
   uint32_t* st_draws;         //                   raw outputs consumed so far
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
+  int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
+  int32_t lds_cap;            // segment capacity of the LDS buffer
 };
 
 constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
@@ -159,6 +161,7 @@ constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (12 B ea
 constexpr int kPlaceRankLds = 1024;   // length-rank table entries kept in LDS
 constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
+template <int KIND>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   __shared__ uint32_t l_ws_start[kPlaceWsLds], l_ws_end[kPlaceWsLds], l_ws_cdf[kPlaceWsLds];
   __shared__ uint32_t l_rank[kPlaceRankLds];
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const int64_t so = (int64_t)sidx * A.n_units + u;
 
   // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
-  const bool kind1 = A.sampler_kind == 1;
+  constexpr bool kind1 = KIND == 1;           // SamplerSegments: fixed number of placements, no trigger
   const int target = Up->n_target;
   const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; range 0 consumes nothing
   const bool drawP = ws_total > 1;
@@ -359,6 +362,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 // k_sampler: one wave per (sample, unit).  Stand-alone it runs the whole of
 // SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
 // placed segments, `remaining`, the pending length and the position in the stream handed over.
+template <int KIND, bool BIG>
 __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
 
   int nout = 0, status = 0, nuns = 0;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
-  if (A.sampler_kind == 1) {
+  if constexpr (KIND == 1) {
     // SamplerSegments.sample (gat/Engine.pyx:695-737): len(segments) placements, no consolidation.  Normally
     // k_place has done all of it (st_length == -2); otherwise the unit is run here from its seed.
     if (pre_len == -2) {
@@ -506,6 +510,16 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         }
         if (!handled) {
           const int n = nU + nS;
+          if (BIG && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
+            // long list straight from the slab k_place wrote: counting sort into LDS (the copy made at resume is overwritten)
+            int nb = 1024;
+            while (nb < n && nb < A.big_buckets) nb <<= 1;
+            uint32_t* big = reinterpret_cast<uint32_t*>(seg + A.lds_cap);
+            if (!wave_sort_bucket_global(seg, out, n, big, nb, lane)) {
+              for (int i = lane; i < n; i += kWave) seg[i] = out[i];
+              wave_sort_by_start(seg, n, lane);
+            }
+          } else
           if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)
           else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments

@@ -693,14 +693,30 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(256), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
-        hipLaunchKernelGGL(gat::k_place, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
+        if (P->sampler == GAT_SAMPLER_SEGMENTS) hipLaunchKernelGGL(gat::k_place<1>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
+        else hipLaunchKernelGGL(gat::k_place<0>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
       }
-      const size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
+      size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
       if ((int64_t)lds > ctx->max_lds)
         return set_err(ctx, GAT_ERR_CAPACITY, "unit needs %zu bytes of LDS (> %d): too many segments in one isochore unit", lds, ctx->max_lds);
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_sampler, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gat::k_sampler, dim3((unsigned)nb, (unsigned)P->h_order.size()), dim3(64), lds, ctx->stream, A);
+      A.lds_cap = P->max_unit_cap;
+      A.big_buckets = 0;
+      uint32_t max_work = 0;
+      for (int32_t u : P->h_order) max_work = std::max(max_work, P->h_units[u].hist_total);
+      if (max_work + max_work / 8 > 1024) {   // lists beyond the register sorts: counting-sort scratch behind the segment buffer, if it fits
+        int nbk = 1024;
+        while (nbk < P->max_unit_cap && nbk < 8192) nbk <<= 1;
+        while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;
+        if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
+      }
+      const void* ks = P->sampler == GAT_SAMPLER_SEGMENTS ? (const void*)gat::k_sampler<1, false>
+                       : A.big_buckets > 0 ? (const void*)gat::k_sampler<0, true> : (const void*)gat::k_sampler<0, false>;
+      HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const dim3 gs((unsigned)nb, (unsigned)P->h_order.size());
+      if (P->sampler == GAT_SAMPLER_SEGMENTS) hipLaunchKernelGGL((gat::k_sampler<1, false>), gs, dim3(64), lds, ctx->stream, A);
+      else if (A.big_buckets > 0) hipLaunchKernelGGL((gat::k_sampler<0, true>), gs, dim3(64), lds, ctx->stream, A);
+      else hipLaunchKernelGGL((gat::k_sampler<0, false>), gs, dim3(64), lds, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
                          (int64_t)nb * P->n_units, P->d_stat.p);
