@@ -375,3 +375,63 @@ def test_sampler_segments_vs_oracle(ctx, monkeypatch):
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     assert P.last_stats["n_full_units"] > 0
     P.close()
+
+
+def test_error_behaviour_and_edge_cases(ctx):
+    """errors mirror the reference: non-normalized input -> AssertionError (gat/Engine.pyx:535-536),
+    segment longer than nbuckets*bucket_size -> ValueError (gat/SegmentList.pyx:1170), coordinates >= 2^31 ->
+    ValueError; empty units / empty annotation lists / zero samples are handled."""
+    w = [(0, 100000)]
+    with pytest.raises(AssertionError):
+        _lib.Problem(ctx, _single_unit_flat([(10, 50), (40, 90)], w, 0, 100000))          # overlapping segments
+    with pytest.raises(AssertionError):
+        _lib.Problem(ctx, _single_unit_flat([(10, 50)], [(500, 900), (0, 100)], 0, 100000))  # unsorted workspace
+    with pytest.raises(ValueError):
+        _lib.Problem(ctx, _single_unit_flat([(0, 500), (1000, 201000)], [(0, 1000000)], 1, 100000))
+    with pytest.raises(ValueError):
+        _lib.Problem(ctx, _single_unit_flat([(10, 50)], [(0, 2200000000)], 0, 100000))
+    # a unit whose segments all lie outside its workspace gives an empty list and consumes nothing
+    s = O.segs([(5000, 5100), (7000, 7050)])
+    flat = dict(n_units=2, segs=np.concatenate([s, O.segs([(10, 60), (200, 260)])]), seg_off=[0, 2, 4],
+                ws=O.segs([(0, 1000), (0, 1000)]), ws_off=[0, 1, 2], unit_contig=[0, 1], n_contigs=2, merge_contigs=0,
+                n_tracks=2, annos=O.segs([(0, 400), (100, 300)]), anno_off=[0, 0, 1, 2, 2], cws_nseg=[1, 1],
+                bucket_size=0, nbuckets=100000)
+    P = _lib.Problem(ctx, flat)
+    counters = list(_lib.COUNTER_IDS.keys())
+    got = P.sample_and_count(counters, 3, 0, 9)
+    want, wsamples = O.run_samples(flat, counters, 3, 1, 0, 9, want_samples=True)
+    for k in range(len(counters)):
+        assert np.array_equal(got[k], want[k])
+    seg, off = P.sample(3, 0, 9)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    assert all(off[2 * i + 1] == off[2 * i] for i in range(9))            # contig 0 always empty
+    for g in P.sample_and_count(counters, 3, 4, 4):                        # zero samples
+        assert g.shape == (2, 0)
+    P.close()
+    # counters on empty lists
+    r = ctx.count_lists(counters, O.segs([]), [0, 0], 1, O.segs([(0, 10)]), [0, 1], 1, [1], 1)
+    assert all(x[0, 0] == 0 for x in r)
+    r = ctx.count_lists(counters, O.segs([(0, 10)]), [0, 1], 1, O.segs([]), [0, 0], 1, [1], 1)
+    assert all(x[0, 0] == 0 for x in r)
+
+
+def test_host_classes_on_device(ctx):
+    """SegmentList.overlapWithSegments / intersectionWithSegments and Counter.__call__ run on the device and agree
+    with the reference-generated pair goldens (tests/golden/algebra.json)."""
+    import gat_amd
+    with open(os.path.join(G, "algebra.json")) as f:
+        cases = [c for c in json.load(f) if c["op"] == "pair"][:40]
+    for c in cases:
+        a = gat_amd.SegmentList(iter=c["a"], normalize=True)
+        b = gat_amd.SegmentList(iter=c["b"], normalize=True)
+        assert a.overlapWithSegments(b) == c["overlap"]
+        assert a.intersectionWithSegments(b) == c["isect_base"]
+        assert a.intersectionWithSegments(b, mode="midpoint") == c["isect_mid"]
+        assert gat_amd.CounterAnnotationOverlap()(a, b) == c["isect_base_rev"]
+        assert gat_amd.CounterNucleotideOverlap()(a, b) == c["overlap"]
+    s = gat_amd.SegmentList(iter=[(x, x + 100) for x in range(0, 10000, 1000)], normalize=True)
+    w = gat_amd.SegmentList(iter=[(0, 10000)], normalize=True)
+    r = gat_amd.SamplerAnnotator(bucket_size=1, nbuckets=100000).sample(s, w, seed=5)
+    rng = O.RandomState(5)
+    want, _ = O.sampler_annotator(rng, s.asList(), w.asList(), 1, 100000)
+    assert r.asList() == O.aslist(want)
