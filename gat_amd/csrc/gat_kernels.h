@@ -60,10 +60,10 @@ struct SamplerArgs {
   const int64_t* rng_off;     // per active index: word offset of the unit's first tile in rng_out
   const int32_t* rng_rows;    // per active index: rows (raw outputs per stream) generated
   uint32_t* rng_out;          // tile (active a, sample block sb): rng_out[rng_off[a] + (sb*rows + j)*64 + lane]
-  int32_t* st_n;              // [batch][n_units] hand-off: segments placed before the first consolidation
-  int32_t* st_remaining;      //                   `remaining` at that point
-  int32_t* st_length;         //                   the pending length (>0), or -1: run the unit in full
-  uint32_t* st_draws;         //                   raw outputs consumed so far
+  int4* st;                   // [batch][n_units] hand-off from k_place, one 16-byte record per work unit:
+                              //   x = segments placed before the first consolidation, y = `remaining` at that point,
+                              //   z = the pending length (>0), -1: run the unit in full, -2: SamplerSegments complete,
+                              //   w = raw outputs consumed so far
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const bool drawL = hist_total > 2;                 // randint(1,total): range total-2; range 0 consumes nothing
   const bool drawP = ws_total > 1;
   if (!drawL || !drawP) {                            // degenerate unit (<= 2 segments / 1-base workspace):
-    if (live) { A.st_n[so] = 0; A.st_remaining[so] = Up->ltotal; A.st_length[so] = -1; A.st_draws[so] = 0; }
+    if (live) A.st[so] = make_int4(0, Up->ltotal, -1, 0);
     return;                                          // k_sampler runs it from its seed
   }
   const uint32_t rangeL = hist_total - 2u, maskL = 0xffffffffu >> __builtin_clz(rangeL);
@@ -350,10 +350,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   }
   if (live) {
     for (int i = nS & ~7; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 3][lane])[i & 1];   // partial last line
-    A.st_n[so] = nS;
-    A.st_remaining[so] = rem;
-    A.st_length[so] = (st == S_HALT && pend != -1 && flag == 0) ? pend : -1;  // rows ran out / overflow: full mode
-    A.st_draws[so] = used;
+    A.st[so] = make_int4(nS, rem, (st == S_HALT && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
+                         (int)used);
     if (flag) atomicOr(A.flags, flag);
   }
 }
@@ -390,8 +388,9 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
   const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
-  const bool have_pre = A.st_length != nullptr;
-  const int32_t pre_len = have_pre ? A.st_length[so] : -1;
+  const bool have_pre = A.st != nullptr;
+  const int4 pre = have_pre ? A.st[so] : make_int4(0, 0, -1, 0);
+  const int32_t pre_len = pre.z;
 
   int nout = 0, status = 0, nuns = 0;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
@@ -399,9 +398,9 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     // SamplerSegments.sample (gat/Engine.pyx:695-737): len(segments) placements, no consolidation.  Normally
     // k_place has done all of it (st_length == -2); otherwise the unit is run here from its seed.
     if (pre_len == -2) {
-      nout = A.st_n[so];
+      nout = pre.x;
       placed = (uint32_t)nout;
-      ndraws = A.st_draws[so];
+      ndraws = (uint32_t)pre.w;
     } else {
       WaveRng rng;
       rng.mt = mt;
@@ -448,11 +447,11 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     uint32_t cov_known = 0, total_known = 0;
     nuns = 0; status = 0; placed = 0;
     if (resume) {
-      nS = A.st_n[so];
+      nS = pre.x;
       for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
-      remaining = A.st_remaining[so];
+      remaining = pre.y;
       pending = pre_len;
-      rng.use_pre = true; rng.exhausted = false; rng.ndraws = A.st_draws[so]; rng.pos = 0; rng.rbuf = 0;
+      rng.use_pre = true; rng.exhausted = false; rng.ndraws = (uint32_t)pre.w; rng.pos = 0; rng.rbuf = 0;
       rng.pre_rows = (uint32_t)A.rng_rows[a];
       rng.pre_j = rng.ndraws;
       rng.pre_base = rng.pre_j - (uint32_t)kWave;     // forces the first prefetch

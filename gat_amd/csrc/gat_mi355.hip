@@ -195,9 +195,10 @@ struct gat_problem {
   std::vector<int32_t> h_rng_rows;       // per active index: raw outputs generated per stream
   std::vector<int64_t> h_rng_off;
   int64_t rng_rows_total = 0;            // sum of h_rng_rows
-  DevBuf<int32_t> d_rng_rows, d_st_n, d_st_remaining, d_st_length;
+  DevBuf<int32_t> d_rng_rows;
+  DevBuf<int4> d_st;
   DevBuf<int64_t> d_rng_off;
-  DevBuf<uint32_t> d_rng_out, d_st_draws, d_ws_stat, d_part;
+  DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
 };
@@ -561,10 +562,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     HIPCHK(ctx, P->d_rng_off.upload(P->h_rng_off, ctx->stream));
     HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
-    HIPCHK(ctx, P->d_st_n.alloc(ns));
-    HIPCHK(ctx, P->d_st_remaining.alloc(ns));
-    HIPCHK(ctx, P->d_st_length.alloc(ns));
-    HIPCHK(ctx, P->d_st_draws.alloc(ns));
+    HIPCHK(ctx, P->d_st.alloc(ns));
   }
   P->batch = b;
   return GAT_OK;
@@ -688,7 +686,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         const unsigned nsb = (unsigned)((nb + 63) / 64);
         (void)nsb_alloc;
         A.rng_off = P->d_rng_off.p; A.rng_rows = P->d_rng_rows.p; A.rng_out = P->d_rng_out.p;
-        A.st_n = P->d_st_n.p; A.st_remaining = P->d_st_remaining.p; A.st_length = P->d_st_length.p; A.st_draws = P->d_st_draws.p;
+        A.st = P->d_st.p;
         const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(256), lds_rng, ctx->stream, A);
