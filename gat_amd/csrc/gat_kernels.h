@@ -195,6 +195,14 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const uint32_t rangeB = bucket - 1u, maskB = drawB ? 0xffffffffu >> __builtin_clz(rangeB) : 0u;
   const uint32_t rangeP = ws_total - 1u, maskP = 0xffffffffu >> __builtin_clz(rangeP);
 
+  // all tiles of a batch are resident at once and the kernel ends with the tiles of the largest unit:
+  // give those waves issue priority (units are ordered by size, a = 0 is the largest)
+  {
+    const int q = (4 * a) / (int)gridDim.y;
+    if (q == 0) __builtin_amdgcn_s_setprio(3);
+    else if (q == 1) __builtin_amdgcn_s_setprio(2);
+    else if (q == 2) __builtin_amdgcn_s_setprio(1);
+  }
   const bool ws_lds = nws <= kPlaceWsLds;
   const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
   if (ws_lds)
