@@ -435,3 +435,18 @@ def test_host_classes_on_device(ctx):
     rng = O.RandomState(5)
     want, _ = O.sampler_annotator(rng, s.asList(), w.asList(), 1, 100000)
     assert r.asList() == O.aslist(want)
+
+
+def test_wave_only_sampler_mode(ctx, monkeypatch):
+    """GAT_SAMPLER_MODE=wave: the stand-alone wave-per-unit sampler (own MT19937 in LDS, no k_rng / k_place),
+    which is also the fallback path of the default pipeline, gives the same bits."""
+    monkeypatch.setenv("GAT_SAMPLER_MODE", "wave")
+    z = np.load(os.path.join(G, "run_small_isochores.npz"))
+    counters = [str(c) for c in z["counters"]]
+    P = _lib.Problem(ctx, _flat(z))
+    counts = P.sample_and_count(counters, int(z["seed"]), 0, int(z["num_samples"]))
+    for k, c in enumerate(counters):
+        want = z["counts_mode1"][k]
+        assert np.array_equal(counts[k] if c == "nucleotide-density" else counts[k].astype(np.float64), want), c
+    assert P.last_stats["n_full_units"] > 0
+    P.close()
