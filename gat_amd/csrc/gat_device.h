@@ -173,21 +173,28 @@ __device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
   return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
+// inclusive wave scans on the VALU cross-lane (DPP) path: shifts by 1, 2, 3 inside a row of 16, then by 4
+// and 8 for the upper banks, then the row broadcasts (lane 15 -> next row, lane 31 -> rows 2, 3).  A lane
+// without a source (row start, masked bank / row) receives the identity.  ~14 VALU instructions, no LDS
+// crossbar round trips (the __shfl_up form costs six dependent ds_bpermute latencies).
+template <typename Op>
+__device__ __forceinline__ int wave_incl_scan_dpp(int v, int id, Op op) {
+  int x = op(v, __builtin_amdgcn_update_dpp(id, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+  x = op(x, __builtin_amdgcn_update_dpp(id, v, 0x112, 0xf, 0xf, false));       // row_shr:2
+  x = op(x, __builtin_amdgcn_update_dpp(id, v, 0x113, 0xf, 0xf, false));       // row_shr:3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xe, false));       // row_shr:4, banks 1-3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xc, false));       // row_shr:8, banks 2-3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));       // row_bcast:15 -> rows 1, 3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));       // row_bcast:31 -> rows 2, 3
+  return x;
+}
 __device__ __forceinline__ int32_t wave_incl_max_i32(int32_t m, int lane) {
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const int32_t o = __shfl_up(m, d);
-    if (lane >= d) m = o > m ? o : m;
-  }
-  return m;
+  (void)lane;
+  return wave_incl_scan_dpp(m, INT32_MIN, [](int a, int b) { return a > b ? a : b; });
 }
 __device__ __forceinline__ uint32_t wave_incl_sum_u32(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const uint32_t o = __shfl_up(v, d);
-    if (lane >= d) v += o;
-  }
-  return v;
+  (void)lane;
+  return (uint32_t)wave_incl_scan_dpp((int)v, 0, [](int a, int b) { return (int)((uint32_t)a + (uint32_t)b); });
 }
 
 // ------------------------------------------------------------------------------------------
