@@ -161,6 +161,24 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
   return v;
 }
+// all-lanes reduction on the DPP path (result broadcast from lane 63); id = identity of op
+template <typename Op>
+__device__ __forceinline__ int wave_reduce_dpp(int v, int id, Op op) {
+  int x = v;
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x141, 0xf, 0xf, false));   // row_half_mirror
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x140, 0xf, 0xf, false));   // row_mirror
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));   // row_bcast15 -> rows 1, 3
+  x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));   // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  return (uint32_t)wave_reduce_dpp((int)v, -1, [](int a, int b) { return (int)((uint32_t)a < (uint32_t)b ? (uint32_t)a : (uint32_t)b); });
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  return (uint32_t)wave_reduce_dpp((int)v, 0, [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); });
+}
 // wave total on the VALU data-parallel-primitive path (no LDS crossbar): quad swaps, row mirrors,
 // then the two row broadcasts; the total lands in lane 63
 __device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
@@ -346,12 +364,7 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
     ks[r] = 0; ke[r] = 0;
     if (i < n) { const uint2 x = seg[i]; ks[r] = x.x; ke[r] = x.y; lo = x.x < lo ? x.x : lo; hi = x.x > hi ? x.x : hi; }
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d), oh = (uint32_t)__shfl_xor((int)hi, d);
-    lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
-  }
-  lo = rfl(lo); hi = rfl(hi);
+  lo = wave_min_u32(lo); hi = wave_max_u32(hi);
   const uint32_t span = hi - lo;
   if (span == 0) return false;
   const bool direct = span < (uint32_t)NB;                       // fewer positions than buckets
@@ -375,9 +388,7 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
 #pragma unroll
   for (int q = 0; q < PER; ++q) { c[q] = scratch[lane * PER + q]; sum += c[q]; maxc = c[q] > maxc ? c[q] : maxc; }
   uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxc, d); maxc = o > maxc ? o : maxc; }
-  maxc = rfl(maxc);
+  maxc = wave_max_u32(maxc);
   if (maxc > 16u) return false;
   wave_sync();
 #pragma unroll
@@ -422,12 +433,7 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
                                                         uint32_t* scratch, int nb, int lane) {
   uint32_t lo = 0xffffffffu, hi = 0u;
   for (int i = lane; i < n; i += kWave) { const uint32_t x = src[i].x; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, d), oh = (uint32_t)__shfl_xor((int)hi, d);
-    lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
-  }
-  lo = rfl(lo); hi = rfl(hi);
+  lo = wave_min_u32(lo); hi = wave_max_u32(hi);
   const uint32_t span = hi - lo;
   if (span == 0) return false;
   const bool direct = span < (uint32_t)nb;
@@ -445,9 +451,7 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
   uint32_t sum = 0, maxc = 0;
   for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
   uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxc, d); maxc = o > maxc ? o : maxc; }
-  if (rfl(maxc) > 48u) return false;
+  if (wave_max_u32(maxc) > 48u) return false;
   for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; scratch[lane * per + q] = run; run += c; }
   wave_sync();
   for (int i = lane; i < n; i += kWave) {
@@ -503,8 +507,7 @@ __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
     }
     int32_t m = wave_incl_max_i32(valid ? (int32_t)e : INT32_MIN, lane);
     const int32_t incl = m > carry ? m : carry;
-    int32_t excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = carry;
+    const int32_t excl = __builtin_amdgcn_update_dpp(carry, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps carry
     const uint64_t vb = __ballot(valid);
     const bool prev_valid = any || (vb & lanemask_lt(lane)) != 0;
     const bool head = valid && (!prev_valid || (int32_t)s > excl);

@@ -540,8 +540,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           } else {
             for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); tot += v.y - v.x; }
           }
-          cov = rfl(wave_sum_u32(cov));
-          total_known = rfl(wave_sum_u32(tot));             // sum() of the merged list, for the trim's position draw
+          cov = wave_total_u32(cov);
+          total_known = wave_total_u32(tot);             // sum() of the merged list, for the trim's position draw
         }
         cov_known = cov;
         cov_valid = true;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
         nout += __popcll(b);
       }
-      total = rfl(wave_sum_u32(total));
+      total = wave_total_u32(total);
       if (!(total > 0)) status |= kStatusAssert;
     }
     break;
