@@ -118,16 +118,18 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
         const int e0 = t * kRngChunk;
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
         const int i0 = (t % kPerBlock) * kRngChunk;
+        uint32_t cur = mt[i0 * kWave];
 #pragma unroll 4
         for (int k = 0; k < cnt; ++k) {
           const int i = i0 + k;
           const int in = i + 1 == kMtN ? 0 : i + 1;                        // word 623 pairs with the NEW word 0
           const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;    // i < 227: old word i+397, else new word i-227
-          const uint32_t cur = mt[i * kWave], far = mt[jf * kWave];
+          const uint32_t far = mt[jf * kWave];
           uint32_t nxt = mt[in * kWave];
           if (wv == 0 && k == kRngChunk - 1) nxt = next_old;               // wave 1 is rewriting that word right now
           const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
           mt[i * kWave] = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+          cur = nxt;                                                        // old word i+1 is the next step's word i
         }
       }
       if (wv == 0) {                                 // first word of chunk 2(s+1)+1: untouched until the next step
