@@ -13,7 +13,8 @@ from . import stats as Stats                             # noqa: F401
 from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator, SamplerSegments,  # noqa: F401
                      Counter, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
-                     UnconditionalWorkspace, computeCounts, AnnotatorResult, AnnotatorResultExtended,
+                     UnconditionalWorkspace, ConditionalWorkspaceCooccurance, ConditionalWorkspaceCentered,
+                     ConditionalWorkspaceAnnotationCentered, ConditionalWorkspaceSegmentCentered, computeCounts, AnnotatorResult, AnnotatorResultExtended,
                      getTwoSidedPValue, updatePValues, get_context)
 
 __version__ = "0.1"
@@ -26,23 +27,37 @@ COUNTERS = collections.OrderedDict([
 
 
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
-                  samples_outfile=None):
+                  samples_outfile=None, workspace_generator=None, only_tracks=None):
     """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
 
     segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
-    Returns [ {annotation: array of num_samples} per counter ] like the reference, or None for an
-    empty workspace.  If torch.distributed is initialised, samples are sharded over the ranks and
-    the count matrix is all-gathered (RCCL)."""
+    workspace_generator (gat/__init__.py:727): segments and workspace the sampler sees are
+    generator(segs, None, workspace); the counters keep the contig form of `workspace`.
+    only_tracks: count these annotation tracks only (the conditional sampler's per-annotation pass).
+    Returns ([ {annotation: array of num_samples} per counter ] like the reference, number of work
+    units), or (None, 0) for an empty workspace.  If torch.distributed is initialised, samples are
+    sharded over the ranks and the count matrix is all-gathered (RCCL)."""
     from . import _lib, distributed
     if workspace.sum() == 0:
         return None, 0
     ctx = ctx or get_context()
-    tracks = list(annotations.tracks)
+    tracks = list(annotations.tracks) if only_tracks is None else list(only_tracks)
+    count_workspace = None
+    if workspace_generator is not None and type(workspace_generator) is not UnconditionalWorkspace:
+        count_workspace = workspace.asArrays()
+        annos = annotations[tracks[0]] if only_tracks is not None else None
+        segs, _, workspace = workspace_generator(segs, annos, workspace)
     flat = problem.flatten_units(segs.asArrays(), workspace.asArrays(),
                                  [(t, annotations[t].asArrays()) for t in tracks],
-                                 getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000))
+                                 getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000),
+                                 count_workspace=count_workspace)
     flat["sampler"] = getattr(sampler, "kind", 0)
     names = [c.name for c in counters]
+    if flat["n_contigs"] == 0:
+        # nothing to place (the generated workspace holds no segments): computeSample skips every unit
+        # (gat/__init__.py:536-538) and each counter sums over no contigs
+        zero = [np.zeros(num_samples, dtype=np.float64 if n == "nucleotide-density" else np.int64) for n in names]
+        return [collections.OrderedDict((t, zero[k].copy()) for t in tracks) for k in range(len(names))], flat["n_units"]
     rank, world = 0, 1
     try:
         import torch.distributed as dist
@@ -93,8 +108,7 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     seed = kwargs.get("random_seed", None)
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 32))
-    if getattr(workspace_generator, "is_conditional", False):
-        raise NotImplementedError("conditional workspaces are outside the accelerated path")
+    conditional = getattr(workspace_generator, "is_conditional", False)
     if not isinstance(sampler, (SamplerAnnotator, SamplerSegments)):
         raise NotImplementedError("only SamplerAnnotator and SamplerSegments run on the GPU path")
 
@@ -105,14 +119,28 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
         outf = None
         if output_samples_pattern:
             outf = open(re.sub("%s", track, output_samples_pattern), "w")
-        r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
-                                   samples_outfile=outf)
+        if conditional:
+            # ConditionalSampler.sample (gat/__init__.py:780-850): one sampling pass per annotation, each in the
+            # workspace conditioned on (segments, that annotation); only that annotation is counted
+            r = None
+            if workspace.sum() > 0:
+                r = [collections.OrderedDict() for _ in counters]
+                for annotation in annotations.tracks:
+                    ra, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples,
+                                                seed, samples_outfile=outf, workspace_generator=workspace_generator,
+                                                only_tracks=[annotation])
+                    for k in range(len(counters)):
+                        r[k][annotation] = ra[k][annotation]
+                    seed = (seed + num_samples * n_units) & 0xFFFFFFFF
+        else:
+            r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
+                                       samples_outfile=outf, workspace_generator=workspace_generator)
+            seed = (seed + num_samples * n_units) & 0xFFFFFFFF    # next track: disjoint unit streams
         if outf:
             outf.close()
         if r is None:
             continue
         sampled_counts[track] = r
-        seed = (seed + num_samples * n_units) & 0xFFFFFFFF        # next track: disjoint unit streams
 
     annotator_results = []
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
@@ -186,6 +214,11 @@ def buildParser(usage=None):
     g.add_option("--truncate-segments-to-workspace", dest="truncate_segments_to_workspace", action="store_true")
     g.add_option("--truncate-workspace-to-annotations", dest="truncate_workspace_to_annotations", action="store_true")
     g.add_option("--restrict-workspace", dest="restrict_workspace", action="store_true")
+    g.add_option("--conditional", dest="conditional", type="choice",
+                 choices=("unconditional", "annotation-centered", "segment-centered", "cooccurance"),
+                 help="conditional workspace creation [default=%default]")
+    g.add_option("--conditional-extension", dest="conditional_extension", type="int")
+    g.add_option("--conditional-expansion", dest="conditional_expansion", type="float")
     g.add_option("--device", dest="device", type="int", help="HIP device ordinal [default=%default]")
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Common options")
@@ -200,6 +233,7 @@ def buildParser(usage=None):
                         overlapping_annotations=False, pseudo_count=1.0, pvalue_method="empirical", qvalue_method="BH",
                         random_seed=None, restrict_workspace=False, sampler="annotator", segment_files=[],
                         truncate_segments_to_workspace=False, truncate_workspace_to_annotations=False,
+                        conditional="unconditional", conditional_extension=None, conditional_expansion=None,
                         workspace_files=[], device=0, loglevel=1, stdout=None, stdlog=None)
     return parser
 
@@ -222,7 +256,20 @@ def fromSegments(options, args=None):
         if counter not in COUNTERS:
             raise ValueError("unknown counter '%s'" % counter)
         counters.append(COUNTERS[counter]())
-    return run(segments, annotations, workspace, sampler, counters, workspace_generator=UnconditionalWorkspace(),
+    # scripts/gat-run.py:162-186 (both centered modes insist on --conditional-expansion, as the reference does)
+    if options.conditional == "unconditional":
+        workspace_generator = UnconditionalWorkspace()
+    elif options.conditional == "cooccurance":
+        workspace_generator = ConditionalWorkspaceCooccurance()
+    elif options.conditional in ("annotation-centered", "segment-centered"):
+        if options.conditional_expansion is None:
+            raise ValueError("please specify either --conditional-expansion or --conditional-extension")
+        cls = (ConditionalWorkspaceAnnotationCentered if options.conditional == "annotation-centered"
+               else ConditionalWorkspaceSegmentCentered)
+        workspace_generator = cls(options.conditional_extension, options.conditional_expansion)
+    else:
+        raise ValueError("unknown conditional workspace '%s'" % options.conditional)
+    return run(segments, annotations, workspace, sampler, counters, workspace_generator=workspace_generator,
                num_samples=options.num_samples, output_counts_pattern=options.output_counts_pattern,
                output_samples_pattern=options.output_samples_pattern, pseudo_count=options.pseudo_count,
                num_threads=options.num_threads, random_seed=options.random_seed)

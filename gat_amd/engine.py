@@ -97,6 +97,30 @@ class SegmentList(object):
         self._a = iv.EMPTY.copy()
         self.isNormalized = 1
 
+    def extend_segments(self, extension):
+        """grow every interval by `extension` on both sides, truncating at 0; the list is not
+        normalized afterwards (gat/SegmentList.pyx:1551-1565)."""
+        start = self._a["start"].astype(np.int64)
+        end = self._a["end"].astype(np.int64)
+        start -= np.minimum(int(extension), start)
+        end += int(extension)
+        self._a = iv.make(start & 0xFFFFFFFF, end & 0xFFFFFFFF)
+        self.isNormalized = 0
+
+    def expand_segments(self, expansion):
+        """scale every interval by `expansion` around its midpoint (gat/SegmentList.pyx:1567-1591)."""
+        if expansion <= 0:
+            raise ValueError("invalid expansion: %f <= 0" % expansion)
+        e_1 = (float(expansion) - 1.0) / 2.0
+        start = self._a["start"].astype(np.int64)
+        end = self._a["end"].astype(np.int64)
+        length = (end - start).astype(np.int32).astype(np.int64)                  # PositionDifference l
+        extension = np.floor(length.astype(np.float64) * e_1).astype(np.int64)
+        start -= np.minimum(extension, start)
+        end += extension
+        self._a = iv.make(start & 0xFFFFFFFF, end & 0xFFFFFFFF)
+        self.isNormalized = 0
+
     def clone(self):
         return SegmentList(clone=self)
 
@@ -231,11 +255,24 @@ class IntervalDictionary(object):
             r[k] = v.clone()
         return r
 
-    def normalize(self):
-        for k in [k for k, v in self.intervals.items() if len(v) == 0]:
-            del self.intervals[k]
+    def normalize(self, remove_empty=False):
+        """gat/Engine.pyx:2731 (a dictionary keeps its empty keys); IntervalCollection.normalize
+        (:2942) drops them."""
+        if remove_empty:
+            for k in [k for k, v in self.intervals.items() if len(v) == 0]:
+                del self.intervals[k]
         for v in self.intervals.values():
             v.normalize()
+
+    def extend(self, extension):
+        """gat/Engine.pyx:2719."""
+        for v in self.intervals.values():
+            v.extend_segments(extension)
+
+    def expand(self, expansion):
+        """gat/Engine.pyx:2725."""
+        for v in self.intervals.values():
+            v.expand_segments(expansion)
 
     def _pairwise(self, other, op):
         for contig in list(self.intervals.keys()):
@@ -337,7 +374,7 @@ class IntervalCollection(object):
 
     def normalize(self):
         for vv in self.intervals.values():
-            vv.normalize()
+            vv.normalize(remove_empty=True)
 
     def sort(self):
         for vv in self.intervals.values():
@@ -517,6 +554,66 @@ class UnconditionalWorkspace(object):
 
     def __call__(self, segments, annotations, workspace):
         return segments, annotations, workspace
+
+    def filter(self, segments, annotations, workspace):  # noqa: A003
+        """restrict annotations and segments to a workspace (gat/Engine.pyx:2071-2091)."""
+        temp_annotations = None
+        if annotations:
+            temp_annotations = annotations.clone()
+            temp_annotations.filter(workspace)
+        temp_segments = None
+        if segments:
+            temp_segments = segments.clone()
+            temp_segments.filter(workspace)
+        return temp_segments, temp_annotations, workspace
+
+
+class ConditionalWorkspaceCooccurance(UnconditionalWorkspace):
+    """only the workspace segments that hold both a segment and an annotation
+    (gat/Engine.pyx:2093-2109)."""
+    is_conditional = True
+
+    def __call__(self, segments, annotations, workspace):
+        temp_workspace = workspace.clone()
+        temp_workspace.filter(annotations)
+        temp_workspace.filter(segments)
+        return self.filter(segments, annotations, temp_workspace)
+
+
+class ConditionalWorkspaceCentered(UnconditionalWorkspace):
+    """a workspace centered on segments or annotations (gat/Engine.pyx:2111-2134)."""
+    is_conditional = True
+
+    def __init__(self, extension=None, expansion=None):
+        self.extension = extension
+        self.expansion = expansion
+        if self.extension is None and self.expansion is None:
+            raise ValueError("need to specify either expansion or extension")
+
+    def __call__(self, segments, annotations, workspace):
+        temp_workspace = self.getCenter(segments, annotations).clone()
+        if self.extension is not None:
+            temp_workspace.extend(self.extension)
+        else:
+            temp_workspace.expand(self.expansion)
+        temp_workspace.normalize()
+        temp_workspace.intersect(workspace)
+        return self.filter(segments, annotations, temp_workspace)
+
+
+class ConditionalWorkspaceAnnotationCentered(ConditionalWorkspaceCentered):
+    """gat/Engine.pyx:2136-2143."""
+
+    def getCenter(self, segments, annotations):
+        return annotations
+
+
+class ConditionalWorkspaceSegmentCentered(ConditionalWorkspaceCentered):
+    """gat/Engine.pyx:2145-2153: computed once per segment track, so not 'conditional'."""
+    is_conditional = False
+
+    def getCenter(self, segments, annotations):
+        return segments
 
 
 def computeCounts(counter, aggregator, segments, annotations, workspace, workspace_generator, append=False):

@@ -58,12 +58,14 @@ def to_isochores(d, isochores, truncate):
     return out
 
 
-def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000):
+def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000, count_workspace=None):
     """segs / workspace: OrderedDict unit key -> SEG array (isochore level);
-    annotations: list of (track, OrderedDict unit key -> SEG array) (isochore level)."""
+    annotations: list of (track, OrderedDict unit key -> SEG array) (isochore level);
+    count_workspace: the workspace the counters see (gat/__init__.py:720 contig_workspace) when a
+    workspace generator made the sampling workspace a different one."""
     units = list(segs.keys())
     contig_annotations = [(t, from_isochores(per)) for t, per in annotations]
-    contig_workspace = from_isochores(workspace)
+    contig_workspace = from_isochores(workspace if count_workspace is None else count_workspace)
     seg_arrays, ws_arrays, unit_contig, contigs = [], [], [], []
     merge = 0
     dotted_any, plain_any = False, False

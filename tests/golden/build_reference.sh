@@ -15,6 +15,9 @@ sed -i 's/numpy\.int_t/numpy.npy_long/; s/numpy\.float_t/numpy.npy_double/; s/= 
         s/dtype *= *numpy\.int *)/dtype=int)/g; s/dtype *= *numpy\.float *)/dtype=float)/g; s/dtype=numpy\.float)/dtype=float)/g' \
     gat/SegmentList.pyx gat/Engine.pyx gat/PositionList.pyx gat/__init__.py
 sed -i 's/numpy\.float\b/float/g; s/numpy\.int\b/int/g' gat/Stats.py gat/IOTools.py gat/IO.py gat/__init__.py gat/Experiment.py
+# ConditionalSampler.sample (gat/__init__.py:832) joins the track name with an int and dies with a TypeError before
+# sampling anything; the one-token fix below lets the conditional workspaces run so that they can be pinned too
+sed -i "s/'_'.join((track, annoid))/'_'.join((track, str(annoid)))/" gat/__init__.py
 cat > setup_probe.py <<'PY'
 import numpy
 from setuptools import setup, Extension

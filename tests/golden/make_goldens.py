@@ -602,6 +602,16 @@ def g5_cli():
                             "--qvalue-method=holm"]),
         ("density_truncated", ["--num-samples=50", "--random-seed=8", "--counter=nucleotide-density",
                                "--truncate-segments-to-workspace", "--order=pvalue", "--pseudo-count=0.5"]),
+        # workspace generators (gat/Engine.pyx:2093-2153); the conditional ones need build_reference.sh's str(annoid) fix
+        ("segment_centered_expansion", ["--num-samples=40", "--random-seed=10", "--conditional=segment-centered",
+                                        "--conditional-expansion=3", "--order=annotation"]),
+        ("segment_centered_extension", ["--num-samples=40", "--random-seed=11", "--conditional=segment-centered",
+                                        "--conditional-extension=700", "--conditional-expansion=1", "--with-segment-tracks",
+                                        "--order=track", "--counter=nucleotide-density"]),
+        ("cooccurance", ["--num-samples=30", "--random-seed=12", "--conditional=cooccurance", "--order=annotation"]),
+        ("annotation_centered", ["--num-samples=30", "--random-seed=13", "--conditional=annotation-centered",
+                                 "--conditional-expansion=1.5", "--order=annotation",
+                                 "--isochores=%s" % os.path.join(cli_dir, "isochores.bed")]),
     ])
     # the reference's own integration-test data (test/data/*.bed.gz, test/check_run.py): real mouse ChIP-seq
     # intervals, 279 844 workspace segments; copied as data fixtures into tests/golden/refdata/
@@ -642,8 +652,67 @@ def g5_cli():
         json.dump(cases, f, indent=1)
 
 
+# ------------------------------------------------------------------------------------------
+# G7 workspace generators (gat/Engine.pyx:2061-2153) and the segment-list operations under them
+# (extend_segments / expand_segments, gat/SegmentList.pyx:1551-1591)
+def g7_workspaces():
+    rng = numpy.random.RandomState(4242)
+
+    def rand_dict(keys, n, span, maxlen):
+        d = Engine.IntervalDictionary()
+        for k in keys:
+            if rng.randint(0, 6) == 0:
+                continue
+            m = int(rng.randint(0, n))
+            starts = rng.randint(0, span, m)
+            lens = rng.randint(1, maxlen, m)
+            d.add(k, sl([(int(a), int(a + b)) for a, b in zip(starts, lens)], normalize=True))
+        return d
+
+    def dump(d):
+        return None if d is None else [[k, v.asList()] for k, v in d.items()]
+
+    cases = []
+    keys = ["chr1", "chr2", "chr3", "chrX"]
+    gens = [("cooccurance", {}), ("annotation-centered", dict(extension=150)), ("annotation-centered", dict(expansion=2.5)),
+            ("segment-centered", dict(extension=40)), ("segment-centered", dict(expansion=0.5)),
+            ("segment-centered", dict(expansion=7.0))]
+    for it in range(15):
+        segs = rand_dict(keys, 40, 100000, 400)
+        annos = rand_dict(keys, 30, 100000, 3000)
+        ws = rand_dict(keys, 8, 100000, 40000)
+        for name, kw in gens:
+            if name == "cooccurance":
+                g = Engine.ConditionalWorkspaceCooccurance()
+            elif name == "annotation-centered":
+                g = Engine.ConditionalWorkspaceAnnotationCentered(**kw)
+            else:
+                g = Engine.ConditionalWorkspaceSegmentCentered(**kw)
+            with_annos = it % 3 != 0
+            a, b, c = g(segs, annos if (with_annos or name != "segment-centered") else None, ws)
+            cases.append(dict(generator=name, kwargs=kw, segments=dump(segs),
+                              annotations=dump(annos) if (with_annos or name != "segment-centered") else None,
+                              workspace=dump(ws), expect=[dump(a), dump(b), dump(c)]))
+    ops = []
+    for it in range(40):
+        m = int(rng.randint(0, 30))
+        starts = rng.randint(0, 5000, m)
+        lens = rng.randint(1, 600, m)
+        pairs_ = [(int(a), int(a + b)) for a, b in zip(starts, lens)]
+        s1 = sl(pairs_)
+        ext = int(rng.randint(0, 3000))
+        s1.extend_segments(ext)
+        s2 = sl(pairs_)
+        exp = float(rng.choice([0.25, 0.5, 0.99, 1.0, 1.5, 2.0, 3.3, 50.0]))
+        s2.expand_segments(exp)
+        ops.append(dict(a=pairs_, extension=ext, extended=s1.asList(), expansion=exp, expanded=s2.asList()))
+    with open(os.path.join(HERE, "workspaces.json"), "w") as f:
+        json.dump(dict(generators=cases, ops=ops), f, separators=(",", ":"))
+    print("G7 workspace generators: %d cases, %d segment ops" % (len(cases), len(ops)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     if "g1" in which:
         g1_algebra()
     if "g2" in which:
@@ -656,3 +725,5 @@ if __name__ == "__main__":
         g5_cli()
     if "g6" in which:
         g6_stats()
+    if "g7" in which:
+        g7_workspaces()

@@ -200,3 +200,55 @@ def test_qvalues_bh():
     want = np.minimum.accumulate((p[o] * len(p) / np.arange(1, len(p) + 1))[::-1])[::-1]
     assert np.allclose(q[o], np.minimum(want, 1.0), rtol=0, atol=1e-15)
     assert np.array_equal(stats.adjustPValues([0.2], "BH"), [0.2])
+
+
+def _dict_from(dump):
+    import gat_amd as gat
+    if dump is None:
+        return None
+    d = gat.IntervalDictionary()
+    for k, pairs in dump:
+        d.add(k, gat.SegmentList(iter=[tuple(p) for p in pairs], normalize=True))
+    return d
+
+
+def _dump(d):
+    return None if d is None else [[k, [list(p) for p in v.asList()]] for k, v in d.items()]
+
+
+def test_workspace_generators_match_reference():
+    """ConditionalWorkspace* (gat/Engine.pyx:2093-2153) against what the reference returned
+    (tests/golden/workspaces.json, make_goldens.py g7)."""
+    import json
+    import os
+    import gat_amd as gat
+    with open(os.path.join(os.path.dirname(__file__), "golden", "workspaces.json")) as f:
+        g = json.load(f)
+    for case in g["generators"]:
+        kw = case["kwargs"]
+        if case["generator"] == "cooccurance":
+            gen = gat.ConditionalWorkspaceCooccurance()
+        elif case["generator"] == "annotation-centered":
+            gen = gat.ConditionalWorkspaceAnnotationCentered(**kw)
+        else:
+            gen = gat.ConditionalWorkspaceSegmentCentered(**kw)
+        segs, annos, ws = _dict_from(case["segments"]), _dict_from(case["annotations"]), _dict_from(case["workspace"])
+        before = (_dump(segs), _dump(annos), _dump(ws))
+        a, b, c = gen(segs, annos, ws)
+        assert [_dump(a), _dump(b), _dump(c)] == case["expect"], (case["generator"], kw)
+        assert (_dump(segs), _dump(annos), _dump(ws)) == before          # inputs are never mutated
+    for op in g["ops"]:
+        s = gat.SegmentList(iter=[tuple(p) for p in op["a"]])
+        s.extend_segments(op["extension"])
+        assert [list(p) for p in s.asList()] == op["extended"]
+        s = gat.SegmentList(iter=[tuple(p) for p in op["a"]])
+        s.expand_segments(op["expansion"])
+        assert [list(p) for p in s.asList()] == op["expanded"]
+
+
+def test_centered_workspace_needs_a_size():
+    import gat_amd as gat
+    with pytest.raises(ValueError):
+        gat.ConditionalWorkspaceSegmentCentered()
+    with pytest.raises(ValueError):
+        gat.SegmentList(iter=[(1, 5)]).expand_segments(0.0)
