@@ -15,7 +15,8 @@ from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sample
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
                      UnconditionalWorkspace, ConditionalWorkspaceCooccurance, ConditionalWorkspaceCentered,
                      ConditionalWorkspaceAnnotationCentered, ConditionalWorkspaceSegmentCentered, computeCounts, AnnotatorResult, AnnotatorResultExtended,
-                     getTwoSidedPValue, updatePValues, get_context)
+                     getTwoSidedPValue, updatePValues, getNormedPValue, getEmpiricalPValue, getQValues, updateQValues,
+                     get_context)
 
 __version__ = "0.1"
 
@@ -203,9 +204,12 @@ def buildParser(usage=None):
     g.add_option("--nbuckets", dest="nbuckets", type="int")
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Statistics options")
-    g.add_option("-p", "--pvalue-method", dest="pvalue_method", type="choice", choices=("empirical",))
+    g.add_option("-p", "--pvalue-method", dest="pvalue_method", type="choice", choices=("empirical", "norm"))
     g.add_option("-q", "--qvalue-method", dest="qvalue_method", type="choice",
-                 choices=("BH", "bonferroni", "holm", "hochberg", "BY", "none"))
+                 choices=("storey", "BH", "bonferroni", "holm", "hommel", "hochberg", "BY", "none"))
+    g.add_option("--qvalue-lambda", dest="qvalue_lambda", type="float", help="fdr computation: lambda")
+    g.add_option("--qvalue-pi0-method", dest="qvalue_pi0_method", type="choice", choices=("smoother", "bootstrap"),
+                 help="fdr computation: method for estimating pi0")
     g.add_option("--pseudo-count", dest="pseudo_count", type="float")
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Processing options")
@@ -231,6 +235,7 @@ def buildParser(usage=None):
                         nbuckets=100000, num_samples=1000, num_threads=0, output_counts_pattern=None,
                         output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",
                         overlapping_annotations=False, pseudo_count=1.0, pvalue_method="empirical", qvalue_method="BH",
+                        qvalue_lambda=None, qvalue_pi0_method="smoother",
                         random_seed=None, restrict_workspace=False, sampler="annotator", segment_files=[],
                         truncate_segments_to_workspace=False, truncate_workspace_to_annotations=False,
                         conditional="unconditional", conditional_extension=None, conditional_expansion=None,

@@ -770,9 +770,40 @@ class AnnotatorResultExtended(AnnotatorResult):
             _toFold(self.overlap_nsegments, self.annotation_nsegments), _toFold(self.overlap_size, self.annotation_size)))
 
 
+def getNormedPValue(value, r):
+    """p-value under a Gaussian fitted to the null distribution (gat/Engine.pyx:1979-1990)."""
+    absval = abs(value - r.expected)
+    if r.stddev == 0:
+        return 1.0
+    import scipy.stats
+    return 1.0 - scipy.stats.norm.cdf(absval, 0, r.stddev)
+
+
+def getEmpiricalPValue(value, r):
+    """gat/Engine.pyx:1995."""
+    return r.getEmpiricalPValue(value)
+
+
 def updatePValues(annotator_results, method="empirical"):
-    """gat/Engine.pyx:2001-2023 (empirical only)."""
-    if method != "empirical":
-        raise ValueError("only the empirical method is implemented (got %r)" % method)
+    """gat/Engine.pyx:2001-2020."""
+    if method == "norm":
+        methodf = getNormedPValue
+    elif method == "empirical":
+        methodf = getEmpiricalPValue
+    else:
+        raise ValueError("unknown method '%s'" % method)
     for r in annotator_results:
-        r.pvalue = r.getEmpiricalPValue(r.observed)
+        r.pvalue = methodf(r.observed, r)
+
+
+def getQValues(pvalues, method="storey", **kwargs):
+    """gat/Engine.pyx:2025-2040."""
+    from . import stats
+    return stats.getQValues(pvalues, method=method, **kwargs)
+
+
+def updateQValues(annotator_results, method="storey", **kwargs):
+    """gat/Engine.pyx:2044-2054."""
+    pvalues = [r.pvalue for r in annotator_results]
+    for r, qvalue in zip(annotator_results, getQValues(pvalues, method, **kwargs)):
+        r.qvalue = qvalue

@@ -168,7 +168,9 @@ def outputResults(results, options, header, description_header=(), description_w
                   format_observed="%i"):
     """gat/IO.py:457-539: q-values, one table per counter, rows ordered by --order."""
     pvalues = [x.pvalue for x in results]
-    qvalues = stats.getQValues(pvalues, method=options.qvalue_method)
+    qvalues = stats.getQValues(pvalues, method=options.qvalue_method,
+                               vlambda=getattr(options, "qvalue_lambda", None),
+                               pi0_method=getattr(options, "qvalue_pi0_method", "smoother"))
     for x, qvalue in zip(results, qvalues):
         x.qvalue = qvalue
         x.format_observed = format_observed

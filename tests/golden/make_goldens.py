@@ -608,6 +608,10 @@ def g5_cli():
         ("segment_centered_extension", ["--num-samples=40", "--random-seed=11", "--conditional=segment-centered",
                                         "--conditional-extension=700", "--conditional-expansion=1", "--with-segment-tracks",
                                         "--order=track", "--counter=nucleotide-density"]),
+        ("storey_norm", ["--num-samples=50", "--random-seed=14", "--qvalue-method=storey", "--pvalue-method=norm",
+                         "--with-segment-tracks"]),
+        ("storey_lambda", ["--num-samples=50", "--random-seed=15", "--qvalue-method=storey", "--qvalue-lambda=0.3",
+                           "--counter=segment-overlap", "--order=qvalue"]),
         ("cooccurance", ["--num-samples=30", "--random-seed=12", "--conditional=cooccurance", "--order=annotation"]),
         ("annotation_centered", ["--num-samples=30", "--random-seed=13", "--conditional=annotation-centered",
                                  "--conditional-expansion=1.5", "--order=annotation",
@@ -650,6 +654,52 @@ def g5_cli():
         os.remove(os.path.join(cli_dir, "ref.log"))
     with open(os.path.join(cli_dir, "cases.json"), "w") as f:
         json.dump(cases, f, indent=1)
+
+
+# ------------------------------------------------------------------------------------------
+# G8 q-values (gat/Engine.pyx:2025-2040 getQValues -> gat/Stats.py:26-160 computeQValues (Storey) and :192-258
+# adjustPValues) and the "norm" p-value (gat/Engine.pyx:1979-1990)
+def g8_qvalues():
+    import warnings
+    rs = numpy.random.RandomState(808)
+    cases = []
+    # vlambda=None is what the command line passes (gat/IO.py:474-477); without the keyword getQValues hands
+    # computeQValues an array, whose `vlambda == None` test (gat/Stats.py:46) is elementwise under numpy >= 1.13 and
+    # makes the call fail into the all-1.0 fallback (gat/Engine.pyx:2033-2035)
+    methods = [("storey", dict(vlambda=None)), ("storey", dict(vlambda=0.5)), ("storey", dict(vlambda=0.0)),
+               ("storey", dict(vlambda=None, pi0_method="bootstrap")), ("BH", {}), ("bonferroni", {}), ("holm", {}),
+               ("hochberg", {}), ("BY", {}), ("none", {}), ("hommel", {})]
+    for it in range(40):
+        m = int(rs.choice([1, 2, 3, 5, 17, 60, 250]))
+        kind = it % 4
+        if kind == 0:
+            pv = rs.uniform(0, 1, m)
+        elif kind == 1:                                   # empirical p-values: multiples of 1/S with ties
+            pv = rs.randint(1, 101, m) / 100.0
+        elif kind == 2:                                   # enriched for small values
+            pv = numpy.minimum(1.0, rs.beta(0.3, 2.0, m))
+        else:
+            pv = numpy.round(rs.uniform(0, 1, m), 1)
+        for name, kw in methods:
+            numpy.random.seed(1000 + it)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    q = Engine.getQValues([float(x) for x in pv], method=name, **kw)
+                    cases.append(dict(pvalues=[float(x) for x in pv], method=name, kwargs=kw, seed=1000 + it,
+                                      expect=[float(x) for x in q]))
+                except Exception as e:                     # noqa: BLE001
+                    cases.append(dict(pvalues=[float(x) for x in pv], method=name, kwargs=kw, seed=1000 + it,
+                                      error=type(e).__name__))
+    normed = []
+    for it in range(30):
+        samples = rs.poisson(float(rs.choice([0.0, 3, 500])), size=int(rs.choice([5, 100]))).astype(float)
+        obs = float(rs.choice(samples)) + float(rs.choice([0, 1, 40]))
+        r = Engine.AnnotatorResult("t", "a", "c", obs, samples, reference=None, pseudo_count=1.0)
+        normed.append(dict(observed=obs, samples=[float(x) for x in samples], expect=float(Engine.getNormedPValue(obs, r))))
+    with open(os.path.join(HERE, "qvalues.json"), "w") as f:
+        json.dump(dict(qvalues=cases, normed=normed), f, separators=(",", ":"))
+    print("G8 q-values: %d cases (%d errors), %d normed p-values" % (len(cases), sum(1 for c in cases if "error" in c), len(normed)))
 
 
 # ------------------------------------------------------------------------------------------
@@ -712,7 +762,7 @@ def g7_workspaces():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     if "g1" in which:
         g1_algebra()
     if "g2" in which:
@@ -727,3 +777,5 @@ if __name__ == "__main__":
         g6_stats()
     if "g7" in which:
         g7_workspaces()
+    if "g8" in which:
+        g8_qvalues()

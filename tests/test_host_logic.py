@@ -252,3 +252,30 @@ def test_centered_workspace_needs_a_size():
         gat.ConditionalWorkspaceSegmentCentered()
     with pytest.raises(ValueError):
         gat.SegmentList(iter=[(1, 5)]).expand_segments(0.0)
+
+
+def test_qvalues_match_reference():
+    """getQValues / computeQValues / adjustPValues and the 'norm' p-value against the reference's output
+    (tests/golden/qvalues.json, make_goldens.py g8): Storey with smoother and bootstrap pi0, p.adjust family."""
+    import json
+    import os
+    import warnings
+    import gat_amd as gat
+    with open(os.path.join(os.path.dirname(__file__), "golden", "qvalues.json")) as f:
+        g = json.load(f)
+    n_storey = 0
+    for case in g["qvalues"]:
+        np.random.seed(case["seed"])
+        if "error" in case:
+            with pytest.raises(NotImplementedError):
+                gat.getQValues(case["pvalues"], method=case["method"], **case["kwargs"])
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q = gat.getQValues(case["pvalues"], method=case["method"], **case["kwargs"])
+        assert [float(x) for x in q] == case["expect"], (case["method"], case["kwargs"], len(case["pvalues"]))
+        n_storey += case["method"] == "storey"
+    assert n_storey >= 100
+    for case in g["normed"]:
+        r = gat.AnnotatorResult("t", "a", "c", case["observed"], case["samples"], reference=None, pseudo_count=1.0)
+        assert float(gat.getNormedPValue(case["observed"], r)) == case["expect"]
