@@ -188,6 +188,10 @@ def buildParser(usage=None):
                  help="the segments file is arranged in tracks")
     g.add_option("--enable-split-tracks", dest="enable_split_tracks", action="store_true")
     g.add_option("--annotations-label", dest="annotations_label", type="string")
+    g.add_option("--input-results-file", dest="input_filename_results", type="string",
+                 help="start from a previous results table (re-computes the fdr)")
+    g.add_option("--descriptions", dest="input_filename_descriptions", type="string",
+                 help="tab-separated file mapping annotations to extra description columns")
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Output options")
     g.add_option("-o", "--order", dest="output_order", type="choice",
@@ -230,7 +234,7 @@ def buildParser(usage=None):
     g.add_option("-S", "--stdout", dest="stdout", type="string", metavar="FILE")
     g.add_option("-L", "--log", dest="stdlog", type="string", metavar="FILE")
     parser.add_option_group(g)
-    parser.set_defaults(annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
+    parser.set_defaults(input_filename_results=None, input_filename_descriptions=None, annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
                         counters=[], enable_split_tracks=False, ignore_segment_tracks=True, isochore_files=[],
                         nbuckets=100000, num_samples=1000, num_threads=0, output_counts_pattern=None,
                         output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",

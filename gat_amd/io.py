@@ -164,6 +164,70 @@ def applyIsochores(segments, annotations, workspaces, options, isochores=None, t
     return workspace
 
 
+class DummyAnnotatorResult(object):
+    """a row read back from a results table (gat/__init__.py:439-485): ten columns are kept and printed."""
+    format_observed = "%i"
+    format_expected = "%6.4f"
+    format_fold = "%6.4f"
+    format_pvalue = "%6.4e"
+
+    @classmethod
+    def _fromLine(cls, line):
+        x = cls()
+        data = line[:-1].split("\t")
+        x.track, x.annotation = data[:2]
+        x.counter = "na"
+        (x.observed, x.expected, x.lower95, x.upper95, x.stddev, x.fold, x.l2fold, x.pvalue,
+         x.qvalue) = [float(v) for v in data[2:11]]
+        if len(data) > 11:
+            [float(v) for v in data[11:24]]                       # parsed (and checked) but not kept, as in the reference
+        return x
+
+    def __str__(self):
+        return "\t".join((self.track, self.annotation, self.format_observed % self.observed,
+                          self.format_expected % self.expected, self.format_expected % self.lower95,
+                          self.format_expected % self.upper95, self.format_expected % self.stddev,
+                          self.format_fold % self.fold, self.format_pvalue % self.pvalue,
+                          self.format_pvalue % self.qvalue))
+
+
+def readAnnotatorResults(filename):
+    """load rows of a tab-separated results table (gat/IO.py:67-81)."""
+    results = []
+    with openFile(filename, "r") as infile:
+        for line in infile:
+            if line.startswith("#") or line.startswith("track"):
+                continue
+            results.append(DummyAnnotatorResult._fromLine(line))
+    return results
+
+
+def readDescriptions(options):
+    """annotation -> description columns from a tab-separated file whose first line is the header
+    (gat/IO.py:296-328).  Returns (description_header, descriptions, description_width)."""
+    description_header, descriptions, description_width = [], {}, 0
+    filename = getattr(options, "input_filename_descriptions", None)
+    if filename:
+        with openFile(filename) as inf:
+            first = True
+            for line in inf:
+                if line.startswith("#"):
+                    continue
+                data = line[:-1].split("\t")
+                if description_width:
+                    assert len(data) - 1 == description_width, "inconsistent number of descriptions in %s" % filename
+                else:
+                    description_width = len(data) - 1
+                if first:
+                    description_header = data[1:]
+                    first = False
+                else:
+                    descriptions[data[0]] = data[1:]
+        assert len(description_header) == description_width, \
+            "number of descriptions (%i) inconsistent with header (%s) in %s" % (description_width, len(description_header), filename)
+    return description_header, descriptions, description_width
+
+
 def outputResults(results, options, header, description_header=(), description_width=0, descriptions=None,
                   format_observed="%i"):
     """gat/IO.py:457-539: q-values, one table per counter, rows ordered by --order."""

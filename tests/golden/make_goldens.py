@@ -648,6 +648,22 @@ def g5_cli():
             with open(out, "w") as f:
                 f.writelines(lines)
             print("G5 cli %s: %d rows" % (name, len(lines) - 1))
+        # results-table round trip: --input-results-file re-computes the fdr of a previous table; --descriptions
+        # appends columns (scripts/gat-run.py:287-291, gat/IO.py:296-328)
+        aux = os.path.join(cli_dir, "aux")
+        os.makedirs(aux, exist_ok=True)
+        with open(os.path.join(aux, "descriptions.tsv"), "w") as f:
+            f.write("annotation\tdescription\tgroup\nt0\tfirst track\tA\nt1\tsecond track\tB\n")
+        for name, extra in (("results_file_descriptions", ["--input-results-file=%s" % os.path.join(cli_dir, "expected_default.tsv"),
+                                                           "--qvalue-method=bonferroni", "--order=annotation",
+                                                           "--descriptions=%s" % os.path.join(aux, "descriptions.tsv")]),
+                            ("results_file_storey", ["--input-results-file=%s" % os.path.join(cli_dir, "expected_segment_tracks.tsv"),
+                                                     "--qvalue-method=storey", "--order=pvalue"])):
+            out = os.path.join(aux, "expected_%s.tsv" % name)
+            mod.main(["gat-run.py", "--stdout=%s" % out, "--log=%s" % os.path.join(cli_dir, "ref.log")] + extra)
+            lines = [l for l in open(out) if not l.startswith("#")]
+            with open(out, "w") as f:
+                f.writelines(lines)
     finally:
         gat.computeSample = original
     if os.path.exists(os.path.join(cli_dir, "ref.log")):

@@ -279,3 +279,28 @@ def test_qvalues_match_reference():
     for case in g["normed"]:
         r = gat.AnnotatorResult("t", "a", "c", case["observed"], case["samples"], reference=None, pseudo_count=1.0)
         assert float(gat.getNormedPValue(case["observed"], r)) == case["expect"]
+
+
+def test_cli_results_file_round_trip(tmp_path):
+    """--input-results-file (fdr re-computed on a previous table) and --descriptions against the reference's
+    output for the same files (tests/golden/cli/aux/, make_goldens.py g5).  No sampling, so no GPU."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gat_run_amd", os.path.join(root, "scripts", "gat-run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cli = os.path.join(root, "tests", "golden", "cli")
+    cases = {
+        "results_file_descriptions": ["--input-results-file=%s" % os.path.join(cli, "expected_default.tsv"),
+                                      "--qvalue-method=bonferroni", "--order=annotation",
+                                      "--descriptions=%s" % os.path.join(cli, "aux", "descriptions.tsv")],
+        "results_file_storey": ["--input-results-file=%s" % os.path.join(cli, "expected_segment_tracks.tsv"),
+                                "--qvalue-method=storey", "--order=pvalue"],
+    }
+    for name, extra in cases.items():
+        out = str(tmp_path / (name + ".tsv"))
+        assert mod.main(["gat-run.py", "--stdout=%s" % out, "--log=%s" % str(tmp_path / "log")] + extra) == 0
+        got = [l for l in open(out) if not l.startswith("#")]
+        want = open(os.path.join(cli, "aux", "expected_%s.tsv" % name)).readlines()
+        assert got == want, name
