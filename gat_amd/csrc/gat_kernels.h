@@ -167,7 +167,7 @@ template <int KIND>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   __shared__ uint32_t l_ws_start[kPlaceWsLds], l_ws_end[kPlaceWsLds], l_ws_cdf[kPlaceWsLds];
   __shared__ uint32_t l_rank[kPlaceRankLds];
-  __shared__ uint4 l_out[4][kWave];       // 8 placed segments per lane, flushed as one 64-byte burst
+  __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = blockIdx.y;
   const int u = A.order[a];
@@ -281,15 +281,10 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
       if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
       else {
-        // scattered 8-byte stores reach HBM as partial lines (4.8x write traffic measured); collect 8
-        // segments per lane in LDS and write the 64-byte line in one go
-        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 3][lane])[nS & 1] = make_uint2(start, end);
+        // scattered 8-byte stores reach HBM as partial lines (4.8x write traffic measured); segments are
+        // collected per lane in an LDS ring and written as whole 64-byte lines (flush(), once per chunk)
+        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);
         nS++;
-        if ((nS & 7) == 0) {
-          uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nS - 8);
-#pragma unroll
-          for (int w = 0; w < 4; ++w) dst[w] = l_out[w][lane];
-        }
         rem -= overlap;
         st = S_L; curmask = maskL; currange = rangeL;
         if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }       // SamplerSegments: n placements
@@ -322,13 +317,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
         const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
         if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
         else {
-          reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 3][lane])[nS & 1] = make_uint2(start, end);
+          reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);
           nS++;
-          if ((nS & 7) == 0) {
-            uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nS - 8);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) dst[w] = l_out[w][lane];
-          }
           rem -= overlap;
           st = S_L; curmask = maskL; currange = rangeL;
           if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }
@@ -337,29 +327,48 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     }
   };
 
-  if (simple) {
-    for (int j = 0; j < rows; j += kPlaceChunk) {
-      if (__ballot(st != S_HALT) == 0) break;
-      uint32_t y[kPlaceChunk];
+  // rows are consumed in chunks of kPlaceChunk; the next chunk is in flight while this one is worked on
+  // (few waves per SIMD: nothing else hides the load latency)
+  // a placement takes at least two accepted outputs, so a chunk adds at most kPlaceChunk/2 = 4 segments to the
+  // at most 7 left by the previous flush: the ring of 16 never wraps onto unwritten segments
+  int nF = 0;                  // segments already written to the slab (multiple of 8)
+  auto flush = [&]() {
+    if (nS - nF >= 8) {
+      uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
+      const int w0 = (nF >> 1) & 7;
 #pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
-      rp += kPlaceChunk * kWave;
-#pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) step_simple(y[c], (uint32_t)(j + c));
+      for (int w = 0; w < 4; ++w) dst[w] = l_out[w0 + w][lane];
+      nF += 8;
     }
-  } else {
-    for (int j = 0; j < rows; j += kPlaceChunk) {
+  };
+  auto run = [&](auto&& one) {
+    uint32_t ya[kPlaceChunk], yb[kPlaceChunk];
+#pragma unroll
+    for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[c * kWave];
+    for (int j = 0; j < rows; j += 2 * kPlaceChunk) {
       if (__ballot(st != S_HALT) == 0) break;
-      uint32_t y[kPlaceChunk];
+      const bool more_b = j + kPlaceChunk < rows;
+      if (more_b) {
 #pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) y[c] = rp[c * kWave];
-      rp += kPlaceChunk * kWave;
+        for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rp[(kPlaceChunk + c) * kWave];
+      }
 #pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) step(y[c], (uint32_t)(j + c));
+      for (int c = 0; c < kPlaceChunk; ++c) one(ya[c], (uint32_t)(j + c));
+      flush();
+      if (!more_b || __ballot(st != S_HALT) == 0) break;
+      if (j + 2 * kPlaceChunk < rows) {
+#pragma unroll
+        for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[(2 * kPlaceChunk + c) * kWave];
+      }
+      rp += 2 * kPlaceChunk * kWave;
+#pragma unroll
+      for (int c = 0; c < kPlaceChunk; ++c) one(yb[c], (uint32_t)(j + kPlaceChunk + c));
+      flush();
     }
-  }
+  };
+  if (simple) run(step_simple); else run(step);
   if (live) {
-    for (int i = nS & ~7; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 3][lane])[i & 1];   // partial last line
+    for (int i = nF; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 7][lane])[i & 1];   // what the last flush left
     A.st[so] = make_int4(nS, rem, (st == S_HALT && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
                          (int)used);
     if (flag) atomicOr(A.flags, flag);
