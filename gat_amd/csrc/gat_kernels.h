@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   uint32_t used = 0;           // raw outputs consumed by this lane when it halted
   int flag = 0;
 
-  auto step = [&](uint32_t y, uint32_t jj) {
+  auto step = [&](uint32_t y, uint32_t, uint32_t jj) __attribute__((always_inline)) {
     const uint32_t v = y & curmask;
     const bool acc = st != S_HALT && v <= currange;
     if (!__any(acc)) return;
@@ -295,44 +295,48 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
   // LDS -- needs no workspace search, no bucket draw and never an immediate placement
   const bool simple = nws == 1 && !drawB && rank_lds && ws0.y - ws0.x > 1u;
-  auto step_simple = [&](uint32_t y, uint32_t jj) {
-    const uint32_t v = y & curmask;
-    const bool acc = st != S_HALT && v <= currange;
-    if (!__any(acc)) return;
-    if (acc) {
-      if (st == S_L) {
-        len = l_rank[1u + v];
-        if (!kind1 && rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }
-        else { st = S_P; curmask = maskP; currange = rangeP; }
-      } else if (st == S_P) {
-        sstart = (int32_t)ws0.x - (int32_t)len + 1;
-        const uint32_t range3 = ws0.y - 1u - (uint32_t)sstart;
-        st = S_O; curmask = 0xffffffffu >> __builtin_clz(range3); currange = range3;
-      } else {
-        const int32_t q = sstart + (int32_t)v;
-        const uint32_t start = (uint32_t)(q > 0 ? q : 0);
-        const uint32_t end = (uint32_t)(q + (int32_t)len);
-        const int32_t omin = (int32_t)ws0.y < (int32_t)end ? (int32_t)ws0.y : (int32_t)end;
-        const int32_t omax = (int32_t)ws0.x > (int32_t)start ? (int32_t)ws0.x : (int32_t)start;
-        const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
-        if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
-        else {
-          reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);
-          nS++;
-          rem -= overlap;
-          st = S_L; curmask = maskL; currange = rangeL;
-          if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }
-        }
-      }
-    }
-  };
+  // Straight-line form: a lane's state only selects which of the three small results it keeps, so the wave runs
+  // one instruction stream instead of three divergent ones.  `lr` is the length of rank 1 + (y & maskL), read
+  // from LDS for the whole chunk up front (one exposed LDS latency per chunk instead of one per output).
+#define GAT_STEP_SIMPLE(Y, LR, JJ)                                                                            \
+  {                                                                                                            \
+    const uint32_t v = (Y) & curmask;                                                                          \
+    const bool acc = st != S_HALT && v <= currange;                                                            \
+    const bool isL = acc && st == S_L, isP = acc && st == S_P, isO = acc && st == S_O;                         \
+    const bool trig = isL && !kind1 && rem <= (int32_t)(LR);           /* :582 -> consolidate */               \
+    len = isL ? (LR) : len;                                                                                    \
+    const int32_t sstartP = (int32_t)ws0.x - (int32_t)len + 1;                                                 \
+    const uint32_t range3 = ws0.y - 1u - (uint32_t)sstartP;                                                    \
+    const uint32_t mask3 = 0xffffffffu >> __builtin_clz(range3 | 1u);                                          \
+    int nst = isL ? S_P : (isP ? S_O : (isO ? S_L : st));                                                      \
+    if (trig) { pend = (int32_t)len; used = (JJ) + 1u; nst = S_HALT; }                                         \
+    if (isO) {                                                                                                 \
+      const int32_t q = sstart + (int32_t)v;                                                                   \
+      const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                        \
+      const uint32_t end = (uint32_t)(q + (int32_t)len);                                                       \
+      const int32_t omin = (int32_t)ws0.y < (int32_t)end ? (int32_t)ws0.y : (int32_t)end;                      \
+      const int32_t omax = (int32_t)ws0.x > (int32_t)start ? (int32_t)ws0.x : (int32_t)start;                  \
+      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
+      if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
+      else {                                                                                                   \
+        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);                \
+        nS++;                                                                                                  \
+        rem -= overlap;                                                                                        \
+        if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
+      }                                                                                                        \
+    }                                                                                                          \
+    sstart = isP ? sstartP : sstart;                                                                           \
+    curmask = isL ? maskP : (isP ? mask3 : (isO ? maskL : curmask));                                           \
+    currange = isL ? rangeP : (isP ? range3 : (isO ? rangeL : currange));                                      \
+    st = nst;                                                                                                  \
+  }
 
   // rows are consumed in chunks of kPlaceChunk; the next chunk is in flight while this one is worked on
   // (few waves per SIMD: nothing else hides the load latency)
   // a placement takes at least two accepted outputs, so a chunk adds at most kPlaceChunk/2 = 4 segments to the
   // at most 7 left by the previous flush: the ring of 16 never wraps onto unwritten segments
   int nF = 0;                  // segments already written to the slab (multiple of 8)
-  auto flush = [&]() {
+  auto flush = [&]() __attribute__((always_inline)) {
     if (nS - nF >= 8) {
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
       const int w0 = (nF >> 1) & 7;
@@ -341,32 +345,39 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       nF += 8;
     }
   };
-  auto run = [&](auto&& one) {
-    uint32_t ya[kPlaceChunk], yb[kPlaceChunk];
-#pragma unroll
-    for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[c * kWave];
-    for (int j = 0; j < rows; j += 2 * kPlaceChunk) {
-      if (__ballot(st != S_HALT) == 0) break;
-      const bool more_b = j + kPlaceChunk < rows;
-      if (more_b) {
-#pragma unroll
-        for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rp[(kPlaceChunk + c) * kWave];
-      }
-#pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) one(ya[c], (uint32_t)(j + c));
-      flush();
-      if (!more_b || __ballot(st != S_HALT) == 0) break;
-      if (j + 2 * kPlaceChunk < rows) {
-#pragma unroll
-        for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[(2 * kPlaceChunk + c) * kWave];
-      }
-      rp += 2 * kPlaceChunk * kWave;
-#pragma unroll
-      for (int c = 0; c < kPlaceChunk; ++c) one(yb[c], (uint32_t)(j + kPlaceChunk + c));
-      flush();
-    }
-  };
-  if (simple) run(step_simple); else run(step);
+  uint32_t ya[kPlaceChunk], yb[kPlaceChunk], lr[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (a macro, not a lambda taking the step closure: that form kept the closures in scratch memory)
+#define GAT_PLACE_LOOP(ONE, RANK)                                                                              \
+  {                                                                                                            \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[c * kWave];                             \
+    for (int j = 0; j < rows; j += 2 * kPlaceChunk) {                                                          \
+      if (__ballot(st != S_HALT) == 0) break;                                                                  \
+      const bool more_b = j + kPlaceChunk < rows;                                                              \
+      if (more_b) {                                                                                            \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rp[(kPlaceChunk + c) * kWave];         \
+      }                                                                                                        \
+      if (RANK) {                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                              \
+          const uint32_t v = ya[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }                       \
+      }                                                                                                        \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya[c], lr[c], (uint32_t)(j + c));            \
+      flush();                                                                                                 \
+      if (!more_b || __ballot(st != S_HALT) == 0) break;                                                       \
+      if (j + 2 * kPlaceChunk < rows) {                                                                        \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[(2 * kPlaceChunk + c) * kWave];     \
+      }                                                                                                        \
+      rp += 2 * kPlaceChunk * kWave;                                                                           \
+      if (RANK) {                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                              \
+          const uint32_t v = yb[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }                       \
+      }                                                                                                        \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb[c], lr[c], (uint32_t)(j + kPlaceChunk + c)); \
+      flush();                                                                                                 \
+    }                                                                                                          \
+  }
+  if (simple) GAT_PLACE_LOOP(GAT_STEP_SIMPLE, true) else GAT_PLACE_LOOP(step, false)
+#undef GAT_PLACE_LOOP
+#undef GAT_STEP_SIMPLE
   if (live) {
     for (int i = nF; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 7][lane])[i & 1];   // what the last flush left
     A.st[so] = make_int4(nS, rem, (st == S_HALT && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
