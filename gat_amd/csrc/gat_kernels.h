@@ -30,7 +30,7 @@ struct UnitDev {
   int32_t contig;
   int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
   int32_t n_target;     // SamplerSegments: len(segments) placements (gat/Engine.pyx:726)
-  int32_t pad;
+  int32_t pad;          // units_o: the unit id
 };
 
 enum : int32_t {
@@ -42,6 +42,7 @@ enum : int32_t {
 struct SamplerArgs {
   const UnitDev* units;
   const int32_t* order;       // active unit ids, largest first
+  const UnitDev* units_o;     // units[order[a]] with the unit id in `pad`: one load instead of two dependent ones
   int32_t n_units;
   int32_t batch;              // samples in this batch
   const uint2* ws;
@@ -93,10 +94,11 @@ constexpr int kRngChunk = 52;      // 624 = 12 * 52
 
 __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keeps all index math scalar
   uint32_t* mt = lds + lane;                        // lane column, stride 64
   const int sb = blockIdx.x, a = blockIdx.y;
-  const int u = A.order[a];
+  const int u = A.units_o[a].pad;
   const int rows = A.rng_rows[a];
   if (wv == 0) {
     const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
   constexpr int kPerBlock = kMtN / kRngChunk;       // 12 chunks per 624-word block
+  constexpr int kGroup = 4;                          // words per batch of LDS reads (rows and kRngChunk are multiples of 4)
   uint32_t next_old = mt[kRngChunk * kWave];         // old first word of chunk 1 (for wave 0, step 0)
   for (int s = 0; 2 * s - 2 < nchunks; ++s) {
     if (wv < 2) {
@@ -119,17 +122,25 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
         const int i0 = (t % kPerBlock) * kRngChunk;
         uint32_t cur = mt[i0 * kWave];
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-          const int i = i0 + k;
-          const int in = i + 1 == kMtN ? 0 : i + 1;                        // word 623 pairs with the NEW word 0
-          const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;    // i < 227: old word i+397, else new word i-227
-          const uint32_t far = mt[jf * kWave];
-          uint32_t nxt = mt[in * kWave];
-          if (wv == 0 && k == kRngChunk - 1) nxt = next_old;               // wave 1 is rewriting that word right now
-          const uint32_t y = (cur & kMtUpper) | (nxt & kMtLower);
-          mt[i * kWave] = far ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
-          cur = nxt;                                                        // old word i+1 is the next step's word i
+        for (int k = 0; k < cnt; k += kGroup) {
+          // all reads of the group first (none of them is a word this group writes: i+397 / i-227 are far away and
+          // the old word i+1 is read before it is rewritten), so one LDS latency is exposed per group, not per word
+          uint32_t far[kGroup], nx[kGroup];
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) {
+            const int i = i0 + k + q;
+            const int in = i + 1 == kMtN ? 0 : i + 1;                        // word 623 pairs with the NEW word 0
+            const int jf = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;    // i < 227: old word i+397, else new word i-227
+            far[q] = mt[jf * kWave];
+            nx[q] = mt[in * kWave];
+          }
+          if (wv == 0 && k + kGroup == kRngChunk) nx[kGroup - 1] = next_old;  // wave 1 is rewriting that word right now
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) {
+            const uint32_t y = (cur & kMtUpper) | (nx[q] & kMtLower);
+            mt[(i0 + k + q) * kWave] = far[q] ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+            cur = nx[q];                                                      // old word i+1 is the next word's word i
+          }
         }
       }
       if (wv == 0) {                                 // first word of chunk 2(s+1)+1: untouched until the next step
@@ -141,9 +152,15 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
       if (t >= 0 && t < nchunks) {
         const int e0 = t * kRngChunk;
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
-        const int i0 = (t % kPerBlock) * kRngChunk;
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) out[(int64_t)(e0 + k) * kWave] = mt_temper(mt[(i0 + k) * kWave]);
+        const uint32_t* __restrict__ src = mt + ((t % kPerBlock) * kRngChunk) * kWave;
+        uint32_t* __restrict__ dst = out + (int64_t)e0 * kWave;
+        for (int k = 0; k < cnt; k += kGroup) {
+          uint32_t w[kGroup];
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) w[q] = src[(k + q) * kWave];
+#pragma unroll
+          for (int q = 0; q < kGroup; ++q) dst[(k + q) * kWave] = mt_temper(w[q]);
+        }
       }
     }
     __syncthreads();
@@ -170,8 +187,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = blockIdx.y;
-  const int u = A.order[a];
-  const UnitDev* __restrict__ Up = A.units + u;
+  const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
   const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
   const int cap = Up->slab_cap;
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   const int rows = A.rng_rows[a];
   const int sidx = sb * kWave + lane;
   const bool live = sidx < A.batch;
-  const int64_t so = (int64_t)sidx * A.n_units + u;
+  const int64_t so = (int64_t)sidx * A.n_units + a;      // hand-off record, indexed by launch position
 
   // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
   constexpr bool kind1 = KIND == 1;           // SamplerSegments: fixed number of placements, no trigger
@@ -398,8 +414,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
   const int a = blockIdx.y;
-  const int u = A.order[a];
-  const UnitDev* __restrict__ Up = A.units + u;
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int u = Up->pad;
   const int nws = Up->n_ws;
   const uint32_t hist_total = Up->hist_total;
   const uint32_t bucket = Up->bucket;
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
   const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
   const bool have_pre = A.st != nullptr;
-  const int4 pre = have_pre ? A.st[so] : make_int4(0, 0, -1, 0);
+  const int4 pre = have_pre ? A.st[(int64_t)sidx * A.n_units + a] : make_int4(0, 0, -1, 0);
   const int32_t pre_len = pre.z;
 
   int nout = 0, status = 0, nuns = 0;

@@ -182,6 +182,7 @@ struct gat_problem {
   int32_t max_unit_cap = 0, max_contig_cap = 0;
   int64_t n_seg_total = 0;               // input segments (for the algorithmic byte count)
   DevBuf<UnitDev> d_units;
+  DevBuf<UnitDev> d_units_o;            // the active units' records in launch order (h_order), unit id in `pad`
   DevBuf<int32_t> d_order, d_contig_unit_off, d_contig_units, d_contig_slab_off, d_count_c_off, d_count_n_index;
   DevBuf<uint2> d_ws;
   DevBuf<uint32_t> d_ws_cdf, d_hist_idx, d_hist_cdf, d_rank_len;
@@ -331,6 +332,14 @@ static int layout_slab(gat_problem* P) {
 
 static int upload_layout(gat_ctx* ctx, gat_problem* P) {
   HIPCHK(ctx, P->d_units.upload(P->h_units, ctx->stream));
+  {
+    // a wave finds its unit with one load (units_o[blockIdx.y]) instead of order[] -> units[]
+    std::vector<UnitDev> o;
+    o.reserve(P->h_order.size());
+    for (int32_t u : P->h_order) { UnitDev x = P->h_units[(size_t)u]; x.pad = u; o.push_back(x); }
+    if (o.empty()) o.push_back(UnitDev{});
+    HIPCHK(ctx, P->d_units_o.upload(o, ctx->stream));
+  }
   HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
   HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
   HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx->stream));
@@ -675,7 +684,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
       memset(&A, 0, sizeof(A));
-      A.units = P->d_units.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
+      A.units = P->d_units.p; A.units_o = P->d_units_o.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
