@@ -90,7 +90,7 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // words i, i+1 and i+397 (old) or i-227 (new, written >= 4 chunks earlier); the only word another
 // wave changes in the same step is the old word that follows chunk 2s, which wave 0 reads one step
 // ahead.
-constexpr int kRngChunk = 52;      // 624 = 12 * 52
+constexpr int kRngChunk = 48;      // 624 = 13 * 48
 
 __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   __syncthreads();
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
-  constexpr int kPerBlock = kMtN / kRngChunk;       // 12 chunks per 624-word block
-  constexpr int kGroup = 4;                          // words per batch of LDS reads (rows and kRngChunk are multiples of 4)
+  constexpr int kPerBlock = kMtN / kRngChunk;       // 13 chunks per 624-word block
+  constexpr int kGroup = 8;                          // words per batch of LDS reads (rows and kRngChunk are multiples of 8)
   uint32_t next_old = mt[kRngChunk * kWave];         // old first word of chunk 1 (for wave 0, step 0)
   for (int s = 0; 2 * s - 2 < nchunks; ++s) {
     if (wv < 2) {
