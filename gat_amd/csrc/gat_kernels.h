@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
   constexpr int kPerBlock = kMtN / kRngChunk;       // 13 chunks per 624-word block
-  constexpr int kGroup = 8;                          // words per batch of LDS reads (rows and kRngChunk are multiples of 8)
+  constexpr int kGroup = 16;                         // words per batch of LDS reads (rows and kRngChunk are multiples of 16)
   uint32_t next_old = mt[kRngChunk * kWave];         // old first word of chunk 1 (for wave 0, step 0)
   for (int s = 0; 2 * s - 2 < nchunks; ++s) {
     if (wv < 2) {

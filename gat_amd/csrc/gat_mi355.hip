@@ -492,7 +492,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       // spread of the raw-output count: ~sqrt(placements) x (std per placement ~1.3), 6 sigma
       const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
       const double need = e * nplace * slack + 6.0 * std::sqrt(nplace * (v + 0.5)) + 64.0;
-      int64_t rows = ((int64_t)std::ceil(need / 8.0)) * 8;          // whole k_place chunks
+      int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
       P->rng_rows_total += rows;
