@@ -84,16 +84,19 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // k_rng: one MT19937 stream per LANE (64 streams of one unit = one tile per workgroup).  The
 // state of lane l is mt[i*64 + l] (bank-conflict free, 156 KB: one workgroup per CU).  Seeding and
 // the twist are the serial reference recurrences run by all 64 lanes at once.  The workgroup has
-// four waves, one per SIMD: in step s waves 0/1 twist chunks 2s / 2s+1 in place while waves 2/3
-// temper chunks 2s-2 / 2s-1 and store them to HBM as rows of 64 (one coalesced 256-B store per
-// output index, the order k_place consumes), one barrier per step.  The twist of word i reads
-// words i, i+1 and i+397 (old) or i-227 (new, written >= 4 chunks earlier); the only word another
-// wave changes in the same step is the old word that follows chunk 2s, which wave 0 reads one step
-// ahead.
+// 2 NT waves (NT = 4, two per SIMD): in step s the twist waves 0..NT-1 twist chunks NT s + w in place while the
+// temper waves temper the chunks of step s-1 and store them to HBM as rows of 64 (one coalesced 256-B store
+// per output index, the order k_place consumes), one barrier per step.  The twist of word i reads words i,
+// i+1 and i+397 (old) or i-227 (new, written >= 4 chunks = one step earlier); the only word another wave
+// changes in the same step is the old word that follows a wave's chunk, which it reads one step ahead.
 constexpr int kRngChunk = 48;      // 624 = 13 * 48
 
-__global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
+constexpr int kRngTwistWaves = 4;  // NT twist waves + NT temper waves per workgroup (two waves per SIMD)
+constexpr int kRngThreads = 2 * kRngTwistWaves * kWave;
+
+__global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  constexpr int NT = kRngTwistWaves;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keeps all index math scalar
   uint32_t* mt = lds + lane;                        // lane column, stride 64
@@ -113,10 +116,16 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
   constexpr int kPerBlock = kMtN / kRngChunk;       // 13 chunks per 624-word block
   constexpr int kGroup = 16;                         // words per batch of LDS reads (rows and kRngChunk are multiples of 16)
-  uint32_t next_old = mt[kRngChunk * kWave];         // old first word of chunk 1 (for wave 0, step 0)
-  for (int s = 0; 2 * s - 2 < nchunks; ++s) {
-    if (wv < 2) {
-      const int t = 2 * s + wv;
+  static_assert(kRngChunk % kGroup == 0 && kMtN % kRngChunk == 0, "chunking");
+  static_assert((kMtN - kMtM) / kRngChunk >= NT, "a step must not read new words written in the same step");
+  // old first word of the chunk after this wave's chunk of the NEXT step; in that step the neighbouring twist wave
+  // rewrites it while this wave still needs the old value (the last twist wave's successor belongs to a later step)
+  uint32_t next_old = 0;
+  if (wv < NT - 1) next_old = mt[((wv + 1) % kPerBlock) * kRngChunk * kWave];
+  __syncthreads();                                   // ... and nobody twists before everybody has it
+  for (int s = 0; NT * (s - 1) < nchunks; ++s) {
+    if (wv < NT) {
+      const int t = NT * s + wv;
       if (t < nchunks) {
         const int e0 = t * kRngChunk;
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
             far[q] = mt[jf * kWave];
             nx[q] = mt[in * kWave];
           }
-          if (wv == 0 && k + kGroup == kRngChunk) nx[kGroup - 1] = next_old;  // wave 1 is rewriting that word right now
+          if (wv < NT - 1 && k + kGroup == kRngChunk) nx[kGroup - 1] = next_old;   // the next wave is rewriting that word right now
 #pragma unroll
           for (int q = 0; q < kGroup; ++q) {
             const uint32_t y = (cur & kMtUpper) | (nx[q] & kMtLower);
@@ -143,12 +152,12 @@ __global__ __launch_bounds__(256) void k_rng(SamplerArgs A) {
           }
         }
       }
-      if (wv == 0) {                                 // first word of chunk 2(s+1)+1: untouched until the next step
-        const int tn = 2 * (s + 1) + 1;
+      if (wv < NT - 1) {                             // first word of chunk NT(s+1)+wv+1: untouched until the next step
+        const int tn = NT * (s + 1) + wv + 1;
         next_old = mt[((tn % kPerBlock) * kRngChunk) * kWave];
       }
     } else {
-      const int t = 2 * s - 4 + wv;                  // waves 2, 3: chunks 2s-2, 2s-1
+      const int t = NT * (s - 1) + (wv - NT);        // temper waves: the chunks twisted in the previous step
       if (t >= 0 && t < nchunks) {
         const int e0 = t * kRngChunk;
         const int cnt = rows - e0 < kRngChunk ? rows - e0 : kRngChunk;

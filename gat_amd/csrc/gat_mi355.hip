@@ -699,7 +699,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         A.st = P->d_st.p;
         const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
-        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(256), lds_rng, ctx->stream, A);
+        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
         if (P->sampler == GAT_SAMPLER_SEGMENTS) hipLaunchKernelGGL(gat::k_place<1>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
         else hipLaunchKernelGGL(gat::k_place<0>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
