@@ -89,9 +89,9 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
 // per output index, the order k_place consumes), one barrier per step.  The twist of word i reads words i,
 // i+1 and i+397 (old) or i-227 (new, written >= 4 chunks = one step earlier); the only word another wave
 // changes in the same step is the old word that follows a wave's chunk, which it reads one step ahead.
-constexpr int kRngChunk = 48;      // 624 = 13 * 48
+constexpr int kRngChunk = 24;      // 624 = 26 * 24
 
-constexpr int kRngTwistWaves = 4;  // NT twist waves + NT temper waves per workgroup (two waves per SIMD)
+constexpr int kRngTwistWaves = 8;  // NT twist waves + NT temper waves per workgroup (four waves per SIMD)
 constexpr int kRngThreads = 2 * kRngTwistWaves * kWave;
 
 __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
   uint32_t* __restrict__ out = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   const int nchunks = (rows + kRngChunk - 1) / kRngChunk;
   constexpr int kPerBlock = kMtN / kRngChunk;       // 13 chunks per 624-word block
-  constexpr int kGroup = 16;                         // words per batch of LDS reads (rows and kRngChunk are multiples of 16)
+  constexpr int kGroup = 8;                          // words per batch of LDS reads (rows and kRngChunk are multiples of 8)
   static_assert(kRngChunk % kGroup == 0 && kMtN % kRngChunk == 0, "chunking");
   static_assert((kMtN - kMtM) / kRngChunk >= NT, "a step must not read new words written in the same step");
   // old first word of the chunk after this wave's chunk of the NEXT step; in that step the neighbouring twist wave
