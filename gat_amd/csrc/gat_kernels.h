@@ -185,13 +185,14 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
 // outputs (masked value > range) leave the state unchanged -- exactly numpy's masked rejection.
 // A lane halts when `remaining <= length` (:582): the pending length, the number of outputs
 // consumed and `remaining` are handed to k_sampler, which consolidates and finishes the unit.
-constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (12 B each)
+constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (16 B each)
 constexpr int kPlaceRankLds = 1024;   // length-rank table entries kept in LDS
 constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
-template <int KIND>
+// ALL_SIMPLE: the host found every unit to be of the single-workspace-segment shape; only that loop is compiled in.
+template <int KIND, bool ALL_SIMPLE>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
-  __shared__ uint32_t l_ws_start[kPlaceWsLds], l_ws_end[kPlaceWsLds], l_ws_cdf[kPlaceWsLds];
+  __shared__ uint4 l_ws[kPlaceWsLds];     // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank[kPlaceRankLds];
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
@@ -232,8 +233,11 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   }
   const bool ws_lds = nws <= kPlaceWsLds;
   const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
-  if (ws_lds)
-    for (int i = lane; i < nws; i += kWave) { const uint2 v = ws[i]; l_ws_start[i] = v.x; l_ws_end[i] = v.y; l_ws_cdf[i] = ws_cdf[i]; }
+  if (!ALL_SIMPLE && ws_lds)
+    for (int i = lane; i < nws; i += kWave) {
+      const uint2 v = ws[i];
+      l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
+    }
   if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   uint32_t used = 0;           // raw outputs consumed by this lane when it halted
   int flag = 0;
 
-  auto step = [&](uint32_t y, uint32_t, uint32_t jj) __attribute__((always_inline)) {
+  auto step = [&](uint32_t y, uint32_t jj) __attribute__((always_inline)) {
     const uint32_t v = y & curmask;
     const bool acc = st != S_HALT && v <= currange;
     if (!__any(acc)) return;
@@ -275,9 +279,9 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
         else {
           int lo = 0, hi = nws;                                      // leftmost k with (int)(cdf[k]-p) >= 0
           if (ws_lds) {
-            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws_cdf[mid] - v) < 0) lo = mid + 1; else hi = mid; }
-            k = lo; cs = l_ws_start[k]; ce = l_ws_end[k];
-            if (k > 0) prev_end = (int32_t)l_ws_end[k - 1];
+            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws[mid].x - v) < 0) lo = mid + 1; else hi = mid; }
+            k = lo; const uint4 c4 = l_ws[k]; cs = c4.y; ce = c4.z;
+            if (k > 0) prev_end = (int32_t)c4.w;
           } else {
             while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(ws_cdf[mid] - v) < 0) lo = mid + 1; else hi = mid; }
             k = lo; const uint2 c = ws[k]; cs = c.x; ce = c.y;
@@ -370,9 +374,82 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       nF += 8;
     }
   };
+  // The general shape in the same straight-line form: several workspace segments (table in LDS), optional bucket
+  // draw.  The workspace lookup of an output depends only on its value, not on the lane's state, so the lookups of
+  // a whole chunk (PCS/PCE/PPE: chosen segment's start, end, previous end) are done up front, interleaved; a lane
+  // keeps the one it needs when it is in state P at that output.
+#define GAT_STEP_TABLE(Y, LR, PCS, PCE, PPE, JJ)                                                               \
+  {                                                                                                            \
+    const uint32_t v = (Y) & curmask;                                                                          \
+    const bool acc = st != S_HALT && v <= currange;                                                            \
+    const bool isL = acc && st == S_L, isB = acc && st == S_B, isP = acc && st == S_P, isO = acc && st == S_O; \
+    len = isL ? (LR) * bucket : (isB ? len + v : len);                 /* :419-433 */                          \
+    const bool have_len = (isL && !drawB) || isB;                                                              \
+    const bool trig = have_len && !kind1 && rem <= (int32_t)len;       /* :582 -> consolidate */               \
+    cs = isP ? (PCS) : cs;                                                                                     \
+    ce = isP ? (PCE) : ce;                                                                                     \
+    int32_t sstartP = (int32_t)(PCS) - (int32_t)len + 1;               /* :318-325 */                          \
+    sstartP = (int32_t)(PPE) > sstartP ? (int32_t)(PPE) : sstartP;                                             \
+    const uint32_t range3 = (PCE) - 1u - (uint32_t)sstartP;                                                    \
+    const uint32_t mask3 = 0xffffffffu >> __builtin_clz(range3 | 1u);                                          \
+    const bool placeP = isP && range3 == 0;                            /* range 0: randint consumes nothing */ \
+    const bool place = isO || placeP;                                                                          \
+    const int32_t q = isO ? sstart + (int32_t)v : sstartP;                                                     \
+    int nst = (isL && drawB) ? S_B : (have_len ? S_P : ((isP && !placeP) ? S_O : (place ? S_L : st)));         \
+    if (trig) { pend = (int32_t)len; used = (JJ) + 1u; nst = S_HALT; }                                         \
+    if (place) {                                                       /* :331-343, :630-635 */                \
+      const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                        \
+      const uint32_t end = (uint32_t)(q + (int32_t)len);                                                       \
+      const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;                            \
+      const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;                        \
+      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
+      if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
+      else {                                                                                                   \
+        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);                \
+        nS++;                                                                                                  \
+        rem -= overlap;                                                                                        \
+        if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
+      }                                                                                                        \
+    }                                                                                                          \
+    sstart = isP ? sstartP : sstart;                                                                           \
+    curmask = nst == S_L ? maskL : (nst == S_B ? maskB : (nst == S_P ? maskP : (nst == S_O ? (isP ? mask3 : curmask) : curmask))); \
+    currange = nst == S_L ? rangeL : (nst == S_B ? rangeB : (nst == S_P ? rangeP : (nst == S_O ? (isP ? range3 : currange) : currange))); \
+    st = nst;                                                                                                  \
+  }
+
   uint32_t ya[kPlaceChunk], yb[kPlaceChunk], lr[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // (a macro, not a lambda taking the step closure: that form kept the closures in scratch memory)
-#define GAT_PLACE_LOOP(ONE, RANK)                                                                              \
+  uint32_t pcs[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0}, pce[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0},
+           ppe[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // per-chunk look-ups that depend only on the output value: length of rank 1 + (y & maskL) ...
+#define GAT_PRE_RANK(Y)                                                                                        \
+  _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                    \
+    const uint32_t v = (Y)[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }
+  // ... and the workspace segment holding position (y & maskP): leftmost k with (int)(cdf[k] - p) >= 0
+  // (utils/gat_utils.c:36 + cmpPosition) by a halving search whose trip count depends on nws only
+#define GAT_PRE_WS(Y)                                                                                          \
+  {                                                                                                            \
+    uint32_t pv[kPlaceChunk]; int lo[kPlaceChunk];                                                             \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; lo[c] = 0; }                        \
+    for (int n = nws; n > 1;) {                                                                                \
+      const int half = n >> 1;                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                  \
+        lo[c] = (int32_t)(l_ws[lo[c] + half - 1].x - pv[c]) < 0 ? lo[c] + half : lo[c];                        \
+      n -= half;                                                                                               \
+    }                                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      uint4 w4 = l_ws[lo[c]];                                                                                  \
+      if ((int32_t)(w4.x - pv[c]) < 0) w4 = l_ws[lo[c] + 1];                                                   \
+      pcs[c] = w4.y; pce[c] = w4.z; ppe[c] = w4.w; }                                                           \
+  }
+#define GAT_PRE_NONE(Y)
+#define GAT_PRE_SIMPLE(Y) GAT_PRE_RANK(Y)
+#define GAT_PRE_TABLE(Y) GAT_PRE_RANK(Y) GAT_PRE_WS(Y)
+#define GAT_ONE_SIMPLE(Y, C, JJ) GAT_STEP_SIMPLE((Y)[C], lr[C], JJ)
+#define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
+#define GAT_ONE_LAMBDA(Y, C, JJ) step((Y)[C], (uint32_t)(JJ));
+  // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
+#define GAT_PLACE_LOOP(PRE, ONE)                                                                               \
   {                                                                                                            \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[c * kWave];                             \
     for (int j = 0; j < rows; j += 2 * kPlaceChunk) {                                                          \
@@ -381,27 +458,34 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       if (more_b) {                                                                                            \
         _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rp[(kPlaceChunk + c) * kWave];         \
       }                                                                                                        \
-      if (RANK) {                                                                                              \
-        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                              \
-          const uint32_t v = ya[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }                       \
-      }                                                                                                        \
-      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya[c], lr[c], (uint32_t)(j + c));            \
+      PRE(ya)                                                                                                  \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + c))                    \
       flush();                                                                                                 \
       if (!more_b || __ballot(st != S_HALT) == 0) break;                                                       \
       if (j + 2 * kPlaceChunk < rows) {                                                                        \
         _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[(2 * kPlaceChunk + c) * kWave];     \
       }                                                                                                        \
       rp += 2 * kPlaceChunk * kWave;                                                                           \
-      if (RANK) {                                                                                              \
-        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                              \
-          const uint32_t v = yb[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }                       \
-      }                                                                                                        \
-      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb[c], lr[c], (uint32_t)(j + kPlaceChunk + c)); \
+      PRE(yb)                                                                                                  \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb, c, (uint32_t)(j + kPlaceChunk + c))      \
       flush();                                                                                                 \
     }                                                                                                          \
   }
-  if (simple) GAT_PLACE_LOOP(GAT_STEP_SIMPLE, true) else GAT_PLACE_LOOP(step, false)
+  if (ALL_SIMPLE || simple) GAT_PLACE_LOOP(GAT_PRE_SIMPLE, GAT_ONE_SIMPLE)
+  else if constexpr (!ALL_SIMPLE) {
+    if (rank_lds && ws_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE, GAT_ONE_TABLE)
+    else GAT_PLACE_LOOP(GAT_PRE_NONE, GAT_ONE_LAMBDA)
+  }
 #undef GAT_PLACE_LOOP
+#undef GAT_ONE_LAMBDA
+#undef GAT_ONE_TABLE
+#undef GAT_ONE_SIMPLE
+#undef GAT_PRE_TABLE
+#undef GAT_PRE_SIMPLE
+#undef GAT_PRE_NONE
+#undef GAT_PRE_WS
+#undef GAT_PRE_RANK
+#undef GAT_STEP_TABLE
 #undef GAT_STEP_SIMPLE
   if (live) {
     for (int i = nF; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 7][lane])[i & 1];   // what the last flush left

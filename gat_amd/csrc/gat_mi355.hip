@@ -202,6 +202,7 @@ struct gat_problem {
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
+  bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
 };
 
@@ -458,6 +459,13 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     return a.first != b.first ? a.first > b.first : a.second < b.second;
   });
   for (auto& w : work) P->h_order.push_back(w.second);
+  P->all_simple = !P->h_order.empty();
+  for (int32_t u : P->h_order) {
+    const UnitDev& U = P->h_units[(size_t)u];
+    const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
+    const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
+    if (!degenerate && !simple) P->all_simple = false;
+  }
   // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
   // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
   // are redone by k_sampler from their seed.
@@ -701,8 +709,14 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
-        if (P->sampler == GAT_SAMPLER_SEGMENTS) hipLaunchKernelGGL(gat::k_place<1>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
-        else hipLaunchKernelGGL(gat::k_place<0>, dim3(nsb, (unsigned)P->h_order.size()), dim3(64), 0, ctx->stream, A);
+        const dim3 gp(nsb, (unsigned)P->h_order.size());
+        if (P->sampler == GAT_SAMPLER_SEGMENTS) {
+          if (P->all_simple) hipLaunchKernelGGL((gat::k_place<1, true>), gp, dim3(64), 0, ctx->stream, A);
+          else hipLaunchKernelGGL((gat::k_place<1, false>), gp, dim3(64), 0, ctx->stream, A);
+        } else {
+          if (P->all_simple) hipLaunchKernelGGL((gat::k_place<0, true>), gp, dim3(64), 0, ctx->stream, A);
+          else hipLaunchKernelGGL((gat::k_place<0, false>), gp, dim3(64), 0, ctx->stream, A);
+        }
         HIPCHK(ctx, hipGetLastError());
       }
       size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
