@@ -233,11 +233,23 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   }
   const bool ws_lds = nws <= kPlaceWsLds;
   const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
-  if (!ALL_SIMPLE && ws_lds)
-    for (int i = lane; i < nws; i += kWave) {
-      const uint2 v = ws[i];
-      l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
+  // longer workspaces: LDS holds every ws_stride-th cumulated length (the last one of each block of ws_stride
+  // segments); a look-up finds the block there and finishes inside the block in global memory
+  const int ws_stride = ws_lds ? 1 : (nws + kPlaceWsLds - 1) / kPlaceWsLds;
+  const int ws_ntop = ws_lds ? nws : (nws + ws_stride - 1) / ws_stride;
+  if (!ALL_SIMPLE) {
+    if (ws_lds) {
+      for (int i = lane; i < nws; i += kWave) {
+        const uint2 v = ws[i];
+        l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
+      }
+    } else {
+      for (int i = lane; i < ws_ntop; i += kWave) {
+        const int last = (i + 1) * ws_stride - 1;
+        l_ws[i] = make_uint4(ws_cdf[last < nws ? last : nws - 1], 0u, 0u, 0u);
+      }
     }
+  }
   if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
@@ -256,74 +268,10 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   uint32_t used = 0;           // raw outputs consumed by this lane when it halted
   int flag = 0;
 
-  auto step = [&](uint32_t y, uint32_t jj) __attribute__((always_inline)) {
-    const uint32_t v = y & curmask;
-    const bool acc = st != S_HALT && v <= currange;
-    if (!__any(acc)) return;
-    bool place = false;
-    int32_t q = 0;
-    if (acc) {
-      const int st0 = st;
-      bool have_len = false;
-      if (st0 == S_L) {                                              // hs.sample(): rank -> length (:419-431)
-        const uint32_t r = 1u + v;
-        len = (rank_lds ? l_rank[r] : rank_len[r]) * bucket;
-        if (drawB) { st = S_B; curmask = maskB; currange = rangeB; } else have_len = true;
-      } else if (st0 == S_B) {                                       // + randint(0, bucket) (:432-433)
-        len += v;
-        have_len = true;
-      } else if (st0 == S_P) {                                       // sls.sample(): workspace position (:299-306)
-        int k = 0;
-        int32_t prev_end = 0;
-        if (nws == 1) { cs = ws0.x; ce = ws0.y; }
-        else {
-          int lo = 0, hi = nws;                                      // leftmost k with (int)(cdf[k]-p) >= 0
-          if (ws_lds) {
-            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(l_ws[mid].x - v) < 0) lo = mid + 1; else hi = mid; }
-            k = lo; const uint4 c4 = l_ws[k]; cs = c4.y; ce = c4.z;
-            if (k > 0) prev_end = (int32_t)c4.w;
-          } else {
-            while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if ((int32_t)(ws_cdf[mid] - v) < 0) lo = mid + 1; else hi = mid; }
-            k = lo; const uint2 c = ws[k]; cs = c.x; ce = c.y;
-            if (k > 0) prev_end = (int32_t)ws[k - 1].y;
-          }
-        }
-        sstart = (int32_t)cs - (int32_t)len + 1;                     // :318-325
-        if (k > 0) sstart = prev_end > sstart ? prev_end : sstart;
-        const uint32_t range3 = ce - 1u - (uint32_t)sstart;
-        if (range3 != 0) { st = S_O; curmask = 0xffffffffu >> __builtin_clz(range3); currange = range3; }
-        else { q = sstart; place = true; }                           // range 0: randint consumes nothing
-      } else {                                                       // offset inside the segment (:326-328)
-        q = sstart + (int32_t)v;
-        place = true;
-      }
-      if (have_len) {
-        if (!kind1 && rem <= (int32_t)len) { pend = (int32_t)len; used = jj + 1u; st = S_HALT; }   // :582 -> consolidate
-        else { st = S_P; curmask = maskP; currange = rangeP; }
-      }
-    }
-    if (place) {                                                     // :331-343, :630-635
-      const uint32_t start = (uint32_t)(q > 0 ? q : 0);
-      const uint32_t end = (uint32_t)(q + (int32_t)len);
-      const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;
-      const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;
-      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
-      if (nS >= cap) { flag |= kStatusOverflow; st = S_HALT; }
-      else {
-        // scattered 8-byte stores reach HBM as partial lines (4.8x write traffic measured); segments are
-        // collected per lane in an LDS ring and written as whole 64-byte lines (flush(), once per chunk)
-        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);
-        nS++;
-        rem -= overlap;
-        st = S_L; curmask = maskL; currange = rangeL;
-        if (kind1 && nS == target) { pend = -2; used = jj + 1u; st = S_HALT; }       // SamplerSegments: n placements
-      }
-    }
-  };
 
   // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
   // LDS -- needs no workspace search, no bucket draw and never an immediate placement
-  const bool simple = nws == 1 && !drawB && rank_lds && ws0.y - ws0.x > 1u;
+  const bool simple_shape = nws == 1 && !drawB && ws0.y - ws0.x > 1u;
   // Straight-line form: a lane's state only selects which of the three small results it keeps, so the wave runs
   // one instruction stream instead of three divergent ones.  `lr` is the length of rank 1 + (y & maskL), read
   // from LDS for the whole chunk up front (one exposed LDS latency per chunk instead of one per output).
@@ -420,10 +368,14 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   uint32_t ya[kPlaceChunk], yb[kPlaceChunk], lr[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t pcs[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0}, pce[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0},
            ppe[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
-  // per-chunk look-ups that depend only on the output value: length of rank 1 + (y & maskL) ...
-#define GAT_PRE_RANK(Y)                                                                                        \
+  // per-chunk look-ups that depend only on the output value: length of rank 1 + (y & maskL), from the LDS copy of the
+  // table or (units with >= kPlaceRankLds segments) from global memory ...
+#define GAT_PRE_RANK_L(Y)                                                                                      \
   _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                    \
     const uint32_t v = (Y)[c] & maskL; lr[c] = l_rank[v <= rangeL ? 1u + v : 0u]; }
+#define GAT_PRE_RANK_G(Y)                                                                                      \
+  _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                    \
+    const uint32_t v = (Y)[c] & maskL; lr[c] = rank_len[v <= rangeL ? 1u + v : 0u]; }
   // ... and the workspace segment holding position (y & maskP): leftmost k with (int)(cdf[k] - p) >= 0
   // (utils/gat_utils.c:36 + cmpPosition) by a halving search whose trip count depends on nws only
 #define GAT_PRE_WS(Y)                                                                                          \
@@ -442,12 +394,43 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       if ((int32_t)(w4.x - pv[c]) < 0) w4 = l_ws[lo[c] + 1];                                                   \
       pcs[c] = w4.y; pce[c] = w4.z; ppe[c] = w4.w; }                                                           \
   }
-#define GAT_PRE_NONE(Y)
-#define GAT_PRE_SIMPLE(Y) GAT_PRE_RANK(Y)
-#define GAT_PRE_TABLE(Y) GAT_PRE_RANK(Y) GAT_PRE_WS(Y)
+  // the same for a workspace beyond the LDS table: block in LDS, then inside the block in global memory (indices
+  // clamped to nws-1, whose cumulated length is >= any position, so the search stays monotone)
+#define GAT_PRE_WS2(Y)                                                                                         \
+  {                                                                                                            \
+    uint32_t pv[kPlaceChunk]; int lo[kPlaceChunk];                                                             \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; lo[c] = 0; }                        \
+    for (int n = ws_ntop; n > 1;) {                                                                            \
+      const int half = n >> 1;                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                  \
+        lo[c] = (int32_t)(l_ws[lo[c] + half - 1].x - pv[c]) < 0 ? lo[c] + half : lo[c];                        \
+      n -= half;                                                                                               \
+    }                                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                    \
+      lo[c] = ((int32_t)(l_ws[lo[c]].x - pv[c]) < 0 ? lo[c] + 1 : lo[c]) * ws_stride;                          \
+    for (int n = ws_stride; n > 1;) {                                                                          \
+      const int half = n >> 1;                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        const int idx = lo[c] + half - 1;                                                                      \
+        lo[c] = (int32_t)(ws_cdf[idx < nws ? idx : nws - 1] - pv[c]) < 0 ? lo[c] + half : lo[c]; }             \
+      n -= half;                                                                                               \
+    }                                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const int idx = lo[c] < nws ? lo[c] : nws - 1;                                                           \
+      lo[c] = (int32_t)(ws_cdf[idx] - pv[c]) < 0 ? idx + 1 : idx; }                                            \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const uint2 w2 = ws[lo[c]];                                                                              \
+      pcs[c] = w2.x; pce[c] = w2.y; ppe[c] = lo[c] > 0 ? ws[lo[c] - 1].y : 0x80000000u; }                      \
+  }
+#define GAT_PRE_SIMPLE_L(Y) GAT_PRE_RANK_L(Y)
+#define GAT_PRE_SIMPLE_G(Y) GAT_PRE_RANK_G(Y)
+#define GAT_PRE_TABLE_LL(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS(Y)
+#define GAT_PRE_TABLE_GL(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS(Y)
+#define GAT_PRE_TABLE_LG(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS2(Y)
+#define GAT_PRE_TABLE_GG(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS2(Y)
 #define GAT_ONE_SIMPLE(Y, C, JJ) GAT_STEP_SIMPLE((Y)[C], lr[C], JJ)
 #define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
-#define GAT_ONE_LAMBDA(Y, C, JJ) step((Y)[C], (uint32_t)(JJ));
   // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
 #define GAT_PLACE_LOOP(PRE, ONE)                                                                               \
   {                                                                                                            \
@@ -471,20 +454,28 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       flush();                                                                                                 \
     }                                                                                                          \
   }
-  if (ALL_SIMPLE || simple) GAT_PLACE_LOOP(GAT_PRE_SIMPLE, GAT_ONE_SIMPLE)
+  if (ALL_SIMPLE || (simple_shape && rank_lds)) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE)
   else if constexpr (!ALL_SIMPLE) {
-    if (rank_lds && ws_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE, GAT_ONE_TABLE)
-    else GAT_PLACE_LOOP(GAT_PRE_NONE, GAT_ONE_LAMBDA)
+    if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE)
+    else if (ws_lds) {
+      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE)
+    } else {
+      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE)
+    }
   }
 #undef GAT_PLACE_LOOP
-#undef GAT_ONE_LAMBDA
 #undef GAT_ONE_TABLE
 #undef GAT_ONE_SIMPLE
-#undef GAT_PRE_TABLE
-#undef GAT_PRE_SIMPLE
-#undef GAT_PRE_NONE
+#undef GAT_PRE_TABLE_GG
+#undef GAT_PRE_TABLE_LG
+#undef GAT_PRE_TABLE_GL
+#undef GAT_PRE_TABLE_LL
+#undef GAT_PRE_SIMPLE_G
+#undef GAT_PRE_SIMPLE_L
+#undef GAT_PRE_WS2
 #undef GAT_PRE_WS
-#undef GAT_PRE_RANK
+#undef GAT_PRE_RANK_G
+#undef GAT_PRE_RANK_L
 #undef GAT_STEP_TABLE
 #undef GAT_STEP_SIMPLE
   if (live) {
