@@ -232,14 +232,22 @@ def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
 
 
 @pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "large_units_swapped_count", "rows_run_out",
-                                  "slab_overflow_retry"])
+                                  "slab_overflow_retry", "large_units_many_workspace_segments",
+                                  "large_units_one_workspace_segment", "mid_workspace_table"])
 def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     """code paths the BASELINE shapes do not reach: workspace lists beyond the register / LDS tables,
     units beyond the register sort, streams that run out of pre-generated rows (redone from the seed),
     and slab overflow (batch redone with doubled capacity).  All must stay bit-exact."""
-    rs = np.random.RandomState(hash(case) % 1000)
-    if case == "many_workspace_segments":
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(case.encode()) % 1000)
+    if case == "many_workspace_segments":          # k_place: rank table in LDS, two-level workspace table
         flat = _big_problem(rs, 900, 400)
+    elif case == "large_units_many_workspace_segments":   # rank table and workspace both beyond the LDS tables
+        flat = _big_problem(rs, 6000, 400)
+    elif case == "large_units_one_workspace_segment":     # single-segment loop with the rank table in global memory
+        flat = _big_problem(rs, 6000, 1)
+    elif case == "mid_workspace_table":                   # 65..256 workspace segments: LDS table, beyond k_sampler's registers
+        flat = _big_problem(rs, 900, 150)
     elif case in ("large_units", "large_units_swapped_count"):
         flat = _big_problem(rs, 6000, 3)
     elif case == "rows_run_out":
