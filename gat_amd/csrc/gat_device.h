@@ -599,6 +599,81 @@ __device__ __forceinline__ uint32_t seg_overlap_with(const uint2* __restrict__ w
   return cov_below(w, cdf, nw, e) - cov_below(w, cdf, nw, s);
 }
 
+// The same searches for a WAVE-UNIFORM target: 64 lanes probe 64 evenly spaced elements per step (a 64-ary search),
+// three dependent loads for a 100 000-segment workspace instead of seventeen.  n >= 0; every lane must call.
+// `less(i)` must be monotone: true for a prefix of the indices.
+template <typename Less>
+__device__ __forceinline__ int wave_partition_point(int n, int lane, Less less) {
+  int lo = 0;
+  while (n > 0) {
+    const int step = (n + kWave - 1) / kWave;
+    const int idx = lo + (lane + 1) * step - 1;              // last element of this lane's stretch
+    const bool lt = idx < lo + n && less(idx);
+    const int c = __popcll(__ballot(lt));                    // stretches that lie wholly below the target
+    const int start = lo + c * step;
+    const int rest = lo + n - start;                         // elements from the undecided stretch on
+    lo = start;
+    n = rest < step - 1 ? rest : step - 1;                   // its last element is known not to be below
+    if (n < 0) n = 0;
+  }
+  return lo;
+}
+__device__ __forceinline__ int bisect_u32_wave(const uint32_t* __restrict__ a, int n, uint32_t t, int lane) {
+  return wave_partition_point(n, lane, [&](int i) { return (int32_t)(a[i] - t) < 0; });
+}
+__device__ __forceinline__ uint32_t cov_below_wave(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                                   int nw, uint32_t p, int lane) {
+  const int k = wave_partition_point(nw, lane, [&](int i) { return w[i].x < p; });   // #segments with start < p
+  if (k == 0) return 0;
+  const uint2 prev = w[k - 1];
+  const uint32_t before = k >= 2 ? cdf[k - 2] + 1u : 0u;
+  return before + (p < prev.y ? p : prev.y) - prev.x;
+}
+__device__ __forceinline__ uint32_t seg_overlap_with_wave(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                                          int nw, uint32_t s, uint32_t e, int lane) {
+  return cov_below_wave(w, cdf, nw, e, lane) - cov_below_wave(w, cdf, nw, s, lane);
+}
+
+// cov_below for U positions per lane at once: a halving search whose trip count depends on nw only, so the U
+// searches of a lane advance in lock step and their loads overlap (the workspace of a long list lives in global
+// memory: one exposed latency per level instead of one per level and position).
+template <int U>
+__device__ __forceinline__ void cov_below_batch(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf, int nw,
+                                                const uint32_t (&p)[U], uint32_t (&out)[U]) {
+  int lo[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) lo[u] = 0;
+  for (int n = nw; n > 1;) {
+    const int half = n >> 1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) lo[u] = w[lo[u] + half - 1].x < p[u] ? lo[u] + half : lo[u];
+    n -= half;
+  }
+  uint2 prev[U];
+  uint32_t before[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    lo[u] += w[lo[u]].x < p[u] ? 1 : 0;                    // k = #segments with start < p
+    prev[u] = w[lo[u] > 0 ? lo[u] - 1 : 0];
+    before[u] = lo[u] >= 2 ? cdf[lo[u] - 2] + 1u : 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    out[u] = lo[u] == 0 ? 0u : before[u] + (p[u] < prev[u].y ? p[u] : prev[u].y) - prev[u].x;
+}
+
+// overlap of R segments per lane with a normalized list in global memory (seg_overlap_with, batched)
+template <int R>
+__device__ __forceinline__ void seg_overlap_batch(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf, int nw,
+                                                  const uint2 (&v)[R], uint32_t (&ov)[R]) {
+  uint32_t p[2 * R], c[2 * R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { p[2 * r] = v[r].x; p[2 * r + 1] = v[r].y; }
+  cov_below_batch<2 * R>(w, cdf, nw, p, c);
+#pragma unroll
+  for (int r = 0; r < R; ++r) ov[r] = c[2 * r + 1] - c[2 * r];
+}
+
 // A unit's workspace held in registers (lane i = workspace segment i), for units with <= 64
 // workspace segments: SegmentListSampler's CDF lookup becomes one v_cmp + ballot and the chosen
 // segment is fetched with v_readlane -- no memory access in the placement loop.

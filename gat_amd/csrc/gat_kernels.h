@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
         const int32_t length = (int32_t)len_u;
         const uint32_t p = rng_range(rng, ws_total - 1u, lane);
-        const int k = bisect_u32(ws_cdf, nws, p);
+        const int k = bisect_u32_wave(ws_cdf, nws, p, lane);
         const uint2 chosen = ws[k];
         int32_t sampling_start = (int32_t)chosen.x - length + 1;
         if (k > 0) { const int32_t pe = (int32_t)ws[k - 1].y; sampling_start = pe > sampling_start ? pe : sampling_start; }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
             wave_insert_sorted(seg, nU, 1, lane);
             nU += 1;
             nS = 0;
-            cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : seg_overlap_with(ws, ws_cdf, nws, xs, xe));
+            cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : seg_overlap_with_wave(ws, ws_cdf, nws, xs, xe, lane));
             total_known += xe - xs;
             handled = true;
           }
@@ -660,7 +660,20 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           if (nws <= kWsLoopMax) {
             for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); tot += v.y - v.x; }
           } else {
-            for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += seg_overlap_with(ws, ws_cdf, nws, v.x, v.y); tot += v.y - v.x; }
+            constexpr int R = 4;                              // segments per lane whose workspace searches run interleaved
+            for (int base = 0; base < nU; base += R * kWave) {
+              uint2 v[R];
+              uint32_t ov[R];
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const int i = base + r * kWave + lane;
+                v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
+                tot += v[r].y - v[r].x;
+              }
+              seg_overlap_batch<R>(ws, ws_cdf, nws, v, ov);
+#pragma unroll
+              for (int r = 0; r < R; ++r) cov += ov[r];
+            }
           }
           cov = wave_total_u32(cov);
           total_known = wave_total_u32(tot);             // sum() of the merged list, for the trim's position draw
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         chosen.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k);
         if (k > 0) prev_end = __builtin_amdgcn_readlane((int)W.end, k - 1);
       } else {
-        k = bisect_u32(ws_cdf, nws, p);
+        k = bisect_u32_wave(ws_cdf, nws, p, lane);
         chosen = ws[k];
         if (k > 0) prev_end = (int32_t)ws[k - 1].y;
       }
@@ -771,17 +784,38 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     if (status == 0) {
       if (dirty) nU = wave_merge0(seg, nU, lane);     // otherwise already merged by the last consolidation
       uint32_t total = 0;
-      for (int base = 0; base < nU; base += kWave) {
-        const int i = base + lane;
-        bool keep = false;
-        uint2 v = make_uint2(0u, 0u);
-        if (i < nU) {
-          v = seg[i];
-          keep = (nws <= kWsLoopMax ? ws_overlap_regs(W, v.x, v.y) : seg_overlap_with(ws, ws_cdf, nws, v.x, v.y)) > 0;
+      if (nws <= kWsLoopMax) {
+        for (int base = 0; base < nU; base += kWave) {
+          const int i = base + lane;
+          bool keep = false;
+          uint2 v = make_uint2(0u, 0u);
+          if (i < nU) {
+            v = seg[i];
+            keep = ws_overlap_regs(W, v.x, v.y) > 0;
+          }
+          const uint64_t b = __ballot(keep);
+          if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
+          nout += __popcll(b);
         }
-        const uint64_t b = __ballot(keep);
-        if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
-        nout += __popcll(b);
+      } else {
+        constexpr int R = 4;
+        for (int base = 0; base < nU; base += R * kWave) {
+          uint2 v[R];
+          uint32_t ov[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int i = base + r * kWave + lane;
+            v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
+          }
+          seg_overlap_batch<R>(ws, ws_cdf, nws, v, ov);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const bool keep = ov[r] > 0;                     // (0,0) fillers overlap nothing
+            const uint64_t b = __ballot(keep);
+            if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v[r]; total += v[r].y - v[r].x; }
+            nout += __popcll(b);
+          }
+        }
       }
       total = wave_total_u32(total);
       if (!(total > 0)) status |= kStatusAssert;
