@@ -335,14 +335,13 @@ __device__ __forceinline__ void wave_sort_regs(uint2* seg, int n, int lane) {
   }
   wave_sync();
 }
-// dispatch on the list length; beyond 1024 elements the in-LDS network is used
+// The sort behind the bucket sort: up to a wave's worth in registers, longer lists through the in-LDS network.
+// It only runs for short lists, clustered keys and units redone from their seed, and it is kept SMALL on purpose:
+// the register networks for 2..16 elements per lane tripled the kernel beyond the instruction cache, which cost
+// the common path more than they saved here.
 __device__ __forceinline__ void wave_sort_auto(uint2* seg, int n, int lane) {
   if (n < 2) return;
   if (n <= 64) wave_sort_regs<1>(seg, n, lane);
-  else if (n <= 128) wave_sort_regs<2>(seg, n, lane);
-  else if (n <= 256) wave_sort_regs<4>(seg, n, lane);
-  else if (n <= 512) wave_sort_regs<8>(seg, n, lane);
-  else if (n <= 1024) wave_sort_regs<16>(seg, n, lane);
   else wave_sort_by_start(seg, n, lane);
 }
 
@@ -599,79 +598,107 @@ __device__ __forceinline__ uint32_t seg_overlap_with(const uint2* __restrict__ w
   return cov_below(w, cdf, nw, e) - cov_below(w, cdf, nw, s);
 }
 
-// The same searches for a WAVE-UNIFORM target: 64 lanes probe 64 evenly spaced elements per step (a 64-ary search),
-// three dependent loads for a 100 000-segment workspace instead of seventeen.  n >= 0; every lane must call.
-// `less(i)` must be monotone: true for a prefix of the indices.
-template <typename Less>
-__device__ __forceinline__ int wave_partition_point(int n, int lane, Less less) {
-  int lo = 0;
-  while (n > 0) {
-    const int step = (n + kWave - 1) / kWave;
-    const int idx = lo + (lane + 1) * step - 1;              // last element of this lane's stretch
-    const bool lt = idx < lo + n && less(idx);
-    const int c = __popcll(__ballot(lt));                    // stretches that lie wholly below the target
-    const int start = lo + c * step;
-    const int rest = lo + n - start;                         // elements from the undecided stretch on
-    lo = start;
-    n = rest < step - 1 ? rest : step - 1;                   // its last element is known not to be below
-    if (n < 0) n = 0;
+// ------------------------------------------------------------------------------------------
+// WsTree: static 16-ary search tree over a sorted u32 array in global memory.  Level 0 is the array
+// itself padded to whole 64-byte nodes; entry j of level l+1 is the largest key of node j of level
+// l.  A search reads ONE node per level (four 16-byte loads) and counts its keys below the target:
+// 4 dependent round trips for a 50 000-segment workspace where a binary search makes 16.  The pad
+// value is never below any target, and a target above every key walks down the last nodes.
+constexpr int kWsTreeMin = 32;      // workspaces with more segments get trees (the shorter ones are searched in registers)
+constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so that the geometry stays in scalar registers
+struct WsTreeGeom {                 // wave-uniform, derived from the number of keys
+  int nlev;
+  int off[kWsTreeLevels];           // first word of the level
+  int nodes[kWsTreeLevels];         // nodes of the level
+};
+__device__ __forceinline__ WsTreeGeom ws_tree_geom(int n) {
+  WsTreeGeom g;
+  int off = 0, l = 0;
+#pragma unroll
+  for (int i = 0; i < kWsTreeLevels; ++i) { g.off[i] = 0; g.nodes[i] = 1; }
+  bool done = false;
+#pragma unroll
+  for (int i = 0; i < kWsTreeLevels; ++i) {
+    if (!done) {
+      const int nodes = (n + 15) >> 4;
+      g.off[i] = off; g.nodes[i] = nodes;
+      off += nodes << 4;
+      l = i + 1;
+      done = n <= 16;
+      n = nodes;
+    }
   }
-  return lo;
+  g.nlev = l;
+  return g;
 }
-__device__ __forceinline__ int bisect_u32_wave(const uint32_t* __restrict__ a, int n, uint32_t t, int lane) {
-  return wave_partition_point(n, lane, [&](int i) { return (int32_t)(a[i] - t) < 0; });
+// SIGNED: keys compare as the reference's cmpPosition does ((int)(key - target) < 0, utils/gat_utils.c:36 +
+// gat/Engine.pyx:119; pad 0x7fffffff); otherwise as unsigned start < target (pad 0xffffffff).
+template <bool SIGNED>
+__device__ __forceinline__ int ws_tree_below16(const uint4 a, const uint4 b, const uint4 c, const uint4 d, uint32_t t) {
+  auto lt = [&](uint32_t k) -> int { return SIGNED ? ((int32_t)(k - t) < 0 ? 1 : 0) : (k < t ? 1 : 0); };
+  return lt(a.x) + lt(a.y) + lt(a.z) + lt(a.w) + lt(b.x) + lt(b.y) + lt(b.z) + lt(b.w) +
+         lt(c.x) + lt(c.y) + lt(c.z) + lt(c.w) + lt(d.x) + lt(d.y) + lt(d.z) + lt(d.w);
 }
-__device__ __forceinline__ uint32_t cov_below_wave(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
-                                                   int nw, uint32_t p, int lane) {
-  const int k = wave_partition_point(nw, lane, [&](int i) { return w[i].x < p; });   // #segments with start < p
-  if (k == 0) return 0;
-  const uint2 prev = w[k - 1];
-  const uint32_t before = k >= 2 ? cdf[k - 2] + 1u : 0u;
-  return before + (p < prev.y ? p : prev.y) - prev.x;
-}
-__device__ __forceinline__ uint32_t seg_overlap_with_wave(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
-                                                          int nw, uint32_t s, uint32_t e, int lane) {
-  return cov_below_wave(w, cdf, nw, e, lane) - cov_below_wave(w, cdf, nw, s, lane);
+// number of keys below each of U targets (the U searches of a lane advance level by level, loads overlapped)
+template <bool SIGNED, int U>
+__device__ __forceinline__ void ws_tree_count(const uint32_t* __restrict__ tree, const WsTreeGeom& g,
+                                              const uint32_t (&t)[U], int (&pos)[U]) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) pos[u] = 0;
+#pragma unroll
+  for (int l = kWsTreeLevels - 1; l >= 0; --l) {
+    if (l >= g.nlev) continue;
+    const uint4* __restrict__ lev = reinterpret_cast<const uint4*>(tree + g.off[l]);
+    const int last = g.nodes[l] - 1;
+    uint4 q[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      pos[u] = pos[u] < last ? pos[u] : last;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) q[u][w] = lev[pos[u] * 4 + w];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) pos[u] = pos[u] * 16 + ws_tree_below16<SIGNED>(q[u][0], q[u][1], q[u][2], q[u][3], t[u]);
+  }
 }
 
-// cov_below for U positions per lane at once: a halving search whose trip count depends on nw only, so the U
-// searches of a lane advance in lock step and their loads overlap (the workspace of a long list lives in global
-// memory: one exposed latency per level instead of one per level and position).
+// bases of a normalized list W below U positions per lane: k = #segments with start < p from the tree, then as cov_below
 template <int U>
-__device__ __forceinline__ void cov_below_batch(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf, int nw,
-                                                const uint32_t (&p)[U], uint32_t (&out)[U]) {
-  int lo[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) lo[u] = 0;
-  for (int n = nw; n > 1;) {
-    const int half = n >> 1;
-#pragma unroll
-    for (int u = 0; u < U; ++u) lo[u] = w[lo[u] + half - 1].x < p[u] ? lo[u] + half : lo[u];
-    n -= half;
-  }
+__device__ __forceinline__ void cov_below_tree(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                               const uint32_t* __restrict__ tree, const WsTreeGeom& g,
+                                               const uint32_t (&p)[U], uint32_t (&out)[U]) {
+  int k[U];
+  ws_tree_count<false, U>(tree, g, p, k);
   uint2 prev[U];
   uint32_t before[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    lo[u] += w[lo[u]].x < p[u] ? 1 : 0;                    // k = #segments with start < p
-    prev[u] = w[lo[u] > 0 ? lo[u] - 1 : 0];
-    before[u] = lo[u] >= 2 ? cdf[lo[u] - 2] + 1u : 0u;
+    prev[u] = w[k[u] > 0 ? k[u] - 1 : 0];
+    before[u] = k[u] >= 2 ? cdf[k[u] - 2] + 1u : 0u;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u)
-    out[u] = lo[u] == 0 ? 0u : before[u] + (p[u] < prev[u].y ? p[u] : prev[u].y) - prev[u].x;
+    out[u] = k[u] == 0 ? 0u : before[u] + (p[u] < prev[u].y ? p[u] : prev[u].y) - prev[u].x;
 }
-
-// overlap of R segments per lane with a normalized list in global memory (seg_overlap_with, batched)
+// overlap of R segments per lane with a long normalized list (seg_overlap_with, via the tree)
 template <int R>
-__device__ __forceinline__ void seg_overlap_batch(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf, int nw,
-                                                  const uint2 (&v)[R], uint32_t (&ov)[R]) {
+__device__ __forceinline__ void seg_overlap_tree(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                                 const uint32_t* __restrict__ tree, const WsTreeGeom& g,
+                                                 const uint2 (&v)[R], uint32_t (&ov)[R]) {
   uint32_t p[2 * R], c[2 * R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { p[2 * r] = v[r].x; p[2 * r + 1] = v[r].y; }
-  cov_below_batch<2 * R>(w, cdf, nw, p, c);
+  cov_below_tree<2 * R>(w, cdf, tree, g, p, c);
 #pragma unroll
   for (int r = 0; r < R; ++r) ov[r] = c[2 * r + 1] - c[2 * r];
+}
+__device__ __forceinline__ uint32_t seg_overlap_tree1(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
+                                                      const uint32_t* __restrict__ tree, const WsTreeGeom& g,
+                                                      uint32_t s, uint32_t e) {
+  const uint2 v[1] = {make_uint2(s, e)};
+  uint32_t ov[1];
+  seg_overlap_tree<1>(w, cdf, tree, g, v, ov);
+  return ov[0];
 }
 
 // A unit's workspace held in registers (lane i = workspace segment i), for units with <= 64

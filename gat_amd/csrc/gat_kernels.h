@@ -19,8 +19,8 @@ namespace gat {
 struct UnitDev {
   int32_t n_ws;         // workspace segments of the unit
   int32_t ws_off;       // offset into ws / ws_cdf
-  int32_t n_hist;       // non-empty histogram buckets
-  int32_t hist_off;     // offset into hist_idx / hist_cdf
+  int32_t tree_start_off;  // offset into ws_tree of the search tree over the workspace starts (-1: short workspace)
+  int32_t tree_cdf_off;    // ... over the cumulated lengths
   uint32_t hist_total;  // HistogramSampler.total_size == number of working segments
   uint32_t bucket;      // bucket size (after the bucket_size==0 rule, gat/SegmentList.pyx:1164)
   uint32_t ws_total;    // SegmentListSampler.total_size == workspace bases
@@ -48,6 +48,7 @@ struct SamplerArgs {
   const uint2* ws;
   const uint32_t* ws_cdf;
   const uint32_t* rank_len;
+  const uint32_t* ws_tree;    // 16-ary search trees of the long workspaces (UnitDev::tree_*_off)
   uint32_t seed;
   int64_t sample_begin;       // global id of sample 0 of this batch
   uint2* slab;                // [batch][slab_stride]
@@ -189,9 +190,12 @@ constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (16 B ea
 constexpr int kPlaceRankLds = 1024;   // length-rank table entries kept in LDS
 constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
-// ALL_SIMPLE: the host found every unit to be of the single-workspace-segment shape; only that loop is compiled in.
-template <int KIND, bool ALL_SIMPLE>
+// MODE (chosen by the host from the units' shapes, so that the common problems run a lean kernel): 1 every unit is of
+// the single-workspace-segment shape, only that loop is compiled in; 0 no workspace beyond the LDS table; 2 everything.
+template <int KIND, int MODE>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
+  constexpr bool ALL_SIMPLE = MODE == 1;
+  constexpr bool TREES = MODE == 2;
   __shared__ uint4 l_ws[kPlaceWsLds];     // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank[kPlaceRankLds];
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
@@ -233,23 +237,14 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   }
   const bool ws_lds = nws <= kPlaceWsLds;
   const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
-  // longer workspaces: LDS holds every ws_stride-th cumulated length (the last one of each block of ws_stride
-  // segments); a look-up finds the block there and finishes inside the block in global memory
-  const int ws_stride = ws_lds ? 1 : (nws + kPlaceWsLds - 1) / kPlaceWsLds;
-  const int ws_ntop = ws_lds ? nws : (nws + ws_stride - 1) / ws_stride;
-  if (!ALL_SIMPLE) {
-    if (ws_lds) {
-      for (int i = lane; i < nws; i += kWave) {
-        const uint2 v = ws[i];
-        l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
-      }
-    } else {
-      for (int i = lane; i < ws_ntop; i += kWave) {
-        const int last = (i + 1) * ws_stride - 1;
-        l_ws[i] = make_uint4(ws_cdf[last < nws ? last : nws - 1], 0u, 0u, 0u);
-      }
+  // longer workspaces are looked up through their 16-ary tree in global memory (WsTree, gat_device.h)
+  const uint32_t* __restrict__ tree_cdf = A.ws_tree + (Up->tree_cdf_off >= 0 ? Up->tree_cdf_off : 0);
+  const WsTreeGeom G = ws_tree_geom(nws);
+  if (!ALL_SIMPLE && ws_lds)
+    for (int i = lane; i < nws; i += kWave) {
+      const uint2 v = ws[i];
+      l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
     }
-  }
   if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
@@ -394,31 +389,19 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       if ((int32_t)(w4.x - pv[c]) < 0) w4 = l_ws[lo[c] + 1];                                                   \
       pcs[c] = w4.y; pce[c] = w4.z; ppe[c] = w4.w; }                                                           \
   }
-  // the same for a workspace beyond the LDS table: block in LDS, then inside the block in global memory (indices
-  // clamped to nws-1, whose cumulated length is >= any position, so the search stays monotone)
+  // the same for a workspace beyond the LDS table: its search tree, eight look-ups level by level
 #define GAT_PRE_WS2(Y)                                                                                         \
   {                                                                                                            \
     uint32_t pv[kPlaceChunk]; int lo[kPlaceChunk];                                                             \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
-      const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; lo[c] = 0; }                        \
-    for (int n = ws_ntop; n > 1;) {                                                                            \
-      const int half = n >> 1;                                                                                 \
-      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                  \
-        lo[c] = (int32_t)(l_ws[lo[c] + half - 1].x - pv[c]) < 0 ? lo[c] + half : lo[c];                        \
-      n -= half;                                                                                               \
+      const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; }                                   \
+    {                                                   /* two batches of four: a node is 16 registers */     \
+      const uint32_t pa[4] = {pv[0], pv[1], pv[2], pv[3]}, pb[4] = {pv[4], pv[5], pv[6], pv[7]};               \
+      int la[4], lb[4];                                                                                        \
+      ws_tree_count<true, 4>(tree_cdf, G, pa, la);                                                             \
+      ws_tree_count<true, 4>(tree_cdf, G, pb, lb);                                                             \
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) { lo[c] = la[c]; lo[4 + c] = lb[c]; }                      \
     }                                                                                                          \
-    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                    \
-      lo[c] = ((int32_t)(l_ws[lo[c]].x - pv[c]) < 0 ? lo[c] + 1 : lo[c]) * ws_stride;                          \
-    for (int n = ws_stride; n > 1;) {                                                                          \
-      const int half = n >> 1;                                                                                 \
-      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
-        const int idx = lo[c] + half - 1;                                                                      \
-        lo[c] = (int32_t)(ws_cdf[idx < nws ? idx : nws - 1] - pv[c]) < 0 ? lo[c] + half : lo[c]; }             \
-      n -= half;                                                                                               \
-    }                                                                                                          \
-    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
-      const int idx = lo[c] < nws ? lo[c] : nws - 1;                                                           \
-      lo[c] = (int32_t)(ws_cdf[idx] - pv[c]) < 0 ? idx + 1 : idx; }                                            \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
       const uint2 w2 = ws[lo[c]];                                                                              \
       pcs[c] = w2.x; pce[c] = w2.y; ppe[c] = lo[c] > 0 ? ws[lo[c] - 1].y : 0x80000000u; }                      \
@@ -459,7 +442,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE)
     else if (ws_lds) {
       if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE)
-    } else {
+    } else if constexpr (TREES) {
       if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE)
     }
   }
@@ -490,7 +473,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 // k_sampler: one wave per (sample, unit).  Stand-alone it runs the whole of
 // SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
 // placed segments, `remaining`, the pending length and the position in the stream handed over.
-template <int KIND, bool BIG>
+// TREE: some unit's workspace is beyond the register loop (> kWsTreeMin segments) and is searched through its trees.
+template <int KIND, bool BIG, bool TREE>
 __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
@@ -510,7 +494,26 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
   const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
   constexpr int kWsRegMax = 64, kWsLoopMax = 32;
+  static_assert(kWsLoopMax == kWsTreeMin, "every workspace beyond the register loop has its search trees");
   const bool ws_in_regs = nws <= kWsRegMax;
+  const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
+  const uint32_t* __restrict__ tree_cdf = A.ws_tree + (Up->tree_cdf_off >= 0 ? Up->tree_cdf_off : 0);
+  const WsTreeGeom G = ws_tree_geom(nws);
+  auto ws_bisect = [&](uint32_t p) -> int {        // leftmost k with (int)(cdf[k] - p) >= 0 (utils/gat_utils.c:36)
+    if constexpr (TREE) {
+      if (nws > kWsTreeMin) {
+        const uint32_t t[1] = {p};
+        int k[1];
+        ws_tree_count<true, 1>(tree_cdf, G, t, k);
+        return k[0];
+      }
+    }
+    return bisect_u32(ws_cdf, nws, p);
+  };
+  auto ws_overlap1 = [&](uint32_t s, uint32_t e) -> uint32_t {   // one segment, a workspace beyond the register loop
+    if constexpr (TREE) return seg_overlap_tree1(ws, ws_cdf, tree_start, G, s, e);
+    else return 0u;                                              // (no such unit in this instantiation)
+  };
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
   uint2* __restrict__ out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int64_t so = (int64_t)sidx * A.n_units + u;
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
         const int32_t length = (int32_t)len_u;
         const uint32_t p = rng_range(rng, ws_total - 1u, lane);
-        const int k = bisect_u32_wave(ws_cdf, nws, p, lane);
+        const int k = ws_bisect(p);
         const uint2 chosen = ws[k];
         int32_t sampling_start = (int32_t)chosen.x - length + 1;
         if (k > 0) { const int32_t pe = (int32_t)ws[k - 1].y; sampling_start = pe > sampling_start ? pe : sampling_start; }
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
             wave_insert_sorted(seg, nU, 1, lane);
             nU += 1;
             nS = 0;
-            cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : seg_overlap_with_wave(ws, ws_cdf, nws, xs, xe, lane));
+            cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : ws_overlap1(xs, xe));
             total_known += xe - xs;
             handled = true;
           }
@@ -659,8 +662,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           uint32_t tot = 0;
           if (nws <= kWsLoopMax) {
             for (int i = lane; i < nU; i += kWave) { const uint2 v = seg[i]; cov += ws_overlap_regs(W, v.x, v.y); tot += v.y - v.x; }
-          } else {
-            constexpr int R = 4;                              // segments per lane whose workspace searches run interleaved
+          } else if constexpr (TREE) {
+            constexpr int R = 2;                              // segments per lane whose workspace searches run interleaved
             for (int base = 0; base < nU; base += R * kWave) {
               uint2 v[R];
               uint32_t ov[R];
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
                 v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
                 tot += v[r].y - v[r].x;
               }
-              seg_overlap_batch<R>(ws, ws_cdf, nws, v, ov);
+              seg_overlap_tree<R>(ws, ws_cdf, tree_start, G, v, ov);
 #pragma unroll
               for (int r = 0; r < R; ++r) cov += ov[r];
             }
@@ -728,7 +731,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
               else { seg[idx] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
               s = 0;
             }
-            if (rb > ra) removed += nws <= kWsLoopMax ? ws_overlap_regs(W, ra, rb) : seg_overlap_with(ws, ws_cdf, nws, ra, rb);
+            if (rb > ra) removed += nws <= kWsLoopMax ? ws_overlap_regs(W, ra, rb) : ws_overlap1(ra, rb);
             if (forward) { idx++; if (idx == nU) idx = 0; }
             else { idx--; if (idx < 0) idx = nU - 1; }
           }
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         chosen.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k);
         if (k > 0) prev_end = __builtin_amdgcn_readlane((int)W.end, k - 1);
       } else {
-        k = bisect_u32_wave(ws_cdf, nws, p, lane);
+        k = ws_bisect(p);
         chosen = ws[k];
         if (k > 0) prev_end = (int32_t)ws[k - 1].y;
       }
@@ -797,8 +800,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
           nout += __popcll(b);
         }
-      } else {
-        constexpr int R = 4;
+      } else if constexpr (TREE) {
+        constexpr int R = 2;
         for (int base = 0; base < nU; base += R * kWave) {
           uint2 v[R];
           uint32_t ov[R];
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
             const int i = base + r * kWave + lane;
             v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
           }
-          seg_overlap_batch<R>(ws, ws_cdf, nws, v, ov);
+          seg_overlap_tree<R>(ws, ws_cdf, tree_start, G, v, ov);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const bool keep = ov[r] > 0;                     // (0,0) fillers overlap nothing

@@ -185,7 +185,8 @@ struct gat_problem {
   DevBuf<UnitDev> d_units_o;            // the active units' records in launch order (h_order), unit id in `pad`
   DevBuf<int32_t> d_order, d_contig_unit_off, d_contig_units, d_contig_slab_off, d_count_c_off, d_count_n_index;
   DevBuf<uint2> d_ws;
-  DevBuf<uint32_t> d_ws_cdf, d_hist_idx, d_hist_cdf, d_rank_len;
+  DevBuf<uint32_t> d_ws_cdf, d_rank_len;
+  DevBuf<uint32_t> d_ws_tree;            // 16-ary search trees over the starts and the cumulated lengths of long workspaces
   DevBuf<int64_t> d_cws_nseg;
   AnnoDev annos;
   // per-batch scratch
@@ -203,6 +204,7 @@ struct gat_problem {
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
+  int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
 };
 
@@ -368,7 +370,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   P->h_cws_nseg.assign(d->cws_nseg, d->cws_nseg + d->n_contigs);
 
   std::vector<uint2> h_ws;
-  std::vector<uint32_t> h_ws_cdf, h_hist_idx, h_hist_cdf, h_rank_len;
+  std::vector<uint32_t> h_ws_cdf, h_rank_len, h_ws_tree;
   std::vector<std::pair<int64_t, int32_t>> work;   // (working segments, unit)
   std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
 
@@ -417,15 +419,11 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
                        u, l, d->nbuckets, (long long)bucket);
       hist[(uint32_t)i] += 1;
     }
-    U.n_hist = (int32_t)hist.size();
-    U.hist_off = (int32_t)h_hist_idx.size();
     uint32_t cum = 0;
     U.rank_off = (int32_t)h_rank_len.size();
     h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
     for (auto& kv : hist) {
       cum += kv.second;
-      h_hist_idx.push_back(kv.first);
-      h_hist_cdf.push_back(cum);
       for (uint32_t q = 0; q < kv.second; ++q) h_rank_len.push_back(kv.first);   // ranks (cum-count, cum]
     }
     U.hist_total = cum;
@@ -440,6 +438,32 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       h_ws_cdf.push_back(tot - 1u);
     }
     U.ws_total = tot;
+    // long workspaces: 16-ary search trees (gat_device.h, WsTree) over the starts and over the cumulated lengths
+    U.tree_start_off = -1;
+    U.tree_cdf_off = -1;
+    if (nuw > ((int64_t)1 << (4 * gat::kWsTreeLevels)))
+      return set_err(ctx, GAT_ERR_CAPACITY, "unit %d: %lld workspace segments (> %lld)", u, (long long)nuw,
+                     (long long)((int64_t)1 << (4 * gat::kWsTreeLevels)));
+    if (nuw > gat::kWsTreeMin) {
+      auto build = [&](auto key, uint32_t pad) {
+        const int32_t off = (int32_t)h_ws_tree.size();
+        std::vector<uint32_t> level((size_t)nuw);
+        for (int64_t i = 0; i < nuw; ++i) level[(size_t)i] = key(i);
+        for (;;) {
+          const size_t n = level.size(), nodes = (n + 15) / 16;
+          h_ws_tree.insert(h_ws_tree.end(), level.begin(), level.end());
+          h_ws_tree.insert(h_ws_tree.end(), nodes * 16 - n, pad);
+          if (n <= 16) break;
+          std::vector<uint32_t> up(nodes);
+          for (size_t j = 0; j < nodes; ++j) up[j] = level[std::min(16 * j + 15, n - 1)];   // largest key of node j
+          level.swap(up);
+        }
+        return off;
+      };
+      U.tree_start_off = build([&](int64_t i) { return uw[i].start; }, 0xffffffffu);
+      const size_t base = h_ws_cdf.size() - (size_t)nuw;
+      U.tree_cdf_off = build([&](int64_t i) { return h_ws_cdf[base + (size_t)i]; }, 0x7fffffffu);
+    }
     U.ltotal = (int32_t)ltotal;
     U.n_target = (int32_t)nus;                       // SamplerSegments places len(segments) segments
     P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(nwork, nus) : nwork);
@@ -465,6 +489,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
     const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
     if (!degenerate && !simple) P->all_simple = false;
+    P->max_nws = std::max(P->max_nws, U.n_ws);
   }
   // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
   // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
@@ -517,8 +542,8 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
   HIPCHK(ctx, P->d_ws.upload(h_ws, ctx->stream));
   HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx->stream));
-  HIPCHK(ctx, P->d_hist_idx.upload(h_hist_idx, ctx->stream));
-  HIPCHK(ctx, P->d_hist_cdf.upload(h_hist_cdf, ctx->stream));
+  if (h_ws_tree.empty()) h_ws_tree.assign(16, 0u);
+  HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx->stream));
   HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx->stream));
   HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
   int rc = upload_layout(ctx, P.get());
@@ -693,7 +718,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       gat::SamplerArgs A;
       memset(&A, 0, sizeof(A));
       A.units = P->d_units.p; A.units_o = P->d_units_o.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
-      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p;
+      A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
@@ -710,12 +735,15 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
         const dim3 gp(nsb, (unsigned)P->h_order.size());
+        const int mode = P->all_simple ? 1 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0);
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
-          if (P->all_simple) hipLaunchKernelGGL((gat::k_place<1, true>), gp, dim3(64), 0, ctx->stream, A);
-          else hipLaunchKernelGGL((gat::k_place<1, false>), gp, dim3(64), 0, ctx->stream, A);
+          if (mode == 1) hipLaunchKernelGGL((gat::k_place<1, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0) hipLaunchKernelGGL((gat::k_place<1, 0>), gp, dim3(64), 0, ctx->stream, A);
+          else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
-          if (P->all_simple) hipLaunchKernelGGL((gat::k_place<0, true>), gp, dim3(64), 0, ctx->stream, A);
-          else hipLaunchKernelGGL((gat::k_place<0, false>), gp, dim3(64), 0, ctx->stream, A);
+          if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0) hipLaunchKernelGGL((gat::k_place<0, 0>), gp, dim3(64), 0, ctx->stream, A);
+          else hipLaunchKernelGGL((gat::k_place<0, 2>), gp, dim3(64), 0, ctx->stream, A);
         }
         HIPCHK(ctx, hipGetLastError());
       }
@@ -732,13 +760,25 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;
         if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
       }
-      const void* ks = P->sampler == GAT_SAMPLER_SEGMENTS ? (const void*)gat::k_sampler<1, false>
-                       : A.big_buckets > 0 ? (const void*)gat::k_sampler<0, true> : (const void*)gat::k_sampler<0, false>;
+      // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
+      const bool tree = P->max_nws > gat::kWsTreeMin;
+      const int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4) : (A.big_buckets > 0 ? 2 : 0) + (tree ? 1 : 0);
+      const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false>
+                     : variant == 1 ? (const void*)gat::k_sampler<0, false, true>
+                     : variant == 2 ? (const void*)gat::k_sampler<0, true, false>
+                     : variant == 3 ? (const void*)gat::k_sampler<0, true, true>
+                     : variant == 4 ? (const void*)gat::k_sampler<1, false, false>
+                                    : (const void*)gat::k_sampler<1, false, true>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const dim3 gs((unsigned)nb, (unsigned)P->h_order.size());
-      if (P->sampler == GAT_SAMPLER_SEGMENTS) hipLaunchKernelGGL((gat::k_sampler<1, false>), gs, dim3(64), lds, ctx->stream, A);
-      else if (A.big_buckets > 0) hipLaunchKernelGGL((gat::k_sampler<0, true>), gs, dim3(64), lds, ctx->stream, A);
-      else hipLaunchKernelGGL((gat::k_sampler<0, false>), gs, dim3(64), lds, ctx->stream, A);
+      switch (variant) {
+        case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 2: hipLaunchKernelGGL((gat::k_sampler<0, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 3: hipLaunchKernelGGL((gat::k_sampler<0, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        default: hipLaunchKernelGGL((gat::k_sampler<1, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
+      }
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
                          (int64_t)nb * P->n_units, P->d_stat.p);
