@@ -144,20 +144,25 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
         sampled_counts[track] = r
 
     annotator_results = []
+    sizes = {}                       # (counts, sum) per dictionary object: the same track / workspace recur in every row
+    keep = []                        # ... and the objects stay alive so that their ids stay theirs
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
         for track, r in observed_count.items():
             if track not in sampled_counts:
                 continue
             for annotation, observed in r.items():
                 temp_segs, temp_annos, temp_workspace = workspace_generator(segments[track], annotations[annotation], workspace)
-                if temp_workspace.sum() == 0:
+                keep.append((temp_segs, temp_annos, temp_workspace))
+                if id(temp_workspace) not in sizes:
+                    sizes[id(temp_workspace)] = (temp_workspace.counts(), temp_workspace.sum())
+                if sizes[id(temp_workspace)][1] == 0:
                     continue
                 ref = reference[track][annotation] if reference else None
                 annotator_results.append(AnnotatorResultExtended(
                     track=track, annotation=annotation, counter=counter.name, observed=observed,
                     samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
                     annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
-                    pseudo_count=pseudo_count))
+                    pseudo_count=pseudo_count, _sizes=sizes))
     if output_counts_pattern:
         for counter in counters:
             with open(re.sub("%s", counter.name, output_counts_pattern), "w") as outfile:

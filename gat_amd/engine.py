@@ -287,6 +287,53 @@ class IntervalDictionary(object):
     def filter(self, other):  # noqa: A003
         self._pairwise(other, lambda a, b: a.filter(b))
 
+    def _flat64(self, order):
+        """all lists as one pair of sorted int64 arrays, the position of the key in `order` in the high bits."""
+        starts, ends = [], []
+        for i, k in enumerate(order):
+            v = self.intervals.get(k)
+            if v is None or len(v) == 0:
+                continue
+            starts.append(v._a["start"].astype(np.int64) + (i << 33))
+            ends.append(v._a["end"].astype(np.int64) + (i << 33))
+        if not starts:
+            return np.empty(0, np.int64), np.empty(0, np.int64)
+        return np.concatenate(starts), np.concatenate(ends)
+
+    def intersect_stats(self, other, _cache=None):
+        """(counts(), sum()) of `clone(); intersect(other)` without building it: the number of overlapping pairs and
+        their total overlap over the keys both dictionaries hold, in two vectorised passes (the per-key loop over
+        small lists dominated gat.run() on isochore-partitioned inputs).  None if a list is not normalized (the
+        caller then takes the list-by-list path, which raises as the reference does)."""
+        if other is self:
+            return None
+        for d in (self, other):
+            if any(not v.isNormalized for v in d.intervals.values()):
+                return None
+        # keys only one side holds contribute nothing, so every key of self keeps its own position and the flat
+        # form of self can be reused for every `other` of a run
+        order = list(self.intervals.keys())
+        ck = ("flat", id(self))
+        if _cache is not None and ck in _cache:
+            a_s, a_e = _cache[ck]
+        else:
+            a_s, a_e = self._flat64(order)
+            if _cache is not None:
+                _cache[ck] = (a_s, a_e)
+        b_s, b_e = other._flat64(order)
+        if len(a_s) == 0 or len(b_s) == 0:
+            return 0, 0
+        j0 = np.searchsorted(b_e, a_s, side="right")
+        j1 = np.searchsorted(b_s, a_e, side="left")
+        npairs = int(np.maximum(j1 - j0, 0).sum())
+        cum = np.concatenate([[0], np.cumsum(b_e - b_s)])
+
+        def below(x):                                  # bases of `other` below position x
+            k = np.searchsorted(b_s, x, side="left")
+            last = np.maximum(k - 1, 0)
+            return np.where(k > 0, cum[k] - (b_e[last] - np.minimum(x, b_e[last])), 0)
+        return npairs, int((below(a_e) - below(a_s)).sum())
+
     def toIsochores(self, isochores, truncate=False):
         """gat/Engine.pyx:2837-2855."""
         for contig in list(self.intervals.keys()):
@@ -762,18 +809,26 @@ class AnnotatorResultExtended(AnnotatorResult):
         "percent_overlap_nsegments_annotation", "percent_overlap_size_annotation"]
 
     def __init__(self, track, annotation, counter, observed, samples, track_segments, annotation_segments,
-                 workspace, reference=None, pseudo_count=1.0):
+                 workspace, reference=None, pseudo_count=1.0, _sizes=None):
         AnnotatorResult.__init__(self, track, annotation, counter, observed, samples, reference=reference,
                                  pseudo_count=pseudo_count)
-        self.track_nsegments = track_segments.counts()
-        self.track_size = track_segments.sum()
-        self.annotation_nsegments = annotation_segments.counts()
-        self.annotation_size = annotation_segments.sum()
-        overlap = track_segments.clone()
-        overlap.intersect(annotation_segments)
-        self.overlap_nsegments = overlap.counts()
-        self.overlap_size = overlap.sum()
-        self.workspace_size = workspace.sum()
+        sizes = _sizes if _sizes is not None else {}
+
+        def cached(obj):                               # (counts, sum) of a dictionary, once per object and run()
+            key = id(obj)
+            if key not in sizes:
+                sizes[key] = (obj.counts(), obj.sum())
+            return sizes[key]
+        self.track_nsegments, self.track_size = cached(track_segments)
+        self.annotation_nsegments, self.annotation_size = cached(annotation_segments)
+        stats = (track_segments.intersect_stats(annotation_segments, _cache=sizes)
+                 if hasattr(track_segments, "intersect_stats") else None)
+        if stats is None:
+            overlap = track_segments.clone()
+            overlap.intersect(annotation_segments)
+            stats = (overlap.counts(), overlap.sum())
+        self.overlap_nsegments, self.overlap_size = stats
+        self.workspace_size = cached(workspace)[1]
 
     def __str__(self):
         def _toFold(a, b):

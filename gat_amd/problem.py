@@ -33,18 +33,19 @@ def split_key(key):
 
 def from_isochores(d):
     """IntervalDictionary.fromIsochores (gat/Engine.pyx:2857-2876) on a dict key -> SEG array."""
-    new = collections.OrderedDict()
+    parts = collections.OrderedDict()
     merged = False
     for key, a in d.items():
         contig, dotted = split_key(key)
         if dotted:
-            new[contig] = np.concatenate([new[contig], a]) if contig in new else a.copy()
+            parts.setdefault(contig, []).append(a)
             merged = True
         else:
-            new[contig] = a
-    if merged:
-        for k in list(new.keys()):
-            new[k] = iv.merge(new[k], 0)
+            parts[contig] = [a]                      # new[isochore] = segmentlist (replaces)
+    new = collections.OrderedDict()
+    for contig, lst in parts.items():
+        a = lst[0] if len(lst) == 1 else np.concatenate(lst)
+        new[contig] = iv.merge(a, 0) if merged else a
     return new
 
 
