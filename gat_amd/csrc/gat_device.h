@@ -572,32 +572,6 @@ __device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, i
   wave_sync();
 }
 
-// bases of a normalized list W (starts/ends + cdf[i] = cumlen_i - 1) below position p.
-__device__ __forceinline__ uint32_t cov_below(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
-                                              int nw, uint32_t p) {
-  int lo = 0, hi = nw;                         // k = #segments with start < p
-  while (lo < hi) {
-    const int mid = lo + ((hi - lo) >> 1);
-    if (w[mid].x < p) lo = mid + 1; else hi = mid;
-  }
-  if (lo == 0) return 0;
-  const uint2 prev = w[lo - 1];
-  const uint32_t before = lo >= 2 ? cdf[lo - 2] + 1u : 0u;
-  return before + (p < prev.y ? p : prev.y) - prev.x;
-}
-
-// overlap in bases of one segment with a normalized list (what intersect().sum() adds up for it,
-// gat/SegmentList.pyx:1469-1549 + :1607)
-__device__ __forceinline__ uint32_t seg_overlap_with(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
-                                                     int nw, uint32_t s, uint32_t e) {
-  if (nw == 1) {
-    const uint2 a = w[0];
-    const uint32_t lo = s > a.x ? s : a.x, hi = e < a.y ? e : a.y;
-    return hi > lo ? hi - lo : 0u;
-  }
-  return cov_below(w, cdf, nw, e) - cov_below(w, cdf, nw, s);
-}
-
 // ------------------------------------------------------------------------------------------
 // WsTree: static 16-ary search tree over a sorted u32 array in global memory.  Level 0 is the array
 // itself padded to whole 64-byte nodes; entry j of level l+1 is the largest key of node j of level
@@ -662,7 +636,8 @@ __device__ __forceinline__ void ws_tree_count(const uint32_t* __restrict__ tree,
   }
 }
 
-// bases of a normalized list W below U positions per lane: k = #segments with start < p from the tree, then as cov_below
+// bases of a normalized list W (starts/ends + cdf[i] = cumlen_i - 1) below U positions per lane: k = #segments with start < p
+// from the tree, then the bases of the first k-1 segments plus the part of segment k-1 below p
 template <int U>
 __device__ __forceinline__ void cov_below_tree(const uint2* __restrict__ w, const uint32_t* __restrict__ cdf,
                                                const uint32_t* __restrict__ tree, const WsTreeGeom& g,
