@@ -474,11 +474,13 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 // SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
 // placed segments, `remaining`, the pending length and the position in the stream handed over.
 // TREE: some unit's workspace is beyond the register loop (> kWsTreeMin segments) and is searched through its trees.
-template <int KIND, bool BIG, bool TREE>
+// HUGE: some unit's list does not fit LDS (about 15 000 segments): the list then lives where k_place left it, in the
+// unit's slab region in global memory, and the same code works on it there -- slow (every pass is a round trip to
+// memory, the sort is the in-place network) but without a size limit.
+template <int KIND, bool BIG, bool TREE, bool HUGE>
 __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
-  uint2* seg = reinterpret_cast<uint2*>(lds + kMtLdsWords);
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
   const int a = blockIdx.y;
@@ -515,7 +517,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     else return 0u;                                              // (no such unit in this instantiation)
   };
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
-  uint2* __restrict__ out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + kMtLdsWords);
   const int64_t so = (int64_t)sidx * A.n_units + u;
 
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
@@ -581,7 +584,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = pre.x;
-      for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
+      if (!HUGE)
+        for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
       remaining = pre.y;
       pending = pre_len;
       rng.use_pre = true; rng.exhausted = false; rng.ndraws = (uint32_t)pre.w; rng.pos = 0; rng.rbuf = 0;
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
         }
         if (!handled) {
           const int n = nU + nS;
-          if (BIG && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
+          if (BIG && !HUGE && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
             // long list straight from the slab k_place wrote: counting sort into LDS (the copy made at resume is overwritten)
             int nb = 1024;
             while (nb < n && nb < A.big_buckets) nb <<= 1;
@@ -870,13 +874,16 @@ struct ContigArgs {
   unsigned long long* stat;
 };
 
+// HUGE: a contig's list does not fit LDS; it is gathered, sorted and merged in its output region in global memory.
+template <bool HUGE>
 __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* scratch = lds;                               // 513 words for the bucket sort
-  uint2* seg = reinterpret_cast<uint2*>(lds + 520);
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
   const int c = blockIdx.y;
+  uint2* out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
+  uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + 520);
   int n = 0;
   const int u0 = A.contig_unit_off[c], u1 = A.contig_unit_off[c + 1];
   for (int ui = u0; ui < u1; ++ui) {
@@ -888,8 +895,8 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   }
   wave_sort_fast(seg, n, scratch, lane);
   n = wave_merge0(seg, n, lane);
-  uint2* __restrict__ out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
-  for (int i = lane; i < n; i += kWave) out[i] = seg[i];
+  if (!HUGE)
+    for (int i = lane; i < n; i += kWave) out[i] = seg[i];
   if (lane == 0) {
     A.contig_n[(int64_t)sidx * A.n_contigs + c] = n;
   }

@@ -748,13 +748,14 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipGetLastError());
       }
       size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
-      if ((int64_t)lds > ctx->max_lds)
-        return set_err(ctx, GAT_ERR_CAPACITY, "unit needs %zu bytes of LDS (> %d): too many segments in one isochore unit", lds, ctx->max_lds);
+      // SamplerSegments never holds a list; a SamplerAnnotator list beyond LDS is worked on in the slab (HUGE variant)
+      const bool huge = P->sampler != GAT_SAMPLER_SEGMENTS && ((int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr);
+      if (huge || P->sampler == GAT_SAMPLER_SEGMENTS) lds = (size_t)gat::kMtLdsWords * 4;
       A.lds_cap = P->max_unit_cap;
       A.big_buckets = 0;
       uint32_t max_work = 0;
       for (int32_t u : P->h_order) max_work = std::max(max_work, P->h_units[u].hist_total);
-      if (max_work + max_work / 8 > 1024) {   // lists beyond the register sorts: counting-sort scratch behind the segment buffer, if it fits
+      if (!huge && max_work + max_work / 8 > 1024) {   // lists beyond the register sorts: counting-sort scratch behind the segment buffer, if it fits
         int nbk = 1024;
         while (nbk < P->max_unit_cap && nbk < 8192) nbk <<= 1;
         while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;
@@ -762,22 +763,27 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       const bool tree = P->max_nws > gat::kWsTreeMin;
-      const int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4) : (A.big_buckets > 0 ? 2 : 0) + (tree ? 1 : 0);
-      const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false>
-                     : variant == 1 ? (const void*)gat::k_sampler<0, false, true>
-                     : variant == 2 ? (const void*)gat::k_sampler<0, true, false>
-                     : variant == 3 ? (const void*)gat::k_sampler<0, true, true>
-                     : variant == 4 ? (const void*)gat::k_sampler<1, false, false>
-                                    : (const void*)gat::k_sampler<1, false, true>;
+      const int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
+                        : huge ? (tree ? 7 : 6) : (A.big_buckets > 0 ? 2 : 0) + (tree ? 1 : 0);
+      const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false, false>
+                     : variant == 1 ? (const void*)gat::k_sampler<0, false, true, false>
+                     : variant == 2 ? (const void*)gat::k_sampler<0, true, false, false>
+                     : variant == 3 ? (const void*)gat::k_sampler<0, true, true, false>
+                     : variant == 4 ? (const void*)gat::k_sampler<1, false, false, false>
+                     : variant == 5 ? (const void*)gat::k_sampler<1, false, true, false>
+                     : variant == 6 ? (const void*)gat::k_sampler<0, false, false, true>
+                                    : (const void*)gat::k_sampler<0, false, true, true>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const dim3 gs((unsigned)nb, (unsigned)P->h_order.size());
       switch (variant) {
-        case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 2: hipLaunchKernelGGL((gat::k_sampler<0, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 3: hipLaunchKernelGGL((gat::k_sampler<0, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        default: hipLaunchKernelGGL((gat::k_sampler<1, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 2: hipLaunchKernelGGL((gat::k_sampler<0, true, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 3: hipLaunchKernelGGL((gat::k_sampler<0, true, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 5: hipLaunchKernelGGL((gat::k_sampler<1, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 6: hipLaunchKernelGGL((gat::k_sampler<0, false, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        default: hipLaunchKernelGGL((gat::k_sampler<0, false, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
       }
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
@@ -791,11 +797,13 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
       B.slab_in = P->d_slab.p; B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
-      const size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
-      if ((int64_t)lds > ctx->max_lds)
-        return set_err(ctx, GAT_ERR_CAPACITY, "contig needs %zu bytes of LDS (> %d)", lds, ctx->max_lds);
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_contig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gat::k_contig, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
+      size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
+      const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
+      if (huge_c) lds = 520 * 4;
+      const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
+      HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
+      else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
       HIPCHK(ctx, hipGetLastError());
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));

@@ -275,6 +275,41 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     P.close()
 
 
+@pytest.mark.parametrize("seed", [2, 3])
+def test_lists_in_global_memory_vs_oracle(ctx, seed, monkeypatch):
+    """the HUGE kernel variants (lists worked on in the slab instead of LDS) forced onto ordinary problems,
+    with and without isochores: same counts and sampled lists as the oracle."""
+    monkeypatch.setenv("GAT_TEST_HUGE", "1")
+    rs = np.random.RandomState(seed)
+    flat = _random_problem(rs, n_contigs=3, n_segs=int(rs.randint(200, 700)), n_tracks=2, isochores=bool(seed % 2))
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S = 24
+    want, wsamples = O.run_samples(flat, counters, 500 + seed, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 500 + seed, 0, S)
+    for k in range(len(counters)):
+        assert np.array_equal(got[k], want[k])
+    seg, off = P.sample(500 + seed, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
+def test_unit_beyond_lds_vs_oracle(ctx):
+    """one unit with about 45 000 segments (LDS holds about 15 000): the list stays in global memory; the reference has
+    no size limit, so neither may the drop-in."""
+    rs = np.random.RandomState(11)
+    flat = _big_problem(rs, 60000, 2, n_contigs=1, mean_len=20)
+    counters = ["nucleotide-overlap"]
+    S = 3
+    want, wsamples = O.run_samples(flat, counters, 31, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 31, 0, S)
+    assert np.array_equal(got[0], want[0])
+    seg, off = P.sample(31, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
 def test_cli_table_matches_reference(ctx, tmp_path):
     """scripts/gat-run.py end to end against the table the reference's gat-run.py printed for the same
     BED files and seed (per-unit stream contract patched into the reference, tests/golden/make_goldens.py)."""
