@@ -645,6 +645,18 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           }
         }
         if (!handled) {
+          if (dirty && nU > 0 && nS <= kWave && nU + nS > 1024) {      // (up to 1024 the bucket sort is cheaper)
+            // the trim left the merged list sorted but for its placeholders, which merge(0) skips wherever they
+            // are: one compaction pass (instead of sorting a long list again with the network) and it is clean and sorted,
+            // ready for the few new segments to be inserted
+            uint2 moved = make_uint2(0u, 0u);
+            if (lane < nS) moved = seg[nU + lane];
+            const int kept = wave_merge0(seg, nU, lane);
+            if (lane < nS) seg[kept + lane] = moved;
+            wave_sync();
+            nU = kept;
+            dirty = false;
+          }
           const int n = nU + nS;
           if (BIG && !HUGE && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
             // long list straight from the slab k_place wrote: counting sort into LDS (the copy made at resume is overwritten)
