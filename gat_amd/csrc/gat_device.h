@@ -430,8 +430,19 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
 // written) when the keys are too clustered for that to be cheap.
 __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2* __restrict__ src, int n,
                                                         uint32_t* scratch, int nb, int lane) {
+  // the three passes over the source read it in batches of kB rounds: kB loads in flight per lane instead of one
+  // (one wave per unit, three waves per CU at these list lengths: nothing else hides the latency)
+  constexpr int kB = 8;
   uint32_t lo = 0xffffffffu, hi = 0u;
-  for (int i = lane; i < n; i += kWave) { const uint32_t x = src[i].x; lo = x < lo ? x : lo; hi = x > hi ? x : hi; }
+  for (int base = 0; base < n; base += kB * kWave) {
+    uint32_t x[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kWave + lane; x[q] = i < n ? src[i].x : 0u; }
+#pragma unroll
+    for (int q = 0; q < kB; ++q) {
+      if (base + q * kWave + lane < n) { lo = x[q] < lo ? x[q] : lo; hi = x[q] > hi ? x[q] : hi; }
+    }
+  }
   lo = wave_min_u32(lo); hi = wave_max_u32(hi);
   const uint32_t span = hi - lo;
   if (span == 0) return false;
@@ -440,9 +451,14 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
   wave_sync();
   for (int i = lane; i <= nb; i += kWave) scratch[i] = 0;
   wave_sync();
-  for (int i = lane; i < n; i += kWave) {
-    const uint32_t d = src[i].x - lo;
-    atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u);
+  for (int base = 0; base < n; base += kB * kWave) {
+    uint32_t x[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kWave + lane; x[q] = i < n ? src[i].x : 0u; }
+#pragma unroll
+    for (int q = 0; q < kB; ++q) {
+      if (base + q * kWave + lane < n) { const uint32_t d = x[q] - lo; atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u); }
+    }
   }
   wave_sync();
   // exclusive prefix: lane owns nb/64 consecutive buckets
@@ -453,11 +469,18 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
   if (wave_max_u32(maxc) > 48u) return false;
   for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; scratch[lane * per + q] = run; run += c; }
   wave_sync();
-  for (int i = lane; i < n; i += kWave) {
-    const uint2 v = src[i];
-    const uint32_t d = v.x - lo;
-    const uint32_t pos = atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u);
-    dst[pos] = v;
+  for (int base = 0; base < n; base += kB * kWave) {
+    uint2 v[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kWave + lane; v[q] = i < n ? src[i] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int q = 0; q < kB; ++q) {
+      if (base + q * kWave + lane < n) {
+        const uint32_t d = v[q].x - lo;
+        const uint32_t pos = atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u);
+        dst[pos] = v[q];
+      }
+    }
   }
   wave_sync();
   // scratch[b] is now the END of bucket b; lane sorts the buckets lane, lane+64, ...

@@ -584,7 +584,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = pre.x;
-      if (!HUGE)
+      // (a list the counting sort will take straight from the slab need not be copied first)
+      if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0))
         for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
       remaining = pre.y;
       pending = pre_len;
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           }
           const int n = nU + nS;
           if (BIG && !HUGE && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
-            // long list straight from the slab k_place wrote: counting sort into LDS (the copy made at resume is overwritten)
+            // long list straight from the slab k_place wrote: counting sort into LDS (it was not copied at resume)
             int nb = 1024;
             while (nb < n && nb < A.big_buckets) nb <<= 1;
             uint32_t* big = reinterpret_cast<uint32_t*>(seg + A.lds_cap);
