@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
           }
         }
         if (!handled) {
-          if (dirty && nU > 0 && nS <= kWave && nU + nS > 1024) {      // (up to 1024 the bucket sort is cheaper)
+          if (BIG && dirty && nU > 0 && nS <= kWave && nU + nS > 1024) {      // (up to 1024 the bucket sort is cheaper)
             // the trim left the merged list sorted but for its placeholders, which merge(0) skips wherever they
             // are: one compaction pass (instead of sorting a long list again with the network) and it is clean and sorted,
             // ready for the few new segments to be inserted
@@ -668,6 +668,11 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
               for (int i = lane; i < n; i += kWave) seg[i] = out[i];
               wave_sort_by_start(seg, n, lane);
             }
+          } else if (BIG && nU > 0 && !dirty && n > 1024 && nS <= 1024) {
+            // a long clean list and some new segments: insert them 64 at a time (a pass over the list each) rather than
+            // sort everything with the network (thousands of passes)
+            for (int done = 0; done < nS; done += kWave)
+              wave_insert_sorted(seg, nU + done, nS - done < kWave ? nS - done : kWave, lane);
           } else
           if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)

@@ -22,8 +22,8 @@ for it in range(2):
     P.sample_and_count(["nucleotide-overlap"], 7, 0, S)
 out = (ctypes.c_ulonglong * 16)()
 _lib.lib().gat_debug_phases(out)
-v = np.array(list(out)[:8], dtype=float)
-names = ["resume copy", "loop: draws/placements", "sort/insert", "merge0", "coverage", "trim", "final filter+write", "fast-path consolidations"]
+v = np.array(list(out)[:10], dtype=float)
+names = ["resume copy", "loop: draws/placements", "sort/insert", "merge0", "coverage", "trim", "final filter+write", "fast-path consolidations", "dirty compaction", "big counting sort"]
 for n, x in zip(names, v):
     print("%-36s %6.2f%%" % (n, 100 * x / v.sum()))
 print("consolidations per unit-sample: %.2f" % (out[8] / (2.0 * S * flat["n_units"])))
