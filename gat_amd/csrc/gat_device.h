@@ -575,21 +575,37 @@ __device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, i
     cu = lo;
   }
   const int newpos = cu + nrank;
+  // the old element at index i moves up by the number of new elements that go in at or before it, i.e. with
+  // insertion index cu <= i.  Lane r gets the r-th smallest insertion index (the new elements in sorted order), so
+  // that number is a ballot for a whole block of 64 old elements plus the few new ones that fall inside the block
+  int cs_sorted = 0x7fffffff;
+  {
+    // scatter cu to the lane given by its rank: lane r reads from the lane whose nrank == r
+    int src_lane = 0;
+    for (int j = 0; j < nS; ++j) {
+      const int rj = __builtin_amdgcn_readlane(nrank, j);
+      if (rj == lane) src_lane = j;
+    }
+    const int got = __builtin_amdgcn_ds_bpermute(src_lane << 2, cu);
+    if (lane < nS) cs_sorted = got;
+  }
   for (int base = ((nU - 1) >> 6) << 6; base >= 0; base -= kWave) {
     const int i = base + lane;
     const bool ok = i < nU;
     uint2 v = make_uint2(0u, 0u);
     if (ok) v = seg[i];
-    int sh = 0;
-    for (int j = 0; j < nS; ++j) {
-      const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)nv.x, j);
-      sh += (ok && sj < v.x) ? 1 : 0;
+    const int below = __popcll(__ballot(cs_sorted < base + 1));            // new elements going in at or before `base`
+    const int upto = __popcll(__ballot(cs_sorted <= base + kWave - 1));    // ... at or before the block's last element
+    int sh = below;
+    for (int j = below; j < upto; ++j) {
+      const int cj = __builtin_amdgcn_readlane(cs_sorted, j);
+      sh += cj <= i ? 1 : 0;
     }
-    const uint64_t moved = __ballot(sh > 0);
+    sh = ok ? sh : 0;
     wave_sync();
     if (sh > 0) seg[i + sh] = v;
     wave_sync();
-    if (moved == 0) break;
+    if (upto == 0) break;                                                  // nothing goes in at or before this block
   }
   if (lane < nS) seg[newpos] = nv;
   wave_sync();

@@ -27,3 +27,4 @@ names = ["resume copy", "loop: draws/placements", "sort/insert", "merge0", "cove
 for n, x in zip(names, v):
     print("%-36s %6.2f%%" % (n, 100 * x / v.sum()))
 print("consolidations per unit-sample: %.2f" % (out[8] / (2.0 * S * flat["n_units"])))
+print("raw:", [int(x) for x in list(out)[:10]])
