@@ -1175,10 +1175,23 @@ __global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
     const int64_t g = A.a_off[(int64_t)t * A.n_contigs + c];
     const int m = (int)(A.a_off[(int64_t)t * A.n_contigs + c + 1] - g);
     uint32_t ov = 0;
-    for (int i = lane; i < m; i += kWave) {
-      uint32_t o1, h1, m1;
-      seg_vs_anno<false>(V, A.a_start[g + i], A.a_end[g + i], o1, h1, m1);
-      ov += o1;
+    constexpr int kB = 4;                                      // rounds whose interval loads are in flight together
+    for (int base = 0; base < m; base += kB * kWave) {
+      uint32_t as[kB], ae[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = base + q * kWave + lane;
+        as[q] = i < m ? A.a_start[g + i] : 0u;
+        ae[q] = i < m ? A.a_end[g + i] : 0u;                   // an empty interval overlaps nothing
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        if (base + q * kWave < m) {
+          uint32_t o1, h1, m1;
+          seg_vs_anno<false>(V, as[q], ae[q], o1, h1, m1);
+          ov += (base + q * kWave + lane < m) ? o1 : 0u;
+        }
+      }
     }
     ov = wave_total_u32(ov);
     if (lane == 0) A.part[pbase + (int64_t)t * A.n_samples] = ov;
