@@ -1098,6 +1098,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
           }
 #pragma unroll
           for (int r = 0; r < kCountXR; ++r) {
+            if (base + r * kWave >= n) break;              // (wave-uniform: whole rounds beyond the list are skipped)
             uint32_t o1, h1, m1;
             seg_vs_anno<WANT_HITS>(Y, x[r].x, x[r].y, o1, h1, m1);
             ov += o1; hit += h1; mid += m1;
