@@ -976,15 +976,23 @@ struct AnnoView {
 //   general form F(xe) - F(xs), F(p) = cumx[k-1] + min(p, end[k-1]) - start[k-1], is used (behind a
 //   wave-uniform __any test).  Measured alternatives that were slower: predicated fixed-count scans
 //   (+7 %), eight lookups advanced in lock step (+37 %).
-template <bool WANT_HITS>
+// SENT: start[m] holds the sentinel 0xffffffff (LDS copies have room for it), which ends both scans by itself: no
+// second grid read, no index checks.
+template <bool WANT_HITS, bool SENT>
 __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint32_t xe,
                                             uint32_t& ov, uint32_t& hit, uint32_t& midhit) {
   uint32_t g = xs >> Y.shift;
   g = g < (uint32_t)(Y.cells - 1) ? g : (uint32_t)(Y.cells - 1);
   int k = (int)Y.grid[g];
-  const int hi = (int)Y.grid[g + 1];
-  uint32_t sk = k < Y.m ? Y.start[k] : 0xffffffffu;
-  while (k < hi && sk < xs) { ++k; sk = k < Y.m ? Y.start[k] : 0xffffffffu; }
+  uint32_t sk;
+  if (SENT) {
+    sk = Y.start[k];
+    while (sk < xs) { ++k; sk = Y.start[k]; }              // stops at the cell's end at the latest: that start is > xs
+  } else {
+    const int hi = (int)Y.grid[g + 1];
+    sk = k < Y.m ? Y.start[k] : 0xffffffffu;
+    while (k < hi && sk < xs) { ++k; sk = k < Y.m ? Y.start[k] : 0xffffffffu; }
+  }
   const int k1 = k;
   const uint32_t pe_raw = Y.end[k1 > 0 ? k1 - 1 : 0];
   const bool reach = k1 > 0 && pe_raw > xs;                // the last interval starting before xs reaches past it
@@ -1000,7 +1008,8 @@ __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint
     if (slow) {
       const uint32_t pe = k1 > 0 ? pe_raw : 0u;
       int k2 = k1 + 1;                                     // #starts < xe
-      while (k2 < Y.m && Y.start[k2] < xe) ++k2;
+      if (SENT) { while (Y.start[k2] < xe) ++k2; }
+      else { while (k2 < Y.m && Y.start[k2] < xe) ++k2; }
       uint32_t f1 = 0;
       if (k1 > 0) f1 = Y.cumx[k1 - 1] + (xs < pe ? xs : pe) - Y.start[k1 - 1];
       const uint32_t ps2 = Y.start[k2 - 1], pe2 = Y.end[k2 - 1];
@@ -1039,20 +1048,21 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
     if (tid == 0) {
       int o = 0;
       for (int t = 0; t < nt; ++t) {
-        tile_off[t] = o;
-        o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]);
+        tile_off[t] = o;                                    // (+1: the sentinel behind every track's starts)
+        o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]) + 1;
       }
       tile_off[nt] = o;
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
       const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
-      const int o = tile_off[t], m = tile_off[t + 1] - o;
+      const int o = tile_off[t], m = tile_off[t + 1] - o - 1;
       for (int i = tid; i < m; i += 256) {
         stage[o + i] = A.a_start[g + i];
         stage[E + o + i] = A.a_end[g + i];
         stage[2 * E + o + i] = A.a_cumx[g + i];
       }
+      if (tid == 0) stage[o + m] = 0xffffffffu;
       const int64_t gg = A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
       for (int i = tid; i <= cells; i += 256) st_grid[t * (cells + 1) + i] = A.a_grid[gg + i];
     }
@@ -1079,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
         const int o = tile_off[t];
         Y.start = stage + o; Y.end = stage + E + o; Y.cumx = stage + 2 * E + o;
         Y.grid = st_grid + t * (cells + 1);
-        Y.m = tile_off[t + 1] - o;
+        Y.m = tile_off[t + 1] - o - 1;
       } else {
         const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
         Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
@@ -1100,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
           for (int r = 0; r < kCountXR; ++r) {
             if (base + r * kWave >= n) break;              // (wave-uniform: whole rounds beyond the list are skipped)
             uint32_t o1, h1, m1;
-            seg_vs_anno<WANT_HITS>(Y, x[r].x, x[r].y, o1, h1, m1);
+            seg_vs_anno<WANT_HITS, STAGED>(Y, x[r].x, x[r].y, o1, h1, m1);
             ov += o1; hit += h1; mid += m1;
           }
         }
@@ -1137,7 +1147,7 @@ __global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
   const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
   const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
   const int64_t pbase = (((int64_t)c * 3) * A.n_tracks) * A.n_samples + s;
-  if (n == 0 || n > capx) {                                   // n > capx cannot happen (capx = slab capacity)
+  if (n == 0 || n >= capx) {                                  // n >= capx cannot happen (capx = slab capacity, never filled)
     for (int t = tid; t < A.n_tracks; t += kSwapThreads) A.part[pbase + (int64_t)t * A.n_samples] = 0;
     return;
   }
@@ -1154,6 +1164,7 @@ __global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
   for (int i = i0; i < i1; ++i) { xcum[i] = base; base += xe[i] - xs[i]; }
   __syncthreads();
   // 2. position grid over the starts: grid[g] = #starts < (g << shift)
+  if (tid == 0) xs[n] = 0xffffffffu;                          // sentinel (n < capx: the slab never fills to capacity)
   const uint32_t maxstart = xs[n - 1];
   const int bits = maxstart ? 32 - __builtin_clz(maxstart) : 1;
   const int shift = bits > lcells ? bits - lcells : 0;
@@ -1189,7 +1200,7 @@ __global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
       for (int q = 0; q < kB; ++q) {
         if (base + q * kWave < m) {
           uint32_t o1, h1, m1;
-          seg_vs_anno<false>(V, as[q], ae[q], o1, h1, m1);
+          seg_vs_anno<false, true>(V, as[q], ae[q], o1, h1, m1);
           ov += (base + q * kWave + lane < m) ? o1 : 0u;
         }
       }
