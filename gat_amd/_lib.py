@@ -67,6 +67,8 @@ class Stats(C.Structure):
         ("n_unsuccessful", C.c_int64),
         ("n_retried", C.c_int64),
         ("n_full_units", C.c_int64),
+        ("ms_count_main", C.c_float),
+        ("reserved0", C.c_float),
     ]
 
     def asdict(self):

@@ -31,6 +31,8 @@ struct gat_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_main[2] = {nullptr, nullptr};   // around the dominant count kernel alone (k_count_seg / k_count_swap)
+  bool main_recorded = false;
   std::string err;
   int max_lds = 65536;
 };
@@ -241,6 +243,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
     ctx->own_stream = true;
   }
   for (auto& ev : ctx->ev) HIPCHK(ctx, hipEventCreate(&ev));
+  for (auto& ev : ctx->ev_main) HIPCHK(ctx, hipEventCreate(&ev));
   *out = ctx;
   return GAT_OK;
 }
@@ -249,6 +252,7 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -673,11 +677,15 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       B.lds_grid = lcells;
       const size_t lds_swap = (size_t)3 * swap_capx * 4 + ((size_t)(1 << lcells) + 1) * 4;
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_swap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_swap));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
       hipLaunchKernelGGL(gat::k_count_swap, dim3((unsigned)A.n_samples, (unsigned)A.n_contigs), dim3(gat::kSwapThreads), lds_swap, ctx->stream, B);
       HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
+      ctx->main_recorded = true;
     } else
     if (A.n_contigs > 0) {
     const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
     if (staged) {
       const void* fn = hits ? (const void*)gat::k_count_seg<true, true> : (const void*)gat::k_count_seg<true, false>;
       HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -688,6 +696,8 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       else hipLaunchKernelGGL((gat::k_count_seg<false, false>), grid, dim3(256), lds, ctx->stream, A);
     }
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
+    ctx->main_recorded = true;
     }
     const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
     hipLaunchKernelGGL(gat::k_count_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, A);
@@ -883,6 +893,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     A.out_stride = S;
     A.out_begin = done;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    ctx->main_recorded = false;
     int swap_capx = 0;
     if (P->swap_capx) {
       const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
@@ -894,6 +905,10 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     local.ms_count += ms;
+    if (ctx->main_recorded) {
+      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_main[0], ctx->ev_main[1]));
+      local.ms_count_main += ms;
+    }
     done += nb;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));

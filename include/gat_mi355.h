@@ -90,6 +90,8 @@ typedef struct {
   int64_t n_unsuccessful;       /* sum of nunsuccessful_rounds (gat/Engine.pyx:570-572)         */
   int64_t n_retried;            /* work units redone with a larger slab                         */
   int64_t n_full_units;         /* work units run without the lane-parallel front end           */
+  float ms_count_main;          /* the dominant count kernel alone (k_count_seg / k_count_swap)   */
+  float reserved0;
 } gat_stats;
 
 /* ---- context ---------------------------------------------------------------------------- */
