@@ -43,5 +43,8 @@ def gather_numpy(local_np, n_total, group=None):
     """numpy convenience wrapper (CPU tensors; used by the host API when results are already on
     the host and by the gloo tests)."""
     import torch
+    import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(local_np))
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":     # RCCL moves device memory only
+        return allgather_counts(t.cuda(), n_total, group).cpu().numpy()
     return allgather_counts(t, n_total, group).numpy()
