@@ -275,6 +275,50 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     P.close()
 
 
+@pytest.mark.parametrize("seed", list(range(100, 164)))
+def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
+    """random combinations of the knobs that select code paths -- segments per unit (register / bucket / counting
+    sorts), workspace pieces (registers / LDS table / search trees), bucket size (with and without the bucket draw),
+    isochores, sampler kind -- against the oracle: counts for all six counters and the sampled lists."""
+    import collections
+    from gat_amd import problem
+    if seed % 6 == 0:
+        monkeypatch.setenv("GAT_TEST_HUGE", "1")          # ... and the list-in-global-memory variants
+    rs = np.random.RandomState(seed)
+    n_contigs = int(rs.randint(1, 4))
+    contigs = collections.OrderedDict(("f%d" % i, int(rs.randint(200000, 3000000))) for i in range(n_contigs))
+    n_segs = int(rs.choice([30, 150, 700, 2500]))
+    mean_len = int(rs.choice([20, 80, 400]))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    annos = [("t%d" % t, synthetic.random_segments(contigs, int(rs.randint(20, 600)), int(rs.randint(50, 3000)),
+                                                   int(rs.randint(1 << 30)))) for t in range(int(rs.randint(1, 4)))]
+    pieces = int(rs.choice([1, 3, 40, 90, 300]))
+    spacing = (min(contigs.values()) - 20000) // pieces
+    ws = synthetic.workspace_ungapped(contigs, pieces=pieces, gap=min(int(rs.choice([50, 600])), max(2, spacing // 3)))
+    iso = synthetic.isochores_blocks(contigs, nclasses=int(rs.randint(2, 4)), block=int(rs.randint(20000, 200000))) \
+        if rs.randint(0, 3) == 0 else None
+    bucket_size = int(rs.choice([0, 1, 7]))
+    nbuckets = 100000 if bucket_size != 1 else 20000
+    flat = problem.flatten_arrays(segs, annos, ws, iso, bucket_size=bucket_size, nbuckets=nbuckets)
+    # (SamplerSegments output is only countable after fromIsochores merged it: the counters assert normalized lists)
+    flat["sampler"] = int(rs.randint(0, 3) == 0 and iso is not None)
+    counters = list(_lib.COUNTER_IDS.keys())
+    S = 12
+    try:
+        want, wsamples = O.run_samples(flat, counters, 7000 + seed, 1, 2, 2 + S, want_samples=True)
+    except ValueError:                                   # a segment longer than nbuckets * bucket_size
+        with pytest.raises(ValueError):
+            _lib.Problem(ctx, flat)
+        return
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 7000 + seed, 2, 2 + S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), (c, n_segs, pieces, bucket_size, iso is not None, flat["sampler"])
+    seg, off = P.sample(7000 + seed, 2, 2 + S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
 @pytest.mark.parametrize("seed", [2, 3])
 def test_lists_in_global_memory_vs_oracle(ctx, seed, monkeypatch):
     """the HUGE kernel variants (lists worked on in the slab instead of LDS) forced onto ordinary problems,
