@@ -147,6 +147,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # the one collective of the path, timed by itself after the timed region (the split the report shows per N)
+    allgather_ms = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(gathered, counts)
+        torch.cuda.synchronize()
+        allgather_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     if rank == 0:
         # HBM bytes of the count kernel per launch from the committed rocprofv3 PMC passes of this same
@@ -197,6 +207,8 @@ def main():
                         "contig_kernel_avg_ms": acc["ms_contig"] / args.steps,
                         "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
                         "work_units": S * args.steps * flat["n_units"]},
+            "allgather": None if allgather_ms is None else
+            {"avg_ms": allgather_ms, "bytes_per_rank": int(counts.numel() * 8), "collective": "RCCL all_gather_into_tensor"},
         }
         if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(flat, counters, args.seed, args.cpu_seconds)
