@@ -100,17 +100,24 @@ def main():
                          (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; GAT_BENCH_SHARE_GPU=1 (testing the N>1 code path on a one-GPU box) lets ranks share devices
+    # and swaps RCCL, which refuses two ranks on one device, for gloo
+    share = os.environ.get("GAT_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synthetic.config(args.config, args.scale)
     counters = [cfg["counter"]]
     S = args.samples or cfg["num_samples"]
     flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(local_rank, stream=stream)
+    ctx = _lib.Context(dev_index, stream=stream)
     P = _lib.Problem(ctx, flat)
     info = P.info()
     K, A = len(counters), flat["n_tracks"]

@@ -537,3 +537,24 @@ def test_wave_only_sampler_mode(ctx, monkeypatch):
         assert np.array_equal(counts[k] if c == "nucleotide-density" else counts[k].astype(np.float64), want), c
     assert P.last_stats["n_full_units"] > 0
     P.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (rank-disjoint sample ranges, all-gather of the count matrix, max-over-ranks timing,
+    one JSON line from rank 0) with two ranks sharing this box's GPU: GAT_BENCH_SHARE_GPU=1 swaps RCCL, which
+    refuses two ranks on one device, for gloo; everything else is the code the multi-GPU launch runs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--samples", "2000"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["allgather"]["bytes_per_rank"] == 2000 * 8
+    assert "cpu_baseline" not in out                      # reported at N = 1 only
