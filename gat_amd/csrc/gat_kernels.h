@@ -49,6 +49,9 @@ struct SamplerArgs {
   const uint32_t* ws_cdf;
   const uint32_t* rank_len;
   const uint32_t* ws_tree;    // 16-ary search trees of the long workspaces (UnitDev::tree_*_off)
+  int4* st2;                  // [batch][n_units] by launch position: first consolidation done by k_merge_big
+                              // {merged segments, workspace bases covered, sum of lengths, 1}, .w == 0 otherwise
+  int32_t n_long;             // launch positions [0, n_long) were given to k_merge_big
   uint32_t seed;
   int64_t sample_begin;       // global id of sample 0 of this batch
   uint2* slab;                // [batch][slab_stride]
@@ -470,6 +473,192 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_merge_big: the FIRST consolidation (sort + merge(0) + workspace coverage, gat/Engine.pyx:582-606) of the long
+// lists, one workgroup of 256 threads per (sample, unit).  A single wave needs dozens of rounds per pass over a list of
+// thousands of segments and, with the list in LDS, only two or three such waves fit a CU; here four waves share the list
+// and the passes: counting sort from the slab k_place wrote into LDS (position buckets, LDS atomics, block prefix sum,
+// one thread per bucket for the final order), merge(0) as a block-wide running maximum of the ends, the merged list
+// written back to the slab, coverage and total length reduced over the block.  k_sampler resumes behind it with a
+// clean merged list (st2) and goes straight to the tail.  Lists the counting sort declines (clustered keys) are left
+// to k_sampler's own sort.
+constexpr int kMergeThreads = 256;
+constexpr int kMergeWaves = kMergeThreads / kWave;
+
+__device__ __forceinline__ uint32_t block_reduce_u32(uint32_t v, uint32_t* red, int tid, bool want_max, bool want_min) {
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t w = want_max ? wave_max_u32(v) : (want_min ? wave_min_u32(v) : wave_total_u32(v));
+  __syncthreads();
+  if (lane == 0) red[wave] = w;
+  __syncthreads();
+  uint32_t r = red[0];
+  for (int k = 1; k < kMergeWaves; ++k) {
+    const uint32_t x = red[k];
+    r = want_max ? (x > r ? x : r) : (want_min ? (x < r ? x : r) : r + x);
+  }
+  return r;
+}
+
+template <bool TREE>
+__global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  __shared__ uint32_t red[kMergeWaves];
+  __shared__ int32_t redi[kMergeWaves];
+  __shared__ uint32_t wsl[2 * kWsTreeMin];                       // short workspaces: starts, ends
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sidx = blockIdx.x, a = blockIdx.y;
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int4 pre = A.st[sa];
+  const int n = pre.x;
+  if (tid == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
+  if (pre.z < 0 || n <= 1024 || n > A.lds_cap) return;          // not handed over by k_place / short list: k_sampler does it
+  uint2* seg = reinterpret_cast<uint2*>(lds);                     // lds_cap entries
+  uint32_t* hist = lds + 2 * (size_t)A.lds_cap;                  // big_buckets + 1
+  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const int nws = Up->n_ws;
+  const uint2* __restrict__ ws = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
+  if (nws <= kWsTreeMin)
+    for (int k = tid; k < nws; k += kMergeThreads) { const uint2 w = ws[k]; wsl[k] = w.x; wsl[kWsTreeMin + k] = w.y; }
+
+  // ---- counting sort by position bucket: src = slab, dst = LDS
+  constexpr int kB = 4;
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  for (int base = 0; base < n; base += kB * kMergeThreads) {
+    uint32_t x[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; x[q] = i < n ? out[i].x : 0u; }
+#pragma unroll
+    for (int q = 0; q < kB; ++q)
+      if (base + q * kMergeThreads + tid < n) { lo = x[q] < lo ? x[q] : lo; hi = x[q] > hi ? x[q] : hi; }
+  }
+  lo = block_reduce_u32(lo, red, tid, false, true);
+  hi = block_reduce_u32(hi, red, tid, true, false);
+  const uint32_t span = hi - lo;
+  if (span == 0) return;
+  int nb = 1024;
+  while (nb < n && nb < A.big_buckets) nb <<= 1;
+  const bool direct = span < (uint32_t)nb;
+  const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)nb << 32) / ((uint64_t)span + 1u));
+  for (int i = tid; i <= nb; i += kMergeThreads) hist[i] = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += kB * kMergeThreads) {
+    uint32_t x[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; x[q] = i < n ? out[i].x : 0u; }
+#pragma unroll
+    for (int q = 0; q < kB; ++q)
+      if (base + q * kMergeThreads + tid < n) { const uint32_t d = x[q] - lo; atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u); }
+  }
+  __syncthreads();
+  {
+    // exclusive prefix over the buckets: thread owns nb/256 consecutive ones
+    const int per = nb / kMergeThreads;
+    uint32_t sum = 0, maxc = 0;
+    for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
+    const uint32_t incl = wave_incl_sum_u32(sum, lane);
+    maxc = block_reduce_u32(maxc, red, tid, true, false);         // (two barriers: red is free again below)
+    if (maxc > 48u) return;                                       // clustered: not worth sorting buckets thread by thread
+    __syncthreads();                                              // everybody has read red
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int k = 0; k < wave; ++k) run += red[k];
+    for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
+  }
+  __syncthreads();
+  for (int base = 0; base < n; base += kB * kMergeThreads) {
+    uint2 v[kB];
+#pragma unroll
+    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < n ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int q = 0; q < kB; ++q)
+      if (base + q * kMergeThreads + tid < n) {
+        const uint32_t d = v[q].x - lo;
+        seg[atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u)] = v[q];
+      }
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += kMergeThreads) {                // hist[b] is now the END of bucket b
+    const int e = (int)hist[b], s0 = b ? (int)hist[b - 1] : 0;
+    for (int i = s0 + 1; i < e; ++i) {
+      const uint2 v = seg[i];
+      int j = i - 1;
+      while (j >= s0 && seg[j].x > v.x) { seg[j + 1] = seg[j]; --j; }
+      seg[j + 1] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- merge(0) (gat/SegmentList.pyx:756-816): head = first non-empty, or int32(start) > running max end
+  int count = 0;
+  int32_t carry = INT32_MIN;
+  bool any = false;
+  for (int base = 0; base < n; base += kMergeThreads) {
+    const int i = base + tid;
+    uint32_t s0 = 0, e0 = 0;
+    bool valid = false;
+    if (i < n) { const uint2 v = seg[i]; s0 = v.x; e0 = v.y; valid = s0 != e0; }
+    const int32_t m = wave_incl_max_i32(valid ? (int32_t)e0 : INT32_MIN, lane);
+    const uint64_t vb = __ballot(valid);
+    if (lane == 63) { redi[wave] = m; }
+    if (lane == 0) red[wave] = vb != 0 ? 1u : 0u;
+    __syncthreads();
+    int32_t before = carry;                                       // running max of everything before this wave
+    bool any_before = any;
+    for (int k = 0; k < wave; ++k) { const int32_t x = redi[k]; before = x > before ? x : before; any_before = any_before || red[k] != 0; }
+    int32_t total = carry;
+    bool any_now = any;
+    for (int k = 0; k < kMergeWaves; ++k) { const int32_t x = redi[k]; total = x > total ? x : total; any_now = any_now || red[k] != 0; }
+    const int32_t incl = m > before ? m : before;
+    const int32_t excl = __builtin_amdgcn_update_dpp(before, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps `before`
+    const bool prev_valid = any_before || (vb & lanemask_lt(lane)) != 0;
+    const bool head = valid && (!prev_valid || (int32_t)s0 > excl);
+    const uint64_t hb = __ballot(head);
+    __syncthreads();                                              // red / redi are reused for the head counts
+    if (lane == 0) red[wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    int pos = count + __popcll(hb & lanemask_lt(lane));
+    int heads = 0;
+    for (int k = 0; k < kMergeWaves; ++k) { if (k < wave) pos += (int)red[k]; heads += (int)red[k]; }
+    if (head) {
+      out[pos].x = s0;
+      if (pos > 0) out[pos - 1].y = (uint32_t)excl;
+    }
+    count += heads;
+    carry = total;
+    any = any_now;
+    __syncthreads();
+  }
+  if (count > 0 && tid == 0) out[count - 1].y = (uint32_t)carry;
+  __syncthreads();                                                // the merged list in the slab, visible to the block
+
+  // ---- coverage of the merged list inside the workspace, and its total length
+  uint32_t cov = 0, tot = 0;
+  if (nws <= kWsTreeMin) {
+    for (int i = tid; i < count; i += kMergeThreads) {
+      const uint2 v = out[i];
+      tot += v.y - v.x;
+      for (int k = 0; k < nws; ++k) {
+        const uint32_t l2 = v.x > wsl[k] ? v.x : wsl[k], h2 = v.y < wsl[kWsTreeMin + k] ? v.y : wsl[kWsTreeMin + k];
+        cov += h2 > l2 ? h2 - l2 : 0u;
+      }
+    }
+  } else if constexpr (TREE) {
+    const uint32_t* __restrict__ tree_start = A.ws_tree + Up->tree_start_off;
+    const WsTreeGeom G = ws_tree_geom(nws);
+    for (int i = tid; i < count; i += kMergeThreads) {
+      const uint2 v = out[i];
+      tot += v.y - v.x;
+      cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y);
+    }
+  }
+  cov = block_reduce_u32(cov, red, tid, false, false);
+  tot = block_reduce_u32(tot, red, tid, false, false);
+  if (tid == 0) A.st2[sa] = make_int4(count, (int)cov, (int)tot, 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_sampler: one wave per (sample, unit).  Stand-alone it runs the whole of
 // SamplerAnnotator.sample; behind k_place it resumes at the first consolidation with the
 // placed segments, `remaining`, the pending length and the position in the stream handed over.
@@ -584,6 +773,18 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
     nuns = 0; status = 0; placed = 0;
     if (resume) {
       nS = pre.x;
+      int4 pre2 = make_int4(0, 0, 0, 0);
+      if (BIG && !HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[(int64_t)sidx * A.n_units + a];
+      if (pre2.w == 1) {
+        // k_merge_big has done the first consolidation: the slab holds the merged list; its coverage and total
+        // length come with it, and the pending length below makes the loop take them up at once
+        nU = pre2.x;
+        nS = 0;
+        cov_known = (uint32_t)pre2.y;
+        total_known = (uint32_t)pre2.z;
+        cov_valid = true;
+        for (int i = lane; i < nU; i += kWave) seg[i] = out[i];
+      } else
       // (a list the counting sort will take straight from the slab need not be copied first)
       if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0))
         for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
@@ -594,7 +795,7 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
       rng.pre_j = rng.ndraws;
       rng.pre_base = rng.pre_j - (uint32_t)kWave;     // forces the first prefetch
       rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
-      placed = (uint32_t)nS;
+      placed = (uint32_t)pre.x;
       wave_sync();
     } else {
       rng_seed(rng, seed, lane);

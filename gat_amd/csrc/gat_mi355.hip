@@ -202,6 +202,7 @@ struct gat_problem {
   int64_t rng_rows_total = 0;            // sum of h_rng_rows
   DevBuf<int32_t> d_rng_rows;
   DevBuf<int4> d_st;
+  DevBuf<int4> d_st2;                    // k_merge_big -> k_sampler hand-off (first consolidation of the long lists)
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
@@ -610,6 +611,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
+    HIPCHK(ctx, P->d_st2.alloc(ns));
   }
   P->batch = b;
   return GAT_OK;
@@ -765,16 +767,41 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.big_buckets = 0;
       uint32_t max_work = 0;
       for (int32_t u : P->h_order) max_work = std::max(max_work, P->h_units[u].hist_total);
-      if (!huge && max_work + max_work / 8 > 1024) {   // lists beyond the register sorts: counting-sort scratch behind the segment buffer, if it fits
+      A.st2 = nullptr;
+      bool long_lists = false;                  // k_sampler<BIG>: the code for lists beyond the bucket sorts
+      if (!huge && max_work + max_work / 8 > 1024) {
+        long_lists = true;
         int nbk = 1024;
         while (nbk < P->max_unit_cap && nbk < 8192) nbk <<= 1;
-        while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;
-        if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
+        // the first consolidation of the long lists by whole workgroups (k_merge_big): its LDS holds one list and the
+        // counting sort's histogram; launched over the long units, which come first in the launch order
+        const size_t lds_m = (size_t)2 * P->max_unit_cap * 4 + (size_t)(nbk + 1) * 4;
+        unsigned n_long = 0;
+        for (int32_t u : P->h_order) { const uint32_t w = P->h_units[u].hist_total; if (w + w / 8 > 1024) ++n_long; else break; }
+        if (P->sampler_mode && P->sampler != GAT_SAMPLER_SEGMENTS && (int64_t)lds_m + 1024 <= ctx->max_lds && n_long > 0 &&
+            !getenv("GAT_NO_MERGE_BIG")) {
+          gat::SamplerArgs M = A;
+          M.st2 = P->d_st2.p;
+          M.big_buckets = nbk;
+          const bool tree_m = P->max_nws > gat::kWsTreeMin;
+          const void* km = tree_m ? (const void*)gat::k_merge_big<true> : (const void*)gat::k_merge_big<false>;
+          HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+          const dim3 gm((unsigned)nb, n_long);
+          if (tree_m) hipLaunchKernelGGL(gat::k_merge_big<true>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
+          else hipLaunchKernelGGL(gat::k_merge_big<false>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
+          HIPCHK(ctx, hipGetLastError());
+          A.st2 = P->d_st2.p;                    // (k_sampler reads it for those units only: see n_long below)
+          A.n_long = (int32_t)n_long;
+        } else {
+          // no workgroup pass: the wave's own counting sort, scratch behind the segment buffer if it fits
+          while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;
+          if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
+        }
       }
       // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       const bool tree = P->max_nws > gat::kWsTreeMin;
       const int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
-                        : huge ? (tree ? 7 : 6) : (A.big_buckets > 0 ? 2 : 0) + (tree ? 1 : 0);
+                        : huge ? (tree ? 7 : 6) : (long_lists ? 2 : 0) + (tree ? 1 : 0);
       const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false, false>
                      : variant == 1 ? (const void*)gat::k_sampler<0, false, true, false>
                      : variant == 2 ? (const void*)gat::k_sampler<0, true, false, false>
