@@ -1,0 +1,28 @@
+"""one-off sweep of the fuzz generator of tests/test_hip_parity.py over many seeds (GPU vs oracle, bit-exact);
+usage: tools/fuzz_sweep.py first_seed n_seeds"""
+import importlib.util, os, sys, time
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, root)
+spec = importlib.util.spec_from_file_location("thp", os.path.join(root, "tests", "test_hip_parity.py"))
+m = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(m)
+from gat_amd import _lib
+
+
+class MP(object):                      # minimal monkeypatch stand-in
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+
+ctx = _lib.Context(0)
+first, n = int(sys.argv[1]), int(sys.argv[2])
+bad = 0
+t0 = time.time()
+for seed in range(first, first + n):
+    os.environ.pop("GAT_TEST_HUGE", None)
+    try:
+        m.test_fuzz_shapes_vs_oracle.__wrapped__(ctx, seed, MP()) if hasattr(m.test_fuzz_shapes_vs_oracle, "__wrapped__") else m.test_fuzz_shapes_vs_oracle(ctx, seed, MP())
+    except Exception as e:             # noqa: BLE001
+        bad += 1
+        print("seed %d: %s: %s" % (seed, type(e).__name__, str(e)[:300]))
+print("%d seeds, %d failures, %.1f s" % (n, bad, time.time() - t0))
