@@ -603,6 +603,9 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
   HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
   HIPCHK(ctx, P->d_ws_stat.alloc((size_t)(b * std::max(1, P->n_units)) * 4));
+  HIPCHK(ctx, hipMemsetAsync(P->d_unit_n.p, 0, (size_t)(b * std::max(1, P->n_units)) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(b * std::max(1, P->n_contigs)) * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(P->d_ws_stat.p, 0, (size_t)(b * std::max(1, P->n_units)) * 16, ctx->stream));
   if (P->sampler_mode) {
     const int64_t nsb = (b + 63) / 64;
     P->h_rng_off.assign(P->h_order.size() + 1, 0);
@@ -720,11 +723,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
     if (P->batch < nb) return set_err(ctx, GAT_ERR_MEMORY, "internal: batch %lld > scratch %lld", (long long)nb, (long long)P->batch);
-    HIPCHK(ctx, hipMemsetAsync(P->d_unit_n.p, 0, (size_t)(nb * std::max(1, P->n_units)) * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(nb * std::max(1, P->n_contigs)) * 4, ctx->stream));
+    // (unit_n, contig_n and ws_stat are zeroed once when allocated: the kernels rewrite every entry of the active units
+    //  in every batch and never touch the others)
     HIPCHK(ctx, hipMemsetAsync(P->d_flags.p, 0, 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 8 * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(P->d_ws_stat.p, 0, (size_t)(nb * std::max(1, P->n_units)) * 16, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
