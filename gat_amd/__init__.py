@@ -204,6 +204,15 @@ def buildParser(usage=None):
     g.add_option("--output-tables-pattern", dest="output_tables_pattern", type="string")
     g.add_option("--output-counts-pattern", dest="output_counts_pattern", type="string")
     g.add_option("--output-samples-pattern", dest="output_samples_pattern", type="string")
+    g.add_option("--output-stats", dest="output_stats", type="choice", action="append",
+                 choices=("all", "annotations", "segments", "workspaces", "isochores", "overlap"),
+                 help="write summary statistics of the collections at the stages of the input pipeline")
+    g.add_option("--output-bed", dest="output_bed", type="choice", action="append",
+                 choices=("all", "annotations", "segments", "workspaces", "isochores"),
+                 help="write the collections after the isochores were applied as bed files")
+    g.add_option("-P", "--output-filename-pattern", dest="output_filename_pattern", type="string",
+                 help="pattern of the side files, %s is replaced by the section [default=%default]")
+    g.add_option("--force", dest="output_force", action="store_true", help="overwrite existing side files")
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Sampling algorithm options")
     g.add_option("-c", "--counter", dest="counters", type="choice", action="append", choices=tuple(COUNTERS.keys()))
@@ -239,7 +248,8 @@ def buildParser(usage=None):
     g.add_option("-S", "--stdout", dest="stdout", type="string", metavar="FILE")
     g.add_option("-L", "--log", dest="stdlog", type="string", metavar="FILE")
     parser.add_option_group(g)
-    parser.set_defaults(input_filename_results=None, input_filename_descriptions=None, annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
+    parser.set_defaults(output_stats=[], output_bed=[], output_filename_pattern="%s", output_force=False,
+                        input_filename_results=None, input_filename_descriptions=None, annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
                         counters=[], enable_split_tracks=False, ignore_segment_tracks=True, isochore_files=[],
                         nbuckets=100000, num_samples=1000, num_threads=0, output_counts_pattern=None,
                         output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",

@@ -482,6 +482,30 @@ class IntervalCollection(object):
         for vv in self.intervals.values():
             vv.fromIsochores()
 
+    def outputStats(self, outfile):
+        """segments and bases per (track, contig) and per track (gat/Engine.pyx:2959-2981)."""
+        outfile.write("section\ttrack\tcontig\tnsegments\tlength\n")
+        for track, vv in self.intervals.items():
+            total_length, total_segments = 0, 0
+            for contig, segmentlist in vv.items():
+                segments, length = len(segmentlist), segmentlist.sum()
+                outfile.write("\t".join((str(self.name), track, contig, "%i" % segments, "%i" % length)) + "\n")
+                total_length = (total_length + length) & 0xFFFFFFFF          # cdef Position accumulators
+                total_segments = (total_segments + segments) & 0xFFFFFFFF
+            outfile.write("\t".join((str(self.name), track, "total", "%i" % total_segments, "%i" % total_length)) + "\n")
+
+    def outputOverlapStats(self, outfile, other):
+        """overlap of every list with `other` (an IntervalDictionary) (gat/Engine.pyx:3152-3165)."""
+        outfile.write("section\ttrack\tcontig\toverlap\tlength\tdensity\n")
+        for track, vv in self.intervals.items():
+            for contig, segmentlist in vv.items():
+                length = segmentlist.sum()
+                if length == 0:
+                    continue
+                overlap = segmentlist.overlapWithSegments(other[contig])
+                outfile.write("\t".join((str(self.name), track, contig, "%i" % overlap, "%i" % length,
+                                         "%f" % (float(overlap) / length))) + "\n")
+
     def save(self, outfile, prefix="", **kwargs):
         for track, vv in self.intervals.items():
             outfile.write("track name=%s%s %s\n" % (prefix, track, " ".join("%s=%s" % kv for kv in kwargs.items())))

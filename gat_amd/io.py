@@ -21,6 +21,35 @@ def openFile(filename, mode="r"):
     return open(filename, mode)
 
 
+def openOutputFile(section, options, mode="w"):
+    """the side files of --output-stats / --output-bed: `section` substituted into --output-filename-pattern
+    (gat/Experiment.py:554-582); "-" is the main output."""
+    fn = re.sub("%s", section, getattr(options, "output_filename_pattern", None) or "%s")
+    if fn == "-":
+        return options.stdout
+    if not getattr(options, "output_force", False) and os.path.exists(fn):
+        raise OSError("file %s already exists, use --force to overwrite existing files." % fn)
+    return openFile(fn, mode)
+
+
+def _wanted(section, selected):
+    return section in selected or "all" in selected or any(re.search(x, section) for x in selected)
+
+
+def dumpStats(coll, section, options):
+    """gat/IO.py:20-25."""
+    if _wanted(section, getattr(options, "output_stats", None) or []):
+        with openOutputFile(section, options) as f:
+            coll.outputStats(f)
+
+
+def dumpBed(coll, section, options):
+    """gat/IO.py:28-32."""
+    if _wanted(section, getattr(options, "output_bed", None) or []):
+        with openOutputFile(section + ".bed", options) as f:
+            coll.save(f)
+
+
 def readFromBed(filenames, allow_multiple=False, ignore_tracks=False):
     """gat/Engine.pyx:2480-2556: track -> IntervalDictionary.  Track name = `track name=...` line,
     else column 4, else the file's base name; ignore_tracks puts everything into 'merged'."""
@@ -115,12 +144,15 @@ def buildSegments(options):
     annotations.normalize()
     workspaces = readSegmentList("workspaces", options.workspace_files, options.enable_split_tracks)
     workspaces.normalize()
+    dumpStats(workspaces, "stats_workspaces_input", options)
     workspaces.collapse()
+    dumpStats(workspaces, "stats_workspaces_collapsed", options)
     workspaces.restrict("collapsed")
     isochores = None
     if options.isochore_files:
         isochores = engine.IntervalCollection(name="isochores")
         isochores.intervals = readFromBed(expandGlobs(options.isochore_files))
+        dumpStats(isochores, "stats_isochores_raw", options)
         isochores.sort()
         isochores.check()
         isochores.normalize()
@@ -141,12 +173,20 @@ def applyIsochores(segments, annotations, workspaces, options, isochores=None, t
             raise ValueError("isochores and annotations do not overlap")
         if segments.sum() == 0:
             raise ValueError("isochores and segments do not overlap")
+        dumpStats(workspaces, "stats_workspaces_isochores", options)
+        dumpStats(annotations, "stats_annotations_isochores", options)
+        dumpStats(segments, "stats_segments_isochores", options)
+        dumpBed(workspaces, "workspaces_isochores", options)
+        dumpBed(annotations, "annotations_isochores", options)
+        dumpBed(segments, "segments_isochores", options)
     else:
         if options.truncate_segments_to_workspace:
             segments.intersect(workspaces["collapsed"])
         else:
             segments.filter(workspaces["collapsed"])
         annotations.intersect(workspaces["collapsed"])
+        dumpStats(annotations, "stats_annotations_truncated", options)
+        dumpStats(segments, "stats_segments_truncated", options)
     workspace = workspaces["collapsed"]
     if restrict_workspace:
         for _ in (segments, annotations):
@@ -156,11 +196,18 @@ def applyIsochores(segments, annotations, workspaces, options, isochores=None, t
                 segments.merge()
                 workspace.filter(segments["merged"])
                 del segments["merged"]
+        dumpStats(workspaces, "stats_workspaces_restricted", options)
     if truncate_workspace_to_annotations:
         annotations.merge()
         annotations["merged"].normalize()
         workspace.intersect(annotations["merged"])
         del annotations["merged"]
+        dumpStats(workspaces, "stats_workspaces_truncated", options)
+    selected = getattr(options, "output_stats", None) or []
+    if "overlap" in selected or "all" in selected:
+        for track in segments.tracks:
+            with openOutputFile("overlap_%s" % track, options) as f:
+                workspaces.outputOverlapStats(f, segments[track])
     return workspace
 
 

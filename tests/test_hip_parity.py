@@ -558,3 +558,19 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["allgather"]["bytes_per_rank"] == 2000 * 8
     assert "cpu_baseline" not in out                      # reported at N = 1 only
+
+
+def test_cli_overlap_stats_match_reference(ctx, tmp_path):
+    """--output-stats=overlap (gat/IO.py:283-289, gat/Engine.pyx:3152-3165; the overlaps are counted on the device)
+    against the file the reference wrote for the same inputs."""
+    import gat_amd as gat
+    from gat_amd import IO
+    cli = os.path.join(G, "cli")
+    opts, _ = gat.buildParser().parse_args(["--segments=%s" % os.path.join(cli, "segments.bed"),
+                                            "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+                                            "--workspace=%s" % os.path.join(cli, "workspace.bed"),
+                                            "--output-stats=overlap", "-P", str(tmp_path / "%s")])
+    segments, annotations, workspaces, isochores = IO.buildSegments(opts)
+    IO.applyIsochores(segments, annotations, workspaces, opts, isochores)
+    assert open(str(tmp_path / "overlap_merged")).read() == \
+        open(os.path.join(cli, "aux", "stats", "overlap_merged_no_isochores")).read()

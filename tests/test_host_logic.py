@@ -304,3 +304,29 @@ def test_cli_results_file_round_trip(tmp_path):
         got = [l for l in open(out) if not l.startswith("#")]
         want = open(os.path.join(cli, "aux", "expected_%s.tsv" % name)).readlines()
         assert got == want, name
+
+
+def test_cli_side_files_match_reference(tmp_path):
+    """--output-stats / --output-bed (-P pattern): the collection summaries and bed dumps of the input pipeline
+    (gat/IO.py:20-32, :150-279; gat/Engine.pyx:2959-2981, :3152-3165) against the files the reference wrote for the
+    same inputs (tests/golden/cli/aux/stats/, from `gat-run.py --isochores=... --output-stats=all --output-bed=all`
+    ; the overlap summary is counted on the device: tests/test_hip_parity.py).  Host only: no sampling."""
+    import os
+    import gat_amd as gat
+    from gat_amd import IO
+    cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli")
+    want_dir = os.path.join(cli, "aux", "stats")
+    base = ["--segments=%s" % os.path.join(cli, "segments.bed"), "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+            "--workspace=%s" % os.path.join(cli, "workspace.bed")]
+    sel = ["--output-stats=annotations", "--output-stats=segments", "--output-stats=workspaces", "--output-stats=isochores",
+           "--output-bed=all", "-P", str(tmp_path / "%s")]
+    opts, _ = gat.buildParser().parse_args(base + ["--isochores=%s" % os.path.join(cli, "isochores.bed")] + sel)
+    segments, annotations, workspaces, isochores = IO.buildSegments(opts)
+    IO.applyIsochores(segments, annotations, workspaces, opts, isochores)
+    names = ["stats_annotations_isochores", "stats_isochores_raw", "stats_segments_isochores", "stats_workspaces_collapsed",
+             "stats_workspaces_input", "stats_workspaces_isochores", "annotations_isochores.bed", "segments_isochores.bed",
+             "workspaces_isochores.bed"]
+    for n in names:
+        assert open(str(tmp_path / n)).read() == open(os.path.join(want_dir, n)).read(), n
+    with pytest.raises(OSError):                          # side files are not overwritten without --force
+        segments, annotations, workspaces, isochores = IO.buildSegments(opts)
