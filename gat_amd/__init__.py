@@ -71,13 +71,17 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
         begin, end = distributed.shard_range(num_samples, rank, world)
         local = P.sample_and_count(names, seed, begin, end)
         if samples_outfile is not None:
-            seg, off = P.sample(seed, begin, end)
-            C = flat["n_contigs"]
+            # --output-samples-pattern (gat/__init__.py:515-559): per sample a track line, then the list the sampler
+            # returned for every non-empty isochore unit under the unit's key
+            seg, off = P.sample(seed, begin, end, unit_level=True)
+            U = flat["n_units"]
             for i in range(end - begin):
                 samples_outfile.write("track name=%i\n" % (begin + i))
-                for c in range(C):
-                    for s, e in seg[off[i * C + c]:off[i * C + c + 1]].tolist():
-                        samples_outfile.write("%s\t%i\t%i\n" % (flat["contig_names"][c], s, e))
+                for u in range(U):
+                    if flat["unit_contig"][u] < 0:
+                        continue
+                    for s, e in seg[off[i * U + u]:off[i * U + u + 1]].tolist():
+                        samples_outfile.write("%s\t%i\t%i\n" % (flat["unit_names"][u], s, e))
     finally:
         P.close()
     if world > 1:

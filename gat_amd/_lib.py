@@ -26,7 +26,7 @@ COUNTER_IDS = {
 SYMBOLS = [
     "gat_ctx_create", "gat_ctx_destroy", "gat_last_error", "gat_version", "gat_ctx_synchronize",
     "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
-    "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample",
+    "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_problem_info",
 ]
 
@@ -114,6 +114,8 @@ def lib():
     L.gat_sample_and_count.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp, C.POINTER(Stats)]
     L.gat_sample.restype = C.c_int
     L.gat_sample.argtypes = [vp, vp, u32, i64, i64, vp, i64, vp, C.POINTER(Stats)]
+    L.gat_sample_units.restype = C.c_int
+    L.gat_sample_units.argtypes = [vp, vp, u32, i64, i64, vp, i64, vp, C.POINTER(Stats)]
     L.gat_count_lists.restype = C.c_int
     L.gat_count_lists.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, i32, vp, i32, vp]
     L.gat_problem_info.restype = C.c_int
@@ -262,16 +264,18 @@ class Problem(object):
         return [host[k].view(np.float64).copy() if c == "nucleotide-density" else host[k].copy()
                 for k, c in enumerate(counters)]
 
-    def sample(self, seed, sample_begin, sample_end):
-        """sampled contig-level segment lists: (segments SEG array, offsets[(n_samples*n_contigs)+1])."""
+    def sample(self, seed, sample_begin, sample_end, unit_level=False):
+        """sampled contig-level segment lists: (segments SEG array, offsets[(n_samples*n_contigs)+1]); with
+        unit_level the lists of every (sample, unit) as the sampler returned them (offsets per n_units)."""
         ns = sample_end - sample_begin
-        off = np.zeros(ns * self.n_contigs + 1, dtype=np.int64)
+        off = np.zeros(ns * (self.n_units if unit_level else self.n_contigs) + 1, dtype=np.int64)
         cap = max(1024, self.info()["slab_segments_per_sample"] * ns // 2)
         st = Stats()
+        fn = lib().gat_sample_units if unit_level else lib().gat_sample
         while True:
             out = np.empty(cap, dtype=SEG)
-            rc = lib().gat_sample(self.ctx._h, self._h, int(seed) & 0xFFFFFFFF, int(sample_begin), int(sample_end),
-                                  _p(out), cap, _p(off), C.byref(st))
+            rc = fn(self.ctx._h, self._h, int(seed) & 0xFFFFFFFF, int(sample_begin), int(sample_end),
+                    _p(out), cap, _p(off), C.byref(st))
             if rc == -3 and off[-1] > cap:
                 cap = int(off[-1])
                 continue

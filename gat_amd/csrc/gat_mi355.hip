@@ -949,15 +949,30 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   return GAT_OK;
 }
 
+// gat_sample / gat_sample_units: the lists of every (sample, contig) after fromIsochores, or of every (sample, unit)
+// as the sampler returned them
+static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sample_begin, int64_t sample_end,
+                        gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats, bool unit_level);
+
 extern "C" int gat_sample(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sample_begin, int64_t sample_end,
                           gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats) {
+  return sample_lists(ctx, P, seed, sample_begin, sample_end, out_host, cap, off_host, stats, false);
+}
+
+extern "C" int gat_sample_units(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sample_begin, int64_t sample_end,
+                                gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats) {
+  return sample_lists(ctx, P, seed, sample_begin, sample_end, out_host, cap, off_host, stats, true);
+}
+
+static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sample_begin, int64_t sample_end,
+                        gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats, bool unit_level) {
   if (!ctx || !P || !off_host) return set_err(ctx, GAT_ERR_ARG, "gat_sample: NULL argument");
   if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   gat_stats local;
   memset(&local, 0, sizeof(local));
   const int64_t S = sample_end - sample_begin;
-  const int C = P->n_contigs;
+  const int C = unit_level ? P->n_units : P->n_contigs;
   int rc;
   int64_t done = 0, total = 0;
   bool overflow = false;
@@ -968,9 +983,10 @@ extern "C" int gat_sample(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t s
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
     if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true))) return rc;
-    const uint2* src = P->merge_contigs ? P->d_cslab.p : P->d_slab.p;
-    const int32_t* nsrc = P->merge_contigs ? P->d_contig_n.p : P->d_unit_n.p;
-    const int nstride = P->merge_contigs ? P->n_contigs : P->n_units;
+    const bool from_contigs = P->merge_contigs && !unit_level;
+    const uint2* src = from_contigs ? P->d_cslab.p : P->d_slab.p;
+    const int32_t* nsrc = from_contigs ? P->d_contig_n.p : P->d_unit_n.p;
+    const int nstride = from_contigs ? P->n_contigs : P->n_units;
     h_slab.resize((size_t)(nb * P->slab_stride));
     h_n.resize((size_t)(nb * std::max(1, nstride)));
     HIPCHK(ctx, hipMemcpyAsync(h_slab.data(), src, h_slab.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
@@ -978,9 +994,11 @@ extern "C" int gat_sample(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t s
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < nb; ++i) {
       for (int c = 0; c < C; ++c) {
-        const int32_t n = h_n[(size_t)(i * nstride + P->h_count_n_index[c])];
+        // (units that computeSample skips keep n == 0: their entries are never written and were zeroed at allocation)
+        const int32_t n = unit_level ? h_n[(size_t)(i * nstride + c)] : h_n[(size_t)(i * nstride + P->h_count_n_index[c])];
+        const int64_t soff = unit_level ? (int64_t)P->h_units[(size_t)c].slab_off : (int64_t)P->h_count_c_off[c];
         if (!overflow && out_host && total + n <= cap)
-          memcpy(out_host + total, h_slab.data() + i * P->slab_stride + P->h_count_c_off[c], (size_t)n * sizeof(uint2));
+          memcpy(out_host + total, h_slab.data() + i * P->slab_stride + soff, (size_t)n * sizeof(uint2));
         else if (n > 0) overflow = true;
         total += n;
         off_host[(done + i) * C + c + 1] = total;

@@ -149,6 +149,13 @@ int gat_sample(gat_ctx* ctx, gat_problem* p, uint32_t seed,
                int64_t sample_begin, int64_t sample_end,
                gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats);
 
+/* The same at unit level: what sampler.sample(segs[isochore], workspace[isochore]) returned for every (sample, unit)
+ * before fromIsochores (gat/__init__.py:541; the lists --output-samples-pattern writes, :549-559).  off_host has
+ * (sample_end-sample_begin)*n_units+1 entries; units computeSample skips are empty. */
+int gat_sample_units(gat_ctx* ctx, gat_problem* p, uint32_t seed,
+                     int64_t sample_begin, int64_t sample_end,
+                     gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats);
+
 /* Counters only, on caller-provided lists: replaces Engine.computeCounts
  * (gat/Engine.pyx:2164-2204; observed counts) and counter(segments, annotations, workspace)
  * (gat/Engine.pyx:1417-1472).  lists: n_lists*n_groups segment lists (HOST, CSR via list_off),

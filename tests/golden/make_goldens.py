@@ -648,6 +648,28 @@ def g5_cli():
             with open(out, "w") as f:
                 f.writelines(lines)
             print("G5 cli %s: %d rows" % (name, len(lines) - 1))
+        # --output-counts-pattern / --output-samples-pattern / --output-tables-pattern (gat/__init__.py:1072-1086,
+        # :515-559; gat/IO.py:497-503): two counters -> one table file per counter, the count matrix per counter, the
+        # sampled lists per segment track at isochore level
+        pat = os.path.join(cli_dir, "aux", "patterns")
+        os.makedirs(pat, exist_ok=True)
+        argv = ["gat-run.py", "--segments=%s" % os.path.join(cli_dir, "segments.bed"),
+                "--annotations=%s" % os.path.join(cli_dir, "annotations.bed"),
+                "--workspace=%s" % os.path.join(cli_dir, "workspace.bed"),
+                "--isochores=%s" % os.path.join(cli_dir, "isochores.bed"), "--with-segment-tracks",
+                "--num-samples=5", "--random-seed=21", "--counter=nucleotide-overlap", "--counter=segment-overlap",
+                "--output-tables-pattern=%s" % os.path.join(pat, "table_%s.tsv"),
+                "--output-counts-pattern=%s" % os.path.join(pat, "counts_%s.tsv"),
+                "--output-samples-pattern=%s" % os.path.join(pat, "samples_%s.bed"),
+                "--stdout=%s" % os.path.join(pat, "stdout.txt"), "--log=%s" % os.path.join(cli_dir, "ref.log")]
+        state.update(track=None, base=21, n_units=0, sampler=None, num_samples=5)
+        mod.main(argv)
+        for fn in os.listdir(pat):
+            if fn.startswith("table_") or fn == "stdout.txt":
+                lines = [l for l in open(os.path.join(pat, fn)) if not l.startswith("#")]
+                with open(os.path.join(pat, fn), "w") as f:
+                    f.writelines(lines)
+        print("G5 patterns: %s" % sorted(os.listdir(pat)))
         # results-table round trip: --input-results-file re-computes the fdr of a previous table; --descriptions
         # appends columns (scripts/gat-run.py:287-291, gat/IO.py:296-328)
         aux = os.path.join(cli_dir, "aux")

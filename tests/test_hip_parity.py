@@ -574,3 +574,23 @@ def test_cli_overlap_stats_match_reference(ctx, tmp_path):
     IO.applyIsochores(segments, annotations, workspaces, opts, isochores)
     assert open(str(tmp_path / "overlap_merged")).read() == \
         open(os.path.join(cli, "aux", "stats", "overlap_merged_no_isochores")).read()
+
+
+def test_cli_pattern_outputs_match_reference(ctx, tmp_path):
+    """--output-tables-pattern (one table per counter), --output-counts-pattern (the count matrix) and
+    --output-samples-pattern (the sampled lists per segment track, at isochore level) byte for byte against the files
+    the reference's gat-run.py wrote for the same inputs and seed (tests/golden/cli/aux/patterns/, make_goldens.py g5)."""
+    cli = os.path.join(G, "cli")
+    want = os.path.join(cli, "aux", "patterns")
+    args = ["--segments=%s" % os.path.join(cli, "segments.bed"), "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+            "--workspace=%s" % os.path.join(cli, "workspace.bed"), "--isochores=%s" % os.path.join(cli, "isochores.bed"),
+            "--with-segment-tracks", "--num-samples=5", "--random-seed=21", "--counter=nucleotide-overlap",
+            "--counter=segment-overlap", "--output-tables-pattern=%s" % str(tmp_path / "table_%s.tsv"),
+            "--output-counts-pattern=%s" % str(tmp_path / "counts_%s.tsv"),
+            "--output-samples-pattern=%s" % str(tmp_path / "samples_%s.bed")]
+    _run_cli(tmp_path, "stdout", args)
+    for fn in sorted(os.listdir(want)):
+        if fn == "stdout.txt":
+            continue
+        got = [l for l in open(str(tmp_path / fn)) if not l.startswith("#")]
+        assert got == open(os.path.join(want, fn)).readlines(), fn
