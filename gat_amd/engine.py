@@ -688,24 +688,26 @@ class ConditionalWorkspaceSegmentCentered(ConditionalWorkspaceCentered):
 
 
 def computeCounts(counter, aggregator, segments, annotations, workspace, workspace_generator, append=False):
-    """observed counts for all track x annotation pairs (gat/Engine.pyx:2164-2204): one device
-    launch per segment track over all (annotation, isochore) lists."""
+    """observed counts for all track x annotation pairs (gat/Engine.pyx:2164-2204): ONE device call over all
+    (segment track, isochore) x (annotation, isochore) lists."""
     counts = collections.defaultdict(lambda: collections.defaultdict(float))
+    if aggregator is not sum:
+        raise NotImplementedError("only aggregator=sum is supported")
     isochores = list(workspace.keys())
     ctx = get_context()
     tracks = list(annotations.tracks)
-    for track in segments.tracks:
-        segs = segments[track]
-        lists = [segs[i].asArray() for i in isochores]
-        annos = [annotations[a][i].asArray() for a in tracks for i in isochores]
-        lcat, loff = _problem._cat(lists)
-        acat, aoff = _problem._cat(annos)
-        ws_nseg = [len(workspace[i]) for i in isochores]
-        if aggregator is not sum:
-            raise NotImplementedError("only aggregator=sum is supported")
-        r = ctx.count_lists([counter.name], lcat, loff, 1, acat, aoff, len(tracks), ws_nseg, len(isochores))[0]
+    seg_tracks = list(segments.tracks)
+    if not seg_tracks or not tracks:
+        return counts
+    lists = [segments[t][i].asArray() for t in seg_tracks for i in isochores]
+    annos = [annotations[a][i].asArray() for a in tracks for i in isochores]
+    lcat, loff = _problem._cat(lists)
+    acat, aoff = _problem._cat(annos)
+    ws_nseg = [len(workspace[i]) for i in isochores]
+    r = ctx.count_lists([counter.name], lcat, loff, len(seg_tracks), acat, aoff, len(tracks), ws_nseg, len(isochores))[0]
+    for l, track in enumerate(seg_tracks):
         for a, annotation in enumerate(tracks):
-            v = r[a, 0]
+            v = r[a, l]
             counts[track][annotation] = float(v) if counter.name == "nucleotide-density" else int(v)
     return counts
 
