@@ -52,6 +52,7 @@ struct SamplerArgs {
   int4* st2;                  // [batch][n_units] by launch position: first consolidation done by k_merge_big
                               // {merged segments, workspace bases covered, sum of lengths, 1}, .w == 0 otherwise
   int32_t n_long;             // launch positions [0, n_long) were given to k_merge_big
+  int32_t n_active;           // active units; their launch position is blockIdx.y + blockIdx.z * gridDim.y (grid y, z <= 65535)
   uint32_t seed;
   int64_t sample_begin;       // global id of sample 0 of this batch
   uint2* slab;                // [batch][slab_stride]
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: keeps all index math scalar
   uint32_t* mt = lds + lane;                        // lane column, stride 64
-  const int sb = blockIdx.x, a = blockIdx.y;
+  const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;                      // (whole workgroup: no barrier has been reached)
   const int u = A.units_o[a].pad;
   const int rows = A.rng_rows[a];
   if (wv == 0) {
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   __shared__ uint32_t l_rank[kPlaceRankLds];
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
-  const int sb = blockIdx.x, a = blockIdx.y;
+  const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
   const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   // all tiles of a batch are resident at once and the kernel ends with the tiles of the largest unit:
   // give those waves issue priority (units are ordered by size, a = 0 is the largest)
   {
-    const int q = (4 * a) / (int)gridDim.y;
+    const int q = (4 * a) / A.n_active;
     if (q == 0) __builtin_amdgcn_s_setprio(3);
     else if (q == 1) __builtin_amdgcn_s_setprio(2);
     else if (q == 2) __builtin_amdgcn_s_setprio(1);
@@ -505,7 +508,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   __shared__ int32_t redi[kMergeWaves];
   __shared__ uint32_t wsl[2 * kWsTreeMin];                       // short workspaces: starts, ends
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sidx = blockIdx.x, a = blockIdx.y;
+  const int sidx = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_long) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int64_t sa = (int64_t)sidx * A.n_units + a;
   const int4 pre = A.st[sa];
@@ -672,7 +676,8 @@ __global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
   uint32_t* mt = lds;
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
-  const int a = blockIdx.y;
+  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int u = Up->pad;
   const int nws = Up->n_ws;

@@ -736,7 +736,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
-      if (P->h_order.size() > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 active units");
+      // the units' launch positions are spread over grid y and z (each <= 65535)
+      const unsigned n_act = (unsigned)P->h_order.size();
+      const unsigned gy = std::min(n_act, 32768u), gz = (n_act + gy - 1) / std::max(gy, 1u);
+      A.n_active = (int32_t)n_act;
       if (P->sampler_mode) {
         // lane-parallel front end: the scratch was sized for P->batch samples, tiles are laid out for that
         const int64_t nsb_alloc = (P->batch + 63) / 64;
@@ -746,9 +749,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         A.st = P->d_st.p;
         const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
-        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, (unsigned)P->h_order.size()), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
+        hipLaunchKernelGGL(gat::k_rng, dim3(nsb, gy, gz), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
-        const dim3 gp(nsb, (unsigned)P->h_order.size());
+        const dim3 gp(nsb, gy, gz);
         const int mode = P->all_simple ? 1 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0);
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
           if (mode == 1) hipLaunchKernelGGL((gat::k_place<1, 1>), gp, dim3(64), 0, ctx->stream, A);
@@ -788,7 +791,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           const bool tree_m = P->max_nws > gat::kWsTreeMin;
           const void* km = tree_m ? (const void*)gat::k_merge_big<true> : (const void*)gat::k_merge_big<false>;
           HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-          const dim3 gm((unsigned)nb, n_long);
+          const unsigned gmy = std::min(n_long, 32768u);
+          const dim3 gm((unsigned)nb, gmy, (n_long + gmy - 1) / gmy);
+          M.n_long = (int32_t)n_long;
           if (tree_m) hipLaunchKernelGGL(gat::k_merge_big<true>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
           else hipLaunchKernelGGL(gat::k_merge_big<false>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
           HIPCHK(ctx, hipGetLastError());
@@ -813,7 +818,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                      : variant == 6 ? (const void*)gat::k_sampler<0, false, false, true>
                                     : (const void*)gat::k_sampler<0, false, true, true>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      const dim3 gs((unsigned)nb, (unsigned)P->h_order.size());
+      const dim3 gs((unsigned)nb, gy, gz);
       switch (variant) {
         case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
         case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;

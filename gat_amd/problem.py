@@ -68,6 +68,7 @@ def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000, 
     contig_annotations = [(t, from_isochores(per)) for t, per in annotations]
     contig_workspace = from_isochores(workspace if count_workspace is None else count_workspace)
     seg_arrays, ws_arrays, unit_contig, contigs = [], [], [], []
+    contig_index = {}
     merge = 0
     dotted_any, plain_any = False, False
     for u in units:
@@ -83,9 +84,10 @@ def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000, 
         if len(sa) == 0 or len(wa) == 0:          # gat/__init__.py:536-538
             unit_contig.append(-1)
             continue
-        if contig not in contigs:
+        if contig not in contig_index:
+            contig_index[contig] = len(contigs)
             contigs.append(contig)
-        unit_contig.append(contigs.index(contig))
+        unit_contig.append(contig_index[contig])
     if dotted_any and plain_any:
         raise ValueError("mixing keys with and without isochores is not supported")
     anno_arrays = []

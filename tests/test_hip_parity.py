@@ -594,3 +594,29 @@ def test_cli_pattern_outputs_match_reference(ctx, tmp_path):
             continue
         got = [l for l in open(str(tmp_path / fn)) if not l.startswith("#")]
         assert got == open(os.path.join(want, fn)).readlines(), fn
+
+
+def test_more_units_than_a_grid_dimension(ctx):
+    """72 000 isochore units (9 000 contigs x 8 classes), 69 827 of them non-empty: the units' launch index is
+    spread over two grid dimensions (about 25 s: the oracle zeroes its 100 000-bin histogram per unit and sample)."""
+    import collections
+    from gat_amd import problem
+    rs = np.random.RandomState(5)
+    n_contigs = 9000
+    contigs = collections.OrderedDict(("s%05d" % i, 40000) for i in range(n_contigs))
+    segs = synthetic.random_segments(contigs, 500000, 60, 321)
+    annos = [("t0", synthetic.random_segments(contigs, 30000, 400, 322))]
+    ws = synthetic.workspace_ungapped(contigs, pieces=1, gap=200)
+    iso = synthetic.isochores_blocks(contigs, nclasses=8, block=2500)
+    flat = problem.flatten_arrays(segs, annos, ws, iso)
+    assert flat["n_units"] == 72000 and int((flat["unit_contig"] >= 0).sum()) > 65535   # beyond one grid dimension
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S = 2
+    want, wsamples = O.run_samples(flat, counters, 17, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 17, 0, S)
+    for k in range(len(counters)):
+        assert np.array_equal(got[k], want[k])
+    seg, off = P.sample(17, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
