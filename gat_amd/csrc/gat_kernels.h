@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   uint32_t* scratch = lds;                               // 513 words for the bucket sort
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
-  const int c = blockIdx.y;
+  const int c = (int)(blockIdx.y + blockIdx.z * gridDim.y);      // (contigs beyond one grid dimension)
+  if (c >= A.n_contigs) return;
   uint2* out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
   uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + 520);
   int n = 0;
@@ -1247,7 +1248,12 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   const int E = A.lds_entries;
   uint32_t* st_grid = stage + 3 * E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s0 = blockIdx.x * SC, t0 = blockIdx.y * TT, c = blockIdx.z;
+  // (track tile, contig) = the linear index over grid y and z, tiles fastest: neither count is bound by a grid dimension
+  const int n_tiles = (A.n_tracks + TT - 1) / TT;
+  const int64_t lin = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+  const int c = (int)(lin / n_tiles);
+  if (c >= A.n_contigs) return;                                     // (whole workgroup, before any barrier)
+  const int s0 = blockIdx.x * SC, t0 = (int)(lin % n_tiles) * TT;
   const int nt = min(TT, A.n_tracks - t0), ns = min(SC, A.n_samples - s0);
   const int shift = A.c_shift[c], cells = A.c_cells[c];
   if (STAGED) {
@@ -1349,7 +1355,8 @@ __global__ __launch_bounds__(kSwapThreads) void k_count_swap(CountArgs A) {
   uint32_t* grid = xcum + capx;                               // (1 << lcells) + 1
   __shared__ uint32_t wsum[kSwapThreads / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int s = blockIdx.x, c = blockIdx.y;
+  const int s = blockIdx.x, c = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (c >= A.n_contigs) return;
   const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
   const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
   const int64_t pbase = (((int64_t)c * 3) * A.n_tracks) * A.n_samples + s;

@@ -670,8 +670,12 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     const size_t need = (size_t)A.n_contigs * 3 * (size_t)A.n_tracks * (size_t)A.n_samples;
     if (part.n < need) HIPCHK(ctx, part.alloc(need));
     A.part = part.p;
-    if (A.n_contigs > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 65535 contigs");
-    dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), (unsigned)((A.n_tracks + TT - 1) / TT), (unsigned)std::max(1, A.n_contigs));
+    // (track tile, contig) pairs over grid y and z, contigs alone likewise for the kernels gridded by contig
+    const int64_t n_pairs = (int64_t)((A.n_tracks + TT - 1) / TT) * std::max(1, A.n_contigs);
+    const unsigned gpy = (unsigned)std::min<int64_t>(n_pairs, 32768), gpz = (unsigned)((n_pairs + gpy - 1) / gpy);
+    if (gpz > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 2^31 (track tile, contig) pairs");
+    dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), gpy, gpz);
+    const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
     const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
     if (A.n_contigs > 0 && swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) {
       // long sample lists against short annotation lists: index the sample list, stream the tracks
@@ -683,7 +687,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       const size_t lds_swap = (size_t)3 * swap_capx * 4 + ((size_t)(1 << lcells) + 1) * 4;
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_swap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_swap));
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
-      hipLaunchKernelGGL(gat::k_count_swap, dim3((unsigned)A.n_samples, (unsigned)A.n_contigs), dim3(gat::kSwapThreads), lds_swap, ctx->stream, B);
+      hipLaunchKernelGGL(gat::k_count_swap, dim3((unsigned)A.n_samples, gcy, gcz), dim3(gat::kSwapThreads), lds_swap, ctx->stream, B);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
       ctx->main_recorded = true;
@@ -846,8 +850,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       if (huge_c) lds = 520 * 4;
       const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
       HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
-      else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, (unsigned)P->n_contigs), dim3(64), lds, ctx->stream, B);
+      const unsigned gcy = (unsigned)std::min(P->n_contigs, 32768), gcz = ((unsigned)P->n_contigs + gcy - 1) / gcy;
+      if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds, ctx->stream, B);
+      else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds, ctx->stream, B);
       HIPCHK(ctx, hipGetLastError());
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));

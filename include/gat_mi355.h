@@ -113,8 +113,8 @@ int gat_memcpy_h2d(gat_ctx* ctx, void* dst_dev, const void* src_host, size_t byt
 /* Uploads the inputs once and hoists what SamplerAnnotator.sample recomputes on every call
  * (gat/Engine.pyx:543-565: filter, ltotal, getLengthDistribution, both sampler CDFs).
  * Returns GAT_ERR_VALUE where the reference's first sample() would raise ValueError.
- * Limits (GAT_ERR_CAPACITY beyond them): 65535 contigs per problem (any number of isochore units), 2^24 workspace
- * segments per unit, 2^31 segments per sample.  There is no limit on the segments of a unit: lists that do not fit
+ * Limits (GAT_ERR_CAPACITY beyond them): 2^24 workspace segments per unit, 2^31 segments per sample; no limit on
+ * the number of units or contigs.  There is no limit on the segments of a unit: lists that do not fit
  * on-chip memory are worked on in device memory. */
 int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* desc, gat_problem** out);
 void gat_problem_destroy(gat_problem* p);

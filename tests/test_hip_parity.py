@@ -620,3 +620,33 @@ def test_more_units_than_a_grid_dimension(ctx):
     seg, off = P.sample(17, 0, S)
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     P.close()
+
+
+def test_more_contigs_than_a_grid_dimension(ctx):
+    """70 000 contigs without isochores (units = contigs): the count kernels index (track tile, contig) pairs and the
+    contig kernels contigs over two grid dimensions."""
+    import collections
+    from gat_amd import intervals as iv, problem
+    n = 70000
+    segs, anno, ws = collections.OrderedDict(), collections.OrderedDict(), collections.OrderedDict()
+    for i in range(n):
+        k = 3 + i % 4
+        st = 5000 + np.arange(k) * 3000 + (i * 37) % 1000
+        ln = 40 + (i * 13 + np.arange(k) * 7) % 100
+        name = "c%05d" % i
+        segs[name] = iv.make(st, st + ln)
+        a0 = 4000 + (i * 53) % 3000
+        anno[name] = iv.make(np.array([a0, a0 + 9000]), np.array([a0 + 2500, a0 + 12000]))
+        ws[name] = iv.make(np.array([200]), np.array([39800]))
+    flat = problem.flatten_arrays(segs, [("t0", anno)], ws, None)
+    assert flat["n_contigs"] == n > 65535
+    counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    S = 2
+    want, wsamples = O.run_samples(flat, counters, 23, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 23, 0, S)
+    for k in range(len(counters)):
+        assert np.array_equal(got[k], want[k])
+    seg, off = P.sample(23, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
