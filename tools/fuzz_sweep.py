@@ -14,56 +14,6 @@ class MP(object):                      # minimal monkeypatch stand-in
         os.environ[k] = v
 
 
-def edge_case(ctx, seed):
-    """the corners: segments longer than workspace pieces, one-base pieces, units of one to three segments, dense units
-    (overshoot trims, unsuccessful rounds), odd bucket sizes"""
-    import collections
-    import numpy as np
-    from gat_amd import problem, synthetic, intervals as iv
-    from oracle import oracle as O
-    rs = np.random.RandomState(seed)
-    contigs = collections.OrderedDict(("e%d" % i, int(rs.randint(3000, 200000))) for i in range(int(rs.randint(1, 4))))
-    segs, ws = collections.OrderedDict(), collections.OrderedDict()
-    for c, size in contigs.items():
-        nseg = int(rs.choice([1, 2, 3, 10, 60, 300]))
-        mean = int(rs.choice([1, 5, 50, 500, 3000]))
-        st = rs.randint(0, size, nseg)
-        ln = 1 + rs.geometric(1.0 / mean, nseg)
-        segs[c] = iv.normalize(iv.make(st, np.minimum(st + ln, size + 5000)))
-        npieces = int(rs.choice([1, 2, 7, 40]))
-        edges = np.sort(rs.choice(np.arange(1, size), size=min(2 * npieces, size - 1), replace=False))
-        ws[c] = iv.normalize(iv.make(edges[0::2][:npieces], edges[1::2][:npieces] + int(rs.choice([0, 0, 1]))))
-        ws[c] = ws[c][ws[c]["end"] > ws[c]["start"]]
-    annos = [("t0", synthetic.random_segments(contigs, int(rs.randint(5, 200)), int(rs.randint(20, 2000)), int(rs.randint(1 << 30))))]
-    bucket_size = int(rs.choice([0, 1, 3, 64]))
-    nbuckets = int(rs.choice([100000, 5000]))
-    try:
-        flat = problem.flatten_arrays(segs, annos, ws, None, bucket_size=bucket_size, nbuckets=nbuckets)
-    except Exception:                  # noqa: BLE001  (degenerate generator output)
-        return "skipped"
-    if flat["n_contigs"] == 0:
-        return "skipped"
-    counters = list(_lib.COUNTER_IDS.keys())
-    S = 10
-    try:
-        want, wsamples = O.run_samples(flat, counters, seed, 1, 0, S, want_samples=True)
-    except (ValueError, AssertionError) as e:
-        try:
-            P = _lib.Problem(ctx, flat)
-            P.sample_and_count(counters, seed, 0, S)
-        except type(e):
-            return "both raised %s" % type(e).__name__
-        raise AssertionError("oracle raised %s, the device path did not" % type(e).__name__)
-    P = _lib.Problem(ctx, flat)
-    got = P.sample_and_count(counters, seed, 0, S)
-    for k, c in enumerate(counters):
-        assert np.array_equal(got[k], want[k]), c
-    seg, off = P.sample(seed, 0, S)
-    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
-    P.close()
-    return "compared"
-
-
 ctx = _lib.Context(0)
 first, n = int(sys.argv[1]), int(sys.argv[2])
 edge = len(sys.argv) > 3 and sys.argv[3] == "edge"
@@ -74,7 +24,7 @@ for seed in range(first, first + n):
     os.environ.pop("GAT_TEST_HUGE", None)
     try:
         if edge:
-            r = edge_case(ctx, seed)
+            r = m._edge_case(ctx, seed)
             outcomes[r] = outcomes.get(r, 0) + 1
         else:
             m.test_fuzz_shapes_vs_oracle(ctx, seed, MP())
