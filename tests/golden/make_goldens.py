@@ -545,6 +545,21 @@ def g6_stats():
         samples = rs.gamma(2.0, 0.15, size=100)
         one(float(rs.choice(samples)) if rs.rand() < 0.5 else float(rs.gamma(2.0, 0.15)), [float(x) for x in samples], pseudo=0.0)
     one(0, [0] * 50)         # expected == 0 -> fold 1.0
+
+    # with a reference result (gat/Engine.pyx:1660-1700: expected, CI and the p-value are scaled by reference.fold)
+    class Ref(object):
+        def __init__(self, fold):
+            self.fold = fold
+    for _ in range(24):
+        n = int(rs.choice([5, 20, 100, 1000]))
+        samples = rs.poisson(float(rs.choice([3, 50, 5000])), size=n)
+        obs = int(rs.choice([0, int(samples.mean()), int(samples.max()) + 3]))
+        fold = float(rs.choice([0.5, 1.0, 1.7, 4.0]))
+        r = Engine.AnnotatorResult("track", "annotation", "counter", obs, samples, reference=Ref(fold), pseudo_count=1.0)
+        text = str(r).split("\t")
+        cases.append(dict(observed=float(obs), samples=[float(x) for x in samples], pseudo_count=1.0, reference_fold=fold,
+                          expected=r.expected, stddev=r.stddev, fold=r.fold, pvalue=r.pvalue,
+                          lower95=float(text[4]), upper95=float(text[5]), row=text[2:]))
     with open(os.path.join(HERE, "stats.json"), "w") as f:
         json.dump(cases, f, separators=(",", ":"))
     print("G6 stats: %d cases" % len(cases))

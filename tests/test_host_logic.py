@@ -142,8 +142,13 @@ def test_flatten_via_collections_matches_arrays():
 def test_enrichment_statistics_against_reference():
     with open(os.path.join(G, "stats.json")) as f:
         cases = json.load(f)
+    class Ref(object):
+        def __init__(self, fold):
+            self.fold = fold
+    assert sum(1 for c in cases if "reference_fold" in c) >= 20
     for c in cases:
-        r = engine.AnnotatorResult("track", "annotation", "counter", c["observed"], c["samples"],
+        ref = Ref(c["reference_fold"]) if "reference_fold" in c else None
+        r = engine.AnnotatorResult("track", "annotation", "counter", c["observed"], c["samples"], reference=ref,
                                    pseudo_count=c["pseudo_count"])
         assert r.expected == c["expected"] and r.stddev == c["stddev"] and r.fold == c["fold"]
         assert r.pvalue == c["pvalue"]
