@@ -177,6 +177,22 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     return annotator_results
 
 
+def fromCounts(filename):
+    """annotator results from a counts table written by --output-counts-pattern (gat/__init__.py:1091-1117; the
+    entry point of gat-compare.py)."""
+    annotator_results = []
+    with IO.openFile(filename, "r") as infile:
+        header = infile.readline()
+        if not header == "track\tannotation\tobserved\tcounts\n":
+            raise ValueError("%s not a counts file: got %s" % (infile, header))
+        for line in infile:
+            track, annotation, observed, counts = line[:-1].split("\t")
+            samples = np.array(list(map(float, counts.split(","))), dtype=np.float64)
+            annotator_results.append(AnnotatorResult(track=track, annotation=annotation, counter="na",
+                                                     observed=float(observed), samples=samples))
+    return annotator_results
+
+
 def buildParser(usage=None):
     """gat command line parser: the options of the reference's buildParser (gat/__init__.py:54-429)
     that concern the accelerated path, with the same names, destinations and defaults."""

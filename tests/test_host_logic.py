@@ -335,3 +335,20 @@ def test_cli_side_files_match_reference(tmp_path):
         assert open(str(tmp_path / n)).read() == open(os.path.join(want_dir, n)).read(), n
     with pytest.raises(OSError):                          # side files are not overwritten without --force
         segments, annotations, workspaces, isochores = IO.buildSegments(opts)
+
+
+def test_from_counts_reads_the_counts_table():
+    """gat.fromCounts (gat/__init__.py:1091-1117) on the counts table the reference wrote (tests/golden/cli/aux/patterns/):
+    rows come back as AnnotatorResults whose statistics are those of the table the same run printed."""
+    import os
+    import gat_amd as gat
+    pat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cli", "aux", "patterns")
+    results = gat.fromCounts(os.path.join(pat, "counts_nucleotide-overlap.tsv"))
+    table = [l.rstrip("\n").split("\t") for l in open(os.path.join(pat, "table_nucleotide-overlap.tsv"))][1:]
+    by_key = dict(((r[0], r[1]), r) for r in table)
+    assert len(results) == len(table) > 0
+    for r in results:
+        row = by_key[(r.track, r.annotation)]
+        assert str(r).split("\t")[2:10] == row[2:10]        # observed .. pvalue (the q-value is set by the output stage)
+    with pytest.raises(ValueError):
+        gat.fromCounts(os.path.join(pat, "table_nucleotide-overlap.tsv"))
