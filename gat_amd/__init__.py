@@ -213,6 +213,8 @@ def buildParser(usage=None):
                  help="the segments file is arranged in tracks")
     g.add_option("--enable-split-tracks", dest="enable_split_tracks", action="store_true")
     g.add_option("--annotations-label", dest="annotations_label", type="string")
+    g.add_option("--input-counts-file", dest="input_filename_counts", type="string",
+                 help="start from a counts table written by --output-counts-pattern (statistics re-computed)")
     g.add_option("--input-results-file", dest="input_filename_results", type="string",
                  help="start from a previous results table (re-computes the fdr)")
     g.add_option("--descriptions", dest="input_filename_descriptions", type="string",
@@ -268,7 +270,7 @@ def buildParser(usage=None):
     g.add_option("-S", "--stdout", dest="stdout", type="string", metavar="FILE")
     g.add_option("-L", "--log", dest="stdlog", type="string", metavar="FILE")
     parser.add_option_group(g)
-    parser.set_defaults(output_stats=[], output_bed=[], output_filename_pattern="%s", output_force=False,
+    parser.set_defaults(input_filename_counts=None, output_stats=[], output_bed=[], output_filename_pattern="%s", output_force=False,
                         input_filename_results=None, input_filename_descriptions=None, annotation_files=[], annotations_label=None, annotations_to_points=None, bucket_size=0,
                         counters=[], enable_split_tracks=False, ignore_segment_tracks=True, isochore_files=[],
                         nbuckets=100000, num_samples=1000, num_threads=0, output_counts_pattern=None,
