@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="scale interval counts (debugging only)")
+    ap.add_argument("--counter", default=None, help="another counter than the configuration's (experiments only)")
     return ap.parse_args()
 
 
@@ -113,7 +114,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = synthetic.config(args.config, args.scale)
-    counters = [cfg["counter"]]
+    counters = [args.counter or cfg["counter"]]
     S = args.samples or cfg["num_samples"]
     flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
     stream = torch.cuda.current_stream().cuda_stream

@@ -1450,6 +1450,107 @@ __global__ __launch_bounds__(256) void k_count_finish(CountArgs A) {
   if (k3 >= 0) A.out[((int64_t)k3 * A.n_tracks + t) * A.out_stride + col] = mid;
 }
 
+// annotation-overlap / annotation-midoverlap with the SAMPLE list indexed in LDS (the k_count_swap scheme): one
+// 256-thread block per (sample, contig) loads the list (starts with a sentinel, ends), builds a position grid over the
+// starts and streams every track's intervals of that contig against it.  For an interval y: k = #starts <= y.start from
+// the grid cell plus a short scan; the first segment with end > y.start is k-1 if that one reaches past y.start, else k
+// (normalized list).  Partials per (contig, sample, track) go to `part`, k_count_anno_finish adds them over the contigs.
+constexpr int kAnnoThreads = 256;
+__global__ __launch_bounds__(kAnnoThreads) void k_count_anno_idx(CountArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int capx = A.lds_entries, lcells = A.lds_grid;
+  uint32_t* xs = lds;
+  uint32_t* xe = xs + capx;
+  uint32_t* grid = xe + capx;                                 // (1 << lcells) + 1
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = blockIdx.x, c = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (c >= A.n_contigs) return;
+  const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
+  const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+  const int64_t pbase = (((int64_t)c * 2) * A.n_tracks) * A.n_samples + s;
+  const int64_t qstride = (int64_t)A.n_tracks * A.n_samples;
+  if (n == 0 || n >= capx) {                                  // (n >= capx cannot happen: capx = capacity + 1)
+    for (int t = tid; t < A.n_tracks; t += kAnnoThreads) {
+      A.part[pbase + (int64_t)t * A.n_samples] = 0;
+      A.part[pbase + qstride + (int64_t)t * A.n_samples] = 0;
+    }
+    return;
+  }
+  for (int i = tid; i < n; i += kAnnoThreads) { const uint2 v = X[i]; xs[i] = v.x; xe[i] = v.y; }
+  if (tid == 0) xs[n] = 0xffffffffu;
+  __syncthreads();
+  const uint32_t maxstart = xs[n - 1];
+  const int bits = maxstart ? 32 - __builtin_clz(maxstart) : 1;
+  const int shift = bits > lcells ? bits - lcells : 0;
+  const int cells = (int)(maxstart >> shift) + 1;
+  for (int g = tid; g <= cells; g += kAnnoThreads) {
+    uint32_t k = (uint32_t)n;
+    if (g < cells) {
+      const uint32_t bound = (uint32_t)g << shift;
+      int lo = 0, hi = n;
+      while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (xs[mid] < bound) lo = mid + 1; else hi = mid; }
+      k = (uint32_t)lo;
+    }
+    grid[g] = k;
+  }
+  __syncthreads();
+  for (int t = wave; t < A.n_tracks; t += kAnnoThreads / kWave) {
+    const int64_t g0 = A.a_off[(int64_t)t * A.n_contigs + c];
+    const int m = (int)(A.a_off[(int64_t)t * A.n_contigs + c + 1] - g0);
+    uint32_t hit = 0, mid = 0;
+    constexpr int kB = 4;
+    for (int base = 0; base < m; base += kB * kWave) {
+      uint32_t ys[kB], ye[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int i = base + q * kWave + lane;
+        ys[q] = i < m ? A.a_start[g0 + i] : 0u;
+        ye[q] = i < m ? A.a_end[g0 + i] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        if (base + q * kWave >= m) break;
+        uint32_t gc = ys[q] >> shift;
+        gc = gc < (uint32_t)(cells - 1) ? gc : (uint32_t)(cells - 1);
+        int k = (int)grid[gc];
+        while (xs[k] <= ys[q]) ++k;                           // k = #starts <= y.start (the sentinel ends the scan)
+        const int j = (k > 0 && xe[k - 1] > ys[q]) ? k - 1 : k;   // first segment with end > y.start
+        if (base + q * kWave + lane < m && j < n) {
+          const uint32_t x0 = xs[j], x1 = xe[j];
+          if (x0 < ye[q]) {                                   // gat/SegmentList.pyx:1127-1144, roles swapped
+            hit++;
+            const uint32_t mp = ys[q] + (ye[q] - ys[q]) / 2u;
+            if (x0 <= mp && mp < x1) mid++;
+          }
+        }
+      }
+    }
+    hit = wave_total_u32(hit);
+    mid = wave_total_u32(mid);
+    if (lane == 0) {
+      A.part[pbase + (int64_t)t * A.n_samples] = hit;
+      A.part[pbase + qstride + (int64_t)t * A.n_samples] = mid;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_count_anno_finish(CountArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)A.n_tracks * A.n_samples) return;
+  const int t = (int)(i / A.n_samples), s = (int)(i - (int64_t)t * A.n_samples);
+  const int64_t q = (int64_t)A.n_tracks * A.n_samples;
+  int64_t hit = 0, mid = 0;
+  for (int c = 0; c < A.n_contigs; ++c) {
+    const int64_t b = (((int64_t)c * 2) * A.n_tracks + t) * A.n_samples + s;
+    hit += (int64_t)A.part[b];
+    mid += (int64_t)A.part[b + q];
+  }
+  const int64_t col = A.out_begin + s;
+  const int k4 = A.counter_slot[4], k5 = A.counter_slot[5];
+  if (k4 >= 0) A.out[((int64_t)k4 * A.n_tracks + t) * A.out_stride + col] = hit;
+  if (k5 >= 0) A.out[((int64_t)k5 * A.n_tracks + t) * A.out_stride + col] = mid;
+}
+
 // annotation-overlap / annotation-midoverlap: roles swapped (gat/Engine.pyx:1458-1472):
 // each annotation interval y is tested against the first sample segment x with x.end > y.start.
 // One wave per (sample, track); lanes stride the annotation intervals, bisecting the sample list.

@@ -638,7 +638,7 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
 
 // launch the count kernels over n_lists sample lists
 static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part,
-                        int swap_capx = 0) {
+                        int swap_capx = 0, int list_cap = 0) {
   for (int i = 0; i < GAT_NUM_COUNTERS; ++i) A.counter_slot[i] = C.slot[i];
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
   A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
@@ -713,9 +713,30 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     HIPCHK(ctx, hipGetLastError());
   }
   if (C.any_anno) {
-    const int64_t waves = (int64_t)A.n_samples * A.n_tracks;
-    hipLaunchKernelGGL(gat::k_count_anno, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, A);
-    HIPCHK(ctx, hipGetLastError());
+    // the sample lists indexed in LDS when they fit (list_cap = longest list possible), else every interval bisects
+    // the list in global memory
+    int lcells = 4;
+    while ((1 << lcells) < list_cap + 1 && lcells < 13) ++lcells;
+    const size_t lds_a = (size_t)2 * (list_cap + 1) * 4 + ((size_t)(1 << lcells) + 1) * 4;
+    if (list_cap > 0 && A.n_contigs > 0 && (int64_t)lds_a + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_SWAP")) {
+      gat::CountArgs B = A;
+      B.lds_entries = list_cap + 1;
+      B.lds_grid = lcells;
+      const size_t need = (size_t)A.n_contigs * 2 * (size_t)A.n_tracks * (size_t)A.n_samples;
+      if (part.n < need) HIPCHK(ctx, part.alloc(need));
+      B.part = part.p;
+      const unsigned gcy = (unsigned)std::min(A.n_contigs, 32768), gcz = ((unsigned)A.n_contigs + gcy - 1) / gcy;
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_anno_idx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+      hipLaunchKernelGGL(gat::k_count_anno_idx, dim3((unsigned)A.n_samples, gcy, gcz), dim3(gat::kAnnoThreads), lds_a, ctx->stream, B);
+      HIPCHK(ctx, hipGetLastError());
+      const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
+      hipLaunchKernelGGL(gat::k_count_anno_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, B);
+      HIPCHK(ctx, hipGetLastError());
+    } else {
+      const int64_t waves = (int64_t)A.n_samples * A.n_tracks;
+      hipLaunchKernelGGL(gat::k_count_anno, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+    }
   }
   return GAT_OK;
 }
@@ -938,7 +959,8 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
       const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
       if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
     }
-    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx))) return rc;
+    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
+                           P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -1068,7 +1090,9 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
     K.n_arr = d_n.p; K.n_stride = 0; K.n_index = d_index.p;
     K.cws_nseg = d_nseg.p; K.n_contigs = n_groups; K.n_tracks = n_tracks; K.n_samples = 1;
     K.out = d_out.p; K.out_stride = n_lists; K.out_begin = l;
-    if ((rc = launch_count(ctx, A, C, K, d_part))) return rc;
+    int32_t longest = 0;
+    for (int g = 0; g < n_groups; ++g) longest = std::max(longest, h_n[(size_t)g]);
+    if ((rc = launch_count(ctx, A, C, K, d_part, 0, longest))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   HIPCHK(ctx, hipMemcpyAsync(counts_host, d_out.p, nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
