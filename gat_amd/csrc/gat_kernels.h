@@ -670,8 +670,10 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
 // HUGE: some unit's list does not fit LDS (about 15 000 segments): the list then lives where k_place left it, in the
 // unit's slab region in global memory, and the same code works on it there -- slow (every pass is a round trip to
 // memory, the sort is the in-place network) but without a size limit.
-template <int KIND, bool BIG, bool TREE, bool HUGE>
-__global__ __launch_bounds__(64, 4) void k_sampler(SamplerArgs A) {
+// WPE: waves per SIMD the register budget is set for: 4 (LDS allows no more for lists of hundreds of segments), or 5 for
+// problems whose lists are so short that registers, not LDS, decide how many waves a CU holds.
+template <int KIND, bool BIG, bool TREE, bool HUGE, int WPE = 4>
+__global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* mt = lds;
   const int lane = threadIdx.x;

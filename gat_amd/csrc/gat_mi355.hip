@@ -832,8 +832,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       const bool tree = P->max_nws > gat::kWsTreeMin;
-      const int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
-                        : huge ? (tree ? 7 : 6) : (long_lists ? 2 : 0) + (tree ? 1 : 0);
+      int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
+                  : huge ? (tree ? 7 : 6) : (long_lists ? 2 : 0) + (tree ? 1 : 0);
+      // short lists only (20 waves of this kernel fit a CU's LDS): the instantiation with registers for 5 waves per SIMD
+      if (variant == 0 && (int64_t)lds * 20 <= ctx->max_lds && !getenv("GAT_NO_WPE5")) variant = 8;
       const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false, false>
                      : variant == 1 ? (const void*)gat::k_sampler<0, false, true, false>
                      : variant == 2 ? (const void*)gat::k_sampler<0, true, false, false>
@@ -841,7 +843,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                      : variant == 4 ? (const void*)gat::k_sampler<1, false, false, false>
                      : variant == 5 ? (const void*)gat::k_sampler<1, false, true, false>
                      : variant == 6 ? (const void*)gat::k_sampler<0, false, false, true>
-                                    : (const void*)gat::k_sampler<0, false, true, true>;
+                     : variant == 7 ? (const void*)gat::k_sampler<0, false, true, true>
+                                    : (const void*)gat::k_sampler<0, false, false, false, 5>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const dim3 gs((unsigned)nb, gy, gz);
       switch (variant) {
@@ -852,7 +855,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
         case 5: hipLaunchKernelGGL((gat::k_sampler<1, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
         case 6: hipLaunchKernelGGL((gat::k_sampler<0, false, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
-        default: hipLaunchKernelGGL((gat::k_sampler<0, false, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        case 7: hipLaunchKernelGGL((gat::k_sampler<0, false, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
+        default: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false, 5>), gs, dim3(64), lds, ctx->stream, A); break;
       }
       HIPCHK(ctx, hipGetLastError());
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
