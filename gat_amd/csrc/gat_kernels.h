@@ -197,12 +197,15 @@ constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
 // MODE (chosen by the host from the units' shapes, so that the common problems run a lean kernel): 1 every unit is of
 // the single-workspace-segment shape, only that loop is compiled in; 0 no workspace beyond the LDS table; 2 everything.
-template <int KIND, int MODE>
+// SMALL: every unit has at most 64 workspace segments and fewer than 256 working segments: quarter-size LDS tables,
+// so that more tiles are resident per CU (the kernel has few waves and hides latency by their number).
+template <int KIND, int MODE, bool SMALL = false>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   constexpr bool ALL_SIMPLE = MODE == 1;
   constexpr bool TREES = MODE == 2;
-  __shared__ uint4 l_ws[kPlaceWsLds];     // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
-  __shared__ uint32_t l_rank[kPlaceRankLds];
+  constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = SMALL ? 256 : kPlaceRankLds;
+  __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
+  __shared__ uint32_t l_rank[kRankTab];
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
@@ -241,8 +244,8 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     else if (q == 1) __builtin_amdgcn_s_setprio(2);
     else if (q == 2) __builtin_amdgcn_s_setprio(1);
   }
-  const bool ws_lds = nws <= kPlaceWsLds;
-  const bool rank_lds = hist_total < (uint32_t)kPlaceRankLds;
+  const bool ws_lds = nws <= kWsTab;
+  const bool rank_lds = hist_total < (uint32_t)kRankTab;
   // longer workspaces are looked up through their 16-ary tree in global memory (WsTree, gat_device.h)
   const uint32_t* __restrict__ tree_cdf = A.ws_tree + (Up->tree_cdf_off >= 0 ? Up->tree_cdf_off : 0);
   const WsTreeGeom G = ws_tree_geom(nws);

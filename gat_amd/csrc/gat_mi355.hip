@@ -208,6 +208,7 @@ struct gat_problem {
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
+  bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
 };
 
@@ -489,13 +490,16 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   });
   for (auto& w : work) P->h_order.push_back(w.second);
   P->all_simple = !P->h_order.empty();
+  uint32_t max_hist = 0;
   for (int32_t u : P->h_order) {
     const UnitDev& U = P->h_units[(size_t)u];
     const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
     const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
     if (!degenerate && !simple) P->all_simple = false;
     P->max_nws = std::max(P->max_nws, U.n_ws);
+    max_hist = std::max(max_hist, U.hist_total);
   }
+  P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
   // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
   // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
   // are redone by k_sampler from their seed.
@@ -784,6 +788,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
           if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && P->small_tables) hipLaunchKernelGGL((gat::k_place<0, 0, true>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<0, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<0, 2>), gp, dim3(64), 0, ctx->stream, A);
         }
