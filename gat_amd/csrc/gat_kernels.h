@@ -1116,12 +1116,38 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + 520);
   int n = 0;
   const int u0 = A.contig_unit_off[c], u1 = A.contig_unit_off[c + 1];
-  for (int ui = u0; ui < u1; ++ui) {
-    const int u = A.contig_units[ui];
-    const int cnt = A.unit_n[(int64_t)sidx * A.n_units + u];
-    const uint2* __restrict__ src = A.slab_in + (int64_t)sidx * A.slab_stride + A.units[u].slab_off;
-    for (int i = lane; i < cnt; i += kWave) seg[n + i] = src[i];
-    n += cnt;
+  // Units are taken 64 at a time: lane k looks up unit k's list (count, place in the slab) -- one round trip for all of
+  // them instead of two dependent ones per unit -- and the first 64 segments of up to eight lists are in flight together.
+  for (int ub = u0; ub < u1; ub += kWave) {
+    const int nu = u1 - ub < kWave ? u1 - ub : kWave;
+    int my_cnt = 0, my_off = 0;
+    if (lane < nu) {
+      const int u = A.contig_units[ub + lane];
+      my_cnt = A.unit_n[(int64_t)sidx * A.n_units + u];
+      my_off = A.units[u].slab_off;
+    }
+    const int my_dst = n + (int)(wave_incl_sum_u32((uint32_t)my_cnt, lane) - (uint32_t)my_cnt);
+    const uint2* __restrict__ base = A.slab_in + (int64_t)sidx * A.slab_stride;
+    constexpr int kU = 8;
+    for (int k0 = 0; k0 < nu; k0 += kU) {
+      uint2 v[kU];
+      int cnt[kU], dst[kU], off[kU];
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        const int k = k0 + q < nu ? k0 + q : nu - 1;
+        cnt[q] = k0 + q < nu ? __builtin_amdgcn_readlane(my_cnt, k) : 0;
+        dst[q] = __builtin_amdgcn_readlane(my_dst, k);
+        off[q] = __builtin_amdgcn_readlane(my_off, k);
+        v[q] = make_uint2(0u, 0u);
+        if (lane < cnt[q]) v[q] = base[off[q] + lane];
+      }
+#pragma unroll
+      for (int q = 0; q < kU; ++q) {
+        if (lane < cnt[q]) seg[dst[q] + lane] = v[q];
+        for (int i = kWave + lane; i < cnt[q]; i += kWave) seg[dst[q] + i] = base[off[q] + i];   // lists beyond 64 segments
+      }
+    }
+    n += (int)wave_total_u32((uint32_t)my_cnt);
   }
   wave_sort_fast(seg, n, scratch, lane);
   n = wave_merge0(seg, n, lane);
