@@ -298,11 +298,17 @@ def run_samples(flat, counters, seed, stream_mode, sample_begin, sample_end, wan
     cap = 0
     if want_samples:
         cap = int(4 * len(keep["segs"]) + 1024) * ns
-        samples = np.empty(cap, dtype=SEG)
         soff = np.zeros(ns * p.n_contigs + 1, dtype=np.int64)
-    rc = L.gato_run_samples(C.byref(p), _p(ids), len(ids), seed, stream_mode, sample_begin, sample_end,
-                            _p(counts), _p(samples) if want_samples else None, cap,
-                            _p(soff) if want_samples else None)
+    while True:
+        if want_samples:
+            samples = np.empty(cap, dtype=SEG)
+        rc = L.gato_run_samples(C.byref(p), _p(ids), len(ids), seed, stream_mode, sample_begin, sample_end,
+                                _p(counts), _p(samples) if want_samples else None, cap,
+                                _p(soff) if want_samples else None)
+        if rc == -3 and want_samples and cap < (1 << 33):   # a few long segments can come back as thousands of short ones
+            cap *= 4
+            continue
+        break
     if rc == -1:
         raise ValueError("oracle run_samples: ValueError")
     if rc:
