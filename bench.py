@@ -2,28 +2,44 @@
 """bench.py -- samples/s of the GAT sampling + overlap-counting hot path on MI355X.
 
 One "step" = one pass of the batch seam (gat_sample_and_count: place every isochore unit, re-combine
-per contig, count every annotation track) over `--samples` Monte-Carlo samples per GPU, on the
-synthetic BASELINE.json configuration (default config2: 10k segments x 1 annotation track x 10k
-intervals, hg19 workspace, 10 000 samples, CounterNucleotideOverlap).  Inputs are resident in HBM
-before the timed region.  With N > 1 (torch.distributed.run, one rank per GPU) every rank takes its
-own contiguous range of sample ids (weak scaling) and the step ends with ONE RCCL all-gather of the
-per-sample count matrix.
+per contig, count every annotation track) over `--samples` Monte-Carlo samples per GPU, followed by the
+read-back of the count matrix to the host ("seed -> count matrix on host").  The headline line is
+BASELINE.json's config2 (10k segments x 1 annotation track x 10k intervals, hg19 workspace, 10 000 samples,
+CounterNucleotideOverlap); the same run then measures the other single-GPU shapes of BASELINE.json (config3, the
+north_star target shape; one call's worth of config5 and config4) and reports them under "configs".  Inputs are
+resident in HBM before the timed region.
+
+`python bench.py --gpus N` without torch.distributed.run in the environment starts its own N ranks (a child process
+running `python -m torch.distributed.run ... bench.py`, before anything here touches a GPU) and relays their one
+JSON line.  With N > 1 every rank takes its own contiguous range of sample ids (weak scaling), the step ends with
+ONE RCCL all-gather of the per-sample count matrix, and rank 0 reads the gathered matrix back.
 
 Prints one JSON line (rank 0): metric/value per the driver contract plus
-  roofline     : the overlap-count kernel, algorithmic bytes / measured kernel time
-  sampler      : the placement kernel, placements/s and MT19937 draws/s (not bandwidth bound)
+  roofline     : the overlap-count kernel: algorithmic bytes / kernel time measured with HIP events in
+                 this run, next to what the counters of the committed rocprofv3 passes say (HBM bytes, VALU issue)
+  kernels      : per-kernel time of the step (HIP events on the launch stream)
+  configs      : the same for config3 / config5 / config4 shapes
   cpu_baseline : the CPU oracle (oracle/gat_oracle.c, a port of the reference) timed on this host
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+METRIC = "Monte Carlo samples/sec + bit-exact p-values, 10k sims, hg19-sized workspace"
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_ACHIEVABLE_GBPS = 6290.0    # ... 6.29 TB/s measured with a float4 copy
+# samples per GPU per step of the extra shapes: config3 = its own 10 000; config5 / config4 are 8-GPU jobs of
+# 125 000 / 12 500 samples per GPU, measured here over one call's worth
+EXTRA_SAMPLES = {"config3": 10000, "config5": 16384, "config4": 2048}
+# the reference itself (Cython engine, one core, build container; BASELINE.md section 2) -- it cannot travel
+REFERENCE_CYTHON = {"config2": 19.1}
 
 
 def parse():
@@ -34,11 +50,27 @@ def parse():
     ap.add_argument("--config", default="config2")
     ap.add_argument("--samples", type=int, default=0, help="samples per GPU per step (default: the config's)")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--extra", default="config3,config5,config4",
+                    help="further BASELINE shapes measured in the same run and reported under 'configs' ('' = none)")
+    ap.add_argument("--extra-steps", type=int, default=4)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="scale interval counts (debugging only)")
     ap.add_argument("--counter", default=None, help="another counter than the configuration's (experiments only)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 and no launcher in the environment: be the launcher.  Nothing has touched a GPU yet (a process
+    that has must never be replaced or forked); the ranks are children and their JSON line passes through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(flat, counters, seed, budget_s):
@@ -87,18 +119,180 @@ def cpu_baseline(flat, counters, seed, budget_s):
                 single_thread_value=n1 / dt1)
 
 
+def counters_profile(config, S):
+    """what the committed rocprofv3 passes of this command say about the kernels of (config, S): HBM-side bytes
+    (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 FETCH correction applied) and VALU issue share.
+    Produced by tools/summarize_profiles.py from gpurun_out/; NOT measured in this run -- the source is named."""
+    for fn in ("r02_kernel_counters.json", "r01_count_kernel_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        rec = json.load(open(path)).get("%s:%d" % (config, S))
+        if rec:
+            return rec, "profiles/" + fn
+    return None, None
+
+
+class Workload(object):
+    """one BASELINE shape resident on this rank's GPU."""
+
+    def __init__(self, name, S, args, dev_index, rank, world):
+        import torch
+        from gat_amd import _lib, problem, synthetic
+        self.name, self.S, self.args, self.rank, self.world = name, S, args, rank, world
+        cfg = synthetic.config(name, args.scale)
+        self.counters = [args.counter or cfg["counter"]]
+        self.flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
+        self.dev = torch.device("cuda", dev_index)
+        self.ctx = _lib.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
+        self.P = _lib.Problem(self.ctx, self.flat)
+        self.info = self.P.info()
+        K, A = len(self.counters), self.flat["n_tracks"]
+        self.counts = torch.zeros((K, A, S), dtype=torch.int64, device=self.dev)
+        self.gathered = torch.zeros((world * K, A, S), dtype=torch.int64, device=self.dev) if world > 1 else None
+        # the matrix a host consumer gets: pinned, filled inside the timed region (rank 0 holds all ranks' columns)
+        self.host = torch.empty((world * K, A, S), dtype=torch.int64, pin_memory=True) if rank == 0 else None
+
+    def step(self, i):
+        import torch.distributed as dist
+        # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
+        begin = (i * self.world + self.rank) * self.S
+        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts.data_ptr())
+        src = self.counts
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.counts)
+            src = self.gathered
+        if self.host is not None:
+            self.host.copy_(src, non_blocking=True)
+        return st
+
+    def measure(self, steps, warmup):
+        import torch
+        import torch.distributed as dist
+        world, dev = self.world, self.dev
+        for i in range(warmup):
+            self.step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        keys = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
+                "n_placed", "n_draws", "n_retried", "n_full_units")
+        acc = dict((k, 0.0) for k in keys)
+        for i in range(steps):
+            st = self.step(warmup + i)
+            for k in keys:
+                acc[k] += st.get(k, 0.0)
+            acc["count_kernel"] = st.get("count_kernel", 1)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        # the one collective of the path, timed by itself after the timed region (the split the report shows per N)
+        allgather = None
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dist.all_gather_into_tensor(self.gathered, self.counts)
+            torch.cuda.synchronize()
+            allgather = {"avg_ms": (time.perf_counter() - t1) / 5 * 1e3, "bytes_per_rank": int(self.counts.numel() * 8),
+                         "collective": "RCCL all_gather_into_tensor", "backend": dist.get_backend(),
+                         "world_size": dist.get_world_size()}
+        return self.report(steps, warmup, dt, acc, allgather)
+
+    def report(self, steps, warmup, dt, acc, allgather):
+        S, world, flat, info = self.S, self.world, self.flat, self.info
+        A = flat["n_tracks"]
+        bytes_per_sample = info["algorithmic_bytes_per_sample"]
+        # the dominant count kernel alone, HIP events on the launch stream right around it; ms_count additionally holds
+        # the small combining kernel
+        main_ms = (acc["ms_count_main"] or acc["ms_count"]) / steps
+        count_s = main_ms / 1e3
+        samp_s = acc["ms_sampler"] / 1e3
+        achieved = bytes_per_sample * S / count_s / 1e9 if count_s > 0 else 0.0
+        from gat_amd import _lib
+        kernel = _lib.COUNT_KERNELS.get(int(acc.get("count_kernel", 1)), "k_count_seg")
+        roof = {"bound": "hbm", "kernel": "%s (overlap counters)" % kernel,
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "traffic_source": None,
+                "algorithmic_bytes_per_launch": bytes_per_sample * S,
+                "algorithmic_bytes_per_sample": bytes_per_sample,
+                "avg_launch_ms": main_ms,
+                "count_phase_ms": acc["ms_count"] / steps,
+                "share_of_gpu_time": acc["ms_count"] / max(1e-9, acc["ms_count"] + acc["ms_sampler"] + acc["ms_contig"]),
+                "note": "achieved/frac follow the SURVEY 8d contract (every annotation interval charged once per sample); "
+                        "the kernel serves annotations from LDS / L2, so real HBM traffic is lower: see hbm_measured_GBps"}
+        prof, src = counters_profile(self.name, S) if self.args.scale == 1.0 else (None, None)
+        if prof:
+            k = prof.get("count_kernel", prof)
+            traffic = (2.0 * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
+            roof["traffic"] = traffic
+            roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; " \
+                                     "not re-measured in this run)" % src
+            if count_s > 0:
+                roof["hbm_measured_GBps"] = traffic / count_s / 1e9
+                roof["frac_of_achievable"] = traffic / count_s / 1e9 / HBM_ACHIEVABLE_GBPS
+            if "valu_busy" in k:
+                roof["valu_busy"] = k["valu_busy"]
+                if k["valu_busy"] > 0.6 and roof.get("frac_of_achievable", 1.0) < 0.3:
+                    roof["bound"] = "valu"
+        out = {
+            "value": S * steps * world / dt,
+            "unit": "samples/s",
+            "ms_per_step": dt / steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "config": {"workload": "%s: %d segments x %d annotation tracks x %d intervals, %d units / %d contigs, "
+                                   "%d samples per GPU per step, %s" %
+                                   (self.name, len(flat["segs"]), A, len(flat["annos"]), flat["n_units"],
+                                    flat["n_contigs"], S, self.counters[0]),
+                       "samples_per_step_per_gpu": S,
+                       "sharding": "samples, contiguous ranges per rank; one RCCL all-gather",
+                       "timed_region": "sampling + counting + all-gather (N > 1) + D2H of the count matrix (%d bytes)"
+                                       % (self.host.numel() * 8 if self.host is not None else 0)},
+            "roofline": roof,
+            "kernels": {"k_rng_ms": acc["ms_rng"] / steps, "k_place_ms": acc["ms_place"] / steps,
+                        "k_merge_ms": acc["ms_merge"] / steps, "k_sampler_ms": acc["ms_tail"] / steps,
+                        "k_contig_ms": acc["ms_contig"] / steps, "count_main_ms": main_ms,
+                        "count_phase_ms": acc["ms_count"] / steps, "sampler_phase_ms": acc["ms_sampler"] / steps},
+            "sampler": {"kernel": "k_rng + k_place + k_merge + k_sampler (random rows, placement, consolidation)",
+                        "avg_launch_ms": acc["ms_sampler"] / steps,
+                        "placements_per_s": acc["n_placed"] / samp_s if samp_s else 0.0,
+                        "mt19937_draws_per_s": acc["n_draws"] / samp_s if samp_s else 0.0,
+                        "kernel_samples_per_s": S * steps / samp_s if samp_s else 0.0,
+                        "contig_kernel_avg_ms": acc["ms_contig"] / steps,
+                        "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
+                        "work_units": S * steps * flat["n_units"]},
+            "allgather": allgather,
+        }
+        return out
+
+    def close(self):
+        self.P.close()
+        self.ctx.close()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
-    from gat_amd import _lib, problem, synthetic
+    from gat_amd import synthetic
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
-                         (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # one rank per GPU; GAT_BENCH_SHARE_GPU=1 (testing the N>1 code path on a one-GPU box) lets ranks share devices
@@ -112,117 +306,40 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
-    cfg = synthetic.config(args.config, args.scale)
-    counters = [args.counter or cfg["counter"]]
-    S = args.samples or cfg["num_samples"]
-    flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = _lib.Context(dev_index, stream=stream)
-    P = _lib.Problem(ctx, flat)
-    info = P.info()
-    K, A = len(counters), flat["n_tracks"]
-    counts = torch.zeros((K, A, S), dtype=torch.int64, device=dev)
-    gathered = torch.zeros((world * K, A, S), dtype=torch.int64, device=dev) if world > 1 else None
-
-    def step(i):
-        # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
-        begin = (i * world + rank) * S
-        st = P.sample_and_count_device(counters, args.seed, begin, begin + S, counts.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, counts)
-        return st
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
+    cfg_samples = synthetic.CONFIG_SAMPLES[args.config]
+    W = Workload(args.config, args.samples or cfg_samples, args, dev_index, rank, world)
+    main_out = W.measure(args.steps, args.warmup)
+    out = {"metric": METRIC, "value": main_out["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
+    for k in ("config", "roofline", "kernels", "sampler", "allgather"):
+        out[k] = main_out[k]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    acc = dict(ms_sampler=0.0, ms_contig=0.0, ms_count=0.0, ms_count_main=0.0, n_placed=0, n_draws=0, n_sampled_segments=0, n_retried=0,
-               n_full_units=0)
-    for i in range(args.steps):
-        st = step(args.warmup + i)
-        for k in acc:
-            acc[k] += st[k]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # the one collective of the path, timed by itself after the timed region (the split the report shows per N)
-    allgather_ms = None
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            dist.all_gather_into_tensor(gathered, counts)
-        torch.cuda.synchronize()
-        allgather_ms = (time.perf_counter() - t1) / 5 * 1e3
-
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
+        out["cpu_baseline"] = cpu_baseline(W.flat, W.counters, args.seed, args.cpu_seconds)
+        if args.config in REFERENCE_CYTHON:
+            out["cpu_baseline"]["reference_cython_engine"] = {
+                "value": REFERENCE_CYTHON[args.config], "unit": "samples/s", "cores": 1,
+                "where": "the reference's Cython engine itself, build container (BASELINE.md section 2); it cannot "
+                         "travel to the GPU box, hence kind = port above"}
+    W.close()
+    del W
+    extras = {}
+    for name in [x for x in args.extra.split(",") if x and x != args.config]:
+        torch.cuda.empty_cache()
+        E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world)
+        r = E.measure(max(1, args.extra_steps), 1)
+        r["n_gpus"] = world
+        extras[name] = r
+        E.close()
+        del E
+    if extras:
+        out["configs"] = extras
     if rank == 0:
-        # HBM bytes of the count kernel per launch from the committed rocprofv3 PMC passes of this same
-        # command (tools/collect_profiles.sh): (2 x FETCH_SIZE + WRITE_SIZE) KiB, gfx950 FETCH correction
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_count_kernel_traffic.json")
-        if os.path.exists(tf) and args.scale == 1.0:
-            rec = json.load(open(tf)).get("%s:%d" % (args.config, S))
-            if rec:
-                traffic = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
-        total_samples = S * args.steps * world
-        bytes_per_sample = info["algorithmic_bytes_per_sample"]
-        # the dominant kernel alone (k_count_seg or k_count_swap), HIP events on the launch stream right around it;
-        # ms_count additionally holds the small combining kernel k_count_finish
-        count_s = (acc["ms_count_main"] or acc["ms_count"]) / 1e3
-        samp_s = acc["ms_sampler"] / 1e3
-        achieved = bytes_per_sample * S * args.steps / count_s / 1e9 if count_s > 0 else 0.0
-        out = {
-            "metric": "Monte Carlo samples/sec + bit-exact p-values, 10k sims, hg19-sized workspace",
-            "value": total_samples / dt,
-            "unit": "samples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": "%s: %d segments x %d annotation tracks x %d intervals, %d units / %d contigs, "
-                                   "%d samples per GPU per step, %s" %
-                                   (args.config, len(flat["segs"]), A, len(flat["annos"]), flat["n_units"],
-                                    flat["n_contigs"], S, counters[0]),
-                       "samples_per_step_per_gpu": S, "sharding": "samples, contiguous ranges per rank; one RCCL all-gather"},
-            "roofline": {"bound": "hbm", "kernel": "k_count_seg (overlap counters)",
-                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_per_sample * S,
-                         "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "avg_launch_ms": (acc["ms_count_main"] or acc["ms_count"]) / args.steps,
-                         "count_phase_ms": acc["ms_count"] / args.steps,
-                         "share_of_gpu_time": acc["ms_count"] / max(1e-9, acc["ms_count"] + acc["ms_sampler"] + acc["ms_contig"])},
-            "sampler": {"kernel": "k_rng + k_place + k_sampler (random rows, placement, consolidation)", "avg_launch_ms": acc["ms_sampler"] / args.steps,
-                        "placements_per_s": acc["n_placed"] / samp_s if samp_s else 0.0,
-                        "mt19937_draws_per_s": acc["n_draws"] / samp_s if samp_s else 0.0,
-                        "kernel_samples_per_s": S * args.steps / samp_s if samp_s else 0.0,
-                        "contig_kernel_avg_ms": acc["ms_contig"] / args.steps,
-                        "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
-                        "work_units": S * args.steps * flat["n_units"]},
-            "allgather": None if allgather_ms is None else
-            {"avg_ms": allgather_ms, "bytes_per_rank": int(counts.numel() * 8), "collective": "RCCL all_gather_into_tensor"},
-        }
-        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(flat, counters, args.seed, args.cpu_seconds)
         print(json.dumps(out))
-    P.close()
-    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,7 +16,7 @@ from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sample
                      UnconditionalWorkspace, ConditionalWorkspaceCooccurance, ConditionalWorkspaceCentered,
                      ConditionalWorkspaceAnnotationCentered, ConditionalWorkspaceSegmentCentered, computeCounts, AnnotatorResult, AnnotatorResultExtended,
                      getTwoSidedPValue, updatePValues, getNormedPValue, getEmpiricalPValue, getQValues, updateQValues,
-                     get_context)
+                     get_context, set_device, default_device)
 
 __version__ = "0.1"
 
@@ -25,6 +25,17 @@ COUNTERS = collections.OrderedDict([
     ("segment-overlap", CounterSegmentOverlap), ("segment-midoverlap", CounterSegmentMidpointOverlap),
     ("annotation-overlap", CounterAnnotationOverlap), ("annotation-midoverlap", CounterAnnotationMidpointOverlap),
 ])
+
+
+def _dist_state():
+    """(rank, world size, backend) of an initialised torch.distributed, else (0, 1, None)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size(), dist.get_backend()
+    except ImportError:
+        pass
+    return 0, 1, None
 
 
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
@@ -59,20 +70,33 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
         # (gat/__init__.py:536-538) and each counter sums over no contigs
         zero = [np.zeros(num_samples, dtype=np.float64 if n == "nucleotide-density" else np.int64) for n in names]
         return [collections.OrderedDict((t, zero[k].copy()) for t in tracks) for k in range(len(names))], flat["n_units"]
-    rank, world = 0, 1
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            rank, world = dist.get_rank(), dist.get_world_size()
-    except ImportError:
-        pass
+    rank, world, backend = _dist_state()
     P = _lib.Problem(ctx, flat)
     try:
         begin, end = distributed.shard_range(num_samples, rank, world)
-        local = P.sample_and_count(names, seed, begin, end)
+        if world > 1 and backend == "nccl":
+            # the shard's matrix stays on the device: one RCCL all-gather of device memory, one read-back
+            import torch
+            per = distributed.padded_shard(num_samples, world)
+            dev = torch.device("cuda", ctx.device)
+            shard = torch.zeros((len(names), len(tracks), end - begin), dtype=torch.int64, device=dev)
+            P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())
+            stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
+            stack_t[:, :, :end - begin] = shard
+            full = distributed.allgather_counts(stack_t, num_samples).cpu().numpy()
+            local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
+        else:
+            local = P.sample_and_count(names, seed, begin, end)
+            if world > 1:
+                per = distributed.padded_shard(num_samples, world)
+                stack = np.zeros((len(names), len(tracks), per), dtype=np.int64)
+                for k in range(len(names)):
+                    stack[k, :, :end - begin] = local[k].view(np.int64)
+                full = distributed.gather_numpy(stack, num_samples)
+                local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
         if samples_outfile is not None:
             # --output-samples-pattern (gat/__init__.py:515-559): per sample a track line, then the list the sampler
-            # returned for every non-empty isochore unit under the unit's key
+            # returned for every non-empty isochore unit under the unit's key (a rank writes its own shard)
             seg, off = P.sample(seed, begin, end, unit_level=True)
             U = flat["n_units"]
             for i in range(end - begin):
@@ -84,13 +108,6 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
                         samples_outfile.write("%s\t%i\t%i\n" % (flat["unit_names"][u], s, e))
     finally:
         P.close()
-    if world > 1:
-        per = distributed.padded_shard(num_samples, world)
-        stack = np.zeros((len(names), len(tracks), per), dtype=np.int64)
-        for k in range(len(names)):
-            stack[k, :, :end - begin] = local[k].view(np.int64)
-        full = distributed.gather_numpy(stack, num_samples)
-        local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
     out = []
     for k in range(len(names)):
         out.append(collections.OrderedDict((t, local[k][a]) for a, t in enumerate(tracks)))
@@ -111,8 +128,15 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     output_counts_pattern = kwargs.get("output_counts_pattern", None)
     output_samples_pattern = kwargs.get("output_samples_pattern", None)
     seed = kwargs.get("random_seed", None)
+    rank, world, _ = _dist_state()
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 32))
+        if world > 1:
+            # one base seed for all ranks: their sample-id shards must belong to one family of unit streams
+            import torch.distributed as dist
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
     conditional = getattr(workspace_generator, "is_conditional", False)
     if not isinstance(sampler, (SamplerAnnotator, SamplerSegments)):
         raise NotImplementedError("only SamplerAnnotator and SamplerSegments run on the GPU path")
@@ -123,7 +147,8 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     for track in segments.tracks:
         outf = None
         if output_samples_pattern:
-            outf = open(re.sub("%s", track, output_samples_pattern), "w")
+            # (under torch.distributed every rank writes the samples of its own shard: <file>.rank<r>)
+            outf = open(re.sub("%s", track, output_samples_pattern) + (".rank%d" % rank if world > 1 else ""), "w")
         if conditional:
             # ConditionalSampler.sample (gat/__init__.py:780-850): one sampling pass per annotation, each in the
             # workspace conditioned on (segments, that annotation); only that annotation is counted
@@ -167,7 +192,7 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                     samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
                     annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
                     pseudo_count=pseudo_count, _sizes=sizes))
-    if output_counts_pattern:
+    if output_counts_pattern and rank == 0:               # (every rank holds the gathered matrix: one writer)
         for counter in counters:
             with open(re.sub("%s", counter.name, output_counts_pattern), "w") as outfile:
                 outfile.write("track\tannotation\tobserved\tcounts\n")

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgat_mi355.so")
+# (GAT_LIB_PATH: a diagnostic build of the same library, tools/diag_sampler.sh)
+LIB_PATH = os.environ.get("GAT_LIB_PATH") or os.path.join(HERE, "libgat_mi355.so")
 
 SEG = np.dtype([("start", "<u4"), ("end", "<u4")])
 
@@ -29,6 +30,9 @@ SYMBOLS = [
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_problem_info",
 ]
+
+
+COUNT_KERNELS = {0: "none", 1: "k_count_seg", 2: "k_count_swap", 3: "k_count_merged"}
 
 
 class GatError(RuntimeError):
@@ -68,7 +72,11 @@ class Stats(C.Structure):
         ("n_retried", C.c_int64),
         ("n_full_units", C.c_int64),
         ("ms_count_main", C.c_float),
-        ("reserved0", C.c_float),
+        ("ms_rng", C.c_float),
+        ("ms_place", C.c_float),
+        ("ms_merge", C.c_float),
+        ("ms_tail", C.c_float),
+        ("count_kernel", C.c_int32),
     ]
 
     def asdict(self):

@@ -73,7 +73,17 @@ struct SamplerArgs {
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
+  unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
 };
+
+// In-kernel stamps of the diagnostic build (tools/diag_sampler.sh): shares of a work unit's life per phase.  Stamps
+// fence the schedule, so that build's run time is not quoted; the product build compiles none of this.
+#ifdef GAT_DIAG
+#define GAT_STAMP(T) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); }
+#define GAT_PHASE(K) { unsigned long long t__; GAT_STAMP(t__); dg[K] += t__ - dg_t; dg_t = t__; }
+#else
+#define GAT_PHASE(K) {}
+#endif
 
 constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
 
@@ -729,6 +739,10 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
 
   int nout = 0, status = 0, nuns = 0;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
+#ifdef GAT_DIAG
+  unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_t;
+  GAT_STAMP(dg_t);
+#endif
   if constexpr (KIND == 1) {
     // SamplerSegments.sample (gat/Engine.pyx:695-737): len(segments) placements, no consolidation.  Normally
     // k_place has done all of it (st_length == -2); otherwise the unit is run here from its seed.
@@ -807,6 +821,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
       rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
       placed = (uint32_t)pre.x;
       wave_sync();
+      GAT_PHASE(0)                                   // prologue: unit record, workspace, hand-off record, list into LDS
     } else {
       rng_seed(rng, seed, lane);
       rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
@@ -824,6 +839,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
         if (bucket > 1) len_u += rng_range(rng, bucket - 1u, lane);
         length = (int32_t)len_u;
       }
+      GAT_PHASE(6)                                   // draws + placement arithmetic
 
       // ---- consolidate (:582-606)
       if (remaining <= length) {
@@ -856,6 +872,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
             handled = true;
           }
         }
+        GAT_PHASE(4)                                 // consolidation fast paths (nothing new / one new segment)
         if (!handled) {
           if (BIG && dirty && nU > 0 && nS <= kWave && nU + nS > 1024) {      // (up to 1024 the bucket sort is cheaper)
             // the trim left the merged list sorted but for its placeholders, which merge(0) skips wherever they
@@ -888,7 +905,9 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
           if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)
           else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
+          GAT_PHASE(1)                               // sort / insert
           nU = wave_merge0(seg, n, lane);
+          GAT_PHASE(2)                               // merge(0)
           nS = 0;
           dirty = false;
           cov = 0;
@@ -913,6 +932,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
           }
           cov = wave_total_u32(cov);
           total_known = wave_total_u32(tot);             // sum() of the merged list, for the trim's position draw
+          GAT_PHASE(3)                               // workspace coverage of the merged list
         }
         cov_known = cov;
         cov_valid = true;
@@ -974,6 +994,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
         wave_sync();
         dirty = true;
         true_remaining = 1;
+        GAT_PHASE(5)                                 // overshoot trim
         continue;
       }
 
@@ -1011,8 +1032,10 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
         placed++;
         remaining -= overlap;
       }
+      GAT_PHASE(6)
     }
     ndraws = rng.ndraws;
+    GAT_PHASE(6)
     if (rng.use_pre && rng.exhausted) continue;       // rows ran out: redo this unit from its seed
 
     // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
@@ -1056,8 +1079,13 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
       total = wave_total_u32(total);
       if (!(total > 0)) status |= kStatusAssert;
     }
+    GAT_PHASE(7)                                     // final merge (after a trim), workspace filter, list to the slab
     break;
   }
+#ifdef GAT_DIAG
+  if (lane == 0 && A.diag != nullptr)
+    for (int k = 0; k < 8; ++k) A.diag[so * 8 + k] = dg[k];
+#endif
   if (lane == 0) {
     A.unit_n[so] = nout;
     if (status) atomicOr(A.flags, status);

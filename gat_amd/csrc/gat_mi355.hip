@@ -33,6 +33,9 @@ struct gat_ctx {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // around the dominant count kernel alone (k_count_seg / k_count_swap)
   bool main_recorded = false;
+  int count_kernel = 0;                         // GAT_COUNT_KERNEL_* of the last launch_count
+  hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // behind k_rng, k_place, k_merge_big, k_sampler
+  bool k_recorded = false;
   std::string err;
   int max_lds = 65536;
 };
@@ -203,6 +206,9 @@ struct gat_problem {
   DevBuf<int32_t> d_rng_rows;
   DevBuf<int4> d_st;
   DevBuf<int4> d_st2;                    // k_merge_big -> k_sampler hand-off (first consolidation of the long lists)
+#ifdef GAT_DIAG
+  DevBuf<unsigned long long> d_diag;     // diagnostic build: per work unit, cycles per phase of k_sampler
+#endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
@@ -246,6 +252,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   }
   for (auto& ev : ctx->ev) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_main) HIPCHK(ctx, hipEventCreate(&ev));
+  for (auto& ev : ctx->ev_k) HIPCHK(ctx, hipEventCreate(&ev));
   *out = ctx;
   return GAT_OK;
 }
@@ -255,6 +262,7 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -695,6 +703,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
       ctx->main_recorded = true;
+      ctx->count_kernel = GAT_COUNT_KERNEL_SWAP;
     } else
     if (A.n_contigs > 0) {
     const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
@@ -711,6 +720,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
     ctx->main_recorded = true;
+    ctx->count_kernel = GAT_COUNT_KERNEL_SEG;
     }
     const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
     hipLaunchKernelGGL(gat::k_count_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, A);
@@ -746,9 +756,13 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
 }
 
 // sampler (+ fromIsochores) for one batch; retries with a larger slab on overflow
+// Returns GAT_OK, an error, or kRelayout: a unit's region overflowed, the slab was laid out again with doubled
+// capacities (scratch released: the batch that fits the budget may now be smaller) and nothing of this batch is valid;
+// the caller sizes the batch again and repeats it (results do not depend on the batching: streams are per unit).
+constexpr int kRelayout = 1;
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
                              gat_stats* st, bool timed) {
-  for (;;) {
+  {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
     if (P->batch < nb) return set_err(ctx, GAT_ERR_MEMORY, "internal: batch %lld > scratch %lld", (long long)nb, (long long)P->batch);
@@ -765,6 +779,14 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
+#ifdef GAT_DIAG
+      {
+        const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
+        if (P->d_diag.n < nd) HIPCHK(ctx, P->d_diag.alloc(nd));
+        HIPCHK(ctx, hipMemsetAsync(P->d_diag.p, 0, nd * 8, ctx->stream));
+        A.diag = P->d_diag.p;
+      }
+#endif
       // the units' launch positions are spread over grid y and z (each <= 65535)
       const unsigned n_act = (unsigned)P->h_order.size();
       const unsigned gy = std::min(n_act, 32768u), gz = (n_act + gy - 1) / std::max(gy, 1u);
@@ -780,6 +802,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, gy, gz), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);
         HIPCHK(ctx, hipGetLastError());
+        if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[0], ctx->stream));
         const dim3 gp(nsb, gy, gz);
         const int mode = P->all_simple ? 1 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0);
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
@@ -793,7 +816,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else hipLaunchKernelGGL((gat::k_place<0, 2>), gp, dim3(64), 0, ctx->stream, A);
         }
         HIPCHK(ctx, hipGetLastError());
+        if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[1], ctx->stream));
       }
+      ctx->k_recorded = timed && P->sampler_mode;
       size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
       // SamplerSegments never holds a list; a SamplerAnnotator list beyond LDS is worked on in the slab (HUGE variant)
       const bool huge = P->sampler != GAT_SAMPLER_SEGMENTS && ((int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr);
@@ -835,6 +860,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
         }
       }
+      if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
       // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       const bool tree = P->max_nws > gat::kWsTreeMin;
       int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
@@ -864,6 +890,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         default: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false, 5>), gs, dim3(64), lds, ctx->stream, A); break;
       }
       HIPCHK(ctx, hipGetLastError());
+      if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[3], ctx->stream));
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
                          (int64_t)nb * P->n_units, P->d_stat.p);
       HIPCHK(ctx, hipGetLastError());
@@ -901,8 +928,24 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       if (layout_slab(P)) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments after growth");
       if ((rc = upload_layout(ctx, P))) return rc;
       if (st) st->n_retried += nb * (int64_t)P->h_order.size();
-      continue;
+      return kRelayout;
     }
+#ifdef GAT_DIAG
+    if (const char* fn = getenv("GAT_DIAG_OUT")) {
+      // shares of a k_sampler work unit's life per phase, summed over the batch (tools/diag_sampler.sh)
+      const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
+      std::vector<unsigned long long> h(nd);
+      HIPCHK(ctx, hipMemcpy(h.data(), P->d_diag.p, nd * 8, hipMemcpyDeviceToHost));
+      double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t i = 0; i < nd; ++i) sum[i & 7] += (double)h[i];
+      if (FILE* f = fopen(fn, "a")) {
+        fprintf(f, "{\"work_units\": %lld, \"cycles\": {\"prologue\": %.0f, \"sort\": %.0f, \"merge\": %.0f, \"coverage\": %.0f, "
+                   "\"fast_paths\": %.0f, \"trim\": %.0f, \"draws_placement\": %.0f, \"final_filter_write\": %.0f}}\n",
+                (long long)nb * (long long)P->h_order.size(), sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[6], sum[7]);
+        fclose(f);
+      }
+    }
+#endif
     if (st) {
       st->n_placed += (int64_t)stat[0];
       st->n_draws += (int64_t)stat[1];
@@ -915,6 +958,16 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         st->ms_sampler += ms;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
         st->ms_contig += ms;
+        if (ctx->k_recorded && !P->h_order.empty()) {
+          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev_k[0]));
+          st->ms_rng += ms;
+          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[0], ctx->ev_k[1]));
+          st->ms_place += ms;
+          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[1], ctx->ev_k[2]));
+          st->ms_merge += ms;
+          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[2], ctx->ev_k[3]));
+          st->ms_tail += ms;
+        }
       }
     }
     return GAT_OK;
@@ -954,7 +1007,8 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true))) return rc;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true)) == kRelayout) continue;
+    if (rc) return rc;
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
@@ -963,6 +1017,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     A.out_begin = done;
     HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     ctx->main_recorded = false;
+    ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
     int swap_capx = 0;
     if (P->swap_capx) {
       const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
@@ -979,6 +1034,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
       HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_main[0], ctx->ev_main[1]));
       local.ms_count_main += ms;
     }
+    local.count_kernel = ctx->count_kernel;
     done += nb;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
@@ -1023,7 +1079,8 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true))) return rc;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true)) == kRelayout) continue;
+    if (rc) return rc;
     const bool from_contigs = P->merge_contigs && !unit_level;
     const uint2* src = from_contigs ? P->d_cslab.p : P->d_slab.p;
     const int32_t* nsrc = from_contigs ? P->d_contig_n.p : P->d_unit_n.p;

@@ -18,13 +18,40 @@ from . import problem as _problem
 SEG = iv.SEG
 
 _CTX = {}
+_DEFAULT_DEVICE = None
 
 
-def get_context(device=0, stream=None):
-    """process-wide gat_ctx per (device, stream)."""
-    key = (device, stream)
+def set_device(device):
+    """the HIP device every later get_context() without an argument uses (gat-run.py --device)."""
+    global _DEFAULT_DEVICE
+    _DEFAULT_DEVICE = int(device)
+
+
+def default_device():
+    """process default: set_device() / the first explicit get_context(device); under an initialised
+    torch.distributed one rank drives one GPU, LOCAL_RANK; else device 0."""
+    if _DEFAULT_DEVICE is not None:
+        return _DEFAULT_DEVICE
+    import os
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and "LOCAL_RANK" in os.environ:
+            return int(os.environ["LOCAL_RANK"])
+    except ImportError:
+        pass
+    return 0
+
+
+def get_context(device=None, stream=None):
+    """process-wide gat_ctx per (device, stream); device None = the process default (see default_device)."""
+    global _DEFAULT_DEVICE
+    if device is None:
+        device = default_device()
+    elif _DEFAULT_DEVICE is None:
+        _DEFAULT_DEVICE = int(device)
+    key = (int(device), stream)
     if key not in _CTX:
-        _CTX[key] = _lib.Context(device, stream)
+        _CTX[key] = _lib.Context(int(device), stream)
     return _CTX[key]
 
 

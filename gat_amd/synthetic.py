@@ -107,6 +107,10 @@ def isochores_blocks(contigs, nclasses=8, block=1000000):
     return out
 
 
+# Monte-Carlo samples of each BASELINE.json configuration (config4 / config5 are 8-GPU jobs: 12 500 / 125 000 per GPU)
+CONFIG_SAMPLES = {"config1": 1000, "config2": 10000, "config3": 10000, "config4": 100000, "config5": 1000000}
+
+
 def config(name, scale=1.0):
     """inputs of a BASELINE.json configuration.
 

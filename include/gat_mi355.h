@@ -90,9 +90,18 @@ typedef struct {
   int64_t n_unsuccessful;       /* sum of nunsuccessful_rounds (gat/Engine.pyx:570-572)         */
   int64_t n_retried;            /* work units redone with a larger slab                         */
   int64_t n_full_units;         /* work units run without the lane-parallel front end           */
-  float ms_count_main;          /* the dominant count kernel alone (k_count_seg / k_count_swap)   */
-  float reserved0;
+  float ms_count_main;          /* the dominant count kernel alone (see count_kernel)             */
+  float ms_rng;                 /* split of ms_sampler: k_rng (MT19937 rows)                      */
+  float ms_place;               /*   k_place (placement up to the first consolidation)            */
+  float ms_merge;               /*   k_merge_big (first consolidation of long lists, if launched) */
+  float ms_tail;                /*   k_sampler (consolidation, trim, filter)                      */
+  int32_t count_kernel;         /* GAT_COUNT_KERNEL_* the call used for the overlap counters      */
 } gat_stats;
+
+#define GAT_COUNT_KERNEL_NONE 0
+#define GAT_COUNT_KERNEL_SEG 1      /* k_count_seg: annotation tiles in LDS, sample segments looked up   */
+#define GAT_COUNT_KERNEL_SWAP 2     /* k_count_swap: sample list indexed in LDS, annotation tracks streamed */
+#define GAT_COUNT_KERNEL_MERGED 3   /* k_count_merged: one look-up per sample segment in a merged index of all tracks */
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* device_id: HIP device ordinal.  stream: a hipStream_t to run on (e.g. torch's current

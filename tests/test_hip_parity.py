@@ -232,7 +232,7 @@ def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
 
 
 @pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "large_units_swapped_count", "rows_run_out",
-                                  "slab_overflow_retry", "large_units_many_workspace_segments",
+                                  "slab_overflow_retry", "slab_overflow_retry_batches_shrink", "large_units_many_workspace_segments",
                                   "large_units_one_workspace_segment", "mid_workspace_table"])
 def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     """code paths the BASELINE shapes do not reach: workspace lists beyond the register / LDS tables,
@@ -253,6 +253,12 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     elif case == "rows_run_out":
         monkeypatch.setenv("GAT_RNG_SLACK", "0.6")
         flat = _big_problem(rs, 700, 5)
+    elif case == "slab_overflow_retry_batches_shrink":
+        # a scratch budget of about 15 samples: the 24 samples run in batches, and after the overflow the doubled regions
+        # make the batch that fits the budget smaller -- the remaining samples must be re-batched, not refused
+        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+        monkeypatch.setenv("GAT_SLAB_BYTES", "300000")
+        flat = _big_problem(rs, 700, 5)
     else:
         monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
         flat = _big_problem(rs, 700, 5)
@@ -270,7 +276,7 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     if case == "rows_run_out":
         assert st["n_full_units"] > 0
-    if case == "slab_overflow_retry":
+    if case.startswith("slab_overflow_retry"):
         assert st["n_retried"] > 0
     P.close()
 
@@ -549,7 +555,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--samples", "2000"]
+           "--warmup", "1", "--samples", "2000", "--extra", ""]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -558,6 +564,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["allgather"]["bytes_per_rank"] == 2000 * 8
     assert "cpu_baseline" not in out                      # reported at N = 1 only
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its two ranks itself (a child
+    torch.distributed.run, before the parent touches a GPU) and relays their one JSON line; one extra shape rides along."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))
+    env["GAT_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples",
+           "1000", "--extra", "config1", "--extra-steps", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["value"] > 0
+    assert out["configs"]["config1"]["value"] > 0 and out["configs"]["config1"]["n_gpus"] == 2
 
 
 def test_cli_overlap_stats_match_reference(ctx, tmp_path):
