@@ -25,6 +25,10 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // compiler has to be kept from reordering; the workgroup is a single wave (launch_bounds 64).
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
+// the same between the lanes of one wave inside a workgroup of several waves that do not run in step (no barrier may be
+// used): LDS operations of a wave execute in order; wait for them and keep the compiler from moving accesses across
+__device__ __forceinline__ void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
 // ------------------------------------------------------------------------------------------

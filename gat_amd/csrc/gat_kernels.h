@@ -1224,6 +1224,15 @@ struct CountArgs {
   int32_t lds_entries;        // staging capacity (intervals); 0 => read annotations from global
   int32_t lds_grid;           // staging capacity (grid words)
   uint32_t* part;             // [n_contigs][3][n_tracks][n_samples] per-contig partial counts
+  // merged multi-track index (k_count_merged): per contig all tracks' intervals sorted by start
+  const uint4* mz;            // entries {start, end, track, 0}; long intervals cut into pieces; a sentinel start ends every contig
+  const int64_t* mz_off;      // n_contigs+1
+  const uint32_t* mfirst;     // per contig and position cell: first entry that reaches into the cell or starts in / after it
+  const int64_t* mf_off;      // n_contigs+1
+  const int32_t* m_shift;     // n_contigs: log2 of the cell width
+  const int32_t* m_cells;     // n_contigs
+  const int32_t* m_slot_off;  // kMergedSlots+1: the contigs of an XCD slot are m_slot_contigs[m_slot_off[x] .. m_slot_off[x+1])
+  const int32_t* m_slot_contigs;
 };
 
 struct AnnoView {
@@ -1396,6 +1405,108 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
       }
     }
   }
+}
+
+// nucleotide-overlap / nucleotide-density against MANY tracks: one look-up per sample segment instead of one per
+// (segment, track).  A sample segment overlaps an interval of very few tracks (config 3: 0.8 of 100 on average), so the
+// host merges all tracks' intervals of a contig into one list sorted by start (entries carry their track; intervals
+// longer than a bound are cut into pieces, which changes no sum) with a position grid first[cell] = the first entry that
+// reaches into the cell or starts in or behind it.  A lane scans from first[cell of x.start] while start < x.end and adds
+// min(ends) - max(starts) of every entry it meets to the track's uint32 accumulator in LDS (gat/SegmentList.pyx:1026-1076
+// sums the same pairs per track; uint32 addition is order independent).
+//   The look-ups are 16-byte gathers all over a contig's index: from the Infinity Cache they ran at its gather rate
+// (2.6 ms per 10 000 samples of config 3).  One contig's index is below 1 MB (config 3), so the work is dealt such
+// that an XCD's L2 serves it: a workgroup owns (contig, group of samples), the contigs are spread over eight slots by
+// the host (balanced by their segment counts), slot = blockIdx % 8 -- the stride with which workgroups are observed to
+// go round the XCDs (speed only; any placement gives the same sums) -- and a slot walks its contigs one after the other.
+// Every wave takes whole samples: its accumulators are wave-private LDS, there is no workgroup barrier.  Per (contig,
+// sample) the T partial sums go to part[c][s][t]; k_count_merged_finish adds them over the contigs in reference order.
+constexpr int kMergedThreads = 256;
+constexpr int kMergedSlots = 8;
+__global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int T = A.n_tracks;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint32_t* acc = lds + (size_t)wave * T;
+  const int slot = blockIdx.x % kMergedSlots, q = blockIdx.x / kMergedSlots;
+  const int SG = A.samples_per_block, n_groups = (A.n_samples + SG - 1) / SG;
+  const int ci = q / n_groups, grp = q - ci * n_groups;
+  if (ci >= A.m_slot_off[slot + 1] - A.m_slot_off[slot]) return;
+  const int c = A.m_slot_contigs[A.m_slot_off[slot] + ci];
+  const uint4* __restrict__ Z = A.mz + A.mz_off[c];
+  const uint32_t* __restrict__ F = A.mfirst + A.mf_off[c];
+  const int shift = A.m_shift[c];
+  const uint32_t last = (uint32_t)(A.m_cells[c] - 1);
+  const int nidx = A.n_index[c], coff = A.c_off[c];
+  for (int t = lane; t < T; t += kWave) acc[t] = 0u;
+  const int s_end = min(A.n_samples, (grp + 1) * SG);
+  for (int s = grp * SG + wave; s < s_end; s += kMergedThreads / kWave) {
+    const int n = A.n_arr[(int64_t)s * A.n_stride + nidx];
+    const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + coff;
+    constexpr int kR = 4;                                            // segments per lane whose look-ups are in flight together
+    for (int base = 0; base < n; base += kR * kWave) {
+      uint2 x[kR];
+      uint32_t k[kR];
+      uint4 z[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int i = base + r * kWave + lane;
+        x[r] = i < n ? X[i] : make_uint2(0u, 0u);                    // (an empty segment meets nothing: start < 0 never holds)
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) z[r] = Z[k[r]];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        while (z[r].x < x[r].y) {                                    // the contig's sentinel start 0xffffffff ends the scan
+          const uint32_t lo = z[r].x > x[r].x ? z[r].x : x[r].x, hi = z[r].y < x[r].y ? z[r].y : x[r].y;
+          if (hi > lo) atomicAdd(&acc[z[r].z], hi - lo);
+          z[r] = Z[++k[r]];
+        }
+      }
+    }
+    wave_fence();
+    uint32_t* __restrict__ dst = A.part + ((int64_t)c * A.n_samples + s) * T;
+    for (int t = lane; t < T; t += kWave) { dst[t] = acc[t]; acc[t] = 0u; }
+    wave_fence();
+  }
+}
+
+// sum([...]) over the contigs in list(sample.keys()) order (gat/__init__.py:578-587) of k_count_merged's partials:
+// Python ints, or left-to-right IEEE doubles of float(overlap)/len(workspace) (gat/Engine.pyx:1437-1441).  A workgroup
+// takes 16 samples x 16 tracks: the partials are read with the tracks along the lanes (as they were written), the matrix
+// is written with the samples along the lanes (its layout), the tile is turned in LDS.
+__global__ __launch_bounds__(256) void k_count_merged_finish(CountArgs A) {
+  __shared__ int64_t t_o[16][17];
+  __shared__ double t_d[16][17];
+  const int T = A.n_tracks;
+  const int tiles_t = (T + 15) / 16;
+  const int t0 = (int)(blockIdx.x % tiles_t) * 16, s0 = (int)(blockIdx.x / tiles_t) * 16;
+  {
+    const int ts = threadIdx.x >> 4, tt = threadIdx.x & 15;
+    const int s = s0 + ts, t = t0 + tt;
+    int64_t ov = 0;
+    double dens = 0.0;
+    if (s < A.n_samples && t < T) {
+      for (int c = 0; c < A.n_contigs; ++c) {
+        const uint32_t o = A.part[((int64_t)c * A.n_samples + s) * T + t];
+        ov += (int64_t)o;
+        const double nseg = (double)(uint32_t)A.cws_nseg[c];
+        if (nseg != 0.0) dens += (double)o / nseg;
+      }
+    }
+    t_o[tt][ts] = ov;
+    t_d[tt][ts] = dens;
+  }
+  __syncthreads();
+  const int tt = threadIdx.x >> 4, ts = threadIdx.x & 15;
+  const int s = s0 + ts, t = t0 + tt;
+  if (s >= A.n_samples || t >= T) return;
+  const int64_t col = A.out_begin + s;
+  const int k0 = A.counter_slot[0], k1 = A.counter_slot[1];
+  if (k0 >= 0) A.out[((int64_t)k0 * T + t) * A.out_stride + col] = t_o[tt][ts];
+  if (k1 >= 0) A.out[((int64_t)k1 * T + t) * A.out_stride + col] = __double_as_longlong(t_d[tt][ts]);
 }
 
 // Roles swapped for long sample lists (overlap is symmetric): one block per (sample, contig) builds

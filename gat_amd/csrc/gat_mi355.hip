@@ -87,6 +87,14 @@ struct AnnoDev {
   DevBuf<int64_t> off, goff;
   DevBuf<int32_t> shift, cells;
   std::vector<int64_t> h_off;
+  // merged multi-track index (k_count_merged), built for problems with several tracks
+  DevBuf<uint4> mz;
+  DevBuf<uint32_t> mfirst;
+  DevBuf<int64_t> mz_off, mf_off;
+  DevBuf<int32_t> m_shift, m_cells, m_slot_off, m_slot_contigs;
+  int max_slot_contigs = 0;
+  bool has_merged = false;
+  int64_t merged_entries = 0;
   int64_t max_m = 0;
   int64_t max_cells = 0;
   int64_t total = 0;
@@ -103,6 +111,101 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
       return set_err(ctx, GAT_ERR_ASSERT, "%s list %lld is not normalized: %u-%u overlaps/precedes %u-%u", what,
                      (long long)idx, s[i - 1].start, s[i - 1].end, s[i].start, s[i].end);
   }
+  return GAT_OK;
+}
+
+// The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, each
+// entry {start, end, track}.  Intervals longer than `bound` (a power of two >= 8 x the group's mean length) are cut into
+// pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more than `bound` bases; first[g] is
+// the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a segment starting in cell g begins.
+static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
+                        int32_t n_groups) {
+  std::vector<uint4> hz;
+  std::vector<uint32_t> hf;
+  std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
+  std::vector<int32_t> h_shift((size_t)n_groups, 0), h_cells((size_t)n_groups, 1);
+  std::vector<uint4> e;
+  for (int c = 0; c < n_groups; ++c) {
+    e.clear();
+    uint64_t total_len = 0, cnt = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) { total_len += annos[i].end - annos[i].start; ++cnt; }
+    }
+    uint32_t bound = 1024;
+    while (cnt > 0 && (uint64_t)bound < 8 * (total_len / cnt) && bound < (1u << 30)) bound <<= 1;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
+        uint32_t s0 = annos[i].start;
+        const uint32_t e0 = annos[i].end;
+        while (e0 - s0 > bound) { e.push_back(make_uint4(s0, s0 + bound, (uint32_t)t, 0u)); s0 += bound; }
+        e.push_back(make_uint4(s0, e0, (uint32_t)t, 0u));
+      }
+    }
+    std::sort(e.begin(), e.end(), [](const uint4& a, const uint4& b) { return a.x != b.x ? a.x < b.x : a.z < b.z; });
+    const size_t ne = e.size();
+    if (ne >= 0xfffffff0ull) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
+    const uint32_t max_start = ne ? e[ne - 1].x : 0u;
+    int64_t target = 64;
+    while (target < (int64_t)ne) target <<= 1;                      // about one entry per cell
+    int sh = 0;
+    while (((int64_t)max_start >> sh) + 1 > target) ++sh;
+    const int64_t cells = ((int64_t)max_start >> sh) + 1;
+    h_shift[(size_t)c] = sh;
+    h_cells[(size_t)c] = (int32_t)cells;
+    const size_t fo = hf.size();
+    hf.resize(fo + (size_t)cells);
+    {
+      size_t k = 0;                                                 // first entry starting at or behind the cell's start
+      for (int64_t g = 0; g < cells; ++g) {
+        const uint64_t cs = (uint64_t)g << sh;
+        while (k < ne && (uint64_t)e[k].x < cs) ++k;
+        hf[fo + (size_t)g] = (uint32_t)k;
+      }
+      for (size_t i = 0; i < ne; ++i) {                             // ... or an earlier one that reaches past it
+        for (int64_t g = ((int64_t)e[i].x >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].y; ++g)
+          if ((uint32_t)i < hf[fo + (size_t)g]) hf[fo + (size_t)g] = (uint32_t)i;
+      }
+    }
+    hz.insert(hz.end(), e.begin(), e.end());
+    hz.push_back(make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u));     // ends every scan
+    hz_off[(size_t)c + 1] = (int64_t)hz.size();
+    hf_off[(size_t)c + 1] = (int64_t)hf.size();
+  }
+  HIPCHK(ctx, A.mz.upload(hz, ctx->stream));
+  HIPCHK(ctx, A.mfirst.upload(hf, ctx->stream));
+  HIPCHK(ctx, A.mz_off.upload(hz_off, ctx->stream));
+  HIPCHK(ctx, A.mf_off.upload(hf_off, ctx->stream));
+  HIPCHK(ctx, A.m_shift.upload(h_shift, ctx->stream));
+  HIPCHK(ctx, A.m_cells.upload(h_cells, ctx->stream));
+  {
+    // the groups dealt to the eight XCD slots of k_count_merged: largest first, each to the slot with the least so far
+    std::vector<std::pair<int64_t, int>> w;
+    for (int c = 0; c < n_groups; ++c) w.push_back(std::make_pair(hz_off[(size_t)c + 1] - hz_off[(size_t)c], c));
+    std::sort(w.begin(), w.end(), [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) {
+      return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    std::vector<std::vector<int32_t>> slots((size_t)gat::kMergedSlots);
+    std::vector<int64_t> load((size_t)gat::kMergedSlots, 0);
+    for (auto& x : w) {
+      size_t best = 0;
+      for (size_t k = 1; k < load.size(); ++k) if (load[k] < load[best]) best = k;
+      slots[best].push_back(x.second);
+      load[best] += x.first;
+    }
+    std::vector<int32_t> so((size_t)gat::kMergedSlots + 1, 0), sc;
+    A.max_slot_contigs = 0;
+    for (size_t k = 0; k < slots.size(); ++k) {
+      for (int32_t c : slots[k]) sc.push_back(c);
+      so[k + 1] = (int32_t)sc.size();
+      A.max_slot_contigs = std::max<int>(A.max_slot_contigs, (int)slots[k].size());
+    }
+    if (sc.empty()) sc.push_back(0);
+    HIPCHK(ctx, A.m_slot_off.upload(so, ctx->stream));
+    HIPCHK(ctx, A.m_slot_contigs.upload(sc, ctx->stream));
+  }
+  A.has_merged = true;
+  A.merged_entries = (int64_t)hz.size();
   return GAT_OK;
 }
 
@@ -171,6 +274,11 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
   HIPCHK(ctx, A.end.upload(he, ctx->stream));
   HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
   HIPCHK(ctx, A.off.upload(A.h_off, ctx->stream));
+  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  if (n_groups > 0 && n_tracks >= (env_mm ? atoi(env_mm) : 4)) {
+    int rc = build_merged(ctx, A, annos, anno_off, n_tracks, n_groups);
+    if (rc) return rc;
+  }
   return GAT_OK;
 }
 
@@ -689,6 +797,34 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), gpy, gpz);
     const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
     const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
+    const size_t lds_merged = (size_t)A.n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
+    if (A.n_contigs > 0 && only_overlap && annos.has_merged && lds_merged <= 64 * 1024 && !getenv("GAT_COUNT_NO_MERGED")) {
+      // several tracks: one look-up per sample segment in the merged index of all tracks
+      A.mz = annos.mz.p; A.mz_off = annos.mz_off.p; A.mfirst = annos.mfirst.p; A.mf_off = annos.mf_off.p;
+      A.m_shift = annos.m_shift.p; A.m_cells = annos.m_cells.p;
+      A.m_slot_off = annos.m_slot_off.p; A.m_slot_contigs = annos.m_slot_contigs.p;
+      const char* env_sg = getenv("GAT_MERGED_SAMPLES_PER_BLOCK");
+      int SG = env_sg ? atoi(env_sg) : 32;                 // samples per workgroup: the contig's index stays hot meanwhile
+      SG = std::max(1, std::min(SG, std::max(1, A.n_samples)));
+      A.samples_per_block = SG;
+      const int64_t n_sgroups = (A.n_samples + SG - 1) / SG;
+      const int64_t nblocks = (int64_t)gat::kMergedSlots * annos.max_slot_contigs * n_sgroups;
+      if (nblocks >= ((int64_t)1 << 31)) return set_err(ctx, GAT_ERR_CAPACITY, "more than 2^31 (contig, sample group) pairs");
+      const size_t need = (size_t)A.n_contigs * (size_t)A.n_tracks * (size_t)A.n_samples;
+      if (part.n < need) HIPCHK(ctx, part.alloc(need));
+      A.part = part.p;
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
+      HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
+      hipLaunchKernelGGL(gat::k_count_merged, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
+      ctx->main_recorded = true;
+      ctx->count_kernel = GAT_COUNT_KERNEL_MERGED;
+      const int64_t tiles = (int64_t)((A.n_tracks + 15) / 16) * ((A.n_samples + 15) / 16);
+      hipLaunchKernelGGL(gat::k_count_merged_finish, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+      goto seg_done;
+    }
     if (A.n_contigs > 0 && swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) {
       // long sample lists against short annotation lists: index the sample list, stream the tracks
       gat::CountArgs B = A;
@@ -722,9 +858,12 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     ctx->main_recorded = true;
     ctx->count_kernel = GAT_COUNT_KERNEL_SEG;
     }
-    const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
-    hipLaunchKernelGGL(gat::k_count_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, A);
-    HIPCHK(ctx, hipGetLastError());
+    {
+      const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
+      hipLaunchKernelGGL(gat::k_count_finish, dim3((unsigned)((nfin + 255) / 256)), dim3(256), 0, ctx->stream, A);
+      HIPCHK(ctx, hipGetLastError());
+    }
+  seg_done:;
   }
   if (C.any_anno) {
     // the sample lists indexed in LDS when they fit (list_cap = longest list possible), else every interval bisects

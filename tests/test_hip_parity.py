@@ -729,3 +729,57 @@ def _edge_case(ctx, seed):
 def test_fuzz_edge_cases_vs_oracle(ctx, seed):
     """the corners (see _edge_case): equal to the oracle, or the same exception on both sides"""
     assert _edge_case(ctx, seed) in ("compared", "skipped", "both raised ValueError", "both raised AssertionError")
+
+
+@pytest.mark.parametrize("seed", list(range(300, 316)))
+def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
+    """k_count_merged (nucleotide counters against several tracks through one merged, position-gridded index of all
+    tracks): forced on from one track up, on shapes that stress it -- intervals far longer than the piece bound (cut into
+    pieces), tracks that overlap each other heavily, empty tracks / contigs, isochores, dense sample lists -- against the
+    oracle, and against the per-track kernel on the same problem."""
+    import collections
+    from gat_amd import problem, intervals as iv
+    monkeypatch.setenv("GAT_MERGED_MIN_TRACKS", "1")
+    rs = np.random.RandomState(seed)
+    contigs = collections.OrderedDict(("m%d" % i, int(rs.randint(100000, 2000000))) for i in range(int(rs.randint(1, 4))))
+    segs = synthetic.random_segments(contigs, int(rs.choice([40, 400, 3000])), int(rs.choice([30, 300, 2000])), int(rs.randint(1 << 30)))
+    n_tracks = int(rs.choice([1, 3, 17, 60]))
+    annos = []
+    for t in range(n_tracks):
+        per = synthetic.random_segments(contigs, int(rs.randint(1, 500)), int(rs.choice([20, 500, 5000])), int(rs.randint(1 << 30)))
+        if t % 5 == 1:                                    # a few giants: far beyond 8 x the mean length
+            for c, size in contigs.items():
+                a0 = int(rs.randint(0, size // 2))
+                per[c] = iv.normalize(np.concatenate([per.get(c, iv.EMPTY), iv.make([a0], [a0 + size // 3])]))
+        if t % 7 == 3:
+            per = collections.OrderedDict()               # an empty track
+        annos.append(("t%d" % t, per))
+    ws = synthetic.workspace_ungapped(contigs, pieces=int(rs.choice([1, 4])), gap=500)
+    iso = synthetic.isochores_blocks(contigs, nclasses=3, block=40000) if seed % 3 == 0 else None
+    flat = problem.flatten_arrays(segs, annos, ws, iso)
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    S = 6
+    want, _ = O.run_samples(flat, counters, 400 + seed, 1, 0, S)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 400 + seed, 0, S)
+    assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), (c, n_tracks)
+    monkeypatch.setenv("GAT_COUNT_NO_MERGED", "1")
+    other = P.sample_and_count(counters, 400 + seed, 0, S)
+    assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] != "k_count_merged"
+    for k in range(2):
+        assert np.array_equal(other[k], want[k])
+    P.close()
+    # observed counts (gat_count_lists) take the same kernel
+    monkeypatch.delenv("GAT_COUNT_NO_MERGED")
+    C = flat["n_contigs"]
+    lists = [flat["segs"][flat["seg_off"][u]:flat["seg_off"][u + 1]] for u in range(flat["n_units"])]
+    if iso is None and C == flat["n_units"]:
+        off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        got = ctx.count_lists(counters, np.concatenate(lists), off, 1, flat["annos"], flat["anno_off"], flat["n_tracks"],
+                              flat["cws_nseg"], C)
+        for t in range(flat["n_tracks"]):
+            vals = [O.counter("nucleotide-overlap", lists[c], flat["annos"][flat["anno_off"][t * C + c]:flat["anno_off"][t * C + c + 1]])
+                    for c in range(C)]
+            assert got[0][t, 0] == int(sum(vals))
