@@ -10,7 +10,7 @@ import numpy as np
 from . import intervals, problem, synthetic            # noqa: F401
 from . import io as IO                                   # noqa: F401
 from . import stats as Stats                             # noqa: F401
-from .engine import (SegmentList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator, SamplerSegments,  # noqa: F401
+from .engine import (SegmentList, PositionList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator, SamplerSegments,  # noqa: F401
                      Counter, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
                      UnconditionalWorkspace, ConditionalWorkspaceCooccurance, ConditionalWorkspaceCentered,
@@ -52,6 +52,14 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
     from . import _lib, distributed
     if workspace.sum() == 0:
         return None, 0
+    if annotations.hasPositions():
+        # point annotations: the reference gets as far as the two counters that call into PositionList without isochores
+        # (probed on the scratch build); anything else dies with this TypeError (gat/Engine.pyx:2866, :1417-1457)
+        from .engine import POINT_COUNTERS, _points_type_error
+        if any("." in k and k != "." for k in segs.keys()):
+            raise _points_type_error()
+        if any(c.name not in POINT_COUNTERS for c in counters):
+            raise _points_type_error("annotations")
     ctx = ctx or get_context()
     tracks = list(annotations.tracks) if only_tracks is None else list(only_tracks)
     count_workspace = None
@@ -238,6 +246,8 @@ def buildParser(usage=None):
                  help="the segments file is arranged in tracks")
     g.add_option("--enable-split-tracks", dest="enable_split_tracks", action="store_true")
     g.add_option("--annotations-label", dest="annotations_label", type="string")
+    g.add_option("--annotations-to-points", dest="annotations_to_points", type="choice", choices=("midpoint", "start", "end"),
+                 help="convert annotations from segments to positions (counters annotation-overlap / annotation-midoverlap)")
     g.add_option("--input-counts-file", dest="input_filename_counts", type="string",
                  help="start from a counts table written by --output-counts-pattern (statistics re-computed)")
     g.add_option("--input-results-file", dest="input_filename_results", type="string",

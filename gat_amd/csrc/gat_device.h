@@ -502,13 +502,16 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
 }
 
 // bucket sort when possible (scratch available, list short enough), else the sorting network
+template <int MAXE = 8>
 __device__ __forceinline__ void wave_sort_fast(uint2* seg, int n, uint32_t* scratch, int lane) {
   if (n < 2) return;
   bool done = false;
   if (scratch != nullptr && n > 64) {
     if (n <= 256) done = wave_sort_bucket<4>(seg, n, scratch, lane);
     else if (n <= 512) done = wave_sort_bucket<8>(seg, n, scratch, lane);
-    else if (n <= 1024) done = wave_sort_bucket<16>(seg, n, scratch, lane);
+    // (k_sampler, MAXE = 8: the first consolidation sorts longer lists straight from the slab, wave_sort_bucket_global;
+    //  a later full sort of such a list -- after a trim with many new segments -- is rare and takes the network)
+    else if (MAXE >= 16 && n <= 1024) done = wave_sort_bucket<16>(seg, n, scratch, lane);
   }
   if (!done) wave_sort_auto(seg, n, lane);
 }

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
         for (int i = lane; i < nU; i += kWave) seg[i] = out[i];
       } else
       // (a list the counting sort will take straight from the slab need not be copied first)
-      if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0))
+      if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0) && !(nS > 512 && nS <= 1024))
         for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
       remaining = pre.y;
       pending = pre_len;
@@ -895,6 +895,14 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
             if (!wave_sort_bucket_global(seg, out, n, big, nb, lane)) {
               for (int i = lane; i < n; i += kWave) seg[i] = out[i];
               wave_sort_by_start(seg, n, lane);
+            }
+          } else if (!HUGE && resume && nU == 0 && !dirty && n > 512 && n <= 1024 && n == pre.x) {
+            // 513..1024 segments, still where k_place wrote them: the same counting sort with 512 buckets (the bucket sort
+            // that holds the whole list in registers needs 16 elements per lane here -- over a hundred registers, which cost
+            // every wave of the kernel spills: 128 VGPRs + 76 bytes of scratch against 106 without)
+            if (!wave_sort_bucket_global(seg, out, n, mt, 512, lane)) {
+              for (int i = lane; i < n; i += kWave) seg[i] = out[i];
+              wave_sort_auto(seg, n, lane);
             }
           } else if (BIG && nU > 0 && !dirty && n > 1024 && nS <= 1024) {
             // a long clean list and some new segments: insert them 64 at a time (a pass over the list each) rather than
@@ -1177,7 +1185,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     }
     n += (int)wave_total_u32((uint32_t)my_cnt);
   }
-  wave_sort_fast(seg, n, scratch, lane);
+  wave_sort_fast<16>(seg, n, scratch, lane);
   n = wave_merge0(seg, n, lane);
   if (!HUGE)
     for (int i = lane; i < n; i += kWave) out[i] = seg[i];

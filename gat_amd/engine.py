@@ -176,6 +176,8 @@ class SegmentList(object):
         self._a = iv.filter(self._a, other._a)
 
     def intersect(self, other):
+        if getattr(other, "is_points", False):
+            raise _points_type_error()
         assert self.isNormalized, "intersection of a non-normalized list"
         assert other.isNormalized, "intersection with non-normalized list"
         if other is self:
@@ -236,6 +238,103 @@ def _count_pair(counter, segments, annotations, ws_nseg=1):
     a, b = segments._a, annotations._a
     r = ctx.count_lists([counter], a, [0, len(a)], 1, b, [0, len(b)], 1, [ws_nseg], 1)
     return r[0][0, 0]
+
+
+POINT_COUNTERS = ("annotation-overlap", "annotation-midoverlap")
+
+
+def _points_type_error(what="other"):
+    """what the reference raises when a PositionList reaches code typed for SegmentList (every counter but the two
+    annotation counters, fromIsochores, merge: gat/Engine.pyx:2200, :2866, :3007)."""
+    return TypeError("Argument '%s' has incorrect type (expected gat.SegmentList.SegmentList, got "
+                     "gat.PositionList.PositionList)" % what)
+
+
+class PositionList(SegmentList):
+    """sorted list of positions (gat/PositionList.pyx:42), what --annotations-to-points turns annotation intervals
+    into.  A position p is held as the one-base interval [p, p+1): "p lies in a segment" (intersectionWithSegments,
+    gat/PositionList.pyx:490-540) is then exactly CounterAnnotationOverlap on that interval, so the flat problem and
+    the device kernels take a PositionList as it is."""
+    is_points = True
+
+    def __init__(self, allocate=0, clone=None, iter=None, sort=False, normalize=False):  # noqa: A002
+        SegmentList.__init__(self, clone=clone)
+        if clone is None and iter is not None:
+            p = np.fromiter(iter, dtype=np.int64)
+            self._a = iv.make(p, p + 1)
+            self.isNormalized = 0
+        if sort:
+            self.sort()
+        if normalize:
+            self.normalize()
+
+    def fromSegmentList(self, segments, method="midpoint"):
+        """gat/PositionList.pyx:288-336: one position per non-empty segment."""
+        a = segments._a[segments._a["end"] != segments._a["start"]]
+        start, end = a["start"].astype(np.int64), a["end"].astype(np.int64)
+        if method == "midpoint":
+            p = start + (end - start) // 2
+        elif method == "start":
+            p = start
+        elif method == "end":
+            p = end
+        else:
+            raise ValueError("unknow method '%s'" % method)
+        self._a = iv.make(p, p + 1)
+        self.isNormalized = 1 if segments.isNormalized else 0
+
+    def __iter__(self):
+        return iter(self._a["start"].tolist())
+
+    def __getitem__(self, i):
+        return int(self._a["start"][i])
+
+    def asList(self):
+        return self._a["start"].tolist()
+
+    def add(self, pos):
+        if pos < 0 or pos >= (1 << 32) - 1:
+            raise OverflowError("can't convert negative value to unsigned int")
+        self._a = np.concatenate([self._a, iv.make([pos], [pos + 1])])
+        self.isNormalized = 0
+
+    def clone(self):
+        return PositionList(clone=self)
+
+    def sort(self):
+        self._a = self._a[np.argsort(self._a["start"], kind="stable")]
+
+    def normalize(self):
+        """sort, equal positions once (gat/PositionList.pyx:350-374)."""
+        self._a = np.unique(self._a)
+        self.isNormalized = 1
+
+    def sum(self):  # noqa: A003
+        """the number of positions (gat/PositionList.pyx:237)."""
+        return len(self._a)
+
+    def max(self):  # noqa: A003
+        return int(self._a["start"][-1]) if len(self._a) else 0
+
+    def min(self):  # noqa: A003
+        return int(self._a["start"][0]) if len(self._a) else 0
+
+    def intersect(self, other):
+        """keep the positions that lie in a segment of `other` (gat/PositionList.pyx:542-585)."""
+        if getattr(other, "is_points", False):
+            raise _points_type_error()
+        assert other.isNormalized, "Intersection with non-normalized segments"
+        self._a = iv.intersect(self._a, other._a)
+
+    def intersectionWithSegments(self, other, mode="base"):
+        """number of positions inside segments of `other`; `mode` is unused (gat/PositionList.pyx:490-540)."""
+        assert other.isNormalized, "Intersection with non-normalized segments"
+        return int(_count_pair("annotation-overlap", other, self))
+
+    def _unsupported(self, *args, **kwargs):
+        raise _points_type_error()
+    # the reference's PositionList has none of these; what reaches for them there dies with a TypeError / AttributeError
+    filter = merge = extend = overlapWithSegments = extend_segments = expand_segments = getLengthDistribution = _unsupported
 
 
 # ------------------------------------------------------------------------------------------------
@@ -335,7 +434,7 @@ class IntervalDictionary(object):
         if other is self:
             return None
         for d in (self, other):
-            if any(not v.isNormalized for v in d.intervals.values()):
+            if any(not v.isNormalized or getattr(v, "is_points", False) for v in d.intervals.values()):
                 return None
         # keys only one side holds contribute nothing, so every key of self keeps its own position and the flat
         # form of self can be reused for every `other` of a run
@@ -382,6 +481,8 @@ class IntervalDictionary(object):
             isochore = isochore.strip()
             if "." in isochore and isochore != ".":
                 contig, _ = isochore.split(".")
+                if getattr(segmentlist, "is_points", False):
+                    raise _points_type_error()               # new[contig] is a SegmentList (gat/Engine.pyx:2866)
                 new[contig].extend(segmentlist)
                 normalize = True
             else:
@@ -460,10 +561,24 @@ class IntervalCollection(object):
             for s in vv.intervals.values():
                 s.check()
 
+    def toPositions(self, method="mid-point"):
+        """every SegmentList becomes the PositionList of its segments' midpoints / starts / ends
+        (gat/Engine.pyx:3103-3109; --annotations-to-points, gat/IO.py:134-135)."""
+        for vv in self.intervals.values():
+            for contig in list(vv.keys()):
+                p = PositionList()
+                p.fromSegmentList(vv[contig], method=method)
+                vv[contig] = p
+
+    def hasPositions(self):
+        return any(getattr(s, "is_points", False) for vv in self.intervals.values() for s in vv.intervals.values())
+
     def merge(self, delete=False):
         merged = IntervalDictionary()
         for track in list(self.intervals.keys()):
             for contig, segmentlist in self.intervals[track].items():
+                if getattr(segmentlist, "is_points", False):
+                    raise _points_type_error()               # merged[contig] is a SegmentList (gat/Engine.pyx:3007)
                 merged[contig].extend(segmentlist)
             if delete:
                 del self.intervals[track]
@@ -726,6 +841,8 @@ def computeCounts(counter, aggregator, segments, annotations, workspace, workspa
     seg_tracks = list(segments.tracks)
     if not seg_tracks or not tracks:
         return counts
+    if counter.name not in POINT_COUNTERS and annotations.hasPositions():
+        raise _points_type_error("annotations")              # gat/Engine.pyx:2200: counter(SegmentList, PositionList, ..)
     lists = [segments[t][i].asArray() for t in seg_tracks for i in isochores]
     annos = [annotations[a][i].asArray() for a in tracks for i in isochores]
     lcat, loff = _problem._cat(lists)
@@ -878,7 +995,10 @@ class AnnotatorResultExtended(AnnotatorResult):
                  if hasattr(track_segments, "intersect_stats") else None)
         if stats is None:
             overlap = track_segments.clone()
-            overlap.intersect(annotation_segments)
+            try:
+                overlap.intersect(annotation_segments)
+            except TypeError:
+                pass       # SegmentList x PositionList: "needs still to be implemented" (gat/Engine.pyx:1917-1923)
             stats = (overlap.counts(), overlap.sum())
         self.overlap_nsegments, self.overlap_size = stats
         self.workspace_size = cached(workspace)[1]

@@ -116,86 +116,99 @@ def expandGlobs(infiles):
     return out
 
 
+# The input pipeline of gat-run.py, the reference's gat/IO.py:88-293, written as two small tables: which files make up
+# which collection and what each collection goes through before the sampler sees it.  The names and the order of the
+# --output-stats / --output-bed side files follow the reference (tests/golden/cli/aux/stats/ pins them byte for byte).
+_REQUIRED_INPUTS = (("segment_files", "segment"), ("annotation_files", "annotation"), ("workspace_files", "workspace"))
+
+
 def buildSegments(options):
-    """gat/IO.py:88-185: load and normalize segments, annotations, workspace (collapsed), isochores."""
-    options.segment_files = expandGlobs(options.segment_files)
-    options.annotation_files = expandGlobs(options.annotation_files)
-    options.workspace_files = expandGlobs(options.workspace_files)
-    if not options.segment_files:
-        raise ValueError("please specify at least one segment file")
-    if not options.annotation_files:
-        raise ValueError("please specify at least one annotation file")
-    if not options.workspace_files:
-        raise ValueError("please specify at least one workspace file")
+    """the four collections of a run -- segment tracks, annotation tracks, the collapsed workspace and (optionally)
+    isochores restricted to it -- loaded and normalized as gat/IO.py:88-185 does."""
+    for attr, what in _REQUIRED_INPUTS:
+        setattr(options, attr, expandGlobs(getattr(options, attr)))
+        if not getattr(options, attr):
+            raise ValueError("please specify at least one %s file" % what)
+
     segments = readSegmentList("segments", options.segment_files, ignore_tracks=options.ignore_segment_tracks)
     segments.normalize()
     if segments.sum() == 0:
         raise ValueError("segments file is empty - run aborted")
     if len(segments) > 1000:
         raise ValueError("too many (%i) segment files - use track definitions or --ignore-segment-tracks" % len(segments))
+
+    relabel = options.annotations_label is not None
     annotations = readSegmentList("annotations", options.annotation_files, enable_split_tracks=options.enable_split_tracks,
-                                  ignore_tracks=options.annotations_label is not None)
-    if options.annotations_label is not None:
+                                  ignore_tracks=relabel)
+    if relabel:
         annotations.setName(options.annotations_label)
-    if getattr(options, "annotations_to_points", None):
-        raise NotImplementedError("--annotations-to-points is outside the accelerated path")
+    points = getattr(options, "annotations_to_points", None)
+    if points:
+        annotations.toPositions(points)                    # before normalizing: coinciding positions count once
     if getattr(options, "overlapping_annotations", False):
         raise NotImplementedError("--overlapping-annotations is outside the accelerated path (counters need normalized lists)")
     annotations.normalize()
-    workspaces = readSegmentList("workspaces", options.workspace_files, options.enable_split_tracks)
+
+    workspaces = readSegmentList("workspaces", options.workspace_files, enable_split_tracks=options.enable_split_tracks)
     workspaces.normalize()
     dumpStats(workspaces, "stats_workspaces_input", options)
     workspaces.collapse()
     dumpStats(workspaces, "stats_workspaces_collapsed", options)
     workspaces.restrict("collapsed")
+
     isochores = None
     if options.isochore_files:
         isochores = engine.IntervalCollection(name="isochores")
         isochores.intervals = readFromBed(expandGlobs(options.isochore_files))
         dumpStats(isochores, "stats_isochores_raw", options)
-        isochores.sort()
-        isochores.check()
-        isochores.normalize()
+        for step in (isochores.sort, isochores.check, isochores.normalize):
+            step()
         isochores.intersect(workspaces["collapsed"])
     return segments, annotations, workspaces, isochores
 
 
+def _all_segments_of(collection):
+    """every track of a collection pooled into one IntervalDictionary; a 'merged' track that is already there is used,
+    one made for the purpose is removed again."""
+    if "merged" in collection:
+        return collection["merged"], False
+    collection.merge()
+    return collection["merged"], True
+
+
 def applyIsochores(segments, annotations, workspaces, options, isochores=None, truncate_segments_to_workspace=False,
                    truncate_workspace_to_annotations=False, restrict_workspace=False):
-    """gat/IO.py:188-293."""
+    """cut the three collections to the workspace -- per isochore when there are isochores -- and return the workspace
+    the sampler runs in (gat/IO.py:188-293)."""
+    truncate = options.truncate_segments_to_workspace
     if isochores:
-        workspaces.toIsochores(isochores, truncate=True)
-        annotations.toIsochores(isochores, truncate=True)
-        segments.toIsochores(isochores, truncate=options.truncate_segments_to_workspace)
-        if workspaces.sum() == 0:
-            raise ValueError("isochores and workspaces do not overlap")
-        if annotations.sum() == 0:
-            raise ValueError("isochores and annotations do not overlap")
-        if segments.sum() == 0:
-            raise ValueError("isochores and segments do not overlap")
-        dumpStats(workspaces, "stats_workspaces_isochores", options)
-        dumpStats(annotations, "stats_annotations_isochores", options)
-        dumpStats(segments, "stats_segments_isochores", options)
-        dumpBed(workspaces, "workspaces_isochores", options)
-        dumpBed(annotations, "annotations_isochores", options)
-        dumpBed(segments, "segments_isochores", options)
+        # (collection, cut to the isochore or keep whole segments that touch it, message if nothing is left)
+        plan = ((workspaces, True, "workspaces"), (annotations, True, "annotations"), (segments, truncate, "segments"))
+        for coll, cut, _ in plan:
+            coll.toIsochores(isochores, truncate=cut)
+        for coll, _, what in plan:
+            if coll.sum() == 0:
+                raise ValueError("isochores and %s do not overlap" % what)
+        for dump, prefix in ((dumpStats, "stats_"), (dumpBed, "")):
+            for coll, _, what in plan:
+                dump(coll, "%s%s_isochores" % (prefix, what), options)
     else:
-        if options.truncate_segments_to_workspace:
-            segments.intersect(workspaces["collapsed"])
+        within = workspaces["collapsed"]
+        if truncate:
+            segments.intersect(within)
         else:
-            segments.filter(workspaces["collapsed"])
-        annotations.intersect(workspaces["collapsed"])
-        dumpStats(annotations, "stats_annotations_truncated", options)
-        dumpStats(segments, "stats_segments_truncated", options)
+            segments.filter(within)
+        annotations.intersect(within)
+        for coll, what in ((annotations, "annotations"), (segments, "segments")):
+            dumpStats(coll, "stats_%s_truncated" % what, options)
+
     workspace = workspaces["collapsed"]
     if restrict_workspace:
-        for _ in (segments, annotations):
-            if "merged" in segments:
-                workspace.filter(segments["merged"])
-            else:
-                segments.merge()
-                workspace.filter(segments["merged"])
-                del segments["merged"]
+        # only workspace segments that hold a segment of some track stay
+        pooled, temporary = _all_segments_of(segments)
+        workspace.filter(pooled)
+        if temporary:
+            del segments["merged"]
         dumpStats(workspaces, "stats_workspaces_restricted", options)
     if truncate_workspace_to_annotations:
         annotations.merge()
@@ -203,8 +216,9 @@ def applyIsochores(segments, annotations, workspaces, options, isochores=None, t
         workspace.intersect(annotations["merged"])
         del annotations["merged"]
         dumpStats(workspaces, "stats_workspaces_truncated", options)
-    selected = getattr(options, "output_stats", None) or []
-    if "overlap" in selected or "all" in selected:
+
+    wanted = getattr(options, "output_stats", None) or []
+    if "overlap" in wanted or "all" in wanted:
         for track in segments.tracks:
             with openOutputFile("overlap_%s" % track, options) as f:
                 workspaces.outputOverlapStats(f, segments[track])
@@ -250,29 +264,22 @@ def readAnnotatorResults(filename):
 
 
 def readDescriptions(options):
-    """annotation -> description columns from a tab-separated file whose first line is the header
-    (gat/IO.py:296-328).  Returns (description_header, descriptions, description_width)."""
-    description_header, descriptions, description_width = [], {}, 0
+    """--descriptions: a tab-separated table, first row the header, first column the annotation, the other columns
+    are appended to the annotation's rows of the result table (gat/IO.py:296-328).
+    Returns (description_header, descriptions, description_width)."""
     filename = getattr(options, "input_filename_descriptions", None)
-    if filename:
-        with openFile(filename) as inf:
-            first = True
-            for line in inf:
-                if line.startswith("#"):
-                    continue
-                data = line[:-1].split("\t")
-                if description_width:
-                    assert len(data) - 1 == description_width, "inconsistent number of descriptions in %s" % filename
-                else:
-                    description_width = len(data) - 1
-                if first:
-                    description_header = data[1:]
-                    first = False
-                else:
-                    descriptions[data[0]] = data[1:]
-        assert len(description_header) == description_width, \
-            "number of descriptions (%i) inconsistent with header (%s) in %s" % (description_width, len(description_header), filename)
-    return description_header, descriptions, description_width
+    if not filename:
+        return [], {}, 0
+    with openFile(filename) as inf:
+        rows = [line[:-1].split("\t") for line in inf if not line.startswith("#")]
+    if not rows:
+        return [], {}, 0
+    width = len(rows[0]) - 1
+    for row in rows:
+        assert len(row) - 1 == width, "inconsistent number of descriptions in %s" % filename
+    header = rows[0][1:]
+    assert len(header) == width, "number of descriptions (%i) inconsistent with header (%s) in %s" % (width, len(header), filename)
+    return header, dict((row[0], row[1:]) for row in rows[1:]), width
 
 
 def outputResults(results, options, header, description_header=(), description_width=0, descriptions=None,

@@ -631,6 +631,14 @@ def g5_cli():
         ("annotation_centered", ["--num-samples=30", "--random-seed=13", "--conditional=annotation-centered",
                                  "--conditional-expansion=1.5", "--order=annotation",
                                  "--isochores=%s" % os.path.join(cli_dir, "isochores.bed")]),
+        # point annotations (gat/IO.py:134-135, gat/PositionList.pyx:288-336, :490-540): the two counters that call into
+        # PositionList run; every other counter, isochores and --truncate-workspace-to-annotations end in a TypeError
+        ("points_midpoint", ["--num-samples=40", "--random-seed=16", "--annotations-to-points=midpoint",
+                             "--counter=annotation-overlap"]),
+        ("points_start_tracks", ["--num-samples=30", "--random-seed=17", "--annotations-to-points=start",
+                                 "--counter=annotation-midoverlap", "--with-segment-tracks", "--order=track"]),
+        ("points_end", ["--num-samples=30", "--random-seed=18", "--annotations-to-points=end",
+                        "--counter=annotation-overlap", "--order=annotation", "--truncate-segments-to-workspace"]),
     ])
     # the reference's own integration-test data (test/data/*.bed.gz, test/check_run.py): real mouse ChIP-seq
     # intervals, 279 844 workspace segments; copied as data fixtures into tests/golden/refdata/

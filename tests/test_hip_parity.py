@@ -783,3 +783,33 @@ def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
             vals = [O.counter("nucleotide-overlap", lists[c], flat["annos"][flat["anno_off"][t * C + c]:flat["anno_off"][t * C + c + 1]])
                     for c in range(C)]
             assert got[0][t, 0] == int(sum(vals))
+
+
+def test_point_annotations_errors_like_the_reference(ctx, tmp_path):
+    """--annotations-to-points: the three tables in tests/golden/cli/expected_points_*.tsv are compared by
+    test_cli_table_matches_reference; here what the reference cannot do with a PositionList (probed on the scratch
+    build): any other counter (TypeError in computeCounts, gat/Engine.pyx:2200), isochores (TypeError in fromIsochores,
+    :2866) and --truncate-workspace-to-annotations (TypeError in merge, :3007); and the observed counts of the point
+    counters against a direct count of positions inside segments."""
+    import gat_amd as gat
+    from gat_amd import IO
+    cli = os.path.join(G, "cli")
+    base = ["--segments=%s" % os.path.join(cli, "segments.bed"), "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+            "--workspace=%s" % os.path.join(cli, "workspace.bed"), "--num-samples=4", "--random-seed=2",
+            "--annotations-to-points=midpoint"]
+    for extra in (["--counter=nucleotide-overlap"], ["--counter=segment-overlap"],
+                  ["--counter=annotation-overlap", "--isochores=%s" % os.path.join(cli, "isochores.bed")],
+                  ["--counter=annotation-overlap", "--truncate-workspace-to-annotations"]):
+        with pytest.raises(TypeError):
+            _run_cli(tmp_path, "points_err", base + extra)
+    opts, _ = gat.buildParser().parse_args(base + ["--counter=annotation-overlap"])
+    segments, annotations, workspaces, isochores = IO.buildSegments(opts)
+    workspace = IO.applyIsochores(segments, annotations, workspaces, opts, isochores)
+    observed = gat.computeCounts(gat.CounterAnnotationOverlap(), sum, segments, annotations, workspace, gat.UnconditionalWorkspace())
+    for track in annotations.tracks:
+        want = 0
+        for contig in workspace.keys():
+            seg = segments["merged"][contig].asArray()
+            for p in annotations[track][contig].asList():
+                want += int(((seg["start"] <= p) & (p < seg["end"])).any())
+        assert observed["merged"][track] == want and want > 0

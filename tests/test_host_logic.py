@@ -352,3 +352,40 @@ def test_from_counts_reads_the_counts_table():
         assert str(r).split("\t")[2:10] == row[2:10]        # observed .. pvalue (the q-value is set by the output stage)
     with pytest.raises(ValueError):
         gat.fromCounts(os.path.join(pat, "table_nucleotide-overlap.tsv"))
+
+
+def test_position_list_host_logic():
+    """PositionList (gat/PositionList.pyx) as --annotations-to-points uses it: positions from segments by
+    midpoint / start / end, normalize = sort + equal positions once, intersect keeps positions inside segments,
+    sum() counts positions; what the reference's PositionList cannot do raises TypeError here too."""
+    import gat_amd as gat
+    s = gat.SegmentList(iter=[(10, 20), (15, 31), (40, 40), (100, 101)])
+    want = {"midpoint": [15, 23, 100], "start": [10, 15, 100], "end": [20, 31, 101]}
+    for method, positions in want.items():
+        p = gat.PositionList()
+        p.fromSegmentList(s, method=method)
+        assert p.asList() == positions and len(p) == 3 and p.sum() == 3
+    with pytest.raises(ValueError):
+        gat.PositionList().fromSegmentList(s, method="centre")
+    p = gat.PositionList(iter=[7, 3, 7, 50, 3, 99], normalize=True)
+    assert p.asList() == [3, 7, 50, 99] and p.isNormalized and p.max() == 99 and p.min() == 3
+    q = p.clone()
+    q.intersect(gat.SegmentList(iter=[(0, 4), (7, 8), (50, 50), (60, 99)], normalize=True))
+    assert q.asList() == [3, 7] and p.asList() == [3, 7, 50, 99]
+    assert isinstance(q, gat.PositionList) and q.asArray()["end"].tolist() == [4, 8]      # one-base intervals on the device side
+    with pytest.raises(TypeError):
+        gat.SegmentList(iter=[(0, 10)], normalize=True).intersect(p)
+    for name in ("filter", "merge", "extend"):
+        with pytest.raises(TypeError):
+            getattr(p, name)(p)
+    c = gat.IntervalCollection("annotations")
+    c.add("t0", "chr1", gat.SegmentList(iter=[(0, 10), (4, 14), (30, 40)]))
+    c.toPositions("start")
+    c.normalize()
+    assert c.hasPositions() and c["t0"]["chr1"].asList() == [0, 4, 30] and c.sum() == 3 and c.counts() == 3
+    with pytest.raises(TypeError):
+        c.merge()
+    d = c["t0"].clone()
+    d.intervals["chr1.iso"] = d.intervals.pop("chr1")
+    with pytest.raises(TypeError):
+        d.fromIsochores()
