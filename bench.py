@@ -178,7 +178,7 @@ class Workload(object):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         keys = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
-                "n_placed", "n_draws", "n_retried", "n_full_units")
+                "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_tail_units")
         acc = dict((k, 0.0) for k in keys)
         for i in range(steps):
             st = self.step(warmup + i)
@@ -260,7 +260,9 @@ class Workload(object):
                                        % (self.host.numel() * 8 if self.host is not None else 0)},
             "roofline": roof,
             "kernels": {"k_rng_ms": acc["ms_rng"] / steps, "k_place_ms": acc["ms_place"] / steps,
-                        "k_merge_ms": acc["ms_merge"] / steps, "k_sampler_ms": acc["ms_tail"] / steps,
+                        "k_merge_ms": acc["ms_merge"] / steps, "k_tail_ms": acc["ms_ktail"] / steps,
+                        "k_finalize_ms": acc["ms_finalize"] / steps,
+                        "k_sampler_ms": (acc["ms_tail"] - acc["ms_ktail"] - acc["ms_finalize"]) / steps,
                         "k_contig_ms": acc["ms_contig"] / steps, "count_main_ms": main_ms,
                         "count_phase_ms": acc["ms_count"] / steps, "sampler_phase_ms": acc["ms_sampler"] / steps},
             "sampler": {"kernel": "k_rng + k_place + k_merge + k_sampler (random rows, placement, consolidation)",
@@ -270,6 +272,7 @@ class Workload(object):
                         "kernel_samples_per_s": S * steps / samp_s if samp_s else 0.0,
                         "contig_kernel_avg_ms": acc["ms_contig"] / steps,
                         "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
+                        "units_finished_by_k_tail": acc["n_tail_units"],
                         "work_units": S * steps * flat["n_units"]},
             "allgather": allgather,
         }

@@ -77,6 +77,9 @@ class Stats(C.Structure):
         ("ms_merge", C.c_float),
         ("ms_tail", C.c_float),
         ("count_kernel", C.c_int32),
+        ("ms_ktail", C.c_float),
+        ("ms_finalize", C.c_float),
+        ("n_tail_units", C.c_int64),
     ]
 
     def asdict(self):

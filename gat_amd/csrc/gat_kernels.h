@@ -73,6 +73,10 @@ struct SamplerArgs {
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
+  const int32_t* skip;        // split path: skip[(sidx * n_units + a) * skip_stride] != 0: the unit was finished by k_tail / k_finalize
+  int32_t skip_stride;
+  const uint32_t* todo_count; // split path: k_sampler works off the queue of units k_tail left alone (k_finalize fills it)
+  const uint32_t* todo;       //   entries sidx * n_active + launch position
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
 };
 
@@ -497,6 +501,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 // written back to the slab, coverage and total length reduced over the block.  k_sampler resumes behind it with a
 // clean merged list (st2) and goes straight to the tail.  Lists the counting sort declines (clustered keys) are left
 // to k_sampler's own sort.
+constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 words, padded to 16 bytes)
 constexpr int kMergeThreads = 256;
 constexpr int kMergeWaves = kMergeThreads / kWave;
 
@@ -685,14 +690,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
 // memory, the sort is the in-place network) but without a size limit.
 // WPE: waves per SIMD the register budget is set for: 4 (LDS allows no more for lists of hundreds of segments), or 5 for
 // problems whose lists are so short that registers, not LDS, decide how many waves a CU holds.
-template <int KIND, bool BIG, bool TREE, bool HUGE, int WPE = 4>
-__global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+template <int KIND, bool BIG, bool TREE, bool HUGE>
+__device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sidx, const int a, uint32_t* lds, const int lane) {
   uint32_t* mt = lds;
-  const int lane = threadIdx.x;
-  const int sidx = blockIdx.x;
-  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
-  if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int u = Up->pad;
   const int nws = Up->n_ws;
@@ -733,6 +733,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
   const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
+  if (A.skip != nullptr && A.skip[((int64_t)sidx * A.n_units + a) * A.skip_stride] != 0) return;
   const bool have_pre = A.st != nullptr;
   const int4 pre = have_pre ? A.st[(int64_t)sidx * A.n_units + a] : make_int4(0, 0, -1, 0);
   const int32_t pre_len = pre.z;
@@ -798,7 +799,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
     if (resume) {
       nS = pre.x;
       int4 pre2 = make_int4(0, 0, 0, 0);
-      if (BIG && !HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[(int64_t)sidx * A.n_units + a];
+      if (!HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[(int64_t)sidx * A.n_units + a];
       if (pre2.w == 1) {
         // k_merge_big has done the first consolidation: the slab holds the merged list; its coverage and total
         // length come with it, and the pending length below makes the loop take them up at once
@@ -1101,25 +1102,50 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
   }
 }
 
+template <int KIND, bool BIG, bool TREE, bool HUGE, int WPE = 4>
+__global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  if (A.todo_count != nullptr) {
+    // behind the split path: the few units k_tail left alone, from a queue (a launch over all units, nearly all of which
+    // leave at once, took longer than everything else the split path does)
+    const uint32_t count = *A.todo_count;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+      const uint32_t e = A.todo[w];
+      sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)(e / (uint32_t)A.n_active), (int)(e % (uint32_t)A.n_active), lds, lane);
+      wave_sync();
+    }
+    return;
+  }
+  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
+  sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)blockIdx.x, a, lds, lane);
+}
+
 // sums the per-work-unit statistics: one atomic per block instead of one per work unit
 __global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict__ ws_stat, int64_t n,
-                                                      unsigned long long* __restrict__ stat) {
-  unsigned long long a0 = 0, a1 = 0, a2 = 0, a4 = 0;
+                                                      unsigned long long* __restrict__ stat,
+                                                      const int32_t* __restrict__ skip, int skip_stride) {
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a4 = 0, a3 = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const uint4 v = *reinterpret_cast<const uint4*>(ws_stat + i * 4);
     a0 += v.x; a1 += v.y; a2 += v.z; a4 += v.w;
   }
-  __shared__ unsigned long long red[4][4];
+  // work units finished on the split path (k_tail's records are indexed by launch position: n_units per sample as well)
+  if (skip != nullptr)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+      a3 += skip[i * skip_stride] != 0 ? 1 : 0;
+  __shared__ unsigned long long red[4][5];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
-    a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); a4 += __shfl_xor(a4, d);
+    a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); a4 += __shfl_xor(a4, d); a3 += __shfl_xor(a3, d);
   }
-  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a4; }
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; red[wave][4] = a4; }
   __syncthreads();
-  if (threadIdx.x < 4) {
+  if (threadIdx.x < 5) {
     const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(&stat[threadIdx.x == 3 ? 4 : threadIdx.x], t);
+    atomicAdd(&stat[threadIdx.x], t);
   }
 }
 

@@ -21,6 +21,7 @@
 #include "../../include/gat_mi355.h"
 #define GAT_NUM_COUNTERS_DEV 6
 #include "gat_kernels.h"
+#include "gat_tail.h"
 
 using gat::UnitDev;
 
@@ -36,6 +37,8 @@ struct gat_ctx {
   int count_kernel = 0;                         // GAT_COUNT_KERNEL_* of the last launch_count
   hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // behind k_rng, k_place, k_merge_big, k_sampler
   bool k_recorded = false;
+  hipEvent_t ev_t[2] = {nullptr, nullptr};      // split path: behind k_tail, k_finalize
+  bool t_recorded = false;
   std::string err;
   int max_lds = 65536;
 };
@@ -319,6 +322,10 @@ struct gat_problem {
 #endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
+  DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
+  DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
+  DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
+  bool split_path = false;               // k_consolidate + k_tail + k_finalize in front of k_sampler
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
@@ -361,6 +368,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_main) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_k) HIPCHK(ctx, hipEventCreate(&ev));
+  for (auto& ev : ctx->ev_t) HIPCHK(ctx, hipEventCreate(&ev));
   *out = ctx;
   return GAT_OK;
 }
@@ -371,6 +379,7 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_t) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -495,6 +504,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   std::vector<uint32_t> h_ws_cdf, h_rank_len, h_ws_tree;
   std::vector<std::pair<int64_t, int32_t>> work;   // (working segments, unit)
   std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
+  std::vector<double> len_cv2((size_t)std::max(1, d->n_units), 0.0);
 
   for (int u = 0; u < d->n_units; ++u) {
     UnitDev& U = P->h_units[u];
@@ -550,6 +560,12 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     }
     U.hist_total = cum;
     U.bucket = (uint32_t)bucket;
+    {
+      double m1 = 0, m2 = 0;                               // squared coefficient of variation of the lengths drawn
+      for (uint32_t l : lens) { m1 += (double)l; m2 += (double)l * (double)l; }
+      m1 /= (double)lens.size(); m2 /= (double)lens.size();
+      len_cv2[(size_t)u] = m1 > 0 ? std::max(0.0, m2 / (m1 * m1) - 1.0) : 0.0;
+    }
     // SegmentListSampler(workspace) (gat/Engine.pyx:261-277)
     U.n_ws = (int32_t)nuw;
     U.ws_off = (int32_t)h_ws.size();
@@ -616,6 +632,14 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     max_hist = std::max(max_hist, U.hist_total);
   }
   P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
+  {
+    // the split path pays when k_tail can take most units: SamplerAnnotator, lists the wave bucket sorts hold, workspaces
+    // of up to kTailMaxWs segments
+    size_t small_ws = 0;
+    for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs) ++small_ws;
+    P->split_path = P->sampler == GAT_SAMPLER_ANNOTATOR && !P->h_order.empty() && 2 * small_ws >= P->h_order.size() &&
+                    max_hist + max_hist / 8 <= 1024 && !getenv("GAT_NO_SPLIT");
+  }
   // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
   // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
   // are redone by k_sampler from their seed.
@@ -646,10 +670,15 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       if (U.bucket > 1) { const double x = expect((uint64_t)U.bucket - 1); e += x; addvar(x); }
       if (U.ws_total > 1) { const double x = expect((uint64_t)U.ws_total - 1); e += x; addvar(x); }
       const char* env_sl = getenv("GAT_RNG_SLACK");
-      const double slack = env_sl ? atof(env_sl) : 1.06;
-      // spread of the raw-output count: ~sqrt(placements) x (std per placement ~1.3), 6 sigma
+      const double slack = env_sl ? atof(env_sl) : 1.0;
+      // Spread of the raw-output count of a stream: the NUMBER of placements until the unit's bases are reproduced varies
+      // by cv(length) x sqrt(n) (a renewal count) and every placement costs e outputs -- that term dominates (measured on
+      // config 2: 97 / 116 / 58 outputs for units of 778 / 444 / 166 segments = e x cv x sqrt(n)) -- plus the rejection
+      // noise v per placement.  7.5 sigma and the tail's few dozen outputs: a stream that runs out is redone from its seed
+      // by ONE wave, placement by placement, and such a straggler (0.5 ms) is now longer than the rest of the sampler.
       const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
-      const double need = e * nplace * slack + 6.0 * std::sqrt(nplace * (v + 0.5)) + 64.0;
+      const double var_n = P->sampler == GAT_SAMPLER_SEGMENTS ? 0.0 : len_cv2[(size_t)u] * e * e;
+      const double need = e * nplace * slack + 7.5 * std::sqrt(nplace * (v + 0.5 + var_n)) + 96.0;
       int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
@@ -714,7 +743,8 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   const char* env = getenv("GAT_SLAB_BYTES");
   const double budget = env ? atof(env) : 12.0 * 1024 * 1024 * 1024;
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
-                             (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0);
+                             (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
+                             (P->split_path ? P->slab_stride * 4 + (int64_t)sizeof(gat::TailPatch) * P->n_units : 0);
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
@@ -735,6 +765,12 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
     HIPCHK(ctx, P->d_st2.alloc(ns));
+    if (P->split_path) {
+      HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride)));
+      HIPCHK(ctx, P->d_patch.alloc(ns));
+      HIPCHK(ctx, P->d_todo.alloc(ns));
+      HIPCHK(ctx, P->d_todo_count.alloc(1));
+    }
   }
   P->batch = b;
   return GAT_OK;
@@ -999,9 +1035,46 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           if (nbk >= 1024) { A.big_buckets = nbk; lds += (size_t)(nbk + 1) * 4; }
         }
       }
-      if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
-      // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       const bool tree = P->max_nws > gat::kWsTreeMin;
+      ctx->t_recorded = false;
+      const bool split = P->split_path && P->sampler_mode && !huge && !long_lists;
+      if (split) {
+        // the split path: first consolidation (wave per unit), the loop's tail (lane per unit), the final list (wave per
+        // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
+        gat::TailArgs T;
+        T.S = A;
+        T.S.st2 = P->d_st2.p;
+        T.cum = P->d_cum.p;
+        T.patch = P->d_patch.p;
+        T.todo = P->d_todo.p;
+        T.todo_count = P->d_todo_count.p;
+        HIPCHK(ctx, hipMemsetAsync(P->d_todo_count.p, 0, 4, ctx->stream));
+        const size_t lds_c = (size_t)(gat::kSortScratchWords + 2 * (size_t)P->max_unit_cap) * 4;
+        const dim3 gu((unsigned)nb, gy, gz), gt((unsigned)((nb + 63) / 64), gy, gz);
+        if (tree) {
+          HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+          hipLaunchKernelGGL(gat::k_consolidate<true>, gu, dim3(64), lds_c, ctx->stream, T);
+        } else {
+          HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+          hipLaunchKernelGGL(gat::k_consolidate<false>, gu, dim3(64), lds_c, ctx->stream, T);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
+        hipLaunchKernelGGL(gat::k_tail, gt, dim3(64), 0, ctx->stream, T);
+        HIPCHK(ctx, hipGetLastError());
+        if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream));
+        if (tree) hipLaunchKernelGGL(gat::k_finalize<true>, gu, dim3(64), 0, ctx->stream, T);
+        else hipLaunchKernelGGL(gat::k_finalize<false>, gu, dim3(64), 0, ctx->stream, T);
+        HIPCHK(ctx, hipGetLastError());
+        if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_t[1], ctx->stream)); ctx->t_recorded = true; }
+        A.st2 = P->d_st2.p;
+        A.n_long = (int32_t)n_act;
+        A.skip = &P->d_patch.p->state;
+        A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+        A.todo = P->d_todo.p;
+        A.todo_count = P->d_todo_count.p;
+      } else if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
+      // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
                   : huge ? (tree ? 7 : 6) : (long_lists ? 2 : 0) + (tree ? 1 : 0);
       // short lists only (20 waves of this kernel fit a CU's LDS): the instantiation with registers for 5 waves per SIMD
@@ -1016,7 +1089,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                      : variant == 7 ? (const void*)gat::k_sampler<0, false, true, true>
                                     : (const void*)gat::k_sampler<0, false, false, false, 5>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      const dim3 gs((unsigned)nb, gy, gz);
+      const dim3 gs = split ? dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)) : dim3((unsigned)nb, gy, gz);
       switch (variant) {
         case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
         case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
@@ -1031,7 +1104,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       HIPCHK(ctx, hipGetLastError());
       if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[3], ctx->stream));
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
-                         (int64_t)nb * P->n_units, P->d_stat.p);
+                         (int64_t)nb * P->n_units, P->d_stat.p, A.skip, A.skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1089,7 +1162,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       st->n_placed += (int64_t)stat[0];
       st->n_draws += (int64_t)stat[1];
       st->n_unsuccessful += (int64_t)stat[2];
-      (void)stat[3];
+      st->n_tail_units += (int64_t)stat[3];
       st->n_full_units += (int64_t)stat[4];
       if (timed) {
         float ms = 0;
@@ -1106,6 +1179,12 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           st->ms_merge += ms;
           HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[2], ctx->ev_k[3]));
           st->ms_tail += ms;
+          if (ctx->t_recorded) {
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[2], ctx->ev_t[0]));
+            st->ms_ktail += ms;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_t[0], ctx->ev_t[1]));
+            st->ms_finalize += ms;
+          }
         }
       }
     }

@@ -1,0 +1,460 @@
+// gat_tail.h -- SamplerAnnotator.sample behind k_place as three lean kernels (the split path of the sampler).
+//
+// k_sampler runs the rest of gat/Engine.pyx:572-646 with one WAVE per (sample, unit): a third of its time is the first
+// consolidation -- lane-parallel work over the whole list -- and the rest is the loop's tail: a handful of draws, two or
+// three placements, one trim, each paid for with 64-wide passes over the list (where does the new segment go, which
+// segment holds base p, shift everything behind it) of which one lane's worth is needed.  Its speed follows the waves a
+// CU holds, not the instructions (1.85 / 2.4 / 3.7 / 5.4 ms at 13 / 10 / 6 / 4 waves per CU on config 2), and LDS -- the
+// list lives there through all of it -- keeps that number low.  Here the parts are matched to the hardware separately:
+//
+//   k_consolidate  one wave per (sample, unit): the first consolidation (:582-606) -- sort, merge(0), workspace coverage --
+//                  and nothing else; leaves the merged list in the slab with its running lengths (cum).
+//   k_tail         one LANE per (sample, unit), like k_place: the tail of the loop as a per-lane state machine whose list
+//                  accesses are binary searches in the merged list (L2): new segments that touch nothing become "extras",
+//                  the overshoot trim becomes (where it starts, direction, segments removed whole, bases off the next).
+//                  Whatever does not fit that shape -- a new segment touching a neighbour, a second trim, more than four
+//                  new segments, a long workspace -- is left, untouched, to k_sampler, which resumes from the merged list.
+//   k_finalize     one wave per (sample, unit): merged list + extras - trim, placeholders dropped, filter(workspace)
+//                  (:639-646), the unit's list written where the count kernels expect it.  No LDS.
+//
+// Results are those of k_sampler (and of the reference) bit for bit: every branch below cites the line it restates.
+#pragma once
+#include "gat_kernels.h"
+
+namespace gat {
+
+constexpr int kTailMaxExtra = 4;      // new segments k_tail keeps aside per unit
+constexpr int kTailMaxWs = 64;        // workspace segments k_tail scans linearly (wave-uniform loop)
+constexpr int kTailMaxWalk = 6;       // segments an overshoot trim may touch
+constexpr int kTailRows = 8;          // random rows fetched at a time
+
+// what k_tail hands to k_finalize, per (sample, unit) by launch position
+struct TailPatch {
+  int32_t state;          // 0: not handled (k_sampler resumes from the merged list), 1: handled
+  int32_t n_extra;
+  uint32_t trim;          // bit 0: a trim happened, bit 1: forward
+  int32_t trim_v0;        // index (in the list with the extras in place) where the trim starts
+  int32_t trim_full;      // segments removed whole, walking from there
+  uint32_t trim_part;     // bases taken off the next one
+  uint32_t placed, ndraws, nuns, pad;
+  uint2 extra[kTailMaxExtra];          // sorted by start
+  int32_t pos[kTailMaxExtra];          // merged-list elements in front of each
+};
+
+struct TailArgs {
+  SamplerArgs S;
+  uint32_t* cum;          // [batch][slab_stride]: inclusive running length of the merged list, parallel to the slab
+  TailPatch* patch;       // [batch][n_units] by launch position
+  uint32_t* todo_count;   // units left to k_sampler: k_finalize queues them
+  uint32_t* todo;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_consolidate: sort + merge(0) + coverage of what k_place placed (gat/Engine.pyx:582-606, first time round).
+template <bool TREE>
+__global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x;
+  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int4 pre = A.st[sa];
+  if (lane == 0) { A.st2[sa] = make_int4(0, 0, 0, 0); T.patch[sa].state = 0; }
+  const int n = pre.x;
+  if (pre.z < 0 || n <= 0 || n > A.lds_cap) return;               // k_place did not hand the unit over: k_sampler runs it in full
+  uint32_t* scratch = lds;                                          // bucket-sort scratch
+  uint2* seg = reinterpret_cast<uint2*>(lds + kSortScratchWords);
+  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint32_t* cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const int nws = Up->n_ws;
+  const uint2* __restrict__ ws = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
+  constexpr int kWsRegMax = 64, kWsLoopMax = 32;
+  const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
+  if (n > 512) {
+    if (!wave_sort_bucket_global(seg, out, n, scratch, 512, lane)) {
+      for (int i = lane; i < n; i += kWave) seg[i] = out[i];
+      wave_sort_auto(seg, n, lane);
+    }
+  } else {
+    // (all loads of the list in flight together: nothing else hides their latency)
+    uint2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; v[r] = i < n ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = v[r]; }
+    wave_sort_fast<8>(seg, n, scratch, lane);
+  }
+  const int nU = wave_merge0(seg, n, lane);
+  // coverage (intersect(workspace).sum()), total length, running lengths; the merged list goes back to the slab
+  uint32_t cov = 0, run = 0;
+  const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
+  const WsTreeGeom G = ws_tree_geom(nws);
+  for (int base = 0; base < nU; base += kWave) {
+    const int i = base + lane;
+    uint2 v = make_uint2(0u, 0u);
+    if (i < nU) v = seg[i];
+    if (nws <= kWsLoopMax) cov += ws_overlap_regs(W, v.x, v.y);
+    else if constexpr (TREE) { if (i < nU) cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y); }
+    const uint32_t incl = run + wave_incl_sum_u32(v.y - v.x, lane);
+    if (i < nU) { out[i] = v; cum[i] = incl; }
+    run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+  }
+  cov = wave_total_u32(cov);
+  if (lane == 0) A.st2[sa] = make_int4(nU, (int)cov, (int)run, 1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_tail: the loop of gat/Engine.pyx:572-635 from behind the first consolidation to its end, one stream per lane.
+// Workgroup = one tile of 64 samples x one unit (the tiles of k_place); everything about the unit is wave-uniform.
+struct TailRng {
+  const uint32_t* rp;     // the lane's column of the tile's rows
+  uint32_t used, rows;    // raw outputs consumed / generated
+  uint32_t buf[kTailRows];
+  uint32_t have;          // buf holds rows [base, base + have)
+  uint32_t base;
+  bool out_of_rows;
+};
+__device__ __forceinline__ void tail_fetch(TailRng& r) {
+  r.base = r.used;
+#pragma unroll
+  for (int k = 0; k < kTailRows; ++k) r.buf[k] = r.used + (uint32_t)k < r.rows ? r.rp[(size_t)(r.used + (uint32_t)k) * kWave] : 0u;
+  r.have = kTailRows;
+}
+__device__ __forceinline__ uint32_t tail_next(TailRng& r) {
+  if (r.used >= r.rows) { r.out_of_rows = true; return 0u; }
+  if (r.used - r.base >= r.have) tail_fetch(r);
+  const uint32_t k = r.used - r.base;
+  uint32_t x = r.buf[0];
+#pragma unroll
+  for (int q = 1; q < kTailRows; ++q) x = k == (uint32_t)q ? r.buf[q] : x;
+  r.used++;
+  return x;
+}
+// numpy's masked rejection (gat_device.h rng_range), per lane
+__device__ __forceinline__ uint32_t tail_range(TailRng& r, uint32_t range) {
+  if (range == 0) return 0;
+  const uint32_t mask = 0xffffffffu >> __builtin_clz(range);
+  uint32_t v;
+  do { v = tail_next(r) & mask; } while (v > range && !r.out_of_rows);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_tail(TailArgs T) {
+  __shared__ uint32_t l_ws[3 * kTailMaxWs];         // starts, ends, cdf of the unit's workspace
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x;
+  const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int nws = Up->n_ws;
+  if (nws > kTailMaxWs) return;                      // long workspace: left to k_sampler (search trees)
+  const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
+  const int32_t ltotal = Up->ltotal;
+  const int cap = Up->slab_cap;
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  for (int i = lane; i < nws; i += kWave) {
+    const uint2 w = A.ws[Up->ws_off + i];
+    l_ws[i] = w.x; l_ws[kTailMaxWs + i] = w.y; l_ws[2 * kTailMaxWs + i] = A.ws_cdf[Up->ws_off + i];
+  }
+  __syncthreads();
+  const int sidx = sb * kWave + lane;
+  if (sidx >= A.batch) return;
+  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int4 pre = A.st[sa];
+  const int4 c2 = A.st2[sa];
+  if (pre.z < 0 || c2.w != 1) return;                // not consolidated: k_sampler's
+  const uint2* __restrict__ U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const uint32_t* __restrict__ cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const int nU = c2.x;
+  if (nU <= 0) return;
+  uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
+
+  TailRng rng;
+  rng.rows = (uint32_t)A.rng_rows[a];
+  rng.rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rng.rows * kWave + lane;
+  rng.used = (uint32_t)pre.w;
+  rng.out_of_rows = false;
+  rng.have = 0; rng.base = rng.used;
+
+  // bases of [s, e) inside the workspace (SegmentList.intersect(workspace).sum() of one segment)
+  auto ws_overlap = [&](uint32_t s, uint32_t e) -> uint32_t {
+    uint32_t ov = 0;
+    for (int j = 0; j < nws; ++j) {
+      const uint32_t ws0 = l_ws[j], we0 = l_ws[kTailMaxWs + j];
+      const uint32_t lo = s > ws0 ? s : ws0, hi = e < we0 ? e : we0;
+      ov += hi > lo ? hi - lo : 0u;
+    }
+    return ov;
+  };
+
+  uint2 ex[kTailMaxExtra];
+  int epos[kTailMaxExtra];
+#pragma unroll
+  for (int j = 0; j < kTailMaxExtra; ++j) { ex[j] = make_uint2(0xffffffffu, 0xffffffffu); epos[j] = 0x7fffffff; }
+  int nE = 0;                  // extras in place (sorted, with their position in the merged list)
+  uint2 pend[kTailMaxExtra];   // placed since the last consolidation, in placement order
+  int nP = 0;
+  uint32_t placed = (uint32_t)pre.x;
+  int32_t length = pre.z;
+  int32_t remaining = ltotal - (int32_t)cov, true_remaining = ltotal;
+  int nuns = 0;
+  if (true_remaining == remaining) nuns++; else true_remaining = remaining;           // :601-605
+  bool done = !(true_remaining != 0 && nuns < 20);
+  bool bail = false;
+  uint32_t trim = 0, trim_part = 0;
+  int trim_v0 = 0, trim_full = 0;
+
+  // element v of the list with the extras in place
+  auto vget = [&](int v) -> uint2 {
+    int c = 0;
+    uint2 r = make_uint2(0u, 0u);
+    bool is_extra = false;
+#pragma unroll
+    for (int j = 0; j < kTailMaxExtra; ++j) {
+      if (j < nE) {
+        const int vj = epos[j] + j;
+        if (vj < v) c++;
+        if (vj == v) { r = ex[j]; is_extra = true; }
+      }
+    }
+    return is_extra ? r : U[v - c];
+  };
+
+  for (int step = 0; step < 48 && !done && !bail; ++step) {
+    // ---- overshoot: trim (:608-626) -- only as the last thing that happens to the unit
+    if (true_remaining < 0) {
+      if (trim) { bail = true; break; }                              // a second trim: k_sampler's
+      const uint32_t p = tail_range(rng, total - 1u);
+      // leftmost element whose inclusive running length exceeds p (searchsorted over cdf = incl - 1)
+      int lo = 0, hi = nU;
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        uint32_t c = cum[mid];
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= mid) c += ex[j].y - ex[j].x;
+        if ((int32_t)(c - 1u - p) >= 0) hi = mid; else lo = mid + 1;
+      }
+      // extras standing right in front of merged-list element lo come first
+      uint32_t before = lo > 0 ? cum[lo - 1] : 0u;
+      int nbefore = 0;
+#pragma unroll
+      for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] < lo) { before += ex[j].y - ex[j].x; nbefore++; }
+      int v = lo + nbefore;                                          // (every extra in front of it counted)
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < kTailMaxExtra; ++j) {
+        if (j < nE && epos[j] == lo && !found) {
+          before += ex[j].y - ex[j].x;
+          if ((int32_t)(before - 1u - p) >= 0) found = true; else v++;
+        }
+      }
+      const int nV = nU + nE;
+      if (v >= nV) { bail = true; break; }                           // (cannot happen: p < total)
+      const uint2 chosen = vget(v);
+      (void)tail_range(rng, chosen.y - 1u - chosen.x);               // position inside the segment: only its index matters
+      const uint32_t forward = tail_range(rng, 1u);                  // numpy.random.randint(0, 2)
+      int32_t s = -true_remaining;
+      if (rng.out_of_rows) break;
+      if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { bail = true; break; }   // gat/SegmentList.pyx:560 asserts: k_sampler reports it
+      // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597)
+      uint32_t removed = 0;
+      int idx = v, full = 0;
+      uint32_t part = 0;
+      for (int w = 0; s > 0; ++w) {
+        if (w >= kTailMaxWalk) { bail = true; break; }
+        const uint2 x = vget(idx);
+        const int32_t l = (int32_t)x.y - (int32_t)x.x;
+        uint32_t ra, rb;
+        if (l < s) { s -= l; ra = x.x; rb = x.y; full++; }
+        else {
+          part = (uint32_t)s;
+          if (forward) { ra = x.x; rb = x.x + (uint32_t)s; } else { ra = (uint32_t)((int32_t)x.y - s); rb = x.y; }
+          s = 0;
+        }
+        if (rb > ra) removed += ws_overlap(ra, rb);
+        if (forward) { idx++; if (idx == nV) idx = 0; } else { idx--; if (idx < 0) idx = nV - 1; }
+      }
+      if (bail) break;
+      trim = 1u | (forward ? 2u : 0u);
+      trim_v0 = v; trim_full = full; trim_part = part;
+      cov -= removed;
+      total -= (uint32_t)(-true_remaining);
+      true_remaining = 1;
+      // back to the top of the loop: hs.sample(), then remaining (still negative) <= length: a consolidation with
+      // nothing new (coverage known)
+    } else {
+      // ---- sls.sample(length) (:279-343)
+      const uint32_t p = tail_range(rng, ws_total - 1u);
+      int k = 0;
+      for (int j = 0; j < nws; ++j) k += ((int32_t)(l_ws[2 * kTailMaxWs + j] - p) < 0) ? 1 : 0;   // searchsorted + cmpPosition
+      k = k < nws ? k : nws - 1;
+      const uint32_t cs = l_ws[k], ce = l_ws[kTailMaxWs + k];
+      int32_t sampling_start = (int32_t)cs - length + 1;
+      if (k > 0) { const int32_t pe = (int32_t)l_ws[kTailMaxWs + k - 1]; sampling_start = pe > sampling_start ? pe : sampling_start; }
+      const uint32_t range = ce - 1u - (uint32_t)sampling_start;
+      const int32_t q = sampling_start + (int32_t)tail_range(rng, range);
+      if (rng.out_of_rows) break;
+      const uint32_t start = (uint32_t)(q > 0 ? q : 0), end = (uint32_t)(q + length);
+      const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;
+      const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;
+      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+      // (true_remaining > 0 here: the loop runs only then)
+      if (nE + nP >= kTailMaxExtra || nU + nE + nP >= cap) { bail = true; break; }
+#pragma unroll
+      for (int j = 0; j < kTailMaxExtra; ++j) if (j == nP) pend[j] = make_uint2(start, end);
+      nP++;
+      placed++;
+      remaining -= overlap;
+    }
+    // ---- hs.sample() (:413-435)
+    {
+      uint32_t r = 1;
+      if (hist_total > 1) r = 1u + tail_range(rng, hist_total - 2u);
+      uint32_t len_u = rank_len[r] * bucket;
+      if (bucket > 1) len_u += tail_range(rng, bucket - 1u);
+      length = (int32_t)len_u;
+      if (rng.out_of_rows) break;
+    }
+    // ---- consolidate (:582-606)
+    if (remaining <= length) {
+      // the new segments join the merged list if none of them is empty or touches anything (merge(0) joins at
+      // start <= previous end); otherwise the general consolidation is needed: k_sampler's
+      for (int q = 0; q < nP && !bail; ++q) {
+        uint2 x = make_uint2(0u, 0u);
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j == q) x = pend[j];
+        if (x.x == x.y) { bail = true; break; }
+        int lo = 0, hi = nU;                                         // merged-list elements with start <= x.start
+        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (U[mid].x <= x.x) lo = mid + 1; else hi = mid; }
+        if (lo > 0 && (int32_t)x.x <= (int32_t)U[lo - 1].y) { bail = true; break; }
+        if (lo < nU && (int32_t)U[lo].x <= (int32_t)x.y) { bail = true; break; }
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) {
+          if (j < nE) {
+            const bool x_first = x.x < ex[j].x;
+            const uint2 f = x_first ? x : ex[j], g = x_first ? ex[j] : x;
+            if ((int32_t)g.x <= (int32_t)f.y) bail = true;
+          }
+        }
+        if (bail) break;
+        // into the sorted extras
+        int at = 0;
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && ex[j].x < x.x) at++;
+#pragma unroll
+        for (int j = kTailMaxExtra - 1; j > 0; --j) if (j > at && j <= nE) { ex[j] = ex[j - 1]; epos[j] = epos[j - 1]; }
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j == at) { ex[j] = x; epos[j] = lo; }
+        nE++;
+        cov += ws_overlap(x.x, x.y);
+        total += x.y - x.x;
+      }
+      if (bail) break;
+      nP = 0;
+      remaining = ltotal - (int32_t)cov;
+      if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+      if (!(true_remaining != 0 && nuns < 20)) done = true;
+    }
+  }
+  if (!done || bail || rng.out_of_rows) return;          // patch.state stays 0: k_sampler resumes from the merged list
+  TailPatch* P = T.patch + sa;
+  P->n_extra = nE;
+  P->trim = trim; P->trim_v0 = trim_v0; P->trim_full = trim_full; P->trim_part = trim_part;
+  P->placed = placed; P->ndraws = rng.used; P->nuns = (uint32_t)nuns;
+#pragma unroll
+  for (int j = 0; j < kTailMaxExtra; ++j) { P->extra[j] = ex[j]; P->pos[j] = epos[j]; }
+  P->state = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_finalize: result = unintersected.merge(0).filter(workspace) (gat/Engine.pyx:639-646) from the merged list and
+// k_tail's record.  The list, extras in place, is held in registers (written where it is read from).
+template <bool TREE>
+__global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x;
+  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active) return;
+  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const TailPatch* __restrict__ P = T.patch + sa;
+  if (P->state != 1) {
+    if (lane == 0) T.todo[atomicAdd(T.todo_count, 1u)] = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
+    return;
+  }
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int u = Up->pad;
+  const int nws = Up->n_ws;
+  const uint2* __restrict__ ws = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
+  constexpr int kWsRegMax = 64, kWsLoopMax = 32;
+  const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
+  const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
+  const WsTreeGeom G = ws_tree_geom(nws);
+  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const int nU = A.st2[sa].x, nE = P->n_extra, nV = nU + nE;
+  uint2 ex[kTailMaxExtra];
+  int vj[kTailMaxExtra];
+#pragma unroll
+  for (int j = 0; j < kTailMaxExtra; ++j) { ex[j] = P->extra[j]; vj[j] = j < nE ? P->pos[j] + j : 0x7fffffff; }
+  const uint32_t trim = P->trim;
+  const int v0 = P->trim_v0, full = P->trim_full;
+  const uint32_t part = P->trim_part;
+  constexpr int kR = 17;                                  // rounds of 64: lists of up to 1024 + extras
+  uint2 x[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    x[r] = make_uint2(0u, 0u);
+    if (r * kWave < nV) {
+      const int v = r * kWave + lane;
+      int c = 0, which = -1;
+#pragma unroll
+      for (int j = 0; j < kTailMaxExtra; ++j) { if (vj[j] < v) c++; if (vj[j] == v) which = j; }
+      if (v < nV) {
+        if (which >= 0) {
+#pragma unroll
+          for (int j = 0; j < kTailMaxExtra; ++j) if (which == j) x[r] = ex[j];
+        } else x[r] = out[v - c];
+      }
+    }
+  }
+  int nout = 0;
+  uint32_t total = 0;
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    if (r * kWave < nV) {
+      const int v = r * kWave + lane;
+      uint2 y = x[r];
+      if (trim & 1u) {
+        // trim_ends walked from v0 (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next
+        int d = (trim & 2u) ? v - v0 : v0 - v;
+        if (d < 0) d += nV;
+        if (v < nV) {
+          if (d < full) y = make_uint2(0u, 0u);
+          else if (d == full && part > 0) { if (trim & 2u) y.x += part; else y.y -= part; }
+        }
+      }
+      bool keep = false;
+      if (v < nV && y.x != y.y) {                           // merge(0) drops the placeholders; nothing touches
+        if (nws <= kWsLoopMax) keep = ws_overlap_regs(W, y.x, y.y) > 0;
+        else if constexpr (TREE) keep = seg_overlap_tree1(ws, ws_cdf, tree_start, G, y.x, y.y) > 0;
+      }
+      const uint64_t b = __ballot(keep);
+      if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = y; total += y.y - y.x; }
+      nout += __popcll(b);
+    }
+  }
+  total = wave_total_u32(total);
+  if (lane == 0) {
+    const int64_t so = (int64_t)sidx * A.n_units + u;
+    A.unit_n[so] = nout;
+    if (!(total > 0)) atomicOr(A.flags, kStatusAssert);
+    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(P->placed, P->ndraws, P->nuns, 0u);
+  }
+}
+
+}  // namespace gat

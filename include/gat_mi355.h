@@ -93,9 +93,12 @@ typedef struct {
   float ms_count_main;          /* the dominant count kernel alone (see count_kernel)             */
   float ms_rng;                 /* split of ms_sampler: k_rng (MT19937 rows)                      */
   float ms_place;               /*   k_place (placement up to the first consolidation)            */
-  float ms_merge;               /*   k_merge_big (first consolidation of long lists, if launched) */
-  float ms_tail;                /*   k_sampler (consolidation, trim, filter)                      */
+  float ms_merge;               /*   first consolidation: k_consolidate, or k_merge_big for long lists */
+  float ms_tail;                /*   everything behind it: k_tail + k_finalize + k_sampler        */
   int32_t count_kernel;         /* GAT_COUNT_KERNEL_* the call used for the overlap counters      */
+  float ms_ktail;               /*   of ms_tail: k_tail (the loop's tail, one stream per lane)    */
+  float ms_finalize;            /*   of ms_tail: k_finalize (extras, trim, filter, final list)    */
+  int64_t n_tail_units;         /* work units finished by k_tail / k_finalize (the rest: k_sampler) */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0
