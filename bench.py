@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # ... 6.29 TB/s measured with a float4 copy
 # samples per GPU per step of the extra shapes: config3 = its own 10 000; config5 / config4 are 8-GPU jobs of
 # 125 000 / 12 500 samples per GPU, measured here over one call's worth
-EXTRA_SAMPLES = {"config3": 10000, "config5": 16384, "config4": 2048}
+EXTRA_SAMPLES = {"config3": 10000, "config5": 16384, "config4": 4096}
 # the reference itself (Cython engine, one core, build container) -- it cannot travel
 REFERENCE_CYTHON = {"config2": 19.1}
 

@@ -73,6 +73,10 @@ struct SamplerArgs {
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
+  int32_t a_base, a_end;      // k_sampler / k_merge_big / k_consolidate: the launch covers launch positions [a_base, a_end) -- one
+                              // launch per size class, so that the dynamic LDS of a launch fits ITS longest list (a_end 0: all)
+  uint32_t* cum;              // split path: inclusive running lengths of the merged lists, parallel to the slab (k_merge_big fills it too)
+  uint2* slab_final;          // split path: where the units' FINAL lists go (a second slab: k_finalize writes out of place)
   const int32_t* skip;        // split path: skip[(sidx * n_units + a) * skip_stride] != 0: the unit was finished by k_tail / k_finalize
   int32_t skip_stride;
   const uint32_t* todo_count; // split path: k_sampler works off the queue of units k_tail left alone (k_finalize fills it)
@@ -526,8 +530,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   __shared__ int32_t redi[kMergeWaves];
   __shared__ uint32_t wsl[2 * kWsTreeMin];                       // short workspaces: starts, ends
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sidx = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
-  if (a >= A.n_long) return;
+  const int sidx = blockIdx.x, a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_long || (A.a_end > 0 && a >= A.a_end)) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int64_t sa = (int64_t)sidx * A.n_units + a;
   const int4 pre = A.st[sa];
@@ -677,6 +681,24 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   }
   cov = block_reduce_u32(cov, red, tid, false, false);
   tot = block_reduce_u32(tot, red, tid, false, false);
+  if (A.cum != nullptr) {
+    // split path: the running lengths k_tail's position draw searches (block-wide inclusive scan, 256 elements a round)
+    uint32_t* __restrict__ cum = A.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+    uint32_t run = 0;
+    for (int base = 0; base < count; base += kMergeThreads) {
+      const int i = base + tid;
+      uint32_t len = 0;
+      if (i < count) { const uint2 v = out[i]; len = v.y - v.x; }
+      const uint32_t incl = wave_incl_sum_u32(len, lane);
+      __syncthreads();
+      if (lane == 63) red[wave] = incl;
+      __syncthreads();
+      uint32_t before = run, all = 0;
+      for (int k = 0; k < kMergeWaves; ++k) { if (k < wave) before += red[k]; all += red[k]; }
+      if (i < count) cum[i] = before + incl;
+      run += all;
+    }
+  }
   if (tid == 0) A.st2[sa] = make_int4(count, (int)cov, (int)tot, 1);
 }
 
@@ -727,6 +749,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
   };
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint2* fin = (!HUGE && A.slab_final != nullptr) ? A.slab_final + (int64_t)sidx * A.slab_stride + Up->slab_off : out;
   uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + kMtLdsWords);
   const int64_t so = (int64_t)sidx * A.n_units + u;
 
@@ -1062,7 +1085,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             keep = ws_overlap_regs(W, v.x, v.y) > 0;
           }
           const uint64_t b = __ballot(keep);
-          if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
+          if (keep) { fin[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
           nout += __popcll(b);
         }
       } else if constexpr (TREE) {
@@ -1080,7 +1103,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
           for (int r = 0; r < R; ++r) {
             const bool keep = ov[r] > 0;                     // (0,0) fillers overlap nothing
             const uint64_t b = __ballot(keep);
-            if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = v[r]; total += v[r].y - v[r].x; }
+            if (keep) { fin[nout + __popcll(b & lanemask_lt(lane))] = v[r]; total += v[r].y - v[r].x; }
             nout += __popcll(b);
           }
         }
@@ -1117,8 +1140,8 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
     }
     return;
   }
-  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
-  if (a >= A.n_active) return;
+  const int a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active || (A.a_end > 0 && a >= A.a_end)) return;
   sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)blockIdx.x, a, lds, lane);
 }
 

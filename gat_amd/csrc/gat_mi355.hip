@@ -322,10 +322,14 @@ struct gat_problem {
 #endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
+  DevBuf<uint2> d_fslab;                 // split path: the units' final lists (k_finalize writes out of place)
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
   DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
+  std::vector<int32_t> h_class_start;    // launch positions where a size class begins (+ the end): one launch per class
   bool split_path = false;               // k_consolidate + k_tail + k_finalize in front of k_sampler
+  bool split_ran = false;                // ... and the last sampler batch took it: the units' lists are in d_fslab
+  const uint2* final_slab() const { return split_ran ? d_fslab.p : d_slab.p; }
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
@@ -473,6 +477,25 @@ static int upload_layout(gat_ctx* ctx, gat_problem* P) {
     for (int32_t u : P->h_order) { UnitDev x = P->h_units[(size_t)u]; x.pad = u; o.push_back(x); }
     if (o.empty()) o.push_back(UnitDev{});
     HIPCHK(ctx, P->d_units_o.upload(o, ctx->stream));
+  }
+  {
+    // size classes of the launch order (largest unit first, capacities do not grow): a new class where the capacity has
+    // dropped to 70 % of the class's first, at most six.  The wave-per-unit kernels keep a unit's list in LDS, their
+    // speed follows the waves a CU holds, and the dynamic LDS of a launch is one number: sized for the longest list of
+    // the PROBLEM, the config-4 shape ran ONE wave per CU (81 KB for chr1's 8 000 segments, 13 KB for chr21's).
+    P->h_class_start.clear();
+    const int N = (int)P->h_order.size();
+    int32_t first_cap = 0;
+    const char* env_c = getenv("GAT_SIZE_CLASSES");
+    const int max_classes = env_c ? std::max(1, atoi(env_c)) : 6;
+    for (int i = 0; i < N; ++i) {
+      const int32_t cap = P->h_units[(size_t)P->h_order[(size_t)i]].slab_cap;
+      if (i == 0 || ((int64_t)cap * 10 <= (int64_t)first_cap * 7 && (int)P->h_class_start.size() < max_classes)) {
+        P->h_class_start.push_back(i);
+        first_cap = cap;
+      }
+    }
+    P->h_class_start.push_back(N);
   }
   HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
   HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
@@ -637,6 +660,8 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     // of up to kTailMaxWs segments
     size_t small_ws = 0;
     for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs) ++small_ws;
+    // (long lists: their tail places dozens of segments, not the handful k_tail keeps aside -- 0.2 % finished there on the
+    //  config-4 shape -- so those problems stay with k_merge_big + k_sampler)
     P->split_path = P->sampler == GAT_SAMPLER_ANNOTATOR && !P->h_order.empty() && 2 * small_ws >= P->h_order.size() &&
                     max_hist + max_hist / 8 <= 1024 && !getenv("GAT_NO_SPLIT");
   }
@@ -744,7 +769,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   const double budget = env ? atof(env) : 12.0 * 1024 * 1024 * 1024;
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
                              (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
-                             (P->split_path ? P->slab_stride * 4 + (int64_t)sizeof(gat::TailPatch) * P->n_units : 0);
+                             (P->split_path ? P->slab_stride * 12 + (int64_t)(sizeof(gat::TailPatch) + 4) * P->n_units : 0);
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
@@ -767,6 +792,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     HIPCHK(ctx, P->d_st2.alloc(ns));
     if (P->split_path) {
       HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride)));
+      HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_patch.alloc(ns));
       HIPCHK(ctx, P->d_todo.alloc(ns));
       HIPCHK(ctx, P->d_todo_count.alloc(1));
@@ -1003,6 +1029,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       uint32_t max_work = 0;
       for (int32_t u : P->h_order) max_work = std::max(max_work, P->h_units[u].hist_total);
       A.st2 = nullptr;
+      // the split path (k_consolidate / k_merge_big + k_tail + k_finalize in front of k_sampler); lists beyond LDS: old path
+      const bool split = P->split_path && P->sampler_mode && !huge;
+      unsigned n_long_big = 0;                  // launch positions k_merge_big was given
       bool long_lists = false;                  // k_sampler<BIG>: the code for lists beyond the bucket sorts
       if (!huge && max_work + max_work / 8 > 1024) {
         long_lists = true;
@@ -1018,15 +1047,26 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           gat::SamplerArgs M = A;
           M.st2 = P->d_st2.p;
           M.big_buckets = nbk;
+          M.cum = split ? P->d_cum.p : nullptr;
+          n_long_big = n_long;
           const bool tree_m = P->max_nws > gat::kWsTreeMin;
           const void* km = tree_m ? (const void*)gat::k_merge_big<true> : (const void*)gat::k_merge_big<false>;
           HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
-          const unsigned gmy = std::min(n_long, 32768u);
-          const dim3 gm((unsigned)nb, gmy, (n_long + gmy - 1) / gmy);
           M.n_long = (int32_t)n_long;
-          if (tree_m) hipLaunchKernelGGL(gat::k_merge_big<true>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
-          else hipLaunchKernelGGL(gat::k_merge_big<false>, gm, dim3(gat::kMergeThreads), lds_m, ctx->stream, M);
-          HIPCHK(ctx, hipGetLastError());
+          for (size_t c = 0; c + 1 < P->h_class_start.size() && (unsigned)P->h_class_start[c] < n_long; ++c) {
+            // one launch per size class: LDS for the class's longest list and its histogram
+            const int a0 = P->h_class_start[c], a1 = std::min<int>(P->h_class_start[c + 1], (int)n_long);
+            const int ccap = P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap;
+            int cnbk = 1024;
+            while (cnbk < ccap && cnbk < 8192) cnbk <<= 1;
+            const size_t lds_c = (size_t)2 * ccap * 4 + (size_t)(cnbk + 1) * 4;
+            M.a_base = a0; M.a_end = a1; M.lds_cap = ccap; M.big_buckets = cnbk;
+            const unsigned cnt = (unsigned)(a1 - a0), gmy = std::min(cnt, 32768u);
+            const dim3 gm((unsigned)nb, gmy, (cnt + gmy - 1) / gmy);
+            if (tree_m) hipLaunchKernelGGL(gat::k_merge_big<true>, gm, dim3(gat::kMergeThreads), lds_c, ctx->stream, M);
+            else hipLaunchKernelGGL(gat::k_merge_big<false>, gm, dim3(gat::kMergeThreads), lds_c, ctx->stream, M);
+            HIPCHK(ctx, hipGetLastError());
+          }
           A.st2 = P->d_st2.p;                    // (k_sampler reads it for those units only: see n_long below)
           A.n_long = (int32_t)n_long;
         } else {
@@ -1037,28 +1077,38 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       const bool tree = P->max_nws > gat::kWsTreeMin;
       ctx->t_recorded = false;
-      const bool split = P->split_path && P->sampler_mode && !huge && !long_lists;
+      P->split_ran = split;
       if (split) {
         // the split path: first consolidation (wave per unit), the loop's tail (lane per unit), the final list (wave per
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
         gat::TailArgs T;
         T.S = A;
         T.S.st2 = P->d_st2.p;
+        T.S.n_long = (int32_t)n_long_big;                           // (whose verdict k_consolidate respects)
+        T.S.lds_cap = std::min(P->max_unit_cap, 1280);              // k_consolidate: the lists the wave bucket sorts take
+        T.S.slab_final = P->d_fslab.p;
         T.cum = P->d_cum.p;
         T.patch = P->d_patch.p;
         T.todo = P->d_todo.p;
         T.todo_count = P->d_todo_count.p;
         HIPCHK(ctx, hipMemsetAsync(P->d_todo_count.p, 0, 4, ctx->stream));
-        const size_t lds_c = (size_t)(gat::kSortScratchWords + 2 * (size_t)P->max_unit_cap) * 4;
+        const size_t lds_max = (size_t)(gat::kSortScratchWords + 2 * (size_t)T.S.lds_cap) * 4;
         const dim3 gu((unsigned)nb, gy, gz), gt((unsigned)((nb + 63) / 64), gy, gz);
-        if (tree) {
-          HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-          hipLaunchKernelGGL(gat::k_consolidate<true>, gu, dim3(64), lds_c, ctx->stream, T);
-        } else {
-          HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-          hipLaunchKernelGGL(gat::k_consolidate<false>, gu, dim3(64), lds_c, ctx->stream, T);
+        if (tree) HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        else HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
+          // one launch per size class, its LDS sized for the class's longest list
+          const int a0 = P->h_class_start[c], a1 = P->h_class_start[c + 1];
+          const int ccap = std::min(P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap, T.S.lds_cap);
+          gat::TailArgs C = T;
+          C.S.a_base = a0; C.S.a_end = a1; C.S.lds_cap = ccap;
+          const size_t lds_c = (size_t)(gat::kSortScratchWords + 2 * (size_t)ccap) * 4;
+          const unsigned cnt = (unsigned)(a1 - a0), cy = std::min(cnt, 32768u);
+          const dim3 gc((unsigned)nb, cy, (cnt + cy - 1) / cy);
+          if (tree) hipLaunchKernelGGL(gat::k_consolidate<true>, gc, dim3(64), lds_c, ctx->stream, C);
+          else hipLaunchKernelGGL(gat::k_consolidate<false>, gc, dim3(64), lds_c, ctx->stream, C);
+          HIPCHK(ctx, hipGetLastError());
         }
-        HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
         hipLaunchKernelGGL(gat::k_tail, gt, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
@@ -1069,6 +1119,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_t[1], ctx->stream)); ctx->t_recorded = true; }
         A.st2 = P->d_st2.p;
         A.n_long = (int32_t)n_act;
+        A.slab_final = P->d_fslab.p;
         A.skip = &P->d_patch.p->state;
         A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
         A.todo = P->d_todo.p;
@@ -1089,17 +1140,34 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                      : variant == 7 ? (const void*)gat::k_sampler<0, false, true, true>
                                     : (const void*)gat::k_sampler<0, false, false, false, 5>;
       HIPCHK(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      const dim3 gs = split ? dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)) : dim3((unsigned)nb, gy, gz);
-      switch (variant) {
-        case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 2: hipLaunchKernelGGL((gat::k_sampler<0, true, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 3: hipLaunchKernelGGL((gat::k_sampler<0, true, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 5: hipLaunchKernelGGL((gat::k_sampler<1, false, true, false>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 6: hipLaunchKernelGGL((gat::k_sampler<0, false, false, true>), gs, dim3(64), lds, ctx->stream, A); break;
-        case 7: hipLaunchKernelGGL((gat::k_sampler<0, false, true, true>), gs, dim3(64), lds, ctx->stream, A); break;
-        default: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false, 5>), gs, dim3(64), lds, ctx->stream, A); break;
+      auto launch_sampler = [&](const dim3& gs, size_t lds_, const gat::SamplerArgs& K) {
+        switch (variant) {
+          case 0: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 1: hipLaunchKernelGGL((gat::k_sampler<0, false, true, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 2: hipLaunchKernelGGL((gat::k_sampler<0, true, false, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 3: hipLaunchKernelGGL((gat::k_sampler<0, true, true, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 4: hipLaunchKernelGGL((gat::k_sampler<1, false, false, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 5: hipLaunchKernelGGL((gat::k_sampler<1, false, true, false>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 6: hipLaunchKernelGGL((gat::k_sampler<0, false, false, true>), gs, dim3(64), lds_, ctx->stream, K); break;
+          case 7: hipLaunchKernelGGL((gat::k_sampler<0, false, true, true>), gs, dim3(64), lds_, ctx->stream, K); break;
+          default: hipLaunchKernelGGL((gat::k_sampler<0, false, false, false, 5>), gs, dim3(64), lds_, ctx->stream, K); break;
+        }
+      };
+      const bool list_in_lds = !huge && P->sampler != GAT_SAMPLER_SEGMENTS;
+      if (split) {
+        launch_sampler(dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)), lds, A);      // off the queue
+      } else if (list_in_lds && A.big_buckets == 0 && P->h_class_start.size() > 2) {
+        // one launch per size class: LDS for the class's longest list
+        for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
+          const int a0 = P->h_class_start[c], a1 = P->h_class_start[c + 1];
+          const int ccap = P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap;
+          gat::SamplerArgs K = A;
+          K.a_base = a0; K.a_end = a1;
+          const unsigned cnt = (unsigned)(a1 - a0), cy = std::min(cnt, 32768u);
+          launch_sampler(dim3((unsigned)nb, cy, (cnt + cy - 1) / cy), (size_t)(gat::kMtLdsWords + 2 * (size_t)ccap) * 4, K);
+        }
+      } else {
+        launch_sampler(dim3((unsigned)nb, gy, gz), lds, A);
       }
       HIPCHK(ctx, hipGetLastError());
       if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[3], ctx->stream));
@@ -1112,7 +1180,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       gat::ContigArgs B;
       B.contig_unit_off = P->d_contig_unit_off.p; B.contig_units = P->d_contig_units.p; B.units = P->d_units.p;
       B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
-      B.slab_in = P->d_slab.p; B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
+      B.slab_in = P->final_slab(); B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
       size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
       const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
@@ -1193,7 +1261,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
 }
 
 static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
-  A.seg = P->merge_contigs ? P->d_cslab.p : P->d_slab.p;
+  A.seg = P->merge_contigs ? P->d_cslab.p : P->final_slab();
   A.seg_stride = P->slab_stride;
   A.c_off = P->d_count_c_off.p;
   A.n_arr = P->merge_contigs ? P->d_contig_n.p : P->d_unit_n.p;
@@ -1300,7 +1368,7 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
     if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true)) == kRelayout) continue;
     if (rc) return rc;
     const bool from_contigs = P->merge_contigs && !unit_level;
-    const uint2* src = from_contigs ? P->d_cslab.p : P->d_slab.p;
+    const uint2* src = from_contigs ? P->d_cslab.p : P->final_slab();
     const int32_t* nsrc = from_contigs ? P->d_contig_n.p : P->d_unit_n.p;
     const int nstride = from_contigs ? P->n_contigs : P->n_units;
     h_slab.resize((size_t)(nb * P->slab_stride));

@@ -57,14 +57,17 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const SamplerArgs& A = T.S;
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
-  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
-  if (a >= A.n_active) return;
+  const int a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_active || (A.a_end > 0 && a >= A.a_end)) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int64_t sa = (int64_t)sidx * A.n_units + a;
   const int4 pre = A.st[sa];
-  if (lane == 0) { A.st2[sa] = make_int4(0, 0, 0, 0); T.patch[sa].state = 0; }
+  if (lane == 0) T.patch[sa].state = 0;
+  // (launched behind k_merge_big when the problem has long lists: launch positions below n_long carry its verdict)
+  if (a < A.n_long) { if (A.st2[sa].w == 1) return; }
+  else if (lane == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
   const int n = pre.x;
-  if (pre.z < 0 || n <= 0 || n > A.lds_cap) return;               // k_place did not hand the unit over: k_sampler runs it in full
+  if (pre.z < 0 || n <= 0 || n > A.lds_cap) return;               // not handed over by k_place / beyond this kernel's LDS: k_sampler's
   uint32_t* scratch = lds;                                          // bucket-sort scratch
   uint2* seg = reinterpret_cast<uint2*>(lds + kSortScratchWords);
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
@@ -372,7 +375,9 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_finalize: result = unintersected.merge(0).filter(workspace) (gat/Engine.pyx:639-646) from the merged list and
-// k_tail's record.  The list, extras in place, is held in registers (written where it is read from).
+// k_tail's record, written OUT OF PLACE into the second slab (the extras shift what is behind them: in place every
+// element would have to be held until everything in front of it is written).  Units k_tail left alone are queued for
+// k_sampler, which writes its final lists to the same slab.
 template <bool TREE>
 __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const SamplerArgs& A = T.S;
@@ -395,7 +400,8 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
   const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
   const WsTreeGeom G = ws_tree_geom(nws);
-  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const uint2* __restrict__ src = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint2* __restrict__ dst = A.slab_final + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int nU = A.st2[sa].x, nE = P->n_extra, nV = nU + nE;
   uint2 ex[kTailMaxExtra];
   int vj[kTailMaxExtra];
@@ -404,31 +410,30 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const uint32_t trim = P->trim;
   const int v0 = P->trim_v0, full = P->trim_full;
   const uint32_t part = P->trim_part;
-  constexpr int kR = 17;                                  // rounds of 64: lists of up to 1024 + extras
-  uint2 x[kR];
+  int nout = 0;
+  uint32_t total = 0;
+  constexpr int kB = 4;                                    // rounds whose loads are in flight together
+  for (int base = 0; base < nV; base += kB * kWave) {
+    uint2 x[kB];
 #pragma unroll
-  for (int r = 0; r < kR; ++r) {
-    x[r] = make_uint2(0u, 0u);
-    if (r * kWave < nV) {
-      const int v = r * kWave + lane;
+    for (int q = 0; q < kB; ++q) {
+      const int v = base + q * kWave + lane;
       int c = 0, which = -1;
 #pragma unroll
       for (int j = 0; j < kTailMaxExtra; ++j) { if (vj[j] < v) c++; if (vj[j] == v) which = j; }
+      x[q] = make_uint2(0u, 0u);
       if (v < nV) {
         if (which >= 0) {
 #pragma unroll
-          for (int j = 0; j < kTailMaxExtra; ++j) if (which == j) x[r] = ex[j];
-        } else x[r] = out[v - c];
+          for (int j = 0; j < kTailMaxExtra; ++j) if (which == j) x[q] = ex[j];
+        } else x[q] = src[v - c];
       }
     }
-  }
-  int nout = 0;
-  uint32_t total = 0;
 #pragma unroll
-  for (int r = 0; r < kR; ++r) {
-    if (r * kWave < nV) {
-      const int v = r * kWave + lane;
-      uint2 y = x[r];
+    for (int q = 0; q < kB; ++q) {
+      if (base + q * kWave >= nV) break;
+      const int v = base + q * kWave + lane;
+      uint2 y = x[q];
       if (trim & 1u) {
         // trim_ends walked from v0 (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next
         int d = (trim & 2u) ? v - v0 : v0 - v;
@@ -439,12 +444,12 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
         }
       }
       bool keep = false;
-      if (v < nV && y.x != y.y) {                           // merge(0) drops the placeholders; nothing touches
+      if (v < nV && y.x != y.y) {                          // merge(0) drops the placeholders; nothing touches
         if (nws <= kWsLoopMax) keep = ws_overlap_regs(W, y.x, y.y) > 0;
         else if constexpr (TREE) keep = seg_overlap_tree1(ws, ws_cdf, tree_start, G, y.x, y.y) > 0;
       }
       const uint64_t b = __ballot(keep);
-      if (keep) { out[nout + __popcll(b & lanemask_lt(lane))] = y; total += y.y - y.x; }
+      if (keep) { dst[nout + __popcll(b & lanemask_lt(lane))] = y; total += y.y - y.x; }
       nout += __popcll(b);
     }
   }

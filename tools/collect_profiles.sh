@@ -1,39 +1,23 @@
 #!/bin/bash
-# rocprofv3 summaries behind DESIGN.md / bench.py's roofline: kernel-trace stats, then HBM traffic
-# counters in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).
-# usage (on the GPU box): bash tools/collect_profiles.sh <tag> [bench args...]
+# rocprofv3 summaries behind DESIGN.md / bench.py's roofline, one BASELINE shape at a time: kernel-trace stats, then the
+# counters in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no --pmc together with
+# trace domains other than --kernel-trace).  usage (GPU box): bash tools/collect_profiles.sh <round tag> [config:samples ...]
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 TAG=$1; shift
-OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_write.log 2>&1
-cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections, json
-out = sys.argv[1]
-res = collections.defaultdict(lambda: collections.defaultdict(float))
-calls = collections.defaultdict(int)
-for kind in ("fetch", "write"):
-    for f in glob.glob(out + "/%s/*/*counter_collection.csv" % kind):
-        for r in csv.DictReader(open(f)):
-            n = r["Kernel_Name"]
-            if "gat::" not in n:
-                continue
-            res[n][r["Counter_Name"]] += float(r["Counter_Value"])
-            if kind == "fetch":
-                calls[n] += 1
-summary = {}
-for n, d in res.items():
-    c = max(1, calls[n])
-    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
-    summary[n] = {"launches": c, "FETCH_SIZE_KiB_per_launch": d.get("FETCH_SIZE", 0.0) / c,
-                  "WRITE_SIZE_KiB_per_launch": d.get("WRITE_SIZE", 0.0) / c}
-json.dump(summary, open(out + "/traffic.json", "w"), indent=1)
-print(json.dumps(summary, indent=1))
-PY
-grep -v "^W\|^E\|^I" $OUT/bench_trace.log | tail -1 > $OUT/bench.json
+SHAPES=${@:-"config2:10000 config3:10000 config5:16384 config4:2048"}
+for SH in $SHAPES; do
+  CFG=${SH%%:*}; S=${SH##*:}
+  OUT=$R/gpurun_out/prof_${TAG}/${CFG}; rm -rf $OUT; mkdir -p $OUT
+  ARGS="--no-cpu-baseline --extra= --config $CFG --samples $S --steps 3 --warmup 1"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1 -- python3 bench.py $ARGS > $OUT/bench_sq1.log 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/sq2 -- python3 bench.py $ARGS > $OUT/bench_sq2.log 2>&1
+  cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+  grep -h "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench.json
+done
+python3 tools/summarize_profiles.py $R/gpurun_out/prof_${TAG} $TAG

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/<config>/) into the summaries that are
+committed under profiles/: per configuration the kernel-trace statistics (CSV, gat:: kernels), a text table of the
+counters per kernel and launch, and <tag>_kernel_counters.json, which bench.py reads for the `traffic` / `valu_busy`
+fields of its roofline block (keyed "config:samples per step").
+
+Counters (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are KiB summed over the 8 XCDs,
+collected in separate passes; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so HBM bytes =
+(2 x FETCH_SIZE + WRITE_SIZE) KiB (the factor was re-checked in round 1 on k_place, whose reads are exactly the rows
+k_rng writes).  VALU issue share = SQ_INSTS_VALU x 2 cycles (a wave64 instruction occupies a SIMD-32 for two cycles) /
+(4 SIMDs x 256 CUs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the XCDs).
+usage: tools/summarize_profiles.py gpurun_out/prof_<tag> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+counters_json = {}
+for d in sorted(glob.glob(os.path.join(src, "*"))):
+    cfg = os.path.basename(d)
+    if not os.path.isdir(d):
+        continue
+    res = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(os.path.join(d, "*", "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            n = r["Kernel_Name"]
+            if "gat::" not in n:
+                continue
+            res[n][r["Counter_Name"]] += float(r["Counter_Value"])
+            calls[n][r["Counter_Name"]] += 1
+    stats = {}
+    ks = os.path.join(d, "kernel_stats.csv")
+    if os.path.exists(ks):
+        rows = [r for r in csv.DictReader(open(ks)) if "gat::" in r["Name"]]
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as out:
+            w = csv.writer(out)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                stats[r["Name"]] = float(r["AverageNs"])
+    bj = os.path.join(d, "bench.json")
+    S = None
+    if os.path.exists(bj) and os.path.getsize(bj):
+        b = json.load(open(bj))
+        S = b["config"]["samples_per_step_per_gpu"]
+        shutil.copy(bj, os.path.join(dst, "%s_%s_bench.json" % (tag, cfg)))
+    with open(os.path.join(dst, "%s_%s_pmc.txt" % (tag, cfg)), "w") as out:
+        out.write("# rocprofv3 --pmc, one pass per counter group (tools/collect_profiles.sh), bench.py --config %s --samples %s "
+                  "--steps 3 --warmup 1; values per launch, summed over the 8 XCDs; FETCH_SIZE / WRITE_SIZE in KiB\n" % (cfg, S))
+        per_kernel = {}
+        for n in sorted(res):
+            out.write(n + "\n")
+            v = dict((c, res[n][c] / max(1, calls[n][c])) for c in res[n])
+            for c in sorted(v):
+                out.write("   %-28s %16.0f per launch\n" % (c, v[c]))
+            rec = {"fetch_kib_per_launch": v.get("FETCH_SIZE", 0.0), "write_kib_per_launch": v.get("WRITE_SIZE", 0.0),
+                   "avg_ns": stats.get(n)}
+            if v.get("GRBM_GUI_ACTIVE") and v.get("SQ_INSTS_VALU") is not None:
+                cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+                rec["valu_busy"] = v["SQ_INSTS_VALU"] * 2.0 / (4 * 256 * cycles)
+                rec["waves_per_cu_avg"] = v.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / cycles / 256.0 if v.get("SQ_WAVE_CYCLES") else None
+                out.write("   %-28s %16.3f\n" % ("valu_issue_share", rec["valu_busy"]))
+                if rec["waves_per_cu_avg"]:
+                    out.write("   %-28s %16.2f\n" % ("avg_waves_per_cu", rec["waves_per_cu_avg"]))
+            hbm = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
+            rec["hbm_bytes_per_launch"] = hbm
+            if stats.get(n):
+                rec["hbm_GBps"] = hbm / stats[n]
+                out.write("   %-28s %16.1f GB/s (2 x FETCH + WRITE over the average launch)\n" % ("hbm_rate", rec["hbm_GBps"]))
+            per_kernel[n] = rec
+    if S is not None:
+        count = [n for n in per_kernel if "k_count_merged(" in n or "k_count_seg<" in n or "k_count_swap" in n]
+        entry = {"kernels": per_kernel}
+        if count:
+            main = max(count, key=lambda n: per_kernel[n].get("avg_ns") or 0)
+            entry["count_kernel"] = dict(per_kernel[main], name=main)
+        counters_json["%s:%d" % (cfg, S)] = entry
+with open(os.path.join(dst, "%s_kernel_counters.json" % tag), "w") as f:
+    json.dump(counters_json, f, indent=1, sort_keys=True)
+print("wrote", sorted(counters_json))
