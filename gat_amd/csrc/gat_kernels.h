@@ -1282,7 +1282,7 @@ struct CountArgs {
   int32_t lds_grid;           // staging capacity (grid words)
   uint32_t* part;             // [n_contigs][3][n_tracks][n_samples] per-contig partial counts
   // merged multi-track index (k_count_merged): per contig all tracks' intervals sorted by start
-  const uint4* mz;            // entries {start, end, track, 0}; long intervals cut into pieces; a sentinel start ends every contig
+  const uint2* mz;            // entries {start, length:16 | track:16}; long intervals cut into pieces; a sentinel start ends every contig
   const int64_t* mz_off;      // n_contigs+1
   const uint32_t* mfirst;     // per contig and position cell: first entry that reaches into the cell or starts in / after it
   const int64_t* mf_off;      // n_contigs+1
@@ -1466,20 +1466,24 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 
 // nucleotide-overlap / nucleotide-density against MANY tracks: one look-up per sample segment instead of one per
 // (segment, track).  A sample segment overlaps an interval of very few tracks (config 3: 0.8 of 100 on average), so the
-// host merges all tracks' intervals of a contig into one list sorted by start (entries carry their track; intervals
-// longer than a bound are cut into pieces, which changes no sum) with a position grid first[cell] = the first entry that
-// reaches into the cell or starts in or behind it.  A lane scans from first[cell of x.start] while start < x.end and adds
-// min(ends) - max(starts) of every entry it meets to the track's uint32 accumulator in LDS (gat/SegmentList.pyx:1026-1076
-// sums the same pairs per track; uint32 addition is order independent).
-//   The look-ups are 16-byte gathers all over a contig's index: from the Infinity Cache they ran at its gather rate
-// (2.6 ms per 10 000 samples of config 3).  One contig's index is below 1 MB (config 3), so the work is dealt such
-// that an XCD's L2 serves it: a workgroup owns (contig, group of samples), the contigs are spread over eight slots by
-// the host (balanced by their segment counts), slot = blockIdx % 8 -- the stride with which workgroups are observed to
-// go round the XCDs (speed only; any placement gives the same sums) -- and a slot walks its contigs one after the other.
-// Every wave takes whole samples: its accumulators are wave-private LDS, there is no workgroup barrier.  Per (contig,
-// sample) the T partial sums go to part[c][s][t]; k_count_merged_finish adds them over the contigs in reference order.
-constexpr int kMergedThreads = 256;
+// host merges all tracks' intervals of a contig into one list sorted by start -- 8-byte entries {start, length:16 |
+// track:16}; intervals longer than a bound are cut into pieces, which changes no sum -- with a position grid first[cell] =
+// the first entry that reaches into the cell or starts in or behind it.  A lane scans from first[cell of x.start] while
+// start < x.end and adds min(ends) - max(starts) of every entry it meets to the track's uint32 accumulator in LDS
+// (gat/SegmentList.pyx:1026-1076 sums the same pairs per track; uint32 addition is order independent).
+//   The look-ups are 8-byte gathers all over a contig's index, bound by the rate at which L2 hands out lines.  The work
+// is dealt so that an XCD's L2 serves them: a workgroup owns (contig, group of samples), the contigs are spread over
+// eight slots by the host (balanced by their entries), slot = blockIdx % 8 -- the stride with which workgroups are
+// observed to go round the XCDs (speed only; any placement gives the same sums) -- and a slot walks its contigs one after
+// the other.  Every wave takes whole samples (four look-ups per lane in flight): its accumulators are wave-private
+// LDS, there is no workgroup barrier.  Per (contig, sample) the T partial sums go to part[c][s][t];
+// k_count_merged_finish adds them over the contigs in reference order.
+//   Measured and dropped: the same join streamed through LDS (index cut into chunks of 4 096 entries staged per workgroup,
+// every wave advancing a cursor through its samples' sorted lists, look-ups in LDS).  It is bit-exact and no faster on
+// config 3 (1.80 vs 1.82 ms per 10 000 samples) and slower on the config-4 shape (54.9 vs 34.1 ms per 4 096 samples: with
+// 1 000 tracks only eight samples' accumulators fit beside a chunk, so a contig's 3.3 MB are staged 512 times).
 constexpr int kMergedSlots = 8;
+constexpr int kMergedThreads = 256;
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int T = A.n_tracks;
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   const int ci = q / n_groups, grp = q - ci * n_groups;
   if (ci >= A.m_slot_off[slot + 1] - A.m_slot_off[slot]) return;
   const int c = A.m_slot_contigs[A.m_slot_off[slot] + ci];
-  const uint4* __restrict__ Z = A.mz + A.mz_off[c];
+  const uint2* __restrict__ Z = A.mz + A.mz_off[c];
   const uint32_t* __restrict__ F = A.mfirst + A.mf_off[c];
   const int shift = A.m_shift[c];
   const uint32_t last = (uint32_t)(A.m_cells[c] - 1);
@@ -1504,7 +1508,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
-      uint4 z[kR];
+      uint2 z[kR];
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
@@ -1517,8 +1521,9 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         while (z[r].x < x[r].y) {                                    // the contig's sentinel start 0xffffffff ends the scan
-          const uint32_t lo = z[r].x > x[r].x ? z[r].x : x[r].x, hi = z[r].y < x[r].y ? z[r].y : x[r].y;
-          if (hi > lo) atomicAdd(&acc[z[r].z], hi - lo);
+          const uint32_t ze = z[r].x + (z[r].y & 0xffffu);
+          const uint32_t lo = z[r].x > x[r].x ? z[r].x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
+          if (hi > lo) atomicAdd(&acc[z[r].y >> 16], hi - lo);
           z[r] = Z[++k[r]];
         }
       }

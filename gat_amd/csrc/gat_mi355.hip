@@ -91,7 +91,7 @@ struct AnnoDev {
   DevBuf<int32_t> shift, cells;
   std::vector<int64_t> h_off;
   // merged multi-track index (k_count_merged), built for problems with several tracks
-  DevBuf<uint4> mz;
+  DevBuf<uint2> mz;
   DevBuf<uint32_t> mfirst;
   DevBuf<int64_t> mz_off, mf_off;
   DevBuf<int32_t> m_shift, m_cells, m_slot_off, m_slot_contigs;
@@ -117,17 +117,20 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
   return GAT_OK;
 }
 
-// The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, each
-// entry {start, end, track}.  Intervals longer than `bound` (a power of two >= 8 x the group's mean length) are cut into
-// pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more than `bound` bases; first[g] is
-// the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a segment starting in cell g begins.
+// The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, 8-byte
+// entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two >= 8 x the group's mean length,
+// at most 32 768) are cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
+// than `bound` bases; first[g] is the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a
+// segment starting in cell g begins.
 static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
                         int32_t n_groups) {
-  std::vector<uint4> hz;
+  if (n_tracks > 65535) return GAT_OK;                              // (track ids are 16 bits: such problems keep the per-track kernel)
+  std::vector<uint2> hz;
   std::vector<uint32_t> hf;
   std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
   std::vector<int32_t> h_shift((size_t)n_groups, 0), h_cells((size_t)n_groups, 1);
-  std::vector<uint4> e;
+  struct Ent { uint32_t s, e, t; };
+  std::vector<Ent> e;
   for (int c = 0; c < n_groups; ++c) {
     e.clear();
     uint64_t total_len = 0, cnt = 0;
@@ -136,22 +139,22 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
       for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) { total_len += annos[i].end - annos[i].start; ++cnt; }
     }
     uint32_t bound = 1024;
-    while (cnt > 0 && (uint64_t)bound < 8 * (total_len / cnt) && bound < (1u << 30)) bound <<= 1;
+    while (cnt > 0 && (uint64_t)bound < 8 * (total_len / cnt) && bound < 32768u) bound <<= 1;
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
       for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
         uint32_t s0 = annos[i].start;
         const uint32_t e0 = annos[i].end;
-        while (e0 - s0 > bound) { e.push_back(make_uint4(s0, s0 + bound, (uint32_t)t, 0u)); s0 += bound; }
-        e.push_back(make_uint4(s0, e0, (uint32_t)t, 0u));
+        while (e0 - s0 > bound) { e.push_back(Ent{s0, s0 + bound, (uint32_t)t}); s0 += bound; }
+        e.push_back(Ent{s0, e0, (uint32_t)t});
       }
     }
-    std::sort(e.begin(), e.end(), [](const uint4& a, const uint4& b) { return a.x != b.x ? a.x < b.x : a.z < b.z; });
+    std::sort(e.begin(), e.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
     const size_t ne = e.size();
     if (ne >= 0xfffffff0ull) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
-    const uint32_t max_start = ne ? e[ne - 1].x : 0u;
+    const uint32_t max_start = ne ? e[ne - 1].s : 0u;
     int64_t target = 64;
-    while (target < (int64_t)ne) target <<= 1;                      // about one entry per cell
+    while (target < (int64_t)(ne / 2)) target <<= 1;                // about two entries per cell
     int sh = 0;
     while (((int64_t)max_start >> sh) + 1 > target) ++sh;
     const int64_t cells = ((int64_t)max_start >> sh) + 1;
@@ -163,16 +166,16 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
       size_t k = 0;                                                 // first entry starting at or behind the cell's start
       for (int64_t g = 0; g < cells; ++g) {
         const uint64_t cs = (uint64_t)g << sh;
-        while (k < ne && (uint64_t)e[k].x < cs) ++k;
+        while (k < ne && (uint64_t)e[k].s < cs) ++k;
         hf[fo + (size_t)g] = (uint32_t)k;
       }
       for (size_t i = 0; i < ne; ++i) {                             // ... or an earlier one that reaches past it
-        for (int64_t g = ((int64_t)e[i].x >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].y; ++g)
+        for (int64_t g = ((int64_t)e[i].s >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].e; ++g)
           if ((uint32_t)i < hf[fo + (size_t)g]) hf[fo + (size_t)g] = (uint32_t)i;
       }
     }
-    hz.insert(hz.end(), e.begin(), e.end());
-    hz.push_back(make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u));     // ends every scan
+    for (size_t i = 0; i < ne; ++i) hz.push_back(make_uint2(e[i].s, ((e[i].t & 0xffffu) << 16) | ((e[i].e - e[i].s) & 0xffffu)));
+    hz.push_back(make_uint2(0xffffffffu, 0u));                      // ends every scan
     hz_off[(size_t)c + 1] = (int64_t)hz.size();
     hf_off[(size_t)c + 1] = (int64_t)hf.size();
   }
@@ -860,7 +863,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
     const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
     const size_t lds_merged = (size_t)A.n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-    if (A.n_contigs > 0 && only_overlap && annos.has_merged && lds_merged <= 64 * 1024 && !getenv("GAT_COUNT_NO_MERGED")) {
+    if (A.n_contigs > 0 && only_overlap && annos.has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED")) {
       // several tracks: one look-up per sample segment in the merged index of all tracks
       A.mz = annos.mz.p; A.mz_off = annos.mz_off.p; A.mfirst = annos.mfirst.p; A.mf_off = annos.mf_off.p;
       A.m_shift = annos.m_shift.p; A.m_cells = annos.m_cells.p;
