@@ -289,7 +289,12 @@ def buildParser(usage=None):
     parser.add_option_group(g)
     g = optparse.OptionGroup(parser, "Processing options")
     g.add_option("-t", "--num-threads", dest="num_threads", type="int", help="accepted and ignored: the GPU replaces the pool")
-    g.add_option("--random-seed", dest="random_seed", type="int")
+    g.add_option("--random-seed", dest="random_seed", type="int",
+                 help="base of the random streams: work unit (sample s, isochore unit u) draws from numpy's legacy "
+                      "RandomState seeded with (seed + s * n_units + u) mod 2^32.  The reference seeds ONE global stream with "
+                      "this value, so its sampled columns are statistically equal to, not identical with, the ones printed here "
+                      "(observed counts, sizes and densities are identical); with the per-unit seeding patched into the "
+                      "reference the tables are byte-identical (tests/golden/make_goldens.py)")
     g.add_option("--truncate-segments-to-workspace", dest="truncate_segments_to_workspace", action="store_true")
     g.add_option("--truncate-workspace-to-annotations", dest="truncate_workspace_to_annotations", action="store_true")
     g.add_option("--restrict-workspace", dest="restrict_workspace", action="store_true")

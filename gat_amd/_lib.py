@@ -29,6 +29,7 @@ SYMBOLS = [
     "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_problem_info",
+    "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts",
 ]
 
 
@@ -131,6 +132,14 @@ def lib():
     L.gat_count_lists.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, i32, vp, i32, vp]
     L.gat_problem_info.restype = C.c_int
     L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.gat_comm_unique_id.restype = C.c_int
+    L.gat_comm_unique_id.argtypes = [vp]
+    L.gat_comm_create.restype = C.c_int
+    L.gat_comm_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, vp]
+    L.gat_comm_destroy.restype = None
+    L.gat_comm_destroy.argtypes = [vp]
+    L.gat_allgather_counts.restype = C.c_int
+    L.gat_allgather_counts.argtypes = [vp, vp, vp, vp, i64]
     _LIB = L
     return L
 
@@ -195,6 +204,35 @@ class Context(object):
                                      _p(anno_off), n_tracks, _p(ws_nseg), n_groups, _p(out)), self._h)
         return [out[k].view(np.float64).copy() if c == "nucleotide-density" else out[k].copy()
                 for k, c in enumerate(counters)]
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 bytes that rank 0 hands to the other ranks (ncclGetUniqueId through the C ABI)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().gat_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm(object):
+    """RCCL communicator of the C ABI (gat_comm): the all-gather of the per-rank count blocks without torch."""
+
+    def __init__(self, ctx, n_ranks, rank, unique_id):
+        self.ctx, self.n_ranks, self.rank = ctx, n_ranks, rank
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _check(lib().gat_comm_create(ctx._h, C.byref(self._h), int(n_ranks), int(rank), buf), ctx._h)
+
+    def allgather_counts(self, send_dev_ptr, recv_dev_ptr, n_slots):
+        _check(lib().gat_allgather_counts(self.ctx._h, self._h, C.c_void_p(send_dev_ptr), C.c_void_p(recv_dev_ptr), int(n_slots)),
+               self.ctx._h)
+
+    def close(self):
+        if self._h:
+            lib().gat_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class Problem(object):

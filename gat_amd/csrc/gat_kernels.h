@@ -217,11 +217,12 @@ constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 // the single-workspace-segment shape, only that loop is compiled in; 0 no workspace beyond the LDS table; 2 everything.
 // SMALL: every unit has at most 64 workspace segments and fewer than 256 working segments: quarter-size LDS tables,
 // so that more tiles are resident per CU (the kernel has few waves and hides latency by their number).
-template <int KIND, int MODE, bool SMALL = false>
+// SMALL 2: at most 64 workspace segments, rank table at full size (a quarter of the workspace table's LDS back).
+template <int KIND, int MODE, int SMALL = 0>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   constexpr bool ALL_SIMPLE = MODE == 1;
   constexpr bool TREES = MODE == 2;
-  constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = SMALL ? 256 : kPlaceRankLds;
+  constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = SMALL == 1 ? 256 : kPlaceRankLds;
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank[kRankTab];
   __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst

@@ -5,6 +5,8 @@
 // and kernel launches.  Sampling, fromIsochores and counting run only as HIP kernels
 // (gat_kernels.h); there is no CPU path for them in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types only: the library is loaded with dlopen at the first collective
 
 #include <algorithm>
 #include <cmath>
@@ -1015,7 +1017,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
           if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
-          else if (mode == 0 && P->small_tables) hipLaunchKernelGGL((gat::k_place<0, 0, true>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && P->small_tables) hipLaunchKernelGGL((gat::k_place<0, 0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && P->max_nws <= 64) hipLaunchKernelGGL((gat::k_place<0, 0, 2>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<0, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<0, 2>), gp, dim3(64), 0, ctx->stream, A);
         }
@@ -1451,6 +1454,92 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   HIPCHK(ctx, hipMemcpyAsync(counts_host, d_out.p, nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The one collective of the path: all-gather of the per-rank count blocks over xGMI (RCCL), replacing the reference's
+// pool result collation (gat/__init__.py:681-700, :770-774).  RCCL is loaded lazily so that single-GPU hosts need not
+// have it (and so that a process that already holds torch's copy does not get a second one by linking).
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (api.handle) break;
+    }
+    if (api.handle) {
+      api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.handle, "ncclGetUniqueId");
+      api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(api.handle, "ncclCommInitRank");
+      api.comm_destroy = (decltype(api.comm_destroy))dlsym(api.handle, "ncclCommDestroy");
+      api.all_gather = (decltype(api.all_gather))dlsym(api.handle, "ncclAllGather");
+      api.error_string = (decltype(api.error_string))dlsym(api.handle, "ncclGetErrorString");
+    }
+  }
+  const bool ok = api.handle && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather;
+  return ok ? &api : nullptr;
+}
+
+struct gat_comm {
+  ncclComm_t comm = nullptr;
+  int n_ranks = 1, rank = 0;
+};
+
+static_assert(sizeof(ncclUniqueId) == GAT_COMM_ID_BYTES, "GAT_COMM_ID_BYTES");
+
+extern "C" int gat_comm_unique_id(void* id_out) {
+  if (!id_out) return set_err(nullptr, GAT_ERR_ARG, "gat_comm_unique_id: NULL argument");
+  RcclApi* R = rccl_api();
+  if (!R) return set_err(nullptr, GAT_ERR_DEVICE, "RCCL (librccl.so) is not available: %s", dlerror() ? dlerror() : "symbols missing");
+  ncclUniqueId id;
+  const ncclResult_t rc = R->get_unique_id(&id);
+  if (rc != ncclSuccess) return set_err(nullptr, GAT_ERR_DEVICE, "ncclGetUniqueId: %s", R->error_string ? R->error_string(rc) : "error");
+  memcpy(id_out, &id, sizeof(id));
+  return GAT_OK;
+}
+
+extern "C" int gat_comm_create(gat_ctx* ctx, gat_comm** out, int n_ranks, int rank, const void* id) {
+  if (!ctx || !out || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return set_err(ctx, GAT_ERR_ARG, "gat_comm_create: bad argument");
+  *out = nullptr;
+  RcclApi* R = rccl_api();
+  if (!R) return set_err(ctx, GAT_ERR_DEVICE, "RCCL (librccl.so) is not available");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  std::unique_ptr<gat_comm> C(new gat_comm());
+  C->n_ranks = n_ranks;
+  C->rank = rank;
+  const ncclResult_t rc = R->comm_init_rank(&C->comm, n_ranks, uid, rank);
+  if (rc != ncclSuccess) return set_err(ctx, GAT_ERR_DEVICE, "ncclCommInitRank: %s", R->error_string ? R->error_string(rc) : "error");
+  *out = C.release();
+  return GAT_OK;
+}
+
+extern "C" void gat_comm_destroy(gat_comm* comm) {
+  if (!comm) return;
+  RcclApi* R = rccl_api();
+  if (R && comm->comm) (void)R->comm_destroy(comm->comm);
+  delete comm;
+}
+
+extern "C" int gat_allgather_counts(gat_ctx* ctx, gat_comm* comm, const void* send_dev, void* recv_dev, int64_t n_slots) {
+  if (!ctx || !comm || !send_dev || !recv_dev || n_slots < 0) return set_err(ctx, GAT_ERR_ARG, "gat_allgather_counts: bad argument");
+  RcclApi* R = rccl_api();
+  if (!R) return set_err(ctx, GAT_ERR_DEVICE, "RCCL (librccl.so) is not available");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const ncclResult_t rc = R->all_gather(send_dev, recv_dev, (size_t)n_slots, ncclInt64, comm->comm, ctx->stream);
+  if (rc != ncclSuccess) return set_err(ctx, GAT_ERR_DEVICE, "ncclAllGather: %s", R->error_string ? R->error_string(rc) : "error");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return GAT_OK;
 }

@@ -178,6 +178,24 @@ int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                     const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
                     const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
 
+/* ---- multi-GPU: the one collective of the path ---------------------------------------------
+ * Replaces the result collation of the reference's process pool (gat/__init__.py:681-700, :770-774):
+ * every rank has computed the columns of its own contiguous sample range (gat_sample_and_count with
+ * [sample_begin, sample_end) = its shard) and ONE all-gather over xGMI makes every rank hold all of them.
+ * RCCL is loaded at the first call (dlopen of librccl.so: the library has no link-time dependency on it);
+ * a host without it gets GAT_ERR_DEVICE.  Ranks are processes, one per GPU; rank 0 calls
+ * gat_comm_unique_id and passes the 128 bytes to the others by whatever means the host has (the Python host
+ * uses torch.distributed's store or MPI; a file works).  torch.distributed's "nccl" backend is the same
+ * RCCL: gat_amd/distributed.py uses it when a process group exists and needs none of this. */
+typedef struct gat_comm gat_comm;
+#define GAT_COMM_ID_BYTES 128
+int gat_comm_unique_id(void* id_out /* GAT_COMM_ID_BYTES */);
+int gat_comm_create(gat_ctx* ctx, gat_comm** out, int n_ranks, int rank, const void* id /* GAT_COMM_ID_BYTES */);
+void gat_comm_destroy(gat_comm* comm);
+/* send_dev: this rank's n_slots 8-byte slots (its [counter][track][shard] block); recv_dev: n_ranks * n_slots
+ * slots, rank r's block at r * n_slots.  Enqueued on the ctx stream; returns after completion. */
+int gat_allgather_counts(gat_ctx* ctx, gat_comm* comm, const void* send_dev, void* recv_dev, int64_t n_slots);
+
 /* queries */
 int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,
                      int64_t* slab_segments_per_sample, int64_t* algorithmic_bytes_per_sample);

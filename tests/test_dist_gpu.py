@@ -84,3 +84,25 @@ def test_run_two_ranks_equals_single_process(tmp_path, seed):
         assert r0 == _run(37, None)
     lines = open(str(tmp_path / "counts_nucleotide-overlap.tsv")).read().split("\n")
     assert lines[0] == "track\tannotation\tobserved\tcounts" and len(lines[1].split("\t")[3].split(",")) == 37
+
+
+def test_c_abi_allgather_counts_single_rank():
+    """gat_comm_* / gat_allgather_counts (RCCL loaded by the library itself, no torch): a communicator of one rank on this
+    box's GPU gathers a count block onto itself."""
+    from gat_amd import _lib
+    ctx = _lib.Context(0)
+    comm = _lib.Comm(ctx, 1, 0, _lib.comm_unique_id())
+    n = 3 * 5 * 7
+    src = np.arange(n, dtype=np.int64) * 3 - 11
+    a, b = ctx.alloc(n * 8), ctx.alloc(n * 8)
+    try:
+        _lib._check(_lib.lib().gat_memcpy_h2d(ctx._h, a, src.ctypes.data, n * 8), ctx._h)
+        comm.allgather_counts(a, b, n)
+        out = np.zeros(n, dtype=np.int64)
+        ctx.d2h(out, b)
+        assert np.array_equal(out, src)
+    finally:
+        ctx.free(a)
+        ctx.free(b)
+        comm.close()
+        ctx.close()

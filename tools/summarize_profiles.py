@@ -69,6 +69,13 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
                 out.write("   %-28s %16.3f\n" % ("valu_issue_share", rec["valu_busy"]))
                 if rec["waves_per_cu_avg"]:
                     out.write("   %-28s %16.2f\n" % ("avg_waves_per_cu", rec["waves_per_cu_avg"]))
+            if v.get("TCC_REQ_sum"):
+                # requests that reach the L2s (128-byte lines) and the share served there
+                rec["l2_requests_per_launch"] = v["TCC_REQ_sum"]
+                rec["l2_hit_rate"] = v.get("TCC_HIT_sum", 0.0) / max(1.0, v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0))
+                if stats.get(n):
+                    rec["l2_requests_per_us"] = v["TCC_REQ_sum"] / (stats[n] / 1e3)
+                    out.write("   %-28s %16.1f per us, hit rate %.3f\n" % ("l2_requests", rec["l2_requests_per_us"], rec["l2_hit_rate"]))
             hbm = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
             rec["hbm_bytes_per_launch"] = hbm
             if stats.get(n):
