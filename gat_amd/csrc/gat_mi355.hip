@@ -1119,8 +1119,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         hipLaunchKernelGGL(gat::k_tail, gt, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream));
-        if (tree) hipLaunchKernelGGL(gat::k_finalize<true>, gu, dim3(64), 0, ctx->stream, T);
-        else hipLaunchKernelGGL(gat::k_finalize<false>, gu, dim3(64), 0, ctx->stream, T);
+        hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_t[1], ctx->stream)); ctx->t_recorded = true; }
         A.st2 = P->d_st2.p;

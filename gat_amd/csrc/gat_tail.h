@@ -32,7 +32,7 @@ constexpr int kTailRows = 8;          // random rows fetched at a time
 struct TailPatch {
   int32_t state;          // 0: not handled (k_sampler resumes from the merged list), 1: handled
   int32_t n_extra;
-  uint32_t trim;          // bit 0: a trim happened, bit 1: forward
+  uint32_t trim;          // bit 0: a trim happened, bit 1: forward, bit 2: what is left of the partly trimmed segment lies outside the workspace
   int32_t trim_v0;        // index (in the list with the extras in place) where the trim starts
   int32_t trim_full;      // segments removed whole, walking from there
   uint32_t trim_part;     // bases taken off the next one
@@ -45,7 +45,7 @@ struct TailArgs {
   SamplerArgs S;
   uint32_t* cum;          // [batch][slab_stride]: inclusive running length of the merged list, parallel to the slab
   TailPatch* patch;       // [batch][n_units] by launch position
-  uint32_t* todo_count;   // units left to k_sampler: k_finalize queues them
+  uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
 };
 
@@ -154,7 +154,11 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
-  if (nws > kTailMaxWs) return;                      // long workspace: left to k_sampler (search trees)
+  if (nws > kTailMaxWs) {                            // long workspace: left to k_sampler (search trees)
+    const int sx = sb * kWave + lane;
+    if (sx < A.batch) T.todo[atomicAdd(T.todo_count, 1u)] = (uint32_t)sx * (uint32_t)A.n_active + (uint32_t)a;
+    return;
+  }
   const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
   const int32_t ltotal = Up->ltotal;
   const int cap = Up->slab_cap;
@@ -169,11 +173,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   const int64_t sa = (int64_t)sidx * A.n_units + a;
   const int4 pre = A.st[sa];
   const int4 c2 = A.st2[sa];
-  if (pre.z < 0 || c2.w != 1) return;                // not consolidated: k_sampler's
+  const uint32_t qe = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
+  // (every unit that is not finished here goes to k_sampler's queue)
+  if (pre.z < 0 || c2.w != 1 || c2.x <= 0) { T.todo[atomicAdd(T.todo_count, 1u)] = qe; return; }   // not consolidated
   const uint2* __restrict__ U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const uint32_t* __restrict__ cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int nU = c2.x;
-  if (nU <= 0) return;
   uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
 
   TailRng rng;
@@ -284,6 +289,14 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       if (bail) break;
       trim = 1u | (forward ? 2u : 0u);
       trim_v0 = v; trim_full = full; trim_part = part;
+      if (part > 0) {
+        // the final filter(workspace) (:644) can only drop what this trim leaves of the partly trimmed segment: every
+        // other segment is a union of placed segments, each of which overlaps its workspace segment (:331-343)
+        const int last = forward ? (idx == 0 ? nV - 1 : idx - 1) : (idx == nV - 1 ? 0 : idx + 1);
+        const uint2 x = vget(last);
+        const uint32_t ks = forward ? x.x + part : x.x, ke = forward ? x.y : x.y - part;
+        if (!(ke > ks && ws_overlap(ks, ke) > 0)) trim |= 4u;
+      }
       cov -= removed;
       total -= (uint32_t)(-true_remaining);
       true_remaining = 1;
@@ -363,7 +376,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       if (!(true_remaining != 0 && nuns < 20)) done = true;
     }
   }
-  if (!done || bail || rng.out_of_rows) return;          // patch.state stays 0: k_sampler resumes from the merged list
+  if (!done || bail || rng.out_of_rows) {                // patch.state stays 0: k_sampler resumes from the merged list
+    T.todo[atomicAdd(T.todo_count, 1u)] = qe;
+    return;
+  }
   TailPatch* P = T.patch + sa;
   P->n_extra = nE;
   P->trim = trim; P->trim_v0 = trim_v0; P->trim_full = trim_full; P->trim_part = trim_part;
@@ -378,7 +394,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 // k_tail's record, written OUT OF PLACE into the second slab (the extras shift what is behind them: in place every
 // element would have to be held until everything in front of it is written).  Units k_tail left alone are queued for
 // k_sampler, which writes its final lists to the same slab.
-template <bool TREE>
 __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const SamplerArgs& A = T.S;
   const int lane = threadIdx.x;
@@ -387,19 +402,9 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   if (a >= A.n_active) return;
   const int64_t sa = (int64_t)sidx * A.n_units + a;
   const TailPatch* __restrict__ P = T.patch + sa;
-  if (P->state != 1) {
-    if (lane == 0) T.todo[atomicAdd(T.todo_count, 1u)] = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
-    return;
-  }
+  if (P->state != 1) return;                             // (k_tail queued it for k_sampler)
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int u = Up->pad;
-  const int nws = Up->n_ws;
-  const uint2* __restrict__ ws = A.ws + Up->ws_off;
-  const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
-  constexpr int kWsRegMax = 64, kWsLoopMax = 32;
-  const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
-  const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
-  const WsTreeGeom G = ws_tree_geom(nws);
   const uint2* __restrict__ src = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   uint2* __restrict__ dst = A.slab_final + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int nU = A.st2[sa].x, nE = P->n_extra, nV = nU + nE;
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const uint32_t trim = P->trim;
   const int v0 = P->trim_v0, full = P->trim_full;
   const uint32_t part = P->trim_part;
+  const bool drop_part = (trim & 4u) != 0;
   int nout = 0;
   uint32_t total = 0;
   constexpr int kB = 4;                                    // rounds whose loads are in flight together
@@ -434,20 +440,19 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
       if (base + q * kWave >= nV) break;
       const int v = base + q * kWave + lane;
       uint2 y = x[q];
+      bool d_part = false;
       if (trim & 1u) {
         // trim_ends walked from v0 (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next
         int d = (trim & 2u) ? v - v0 : v0 - v;
         if (d < 0) d += nV;
         if (v < nV) {
           if (d < full) y = make_uint2(0u, 0u);
-          else if (d == full && part > 0) { if (trim & 2u) y.x += part; else y.y -= part; }
+          else if (d == full && part > 0) { d_part = true; if (trim & 2u) y.x += part; else y.y -= part; }
         }
       }
-      bool keep = false;
-      if (v < nV && y.x != y.y) {                          // merge(0) drops the placeholders; nothing touches
-        if (nws <= kWsLoopMax) keep = ws_overlap_regs(W, y.x, y.y) > 0;
-        else if constexpr (TREE) keep = seg_overlap_tree1(ws, ws_cdf, tree_start, G, y.x, y.y) > 0;
-      }
+      // merge(0) drops the placeholders (nothing touches); filter(workspace) can only drop the partly trimmed segment,
+      // which k_tail has looked at (every other one is a union of placed segments, each overlapping its workspace)
+      const bool keep = v < nV && y.x != y.y && !(drop_part && d_part);
       const uint64_t b = __ballot(keep);
       if (keep) { dst[nout + __popcll(b & lanemask_lt(lane))] = y; total += y.y - y.x; }
       nout += __popcll(b);
