@@ -1187,7 +1187,18 @@ struct ContigArgs {
   const int32_t* unit_n;           // [batch][n_units]
   int32_t* contig_n;               // [batch][n_contigs]
   unsigned long long* stat;
+  // split path without k_finalize: units k_tail finished are taken as (merged list in slab_merged, k_tail's record)
+  const uint2* slab_merged;        // nullptr: every unit's final list is in slab_in
+  const int32_t* unit_pos;         // unit id -> launch position (patch / st2 are indexed by it), -1: inactive
+  const int4* st2;                 // .x = merged segments
+  const int32_t* patch;            // TailPatch records as words (layout: gat_tail.h), patch_stride words each
+  int32_t patch_stride;
+  uint32_t* ws_stat;               // per-unit statistics (k_finalize's job otherwise)
 };
+
+// layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
+constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchTrim = 2, kPatchV0 = 3, kPatchFull = 4, kPatchPart = 5, kPatchPlaced = 6,
+              kPatchNdraws = 7, kPatchNuns = 8, kPatchExtra = 10, kPatchPos = 18, kPatchWords = 22;
 
 // HUGE: a contig's list does not fit LDS; it is gathered, sorted and merged in its output region in global memory.
 template <bool HUGE>
@@ -1206,32 +1217,82 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   // them instead of two dependent ones per unit -- and the first 64 segments of up to eight lists are in flight together.
   for (int ub = u0; ub < u1; ub += kWave) {
     const int nu = u1 - ub < kWave ? u1 - ub : kWave;
-    int my_cnt = 0, my_off = 0;
+    int my_cnt = 0, my_off = 0, my_copy = 0;
+    bool my_patched = false;
+    const int32_t* my_patch = nullptr;
     if (lane < nu) {
       const int u = A.contig_units[ub + lane];
-      my_cnt = A.unit_n[(int64_t)sidx * A.n_units + u];
       my_off = A.units[u].slab_off;
+      if (A.slab_merged != nullptr && A.unit_pos[u] >= 0) {
+        const int64_t sa = (int64_t)sidx * A.n_units + A.unit_pos[u];
+        my_patch = A.patch + sa * A.patch_stride;
+        my_patched = my_patch[kPatchState] == 1;
+        if (my_patched) { my_copy = A.st2[sa].x; my_cnt = my_copy + my_patch[kPatchNExtra]; }
+      }
+      if (!my_patched) my_cnt = my_copy = A.unit_n[(int64_t)sidx * A.n_units + u];
     }
     const int my_dst = n + (int)(wave_incl_sum_u32((uint32_t)my_cnt, lane) - (uint32_t)my_cnt);
-    const uint2* __restrict__ base = A.slab_in + (int64_t)sidx * A.slab_stride;
+    const uint2* __restrict__ base_final = A.slab_in + (int64_t)sidx * A.slab_stride;
+    const uint2* __restrict__ base_merged = A.slab_merged != nullptr ? A.slab_merged + (int64_t)sidx * A.slab_stride : base_final;
+    const uint64_t patched_mask = __ballot(my_patched);
     constexpr int kU = 8;
     for (int k0 = 0; k0 < nu; k0 += kU) {
       uint2 v[kU];
       int cnt[kU], dst[kU], off[kU];
+      const uint2* src[kU];
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
         const int k = k0 + q < nu ? k0 + q : nu - 1;
-        cnt[q] = k0 + q < nu ? __builtin_amdgcn_readlane(my_cnt, k) : 0;
+        cnt[q] = k0 + q < nu ? __builtin_amdgcn_readlane(my_copy, k) : 0;
         dst[q] = __builtin_amdgcn_readlane(my_dst, k);
         off[q] = __builtin_amdgcn_readlane(my_off, k);
+        src[q] = ((patched_mask >> k) & 1ull) ? base_merged : base_final;
         v[q] = make_uint2(0u, 0u);
-        if (lane < cnt[q]) v[q] = base[off[q] + lane];
+        if (lane < cnt[q]) v[q] = src[q][off[q] + lane];
       }
 #pragma unroll
       for (int q = 0; q < kU; ++q) {
         if (lane < cnt[q]) seg[dst[q] + lane] = v[q];
-        for (int i = kWave + lane; i < cnt[q]; i += kWave) seg[dst[q] + i] = base[off[q] + i];   // lists beyond 64 segments
+        for (int i = kWave + lane; i < cnt[q]; i += kWave) seg[dst[q] + i] = src[q][off[q] + i];   // lists beyond 64 segments
       }
+    }
+    if (patched_mask != 0) {
+      // one lane per finished unit: its extras behind the merged list, then the trim (gat/SegmentList.pyx:567-596) walked
+      // from its first segment: `full` segments emptied, `part` bases off the next (dropped when what is left lies outside
+      // the workspace: k_tail looked).  The order inside the contig's list does not matter: it is sorted below, and
+      // merge(0) drops the emptied segments.
+      wave_sync();
+      if (my_patched) {
+        const int nU = my_copy, nE = my_patch[kPatchNExtra], nV = nU + nE;
+        int vj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          vj[j] = j < nE ? my_patch[kPatchPos + j] + j : 0x7fffffff;
+          if (j < nE) seg[my_dst + nU + j] = make_uint2((uint32_t)my_patch[kPatchExtra + 2 * j], (uint32_t)my_patch[kPatchExtra + 2 * j + 1]);
+        }
+        const uint32_t trim = (uint32_t)my_patch[kPatchTrim];
+        if (trim & 1u) {
+          const int v0 = my_patch[kPatchV0], full = my_patch[kPatchFull];
+          const uint32_t part = (uint32_t)my_patch[kPatchPart];
+          for (int d = 0; d <= full; ++d) {
+            if (d == full && part == 0) break;
+            int v = (trim & 2u) ? v0 + d : v0 - d;
+            v = v >= nV ? v - nV : (v < 0 ? v + nV : v);
+            int c = 0, which = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (vj[j] < v) c++; if (vj[j] == v) which = j; }
+            const int slot = my_dst + (which >= 0 ? nU + which : v - c);
+            uint2 y = seg[slot];
+            if (d < full || (trim & 4u)) y = make_uint2(0u, 0u);
+            else if (trim & 2u) y.x += part; else y.y -= part;
+            seg[slot] = y;
+          }
+        }
+        const int u = A.contig_units[ub + lane];
+        *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + u) * 4) =
+            make_uint4((uint32_t)my_patch[kPatchPlaced], (uint32_t)my_patch[kPatchNdraws], (uint32_t)my_patch[kPatchNuns], 0u);
+      }
+      wave_sync();
     }
     n += (int)wave_total_u32((uint32_t)my_cnt);
   }

@@ -331,6 +331,8 @@ struct gat_problem {
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
   DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
+  DevBuf<int32_t> d_unit_pos;            // unit id -> launch position (k_contig reads k_tail's records by it)
+  bool patched_contigs = false;          // the last batch skipped k_finalize: k_contig took (merged list, record)
   std::vector<int32_t> h_class_start;    // launch positions where a size class begins (+ the end): one launch per class
   bool split_path = false;               // k_consolidate + k_tail + k_finalize in front of k_sampler
   bool split_ran = false;                // ... and the last sampler batch took it: the units' lists are in d_fslab
@@ -721,6 +723,11 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   if (layout_slab(P.get())) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
 
   HIPCHK(ctx, P->d_order.upload(P->h_order, ctx->stream));
+  {
+    std::vector<int32_t> pos((size_t)std::max(1, d->n_units), -1);
+    for (size_t a = 0; a < P->h_order.size(); ++a) pos[(size_t)P->h_order[a]] = (int32_t)a;
+    HIPCHK(ctx, P->d_unit_pos.upload(pos, ctx->stream));
+  }
   HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx->stream));
   HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx->stream));
   HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
@@ -967,7 +974,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
 // the caller sizes the batch again and repeats it (results do not depend on the batching: streams are per unit).
 constexpr int kRelayout = 1;
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
-                             gat_stats* st, bool timed) {
+                             gat_stats* st, bool timed, bool need_unit_lists = false) {
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -977,6 +984,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     HIPCHK(ctx, hipMemsetAsync(P->d_flags.p, 0, 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 8 * 8, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    const int32_t* skip_ptr = nullptr;
+    int skip_stride = 0;
     if (!P->h_order.empty()) {
       gat::SamplerArgs A;
       memset(&A, 0, sizeof(A));
@@ -1084,6 +1093,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       const bool tree = P->max_nws > gat::kWsTreeMin;
       ctx->t_recorded = false;
       P->split_ran = split;
+      P->patched_contigs = false;
       if (split) {
         // the split path: first consolidation (wave per unit), the loop's tail (lane per unit), the final list (wave per
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
@@ -1119,7 +1129,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         hipLaunchKernelGGL(gat::k_tail, gt, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream));
-        hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
+        // isochore problems: k_contig re-sorts the units of a contig anyway and takes (merged list, k_tail's record) as
+        // it is -- no final unit lists unless somebody asked for them (gat_sample_units)
+        P->patched_contigs = P->merge_contigs && P->n_contigs > 0 && !need_unit_lists && !getenv("GAT_CONTIG_FINAL_LISTS");
+        if (!P->patched_contigs) hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_t[1], ctx->stream)); ctx->t_recorded = true; }
         A.st2 = P->d_st2.p;
@@ -1176,9 +1189,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       HIPCHK(ctx, hipGetLastError());
       if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[3], ctx->stream));
-      hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
-                         (int64_t)nb * P->n_units, P->d_stat.p, A.skip, A.skip_stride);
-      HIPCHK(ctx, hipGetLastError());
+      skip_ptr = A.skip;
+      skip_stride = A.skip_stride;
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     if (P->merge_contigs && P->n_contigs > 0) {
@@ -1187,6 +1199,14 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
       B.slab_in = P->final_slab(); B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
+      B.slab_merged = nullptr; B.unit_pos = P->d_unit_pos.p; B.st2 = nullptr; B.patch = nullptr; B.patch_stride = 0;
+      B.ws_stat = P->d_ws_stat.p;
+      if (P->split_ran && P->patched_contigs) {
+        B.slab_merged = P->d_slab.p;
+        B.st2 = P->d_st2.p;
+        B.patch = reinterpret_cast<const int32_t*>(P->d_patch.p);
+        B.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+      }
       size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
       const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
       if (huge_c) lds = 520 * 4;
@@ -1198,6 +1218,12 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       HIPCHK(ctx, hipGetLastError());
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (!P->h_order.empty()) {
+      // (behind k_contig: on isochore problems it is k_contig that writes the statistics of the units k_tail finished)
+      hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
+                         (int64_t)nb * P->n_units, P->d_stat.p, skip_ptr, skip_stride);
+      HIPCHK(ctx, hipGetLastError());
+    }
     int32_t flags = 0;
     unsigned long long stat[8];
     HIPCHK(ctx, hipMemcpyAsync(&flags, P->d_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1370,7 +1396,7 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true)) == kRelayout) continue;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, unit_level)) == kRelayout) continue;
     if (rc) return rc;
     const bool from_contigs = P->merge_contigs && !unit_level;
     const uint2* src = from_contigs ? P->d_cslab.p : P->final_slab();

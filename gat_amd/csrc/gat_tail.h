@@ -19,6 +19,7 @@
 //
 // Results are those of k_sampler (and of the reference) bit for bit: every branch below cites the line it restates.
 #pragma once
+#include <cstddef>
 #include "gat_kernels.h"
 
 namespace gat {
@@ -40,6 +41,10 @@ struct TailPatch {
   uint2 extra[kTailMaxExtra];          // sorted by start
   int32_t pos[kTailMaxExtra];          // merged-list elements in front of each
 };
+
+static_assert(sizeof(TailPatch) == kPatchWords * 4 && offsetof(TailPatch, extra) == kPatchExtra * 4 &&
+              offsetof(TailPatch, pos) == kPatchPos * 4 && offsetof(TailPatch, placed) == kPatchPlaced * 4,
+              "k_contig reads TailPatch records as words");
 
 struct TailArgs {
   SamplerArgs S;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   if (true_remaining == remaining) nuns++; else true_remaining = remaining;           // :601-605
   bool done = !(true_remaining != 0 && nuns < 20);
   bool bail = false;
-  uint32_t trim = 0, trim_part = 0;
+  uint32_t trim = 0, trim_part = 0, drop_len = 0;
   int trim_v0 = 0, trim_full = 0;
 
   // element v of the list with the extras in place
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
         const int last = forward ? (idx == 0 ? nV - 1 : idx - 1) : (idx == nV - 1 ? 0 : idx + 1);
         const uint2 x = vget(last);
         const uint32_t ks = forward ? x.x + part : x.x, ke = forward ? x.y : x.y - part;
-        if (!(ke > ks && ws_overlap(ks, ke) > 0)) trim |= 4u;
+        if (!(ke > ks && ws_overlap(ks, ke) > 0)) { trim |= 4u; drop_len = ke > ks ? ke - ks : 0u; }
       }
       cov -= removed;
       total -= (uint32_t)(-true_remaining);
@@ -376,6 +381,8 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       if (!(true_remaining != 0 && nuns < 20)) done = true;
     }
   }
+  // (result.sum() > 0 is asserted at the end, gat/Engine.pyx:645: a unit that would fail is k_sampler's to report)
+  if (total - drop_len == 0u) bail = true;
   if (!done || bail || rng.out_of_rows) {                // patch.state stays 0: k_sampler resumes from the merged list
     T.todo[atomicAdd(T.todo_count, 1u)] = qe;
     return;
