@@ -41,6 +41,10 @@ struct gat_ctx {
   bool k_recorded = false;
   hipEvent_t ev_t[2] = {nullptr, nullptr};      // split path: behind k_tail, k_finalize
   bool t_recorded = false;
+  hipEvent_t ev_cnt[2] = {nullptr, nullptr};    // around the count phase
+  // status word and statistics of a sampler batch, copied behind its kernels and read after the batch's ONE synchronisation
+  int32_t* h_flags = nullptr;                   // pinned
+  unsigned long long* h_stat = nullptr;         // pinned, 8 words
   std::string err;
   int max_lds = 65536;
 };
@@ -380,6 +384,9 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev_main) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_k) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_t) HIPCHK(ctx, hipEventCreate(&ev));
+  for (auto& ev : ctx->ev_cnt) HIPCHK(ctx, hipEventCreate(&ev));
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 64, hipHostMallocDefault));
   *out = ctx;
   return GAT_OK;
 }
@@ -391,6 +398,9 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_t) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ev_cnt) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+  if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -973,8 +983,10 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
 // capacities (scratch released: the batch that fits the budget may now be smaller) and nothing of this batch is valid;
 // the caller sizes the batch again and repeats it (results do not depend on the batching: streams are per unit).
 constexpr int kRelayout = 1;
+static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed);
+// defer: only enqueue (the caller adds the count kernels behind, synchronises once and calls finish_sampler_batch)
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
-                             gat_stats* st, bool timed, bool need_unit_lists = false) {
+                             gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false) {
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -1224,11 +1236,20 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                          (int64_t)nb * P->n_units, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
-    int32_t flags = 0;
-    unsigned long long stat[8];
-    HIPCHK(ctx, hipMemcpyAsync(&flags, P->d_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(stat, P->d_stat.p, sizeof(stat), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, P->d_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stat, P->d_stat.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    if (defer) return GAT_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return finish_sampler_batch(ctx, P, nb, st, timed);
+  }
+}
+
+// the checks and statistics of a sampler batch whose kernels have completed (the stream has been synchronised)
+static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed) {
+  {
+    int rc;
+    const int32_t flags = *ctx->h_flags;
+    const unsigned long long* stat = ctx->h_stat;
     if (flags & (gat::kStatusAssert | gat::kStatusTrimAssert))
       return set_err(ctx, GAT_ERR_ASSERT, "sampler assertion failed on device (flags=%d): %s", flags,
                      (flags & gat::kStatusAssert) ? "sampled list has no overlap with the workspace (gat/Engine.pyx:645)"
@@ -1324,15 +1345,14 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true)) == kRelayout) continue;
-    if (rc) return rc;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
     A.out = (int64_t*)counts_dev;
     A.out_stride = S;
     A.out_begin = done;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     ctx->main_recorded = false;
     ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
     int swap_capx = 0;
@@ -1342,10 +1362,14 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     }
     if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+    // ONE synchronisation per batch: the sampler's status word is read behind the count kernels (which ran on whatever
+    // an overflowed unit left -- harmless, the batch is redone with doubled regions)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) continue;
+    if (rc) return rc;
     float ms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]));
     local.ms_count += ms;
     if (ctx->main_recorded) {
       HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_main[0], ctx->ev_main[1]));
