@@ -1,5 +1,5 @@
 """one-off sweep of the fuzz generator of tests/test_hip_parity.py over many seeds (GPU vs oracle, bit-exact);
-usage: tools/fuzz_sweep.py first_seed n_seeds [edge]"""
+usage: tools/fuzz_sweep.py first_seed n_seeds [edge|merged]"""
 import importlib.util, os, sys, time
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, root)
@@ -13,17 +13,25 @@ class MP(object):                      # minimal monkeypatch stand-in
     def setenv(self, k, v):
         os.environ[k] = v
 
+    def delenv(self, k):
+        os.environ.pop(k, None)
+
 
 ctx = _lib.Context(0)
 first, n = int(sys.argv[1]), int(sys.argv[2])
 edge = len(sys.argv) > 3 and sys.argv[3] == "edge"
+merged = len(sys.argv) > 3 and sys.argv[3] == "merged"
 bad = 0
 outcomes = {}
 t0 = time.time()
 for seed in range(first, first + n):
     os.environ.pop("GAT_TEST_HUGE", None)
     try:
-        if edge:
+        if merged:
+            for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED"):
+                os.environ.pop(k, None)
+            m.test_merged_track_index_vs_oracle(ctx, seed, MP())
+        elif edge:
             r = m._edge_case(ctx, seed)
             outcomes[r] = outcomes.get(r, 0) + 1
         else:
