@@ -27,6 +27,11 @@ COUNTERS = collections.OrderedDict([
 ])
 
 
+class _CountsPerTrack(list):
+    """[ {annotation: counts} per counter ] as the reference returns it, plus the device's statistics of those rows."""
+    stats = None
+
+
 def _dist_state():
     """(rank, world size, backend) of an initialised torch.distributed, else (0, 1, None)."""
     try:
@@ -38,14 +43,27 @@ def _dist_state():
     return 0, 1, None
 
 
+def _device_stats_wanted(n_values):
+    """null-distribution statistics on the device (gat_null_stats) for large count matrices: the host needs about 2 ms
+    per row of 100 000 samples.  GAT_DEVICE_STATS=1 / 0 forces / forbids it."""
+    import os
+    env = os.environ.get("GAT_DEVICE_STATS")
+    if env is not None:
+        return env not in ("0", "")
+    return n_values >= 2000000
+
+
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
-                  samples_outfile=None, workspace_generator=None, only_tracks=None):
+                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None):
     """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
 
     segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
     workspace_generator (gat/__init__.py:727): segments and workspace the sampler sees are
     generator(segs, None, workspace); the counters keep the contig form of `workspace`.
     only_tracks: count these annotation tracks only (the conditional sampler's per-annotation pass).
+    stat_vals: {counter name: {annotation: value}} -- the values whose p-value will be asked for (observed, or
+    observed / reference fold); given them, large matrices get their statistics on the device (gat_null_stats) and the
+    result carries `.stats[counter index][annotation]` for AnnotatorResult.
     Returns ([ {annotation: array of num_samples} per counter ] like the reference, number of work
     units), or (None, 0) for an empty workspace.  If torch.distributed is initialised, samples are
     sharded over the ranks and the count matrix is all-gathered (RCCL)."""
@@ -80,6 +98,15 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
         return [collections.OrderedDict((t, zero[k].copy()) for t in tracks) for k in range(len(names))], flat["n_units"]
     rank, world, backend = _dist_state()
     P = _lib.Problem(ctx, flat)
+    stats = None
+    want_stats = stat_vals is not None and _device_stats_wanted(len(names) * len(tracks) * num_samples)
+
+    def device_stats(ptr):
+        vals = np.array([[stat_vals[n][t] for t in tracks] for n in names], dtype=np.float64).ravel()
+        dbl = np.repeat([1 if n == "nucleotide-density" else 0 for n in names], len(tracks)).astype(np.uint8)
+        st = ctx.null_stats(ptr, len(names) * len(tracks), num_samples, dbl, vals).reshape(len(names), len(tracks), 8)
+        return [collections.OrderedDict((t, tuple(st[k, a, :6])) for a, t in enumerate(tracks)) for k in range(len(names))]
+
     try:
         begin, end = distributed.shard_range(num_samples, rank, world)
         if world > 1 and backend == "nccl":
@@ -91,8 +118,23 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
             P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())
             stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
             stack_t[:, :, :end - begin] = shard
-            full = distributed.allgather_counts(stack_t, num_samples).cpu().numpy()
+            full_t = distributed.allgather_counts(stack_t, num_samples)
+            if want_stats:
+                stats = device_stats(full_t.data_ptr())
+            full = full_t.cpu().numpy()
             local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
+        elif world == 1 and want_stats and num_samples > 0:
+            # the matrix stays on the device until its statistics are taken
+            nslots = len(names) * len(tracks) * num_samples
+            dev = ctx.alloc(nslots * 8)
+            try:
+                P.sample_and_count_device(names, seed, 0, num_samples, dev)
+                stats = device_stats(dev)
+                host = np.zeros((len(names), len(tracks), num_samples), dtype=np.int64)
+                ctx.d2h(host, dev)
+            finally:
+                ctx.free(dev)
+            local = [host[k].view(np.float64).copy() if n == "nucleotide-density" else host[k].copy() for k, n in enumerate(names)]
         else:
             local = P.sample_and_count(names, seed, begin, end)
             if world > 1:
@@ -116,9 +158,10 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
                         samples_outfile.write("%s\t%i\t%i\n" % (flat["unit_names"][u], s, e))
     finally:
         P.close()
-    out = []
+    out = _CountsPerTrack()
     for k in range(len(names)):
         out.append(collections.OrderedDict((t, local[k][a]) for a, t in enumerate(tracks)))
+    out.stats = stats
     return out, flat["n_units"]
 
 
@@ -171,8 +214,18 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                         r[k][annotation] = ra[k][annotation]
                     seed = (seed + num_samples * n_units) & 0xFFFFFFFF
         else:
+            # the values whose p-values the rows will ask for: large matrices get their statistics on the device
+            stat_vals = {}
+            for c, oc in zip(counters, observed_counts):
+                stat_vals[c.name] = {}
+                for annotation in annotations.tracks:
+                    v = float(oc[track][annotation]) if track in oc and annotation in oc[track] else 0.0
+                    if reference:
+                        f = reference[track][annotation].fold
+                        v = v / f if f > 0 else v
+                    stat_vals[c.name][annotation] = v
             r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
-                                       samples_outfile=outf, workspace_generator=workspace_generator)
+                                       samples_outfile=outf, workspace_generator=workspace_generator, stat_vals=stat_vals)
             seed = (seed + num_samples * n_units) & 0xFFFFFFFF    # next track: disjoint unit streams
         if outf:
             outf.close()
@@ -195,11 +248,13 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                 if sizes[id(temp_workspace)][1] == 0:
                     continue
                 ref = reference[track][annotation] if reference else None
+                dev_stats = getattr(sampled_counts[track], "stats", None)
                 annotator_results.append(AnnotatorResultExtended(
                     track=track, annotation=annotation, counter=counter.name, observed=observed,
                     samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
                     annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
-                    pseudo_count=pseudo_count, _sizes=sizes))
+                    pseudo_count=pseudo_count, _sizes=sizes,
+                    _stats=dev_stats[counter_id][annotation] if dev_stats else None))
     if output_counts_pattern and rank == 0:               # (every rank holds the gathered matrix: one writer)
         for counter in counters:
             with open(re.sub("%s", counter.name, output_counts_pattern), "w") as outfile:

@@ -29,7 +29,7 @@ SYMBOLS = [
     "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_problem_info",
-    "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts",
+    "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
 ]
 
 
@@ -132,6 +132,8 @@ def lib():
     L.gat_count_lists.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, i32, vp, i32, vp]
     L.gat_problem_info.restype = C.c_int
     L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    L.gat_null_stats.restype = C.c_int
+    L.gat_null_stats.argtypes = [vp, vp, i64, i64, vp, vp, i64, i64, vp]
     L.gat_comm_unique_id.restype = C.c_int
     L.gat_comm_unique_id.argtypes = [vp]
     L.gat_comm_create.restype = C.c_int
@@ -190,6 +192,21 @@ class Context(object):
 
     def d2h(self, host_array, dev_ptr):
         _check(lib().gat_memcpy_d2h(self._h, _p(host_array), C.c_void_p(dev_ptr), host_array.nbytes), self._h)
+
+    def null_stats(self, counts_dev_ptr, n_rows, n_samples, is_double, vals):
+        """per row of a device count matrix: (mean, std, lower95 value, upper95 value, n < val, n == val) -- what
+        AnnotatorResult reads off a null distribution (gat/Engine.pyx:1635-1718), numpy.mean / numpy.std bit for bit."""
+        l = int(n_samples)  # noqa: E741
+        offset = int(0.05 * l)
+        lo_i, hi_i = (min(offset, l - 1), max(l - offset, 0)) if offset > 0 else (0, l - 1)      # gat/Engine.pyx:1689-1696
+        hi_i = min(hi_i, l - 1)
+        is_double = np.ascontiguousarray(is_double, dtype=np.uint8)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        out = np.zeros((int(n_rows), 8), dtype=np.float64)
+        _check(lib().gat_null_stats(self._h, C.c_void_p(counts_dev_ptr), int(n_rows), l, _p(is_double), _p(vals), lo_i, hi_i,
+                                    _p(out)), self._h)
+        out[:, 1] = np.sqrt(out[:, 1] / l)                # numpy.std's last two steps (sum of squares from the device)
+        return out
 
     def count_lists(self, counters, lists, list_off, n_lists, annos, anno_off, n_tracks, ws_nseg, n_groups):
         """Counter*(list, annotation, workspace) for n_lists x n_groups lists (observed counts)."""

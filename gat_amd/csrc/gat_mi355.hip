@@ -24,6 +24,7 @@
 #define GAT_NUM_COUNTERS_DEV 6
 #include "gat_kernels.h"
 #include "gat_tail.h"
+#include "gat_stats.h"
 
 using gat::UnitDev;
 
@@ -1589,6 +1590,64 @@ extern "C" int gat_allgather_counts(gat_ctx* ctx, gat_comm* comm, const void* se
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const ncclResult_t rc = R->all_gather(send_dev, recv_dev, (size_t)n_slots, ncclInt64, comm->comm, ctx->stream);
   if (rc != ncclSuccess) return set_err(ctx, GAT_ERR_DEVICE, "ncclAllGather: %s", R->error_string ? R->error_string(rc) : "error");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// numpy's pairwise summation of a block of `n` elements starting at `off` (numpy/_core/src/umath/loops_utils.h.src,
+// pairwise_sum): the blocks of at most 128 elements and the order in which their sums are added
+static void np_pairwise_plan(int off, int n, std::vector<int32_t>& leaf_off, std::vector<int32_t>& leaf_len, std::vector<int32_t>& prog) {
+  if (n <= gat::kNpBlock) {
+    prog.push_back((int32_t)leaf_off.size());
+    leaf_off.push_back(off);
+    leaf_len.push_back(n);
+    return;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  np_pairwise_plan(off, n2, leaf_off, leaf_len, prog);
+  np_pairwise_plan(off + n2, n - n2, leaf_off, leaf_len, prog);
+  prog.push_back(-1);
+}
+
+extern "C" int gat_null_stats(gat_ctx* ctx, const void* counts_dev, int64_t n_rows, int64_t n_samples,
+                              const uint8_t* is_double_host, const double* vals_host, int64_t lo_index, int64_t hi_index,
+                              double* out_host) {
+  if (!ctx || !counts_dev || !is_double_host || !vals_host || !out_host) return set_err(ctx, GAT_ERR_ARG, "gat_null_stats: NULL argument");
+  if (n_rows <= 0) return GAT_OK;
+  if (n_samples < 1 || n_samples >= ((int64_t)1 << 31) || lo_index < 0 || hi_index < 0 || lo_index >= n_samples || hi_index >= n_samples)
+    return set_err(ctx, GAT_ERR_ARG, "gat_null_stats: bad sample count / positions");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<int32_t> leaf_off, leaf_len, prog;
+  const int rest = (int)(n_samples % gat::kNpChunk);
+  if (rest > 0) np_pairwise_plan(0, rest, leaf_off, leaf_len, prog);
+  DevBuf<int32_t> d_off, d_len, d_prog;
+  DevBuf<uint8_t> d_dbl;
+  DevBuf<double> d_vals, d_out;
+  if (leaf_off.empty()) { leaf_off.push_back(0); leaf_len.push_back(0); prog.push_back(0); }
+  HIPCHK(ctx, d_off.upload(leaf_off, ctx->stream));
+  HIPCHK(ctx, d_len.upload(leaf_len, ctx->stream));
+  HIPCHK(ctx, d_prog.upload(prog, ctx->stream));
+  HIPCHK(ctx, d_dbl.upload(std::vector<uint8_t>(is_double_host, is_double_host + n_rows), ctx->stream));
+  HIPCHK(ctx, d_vals.upload(std::vector<double>(vals_host, vals_host + n_rows), ctx->stream));
+  HIPCHK(ctx, d_out.alloc((size_t)n_rows * 8));
+  gat::StatsArgs A;
+  A.counts = (const int64_t*)counts_dev; A.row_stride = n_samples; A.n_rows = (int32_t)n_rows; A.S = (int32_t)n_samples;
+  A.is_double = d_dbl.p; A.vals = d_vals.p; A.out = d_out.p; A.lo_i = (int32_t)lo_index; A.hi_i = (int32_t)hi_index;
+  A.leaf_off = d_off.p; A.leaf_len = d_len.p; A.n_leaves = rest > 0 ? (int32_t)leaf_off.size() : 0;
+  A.prog = d_prog.p; A.n_prog = rest > 0 ? (int32_t)prog.size() : 0;
+  const size_t lds = (size_t)(n_samples / gat::kNpChunk + 1 + leaf_off.size()) * 8;
+  if ((int64_t)lds > ctx->max_lds - 4096) return set_err(ctx, GAT_ERR_CAPACITY, "gat_null_stats: %lld samples per row", (long long)n_samples);
+  HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_null_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int64_t r0 = 0; r0 < n_rows; r0 += 1 << 20) {               // (grid x: rows)
+    gat::StatsArgs B = A;
+    const int64_t nr = std::min<int64_t>(n_rows - r0, 1 << 20);
+    B.counts = A.counts + r0 * n_samples; B.is_double = A.is_double + r0; B.vals = A.vals + r0; B.out = A.out + r0 * 8; B.n_rows = (int32_t)nr;
+    hipLaunchKernelGGL(gat::k_null_stats, dim3((unsigned)nr), dim3(gat::kStatsThreads), lds, ctx->stream, B);
+    HIPCHK(ctx, hipGetLastError());
+  }
+  HIPCHK(ctx, hipMemcpyAsync(out_host, d_out.p, (size_t)n_rows * 64, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return GAT_OK;
 }

@@ -887,7 +887,9 @@ class AnnotatorResult(object):
     headers = ["track", "annotation", "observed", "expected", "CI95low", "CI95high", "stddev", "fold", "l2fold",
                "pvalue", "qvalue"]
 
-    def __init__(self, track, annotation, counter, observed, samples, reference=None, pseudo_count=1.0):
+    def __init__(self, track, annotation, counter, observed, samples, reference=None, pseudo_count=1.0, _stats=None):
+        """_stats: (mean, std, value at the lower / upper interval position, samples < val, samples == val) of `samples`
+        as gat_null_stats computed them on the device (val = observed, or observed / reference.fold); None = numpy here."""
         self.track, self.annotation, self.counter = track, annotation, counter
         # the reference builds a Python list of floats and sorts it; the same numbers come out of array operations
         # without the sort (two order statistics by selection, the p-value from two counts), which is what keeps
@@ -899,19 +901,25 @@ class AnnotatorResult(object):
         self.observed = float(observed)
         self.nsamples = l
         self._sorted_cache = None
-        self.expected = float(np.mean(self._samples))
+        self._val_counts = None
+        self.expected = float(_stats[0]) if _stats is not None else float(np.mean(self._samples))
         if reference is not None:
             self.expected *= reference.fold
         if self.expected != 0:
             self.fold = (self.observed + pseudo_count) / (self.expected + pseudo_count)
         else:
             self.fold = 1.0
-        self.stddev = float(np.std(self._samples))
-        offset = int(0.05 * l)
-        lo_i, hi_i = (min(offset, l - 1), max(l - offset, 0)) if offset > 0 else (0, l - 1)
-        part = np.partition(self._samples, sorted(set((lo_i, hi_i))))
-        self.lower95 = float(part[lo_i])
-        self.upper95 = float(part[hi_i])
+        if _stats is not None:
+            self.stddev, self.lower95, self.upper95 = float(_stats[1]), float(_stats[2]), float(_stats[3])
+            self._val_counts = (self.observed if reference is None else self.observed / reference.fold if reference.fold > 0 else None,
+                                int(_stats[4]), int(_stats[5]))
+        else:
+            self.stddev = float(np.std(self._samples))
+            offset = int(0.05 * l)
+            lo_i, hi_i = (min(offset, l - 1), max(l - offset, 0)) if offset > 0 else (0, l - 1)
+            part = np.partition(self._samples, sorted(set((lo_i, hi_i))))
+            self.lower95 = float(part[lo_i])
+            self.upper95 = float(part[hi_i])
         if reference is None:
             self.pvalue = self._two_sided(self.observed)
         else:
@@ -928,8 +936,11 @@ class AnnotatorResult(object):
         n_less values below val and n_eq equal to it, searchsorted gives n_less and the tie loops move to the other
         side of the run of equal values (downwards only while the index stays positive)."""
         l = self.nsamples  # noqa: E741
-        n_less = int(np.count_nonzero(self._samples < val))
-        n_eq = int(np.count_nonzero(self._samples == val))
+        if self._val_counts is not None and self._val_counts[0] == val:      # counted on the device for this very value
+            n_less, n_eq = self._val_counts[1], self._val_counts[2]
+        else:
+            n_less = int(np.count_nonzero(self._samples < val))
+            n_eq = int(np.count_nonzero(self._samples == val))
         idx = n_less
         if idx == l:
             idx = 1
@@ -979,9 +990,9 @@ class AnnotatorResultExtended(AnnotatorResult):
         "percent_overlap_nsegments_annotation", "percent_overlap_size_annotation"]
 
     def __init__(self, track, annotation, counter, observed, samples, track_segments, annotation_segments,
-                 workspace, reference=None, pseudo_count=1.0, _sizes=None):
+                 workspace, reference=None, pseudo_count=1.0, _sizes=None, _stats=None):
         AnnotatorResult.__init__(self, track, annotation, counter, observed, samples, reference=reference,
-                                 pseudo_count=pseudo_count)
+                                 pseudo_count=pseudo_count, _stats=_stats)
         sizes = _sizes if _sizes is not None else {}
 
         def cached(obj):                               # (counts, sum) of a dictionary, once per object and run()

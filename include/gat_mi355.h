@@ -178,6 +178,17 @@ int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                     const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
                     const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
 
+/* ---- null-distribution statistics on the device -----------------------------------------
+ * The numbers AnnotatorResult takes from a row of sampled counts (makeEnrichmentStatistics / getTwoSidedPValue,
+ * gat/Engine.pyx:1635-1718, :1543-1576), computed from the count matrix where gat_sample_and_count left it:
+ * counts_dev = n_rows rows of n_samples 8-byte slots (int64, or IEEE double for rows with is_double != 0 --
+ * nucleotide-density).  Per row r, out_host[8r..8r+8) = { numpy.mean, the sum of squared deviations from it as numpy.std
+ * forms it (std = sqrt(that / n_samples); bit for bit: numpy's chunked pairwise summation is restated), the values at sorted positions lo_index and hi_index, the number of samples < vals[r], the
+ * number == vals[r], 0, 0 }.  The caller turns them into expected / CI / stddev / p-value as the reference does. */
+int gat_null_stats(gat_ctx* ctx, const void* counts_dev, int64_t n_rows, int64_t n_samples,
+                   const uint8_t* is_double_host, const double* vals_host, int64_t lo_index, int64_t hi_index,
+                   double* out_host);
+
 /* ---- multi-GPU: the one collective of the path ---------------------------------------------
  * Replaces the result collation of the reference's process pool (gat/__init__.py:681-700, :770-774):
  * every rank has computed the columns of its own contiguous sample range (gat_sample_and_count with

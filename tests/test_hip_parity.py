@@ -813,3 +813,60 @@ def test_point_annotations_errors_like_the_reference(ctx, tmp_path):
             for p in annotations[track][contig].asList():
                 want += int(((seg["start"] <= p) & (p < seg["end"])).any())
         assert observed["merged"][track] == want and want > 0
+
+
+@pytest.mark.parametrize("S", [1, 5, 8, 77, 128, 129, 1000, 8192, 8193, 20011])
+def test_device_null_stats_equal_numpy(ctx, S):
+    """gat_null_stats (mean, std, interval values, counts below / equal to the observed value, from the device count
+    matrix) against what AnnotatorResult computes with numpy on the host, bit for bit: integer rows with heavy ties,
+    double rows (density), observed values inside, below and above the distribution, and the reference's p-value known
+    answers of tests/golden/stats.json run through the device path."""
+    import gat_amd
+    rs = np.random.RandomState(S)
+    rows = []
+    rows.append(rs.randint(0, 50, S).astype(np.int64))                      # ties everywhere
+    rows.append(rs.randint(0, 10 ** 7, S).astype(np.int64))
+    rows.append((rs.random_sample(S) * 1e5).view(np.int64))                 # IEEE doubles (density)
+    rows.append(np.full(S, 7, dtype=np.int64))                              # constant
+    rows.append(np.abs(rs.standard_cauchy(S) * 1e3).view(np.int64))         # heavy tail, doubles
+    is_double = np.array([0, 0, 1, 0, 1], dtype=np.uint8)
+    mat = np.ascontiguousarray(np.stack(rows))
+    as_float = [r.view(np.float64) if d else r.astype(np.float64) for r, d in zip(rows, is_double)]
+    vals = np.array([float(np.median(as_float[0])), -1.0, float(as_float[2][0]), 7.0, 1e12])
+    dev = ctx.alloc(mat.nbytes)
+    try:
+        _lib._check(_lib.lib().gat_memcpy_h2d(ctx._h, dev, mat.ctypes.data, mat.nbytes), ctx._h)
+        st = ctx.null_stats(dev, len(rows), S, is_double, vals)
+    finally:
+        ctx.free(dev)
+    for r in range(len(rows)):
+        host = gat_amd.AnnotatorResult("t", "a", "c", vals[r], as_float[r])
+        devr = gat_amd.AnnotatorResult("t", "a", "c", vals[r], as_float[r], _stats=tuple(st[r, :6]))
+        for f in ("expected", "stddev", "lower95", "upper95", "fold", "pvalue"):
+            assert getattr(host, f) == getattr(devr, f), (S, r, f, getattr(host, f), getattr(devr, f))
+        assert str(host) == str(devr)
+
+
+def test_device_null_stats_golden_and_run(ctx, monkeypatch):
+    """the reference's statistics goldens (tests/golden/stats.json, incl. its p-value known answers) through the device
+    path, and gat_amd.run() with GAT_DEVICE_STATS=1 against the rows the reference printed (run_small_isochores)."""
+    import gat_amd
+    with open(os.path.join(G, "stats.json")) as f:
+        cases = [c for c in json.load(f) if "reference_fold" not in c]
+    for c in cases:
+        samples = np.array(c["samples"], dtype=np.float64)
+        mat = samples.view(np.int64).reshape(1, -1).copy()
+        dev = ctx.alloc(mat.nbytes)
+        try:
+            _lib._check(_lib.lib().gat_memcpy_h2d(ctx._h, dev, mat.ctypes.data, mat.nbytes), ctx._h)
+            st = ctx.null_stats(dev, 1, len(samples), np.array([1], dtype=np.uint8), np.array([c["observed"]]))
+        finally:
+            ctx.free(dev)
+        host = gat_amd.AnnotatorResult("t", "a", "c", c["observed"], samples, pseudo_count=c["pseudo_count"])
+        devr = gat_amd.AnnotatorResult("t", "a", "c", c["observed"], samples, pseudo_count=c["pseudo_count"], _stats=tuple(st[0, :6]))
+        assert str(host) == str(devr)
+        for key in ("expected", "stddev", "pvalue", "fold"):
+            if key in c:
+                assert getattr(devr, key) == c[key], key
+    monkeypatch.setenv("GAT_DEVICE_STATS", "1")
+    test_run_api_rows_match_reference(ctx)

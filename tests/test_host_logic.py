@@ -389,3 +389,48 @@ def test_position_list_host_logic():
     d.intervals["chr1.iso"] = d.intervals.pop("chr1")
     with pytest.raises(TypeError):
         d.fromIsochores()
+
+
+def test_numpy_summation_model():
+    """gat_null_stats restates numpy.mean / numpy.std on the device; what it restates is numpy's summation order for a
+    contiguous float64 array: chunks of 8 192 elements (the ufunc buffer), each summed pairwise (halves split at a
+    multiple of 8 down to blocks of at most 128, a block with 8 running sums and a serial remainder), chunk sums added
+    left to right.  This pins that model against the numpy at hand for many lengths."""
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for x in a:
+                r = r + x
+            return r
+        if n <= 128:
+            r = [a[j] for j in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = r[j] + a[i + j]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res = res + a[i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(a[:n2]) + pw(a[n2:])
+
+    def np_sum(a):
+        r = None
+        for i in range(0, len(a), 8192):
+            p = pw(a[i:i + 8192])
+            r = p if r is None else r + p
+        return r
+
+    rs = np.random.RandomState(3)
+    for n in list(range(1, 140)) + [255, 1000, 8191, 8192, 8193, 10000, 16385, 30011]:
+        a = rs.random_sample(n) * 1e5 if n % 2 else rs.randint(0, 10 ** 7, n).astype(np.float64)
+        al = [float(x) for x in a]
+        m = np_sum(al) / n
+        assert m == float(np.mean(a)), n
+        v = np_sum([(x - m) * (x - m) for x in al]) / n
+        assert float(np.sqrt(v)) == float(np.std(a)), n
