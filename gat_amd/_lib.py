@@ -81,6 +81,7 @@ class Stats(C.Structure):
         ("ms_ktail", C.c_float),
         ("ms_finalize", C.c_float),
         ("n_tail_units", C.c_int64),
+        ("lists_from_records", C.c_int64),
     ]
 
     def asdict(self):

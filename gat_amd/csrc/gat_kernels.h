@@ -1197,8 +1197,8 @@ struct ContigArgs {
 };
 
 // layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
-constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchTrim = 2, kPatchV0 = 3, kPatchFull = 4, kPatchPart = 5, kPatchPlaced = 6,
-              kPatchNdraws = 7, kPatchNuns = 8, kPatchExtra = 10, kPatchPos = 18, kPatchWords = 22;
+constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchPlaced = 2, kPatchNdraws = 3, kPatchNuns = 4, kPatchExtra = 6,
+              kPatchPos = 14, kPatchWords = 18;
 
 // HUGE: a contig's list does not fit LDS; it is gathered, sorted and merged in its output region in global memory.
 template <bool HUGE>
@@ -1257,37 +1257,14 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
       }
     }
     if (patched_mask != 0) {
-      // one lane per finished unit: its extras behind the merged list, then the trim (gat/SegmentList.pyx:567-596) walked
-      // from its first segment: `full` segments emptied, `part` bases off the next (dropped when what is left lies outside
-      // the workspace: k_tail looked).  The order inside the contig's list does not matter: it is sorted below, and
-      // merge(0) drops the emptied segments.
+      // one lane per finished unit: its extras behind the merged list (k_tail has applied the trim to both; the order
+      // inside the contig's list does not matter: it is sorted below, and merge(0) drops the emptied segments)
       wave_sync();
       if (my_patched) {
-        const int nU = my_copy, nE = my_patch[kPatchNExtra], nV = nU + nE;
-        int vj[4];
+        const int nU = my_copy, nE = my_patch[kPatchNExtra];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          vj[j] = j < nE ? my_patch[kPatchPos + j] + j : 0x7fffffff;
+        for (int j = 0; j < 4; ++j)
           if (j < nE) seg[my_dst + nU + j] = make_uint2((uint32_t)my_patch[kPatchExtra + 2 * j], (uint32_t)my_patch[kPatchExtra + 2 * j + 1]);
-        }
-        const uint32_t trim = (uint32_t)my_patch[kPatchTrim];
-        if (trim & 1u) {
-          const int v0 = my_patch[kPatchV0], full = my_patch[kPatchFull];
-          const uint32_t part = (uint32_t)my_patch[kPatchPart];
-          for (int d = 0; d <= full; ++d) {
-            if (d == full && part == 0) break;
-            int v = (trim & 2u) ? v0 + d : v0 - d;
-            v = v >= nV ? v - nV : (v < 0 ? v + nV : v);
-            int c = 0, which = -1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { if (vj[j] < v) c++; if (vj[j] == v) which = j; }
-            const int slot = my_dst + (which >= 0 ? nU + which : v - c);
-            uint2 y = seg[slot];
-            if (d < full || (trim & 4u)) y = make_uint2(0u, 0u);
-            else if (trim & 2u) y.x += part; else y.y -= part;
-            seg[slot] = y;
-          }
-        }
         const int u = A.contig_units[ub + lane];
         *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + u) * 4) =
             make_uint4((uint32_t)my_patch[kPatchPlaced], (uint32_t)my_patch[kPatchNdraws], (uint32_t)my_patch[kPatchNuns], 0u);
@@ -1352,6 +1329,13 @@ struct CountArgs {
   const int32_t* m_cells;     // n_contigs
   const int32_t* m_slot_off;  // kMergedSlots+1: the contigs of an XCD slot are m_slot_contigs[m_slot_off[x] .. m_slot_off[x+1])
   const int32_t* m_slot_contigs;
+  // split path without k_finalize (k_count_seg<.., PATCH>; contig == unit): a unit k_tail finished is read as (merged
+  // list in seg_merged, k_tail's record), any other from seg as usual
+  const uint2* seg_merged;
+  const int32_t* unit_pos;    // unit id -> launch position (patch / st2 are indexed by it), -1: inactive
+  const int4* st2;            // .x = merged segments
+  const int32_t* patch;       // TailPatch records as words (kPatch*), patch_stride words each
+  int32_t patch_stride, n_units;
 };
 
 struct AnnoView {
@@ -1426,7 +1410,10 @@ constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per
 // streams its samples' segment lists against them.  Per (sample, track, contig) the wave leaves
 // three uint32 partials (overlap bases, segments hit, midpoint hits) in `part`; k_count_finish
 // adds them up over the contigs in reference order.
-template <bool STAGED, bool WANT_HITS>
+// PATCH: the unit lists are taken as k_tail left them -- merged list (trimmed in place, emptied segments read as padding)
+// + the record's extras -- so k_finalize and its round trip of the lists through HBM are not needed when only counts are
+// asked for.  The sums do not depend on the order or on the padding; the elements are those k_finalize would write.
+template <bool STAGED, bool WANT_HITS, bool PATCH = false>
 __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int TT = A.tracks_per_block, SC = A.samples_per_block;
@@ -1468,18 +1455,61 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   }
   __syncthreads();
   const int64_t qstride = (int64_t)A.n_tracks * A.n_samples;
+  const int upos = PATCH ? A.unit_pos[A.n_index[c]] : -1;
+  const int nidx = A.n_index[c];
+  const int64_t coff = A.c_off[c];
+  // what a wave needs to know of a list before it can ask for its segments -- fetched one list ahead (the loop is a
+  // chain of two dependent round trips per list otherwise): length; PATCH: state, extras, merged length of the unit
+  struct Meta { int n, state, nE, nM; };
+  auto fetch_meta = [&](int sl_) -> Meta {
+    Meta m = {0, 0, 0, 0};
+    if (sl_ < ns) {
+      const int64_t s_ = s0 + sl_;
+      m.n = A.n_arr[s_ * A.n_stride + nidx];
+      if (PATCH && upos >= 0) {
+        const int64_t sa = s_ * A.n_units + upos;
+        const int32_t* __restrict__ R = A.patch + sa * A.patch_stride;
+        m.state = R[kPatchState]; m.nE = R[kPatchNExtra]; m.nM = A.st2[sa].x;
+      }
+    }
+    return m;
+  };
+  // a list as the wave reads it.  PATCH, a unit k_tail finished: merged list (nU segments, trimmed in place) and the
+  // record's extras behind it
+  struct View { int n, nU; const uint2* X; const uint2* Rex; };
+  const uint2 kPad = make_uint2(0xffffffffu, 0xffffffffu);              // padding: beyond every interval, adds 0
+  auto view_of = [&](const Meta& m, int sl_) -> View {
+    const int64_t s_ = s0 + sl_;
+    View v;
+    v.n = m.n; v.nU = m.n;
+    v.X = A.seg + s_ * A.seg_stride + coff;
+    v.Rex = v.X;
+    if (PATCH && m.state == 1) {
+      v.nU = m.nM; v.n = m.nM + m.nE;
+      v.X = A.seg_merged + s_ * A.seg_stride + coff;
+      v.Rex = reinterpret_cast<const uint2*>(A.patch + (s_ * A.n_units + upos) * A.patch_stride + kPatchExtra) - m.nM;
+    }
+    return v;
+  };
+  auto load = [&](const View& v, int i) -> uint2 {
+    if (i >= v.n) return kPad;
+    if (!PATCH) return v.X[i];
+    const uint2 y = *(i < v.nU ? v.X + i : v.Rex + i);
+    return y.x == y.y ? kPad : y;                            // (emptied by the trim: merge(0) drops it)
+  };
+  // (measured and dropped: the next list's first 512 segments in registers while the current one is counted -- 16 more
+  //  registers per lane cost more occupancy than the overlap gains: 0.29 -> 0.33 ms on config 2)
+  Meta next = fetch_meta(wave);
   for (int sl = wave; sl < ns; sl += 4) {
     const int s = s0 + sl;
-    const int n = A.n_arr[(int64_t)s * A.n_stride + A.n_index[c]];
-    const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + A.c_off[c];
+    const View V = view_of(next, sl);
+    next = fetch_meta(sl + 4);
+    const int n = V.n;
     const bool one_pass = n <= kWave * kCountXR;
     uint2 x[kCountXR];
     if (one_pass) {
 #pragma unroll
-      for (int r = 0; r < kCountXR; ++r) {
-        const int i = r * kWave + lane;
-        x[r] = i < n ? X[i] : make_uint2(0xffffffffu, 0xffffffffu);   // padding: beyond every interval, adds 0
-      }
+      for (int r = 0; r < kCountXR; ++r) x[r] = load(V, r * kWave + lane);
     }
     for (int t = 0; t < nt; ++t) {
       AnnoView Y;
@@ -1500,10 +1530,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
         for (int base = 0; base < n; base += kWave * kCountXR) {
           if (!one_pass) {
 #pragma unroll
-            for (int r = 0; r < kCountXR; ++r) {
-              const int i = base + r * kWave + lane;
-              x[r] = i < n ? X[i] : make_uint2(0xffffffffu, 0xffffffffu);
-            }
+            for (int r = 0; r < kCountXR; ++r) x[r] = load(V, base + r * kWave + lane);
           }
 #pragma unroll
           for (int r = 0; r < kCountXR; ++r) {

@@ -338,6 +338,7 @@ struct gat_problem {
   DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
   DevBuf<int32_t> d_unit_pos;            // unit id -> launch position (k_contig reads k_tail's records by it)
   bool patched_contigs = false;          // the last batch skipped k_finalize: k_contig took (merged list, record)
+  bool patched_counts = false;           // ... k_count_seg takes (merged list, record)
   std::vector<int32_t> h_class_start;    // launch positions where a size class begins (+ the end): one launch per class
   bool split_path = false;               // k_consolidate + k_tail + k_finalize in front of k_sampler
   bool split_ran = false;                // ... and the last sampler batch took it: the units' lists are in d_fslab
@@ -841,6 +842,17 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
   return GAT_OK;
 }
 
+// which kernel serves the segment-side counters (the choice launch_count makes)
+static int count_route(const gat_ctx* ctx, const AnnoDev& annos, const Counters& C, int n_contigs, int n_tracks, int swap_capx) {
+  if (!C.any_seg || n_contigs <= 0) return GAT_COUNT_KERNEL_NONE;
+  const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
+  const size_t lds_merged = (size_t)n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
+  if (only_overlap && annos.has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED"))
+    return GAT_COUNT_KERNEL_MERGED;
+  if (swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) return GAT_COUNT_KERNEL_SWAP;
+  return GAT_COUNT_KERNEL_SEG;
+}
+
 // launch the count kernels over n_lists sample lists
 static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part,
                         int swap_capx = 0, int list_cap = 0) {
@@ -881,9 +893,9 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     if (gpz > 65535) return set_err(ctx, GAT_ERR_CAPACITY, "more than 2^31 (track tile, contig) pairs");
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), gpy, gpz);
     const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
-    const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
     const size_t lds_merged = (size_t)A.n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-    if (A.n_contigs > 0 && only_overlap && annos.has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED")) {
+    const int route = count_route(ctx, annos, C, A.n_contigs, A.n_tracks, swap_capx);
+    if (route == GAT_COUNT_KERNEL_MERGED) {
       // several tracks: one look-up per sample segment in the merged index of all tracks
       A.mz = annos.mz.p; A.mz_off = annos.mz_off.p; A.mfirst = annos.mfirst.p; A.mf_off = annos.mf_off.p;
       A.m_shift = annos.m_shift.p; A.m_cells = annos.m_cells.p;
@@ -910,7 +922,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       HIPCHK(ctx, hipGetLastError());
       goto seg_done;
     }
-    if (A.n_contigs > 0 && swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) {
+    if (route == GAT_COUNT_KERNEL_SWAP) {
       // long sample lists against short annotation lists: index the sample list, stream the tracks
       gat::CountArgs B = A;
       int lcells = 4;
@@ -929,14 +941,21 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     if (A.n_contigs > 0) {
     const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
     HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
-    if (staged) {
-      const void* fn = hits ? (const void*)gat::k_count_seg<true, true> : (const void*)gat::k_count_seg<true, false>;
-      HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (hits) hipLaunchKernelGGL((gat::k_count_seg<true, true>), grid, dim3(256), lds, ctx->stream, A);
-      else hipLaunchKernelGGL((gat::k_count_seg<true, false>), grid, dim3(256), lds, ctx->stream, A);
-    } else {
-      if (hits) hipLaunchKernelGGL((gat::k_count_seg<false, true>), grid, dim3(256), lds, ctx->stream, A);
-      else hipLaunchKernelGGL((gat::k_count_seg<false, false>), grid, dim3(256), lds, ctx->stream, A);
+    const int kv = (staged ? 4 : 0) + (hits ? 2 : 0) + (A.seg_merged != nullptr ? 1 : 0);
+    const void* fn = kv == 7 ? (const void*)gat::k_count_seg<true, true, true> : kv == 6 ? (const void*)gat::k_count_seg<true, true, false>
+                   : kv == 5 ? (const void*)gat::k_count_seg<true, false, true> : kv == 4 ? (const void*)gat::k_count_seg<true, false, false>
+                   : kv == 3 ? (const void*)gat::k_count_seg<false, true, true> : kv == 2 ? (const void*)gat::k_count_seg<false, true, false>
+                   : kv == 1 ? (const void*)gat::k_count_seg<false, false, true> : (const void*)gat::k_count_seg<false, false, false>;
+    if (staged) HIPCHK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    switch (kv) {
+      case 7: hipLaunchKernelGGL((gat::k_count_seg<true, true, true>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 6: hipLaunchKernelGGL((gat::k_count_seg<true, true, false>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 5: hipLaunchKernelGGL((gat::k_count_seg<true, false, true>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 4: hipLaunchKernelGGL((gat::k_count_seg<true, false, false>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 3: hipLaunchKernelGGL((gat::k_count_seg<false, true, true>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 2: hipLaunchKernelGGL((gat::k_count_seg<false, true, false>), grid, dim3(256), lds, ctx->stream, A); break;
+      case 1: hipLaunchKernelGGL((gat::k_count_seg<false, false, true>), grid, dim3(256), lds, ctx->stream, A); break;
+      default: hipLaunchKernelGGL((gat::k_count_seg<false, false, false>), grid, dim3(256), lds, ctx->stream, A); break;
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
@@ -986,8 +1005,9 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
 constexpr int kRelayout = 1;
 static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed);
 // defer: only enqueue (the caller adds the count kernels behind, synchronises once and calls finish_sampler_batch)
+// records_ok: the consumer is k_count_seg alone, which reads (merged list, k_tail's record): no k_finalize
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
-                             gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false) {
+                             gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false) {
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -1107,6 +1127,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       ctx->t_recorded = false;
       P->split_ran = split;
       P->patched_contigs = false;
+      P->patched_counts = false;
       if (split) {
         // the split path: first consolidation (wave per unit), the loop's tail (lane per unit), the final list (wave per
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
@@ -1145,7 +1166,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // isochore problems: k_contig re-sorts the units of a contig anyway and takes (merged list, k_tail's record) as
         // it is -- no final unit lists unless somebody asked for them (gat_sample_units)
         P->patched_contigs = P->merge_contigs && P->n_contigs > 0 && !need_unit_lists && !getenv("GAT_CONTIG_FINAL_LISTS");
-        if (!P->patched_contigs) hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
+        P->patched_counts = !P->merge_contigs && records_ok && !need_unit_lists;
+        if (!P->patched_contigs && !P->patched_counts) hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_t[1], ctx->stream)); ctx->t_recorded = true; }
         A.st2 = P->d_st2.p;
@@ -1284,6 +1306,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       st->n_draws += (int64_t)stat[1];
       st->n_unsuccessful += (int64_t)stat[2];
       st->n_tail_units += (int64_t)stat[3];
+      if (P->split_ran && (P->patched_contigs || P->patched_counts)) st->lists_from_records += 1;
       st->n_full_units += (int64_t)stat[4];
       if (timed) {
         float ms = 0;
@@ -1324,6 +1347,14 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
   A.n_contigs = P->n_contigs;
   A.n_tracks = P->n_tracks;
   A.n_samples = (int32_t)nb;
+  if (P->split_ran && P->patched_counts) {     // no k_finalize ran: k_count_seg<.., PATCH> reads merged lists + records
+    A.seg_merged = P->d_slab.p;
+    A.unit_pos = P->d_unit_pos.p;
+    A.st2 = P->d_st2.p;
+    A.patch = reinterpret_cast<const int32_t*>(P->d_patch.p);
+    A.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+    A.n_units = P->n_units;
+  }
 }
 
 extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
@@ -1346,7 +1377,15 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true))) return rc;   // (enqueued only)
+    int swap_capx = 0;
+    if (P->swap_capx) {
+      const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
+      if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
+    }
+    // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
+    const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
+                            count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx) == GAT_COUNT_KERNEL_SEG;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
@@ -1356,11 +1395,6 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     ctx->main_recorded = false;
     ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
-    int swap_capx = 0;
-    if (P->swap_capx) {
-      const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
-      if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
-    }
     if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));

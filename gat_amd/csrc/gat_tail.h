@@ -14,8 +14,9 @@
 //                  the overshoot trim becomes (where it starts, direction, segments removed whole, bases off the next).
 //                  Whatever does not fit that shape -- a new segment touching a neighbour, a second trim, more than four
 //                  new segments, a long workspace -- is left, untouched, to k_sampler, which resumes from the merged list.
-//   k_finalize     one wave per (sample, unit): merged list + extras - trim, placeholders dropped, filter(workspace)
-//                  (:639-646), the unit's list written where the count kernels expect it.  No LDS.
+//   k_finalize     one wave per (sample, unit): merged list (trimmed in place by k_tail) + extras, placeholders dropped
+//                  (:639-646), the unit's list written where its consumers expect it.  No LDS.  Not run when the
+//                  consumer takes (merged list, extras) as they are: k_contig, k_count_seg<.., PATCH>.
 //
 // Results are those of k_sampler (and of the reference) bit for bit: every branch below cites the line it restates.
 #pragma once
@@ -29,22 +30,20 @@ constexpr int kTailMaxWs = 64;        // workspace segments k_tail scans linearl
 constexpr int kTailMaxWalk = 6;       // segments an overshoot trim may touch
 constexpr int kTailRows = 8;          // random rows fetched at a time
 
-// what k_tail hands to k_finalize, per (sample, unit) by launch position
+// what k_tail hands on, per (sample, unit) by launch position.  A finished unit (state 1) is: its merged list in the
+// slab -- the overshoot trim already applied to it in place, emptied segments left as [0, 0) -- plus these extras.
 struct TailPatch {
-  int32_t state;          // 0: not handled (k_sampler resumes from the merged list), 1: handled
+  int32_t state;          // 0: not handled (k_sampler resumes from the merged list, which is untouched), 1: finished
   int32_t n_extra;
-  uint32_t trim;          // bit 0: a trim happened, bit 1: forward, bit 2: what is left of the partly trimmed segment lies outside the workspace
-  int32_t trim_v0;        // index (in the list with the extras in place) where the trim starts
-  int32_t trim_full;      // segments removed whole, walking from there
-  uint32_t trim_part;     // bases taken off the next one
   uint32_t placed, ndraws, nuns, pad;
-  uint2 extra[kTailMaxExtra];          // sorted by start
+  uint2 extra[kTailMaxExtra];          // sorted by start, trim applied
   int32_t pos[kTailMaxExtra];          // merged-list elements in front of each
 };
 
 static_assert(sizeof(TailPatch) == kPatchWords * 4 && offsetof(TailPatch, extra) == kPatchExtra * 4 &&
-              offsetof(TailPatch, pos) == kPatchPos * 4 && offsetof(TailPatch, placed) == kPatchPlaced * 4,
-              "k_contig reads TailPatch records as words");
+              offsetof(TailPatch, pos) == kPatchPos * 4 && offsetof(TailPatch, placed) == kPatchPlaced * 4 &&
+              offsetof(TailPatch, n_extra) == kPatchNExtra * 4 && offsetof(TailPatch, ndraws) == kPatchNdraws * 4,
+              "k_contig / k_count_seg read TailPatch records as words");
 
 struct TailArgs {
   SamplerArgs S;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   const uint32_t qe = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
   // (every unit that is not finished here goes to k_sampler's queue)
   if (pre.z < 0 || c2.w != 1 || c2.x <= 0) { T.todo[atomicAdd(T.todo_count, 1u)] = qe; return; }   // not consolidated
-  const uint2* __restrict__ U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint2* U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;     // (read; the trim is written into it at the very end)
   const uint32_t* __restrict__ cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int nU = c2.x;
   uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
@@ -387,13 +386,42 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
     T.todo[atomicAdd(T.todo_count, 1u)] = qe;
     return;
   }
+  if (trim & 1u) {
+    // the unit is finished here, the trim was the last thing that happened to its list (a placement behind a trim cannot
+    // be: the trim leaves remaining <= 0): apply it where the segments are -- trim_ends walked from v0
+    // (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next, which is dropped altogether
+    // when what is left of it lies outside the workspace (the final filter, :644)
+    const int nV = nU + nE;
+    int v = trim_v0;
+    for (int d = 0; d <= trim_full; ++d) {
+      if (d == trim_full && trim_part == 0) break;
+      int c = 0, which = -1;
+#pragma unroll
+      for (int j = 0; j < kTailMaxExtra; ++j) {
+        if (j < nE) { const int vj = epos[j] + j; if (vj < v) c++; if (vj == v) which = j; }
+      }
+      uint2 y = make_uint2(0u, 0u);
+      if (d == trim_full && !(trim & 4u)) {
+        y = which >= 0 ? make_uint2(0u, 0u) : U[v - c];
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (which == j) y = ex[j];
+        if (trim & 2u) y.x += trim_part; else y.y -= trim_part;
+      }
+      if (which >= 0) {
+#pragma unroll
+        for (int j = 0; j < kTailMaxExtra; ++j) if (which == j) ex[j] = y;
+      } else U[v - c] = y;
+      if (trim & 2u) { v++; if (v == nV) v = 0; } else { v--; if (v < 0) v = nV - 1; }
+    }
+  }
   TailPatch* P = T.patch + sa;
   P->n_extra = nE;
-  P->trim = trim; P->trim_v0 = trim_v0; P->trim_full = trim_full; P->trim_part = trim_part;
   P->placed = placed; P->ndraws = rng.used; P->nuns = (uint32_t)nuns;
 #pragma unroll
   for (int j = 0; j < kTailMaxExtra; ++j) { P->extra[j] = ex[j]; P->pos[j] = epos[j]; }
   P->state = 1;
+  // (the unit's statistics: its consumers may take the record as it is, without k_finalize)
+  *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + Up->pad) * 4) = make_uint4(placed, rng.used, (uint32_t)nuns, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -419,10 +447,6 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   int vj[kTailMaxExtra];
 #pragma unroll
   for (int j = 0; j < kTailMaxExtra; ++j) { ex[j] = P->extra[j]; vj[j] = j < nE ? P->pos[j] + j : 0x7fffffff; }
-  const uint32_t trim = P->trim;
-  const int v0 = P->trim_v0, full = P->trim_full;
-  const uint32_t part = P->trim_part;
-  const bool drop_part = (trim & 4u) != 0;
   int nout = 0;
   uint32_t total = 0;
   constexpr int kB = 4;                                    // rounds whose loads are in flight together
@@ -446,20 +470,11 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
     for (int q = 0; q < kB; ++q) {
       if (base + q * kWave >= nV) break;
       const int v = base + q * kWave + lane;
-      uint2 y = x[q];
-      bool d_part = false;
-      if (trim & 1u) {
-        // trim_ends walked from v0 (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next
-        int d = (trim & 2u) ? v - v0 : v0 - v;
-        if (d < 0) d += nV;
-        if (v < nV) {
-          if (d < full) y = make_uint2(0u, 0u);
-          else if (d == full && part > 0) { d_part = true; if (trim & 2u) y.x += part; else y.y -= part; }
-        }
-      }
-      // merge(0) drops the placeholders (nothing touches); filter(workspace) can only drop the partly trimmed segment,
-      // which k_tail has looked at (every other one is a union of placed segments, each overlapping its workspace)
-      const bool keep = v < nV && y.x != y.y && !(drop_part && d_part);
+      const uint2 y = x[q];
+      // merge(0) drops the placeholders and what the trim emptied (nothing touches); filter(workspace) could only drop
+      // the partly trimmed segment, which k_tail has looked at (every other one is a union of placed segments, each
+      // overlapping its workspace)
+      const bool keep = v < nV && y.x != y.y;
       const uint64_t b = __ballot(keep);
       if (keep) { dst[nout + __popcll(b & lanemask_lt(lane))] = y; total += y.y - y.x; }
       nout += __popcll(b);

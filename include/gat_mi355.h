@@ -97,8 +97,10 @@ typedef struct {
   float ms_tail;                /*   everything behind it: k_tail + k_finalize + k_sampler        */
   int32_t count_kernel;         /* GAT_COUNT_KERNEL_* the call used for the overlap counters      */
   float ms_ktail;               /*   of ms_tail: k_tail (the loop's tail, one stream per lane)    */
-  float ms_finalize;            /*   of ms_tail: k_finalize (extras, trim, filter, final list)    */
+  float ms_finalize;            /*   of ms_tail: k_finalize (merged list + extras -> final list)   */
   int64_t n_tail_units;         /* work units finished by k_tail / k_finalize (the rest: k_sampler) */
+  int64_t lists_from_records;   /* != 0: no final unit lists were written; their consumer (k_contig or k_count_seg) took
+                                   the merged lists and k_tail's records                              */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0

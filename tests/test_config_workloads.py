@@ -7,6 +7,8 @@ result for the same sample ids (the per-unit stream contract makes any column co
 under splitting the sample range, and the reference's own sampler invariants (test/benchmark_gat.py:773-780,
 :828-837: normalized lists inside the workspace that cover exactly the observed number of workspace bases).
 Bit-exact throughout: int64 counts, IEEE doubles for the density counter, uint32 coordinates."""
+import os
+
 import numpy as np
 import pytest
 
@@ -74,6 +76,19 @@ def test_config_workloads_full_size_properties(ctx, name):
     try:
         full = P.sample_and_count(counters, seed, 0, S)[0]
         assert full.shape == (flat["n_tracks"], S)
+        if name in ("config2", "config3", "config5"):
+            # counts alone: no final unit lists are written, k_count_seg (config 2, 5) / k_contig (config 3) take the
+            # merged lists and k_tail's records; the same matrix must come from the final lists
+            assert P.last_stats["lists_from_records"] > 0, name
+            os.environ["GAT_COUNT_FINAL_LISTS"] = "1"
+            os.environ["GAT_CONTIG_FINAL_LISTS"] = "1"
+            try:
+                again = P.sample_and_count(counters, seed, 0, S)[0]
+                assert P.last_stats["lists_from_records"] == 0
+            finally:
+                os.environ.pop("GAT_COUNT_FINAL_LISTS")
+                os.environ.pop("GAT_CONTIG_FINAL_LISTS")
+            assert np.array_equal(again, full), name
         cols = sorted(set([0, S - 1] + [int(x) for x in np.random.RandomState(1).randint(0, S, ncheck)]))[:max(2, ncheck)]
         for s in cols:
             want, _ = O.run_samples(flat, counters, seed, 1, s, s + 1)

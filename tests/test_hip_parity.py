@@ -94,6 +94,26 @@ def _random_problem(rs, n_contigs, n_segs, n_tracks, isochores, dense=False):
     return problem.flatten_arrays(segs, annos, ws, iso)
 
 
+SEGMENT_SIDE = ["nucleotide-overlap", "nucleotide-density", "segment-overlap", "segment-midoverlap"]
+
+
+def _check_counts_alone(P, counters, want, seed, lo, hi):
+    """counts without lists: when only segment-side counters are asked for, the count kernel may take the units as
+    k_tail left them (merged list + record, no k_finalize); the same numbers must come out -- of both that path and the
+    final lists (GAT_COUNT_FINAL_LISTS)"""
+    for sub in (SEGMENT_SIDE, ["nucleotide-overlap"], ["segment-overlap"]):
+        got = P.sample_and_count(sub, seed, lo, hi)
+        for k, c in enumerate(sub):
+            assert np.array_equal(got[k], want[counters.index(c)]), ("counts alone", c, P.last_stats["lists_from_records"])
+    os.environ["GAT_COUNT_FINAL_LISTS"] = "1"
+    try:
+        got = P.sample_and_count(SEGMENT_SIDE, seed, lo, hi)
+    finally:
+        os.environ.pop("GAT_COUNT_FINAL_LISTS", None)
+    for k, c in enumerate(SEGMENT_SIDE):
+        assert np.array_equal(got[k], want[counters.index(c)]), ("final lists", c)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_problems_vs_oracle(ctx, seed):
     rs = np.random.RandomState(seed)
@@ -109,6 +129,7 @@ def test_random_problems_vs_oracle(ctx, seed):
     seg, off = P.sample(1000 + seed, 5, 5 + S)
     assert np.array_equal(off, wsamples[1])
     assert np.array_equal(seg, wsamples[0])
+    _check_counts_alone(P, counters, want, 1000 + seed, 5, 5 + S)
     P.close()
 
 
@@ -322,6 +343,8 @@ def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
         assert np.array_equal(got[k], want[k]), (c, n_segs, pieces, bucket_size, iso is not None, flat["sampler"])
     seg, off = P.sample(7000 + seed, 2, 2 + S)
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    if not flat["sampler"]:
+        _check_counts_alone(P, counters, want, 7000 + seed, 2, 2 + S)
     P.close()
 
 
@@ -721,6 +744,7 @@ def _edge_case(ctx, seed):
         assert np.array_equal(got[k], want[k]), c
     seg, off = P.sample(seed, 0, S)
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    _check_counts_alone(P, counters, want, seed, 0, S)
     P.close()
     return "compared"
 
