@@ -218,14 +218,16 @@ constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 // SMALL: every unit has at most 64 workspace segments and fewer than 256 working segments: quarter-size LDS tables,
 // so that more tiles are resident per CU (the kernel has few waves and hides latency by their number).
 // SMALL 2: at most 64 workspace segments, rank table at full size (a quarter of the workspace table's LDS back).
-template <int KIND, int MODE, int SMALL = 0>
-__global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
+// PIPE: the rows are prefetched into pinned registers (v96..v127) by hand-written loads and waits, see
+// GAT_PLACE_LOOP_PIPE below; only k_place_pipe, which is compiled for 96 registers of its own, may set it.
+template <int KIND, int MODE, int SMALL, bool PIPE>
+__device__ __forceinline__ void place_body(const SamplerArgs& A) {
   constexpr bool ALL_SIMPLE = MODE == 1;
   constexpr bool TREES = MODE == 2;
   constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = SMALL == 1 ? 256 : kPlaceRankLds;
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank[kRankTab];
-  __shared__ uint4 l_out[8][kWave];       // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
+  __shared__ uint2 l_out[16][kWave];      // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_active) return;
@@ -273,10 +275,17 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       const uint2 v = ws[i];
       l_ws[i] = make_uint4(ws_cdf[i], v.x, v.y, i > 0 ? ws[i - 1].y : 0x80000000u);
     }
-  if (rank_lds)
+  const uint2 ws0 = ws[0];
+  // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
+  // LDS -- needs no workspace search, no bucket draw and never an immediate placement
+  const bool simple_shape = nws == 1 && !drawB && ws0.y - ws0.x > 1u;
+  const bool simple_lds = ALL_SIMPLE || (simple_shape && rank_lds);      // GAT_STEP_SIMPLE_B's loop runs
+  if (simple_lds) {
+    // entry v = length of rank 1 + v for v <= rangeL (the others are never accepted)
+    for (int i = lane; i <= (int)maskL && i < kRankTab; i += kWave) l_rank[i] = (uint32_t)i <= rangeL ? rank_len[i + 1] : 0u;
+  } else if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
-  const uint2 ws0 = ws[0];
   const uint32_t* __restrict__ rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
 
@@ -292,9 +301,6 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
   int flag = 0;
 
 
-  // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
-  // LDS -- needs no workspace search, no bucket draw and never an immediate placement
-  const bool simple_shape = nws == 1 && !drawB && ws0.y - ws0.x > 1u;
   // Straight-line form: a lane's state only selects which of the three small results it keeps, so the wave runs
   // one instruction stream instead of three divergent ones.  `lr` is the length of rank 1 + (y & maskL), read
   // from LDS for the whole chunk up front (one exposed LDS latency per chunk instead of one per output).
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
       if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
       else {                                                                                                   \
-        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);                \
+        l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
         nS++;                                                                                                  \
         rem -= overlap;                                                                                        \
         if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
@@ -331,17 +337,63 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
     st = nst;                                                                                                  \
   }
 
+  // The same step with the lane's state held as three booleans (in L / in P / in O; none: halted) instead of a number:
+  // the compiler keeps them as lane masks in scalar registers and the transitions become scalar logic beside the vector
+  // work (51 -> 3x vector instructions per output).  LR1 is read from the rank table shifted by one (entry v = length of
+  // rank 1 + v), filled that way when this loop is the one that runs.
+  bool sL = live, sP = false, sO = false;
+  const int32_t c_ss = (int32_t)ws0.x + 1;               // sampling_start = ws.start - length + 1 (:318)
+  const uint32_t c_r3 = ws0.y - ws0.x - 2u;              // its range: ws.end - 1 - sampling_start = c_r3 + length
+#define GAT_STEP_SIMPLE_B(Y, LR1, JJ)                                                                          \
+  {                                                                                                            \
+    const uint32_t y_ = (Y);                                                                                   \
+    /* would this output be accepted as a rank draw / a position draw / an offset draw (numpy's masked rejection; the   \
+       offset's range follows from the length drawn last: sampling_start = c_ss - len, range c_r3 + len) */    \
+    const bool accL = (y_ & maskL) <= rangeL;                                                                  \
+    const bool accP = (y_ & maskP) <= rangeP;                                                                  \
+    const uint32_t range3 = c_r3 + len;                                                                        \
+    const uint32_t vO = y_ & (0xffffffffu >> __builtin_clz(range3 | 1u));                                      \
+    const bool accO = vO <= range3;                                                                            \
+    const bool isL = sL && accL, isP = sP && accP, isO = sO && accO;                                           \
+    const bool trig = isL && !kind1 && rem <= (int32_t)(LR1);          /* :582 -> consolidate */               \
+    const int32_t q = c_ss - (int32_t)len + (int32_t)vO;                                                       \
+    const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                          \
+    const uint32_t end = (uint32_t)(q + (int32_t)len);                                                         \
+    const int32_t omin = (int32_t)ws0.y < (int32_t)end ? (int32_t)ws0.y : (int32_t)end;                        \
+    const int32_t omax = (int32_t)ws0.x > (int32_t)start ? (int32_t)ws0.x : (int32_t)start;                    \
+    const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                                 \
+    const bool full = isO && nS >= cap;                                                                        \
+    const bool put = isO && !full;                                                                             \
+    if (put) l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
+    nS += put ? 1 : 0;                                                                                         \
+    rem -= put ? overlap : 0;                                                                                  \
+    flag |= full ? kStatusOverflow : 0;                                                                        \
+    const bool fin = kind1 && put && nS == target;                                                             \
+    len = isL ? (LR1) : len;                                                                                   \
+    pend = trig ? (int32_t)len : (fin ? -2 : pend);                                                            \
+    used = (trig || fin) ? (JJ) + 1u : used;                                                                   \
+    sL = (sL && !isL) || (put && !fin);                                                                        \
+    sP = (sP && !isP) || (isL && !trig);                                                                       \
+    sO = (sO && !isO) || isP;                                                                                  \
+  }
+
   // rows are consumed in chunks of kPlaceChunk; the next chunk is in flight while this one is worked on
   // (few waves per SIMD: nothing else hides the load latency)
   // a placement takes at least two accepted outputs, so a chunk adds at most kPlaceChunk/2 = 4 segments to the
   // at most 7 left by the previous flush: the ring of 16 never wraps onto unwritten segments
   int nF = 0;                  // segments already written to the slab (multiple of 8)
   auto flush = [&]() __attribute__((always_inline)) {
+#ifdef GAT_EXP_NOFLUSH
+    if (nS - nF >= 8) { nF += 8; return; }
+#endif
     if (nS - nF >= 8) {
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
-      const int w0 = (nF >> 1) & 7;
+      const int w0 = nF & 15;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) dst[w] = l_out[w0 + w][lane];
+      for (int w = 0; w < 4; ++w) {
+        const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
+        dst[w] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+      }
       nF += 8;
     }
   };
@@ -376,7 +428,7 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
       if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
       else {                                                                                                   \
-        reinterpret_cast<uint2*>(&l_out[(nS >> 1) & 7][lane])[nS & 1] = make_uint2(start, end);                \
+        l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
         nS++;                                                                                                  \
         rem -= overlap;                                                                                        \
         if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
@@ -434,49 +486,124 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
       const uint2 w2 = ws[lo[c]];                                                                              \
       pcs[c] = w2.x; pce[c] = w2.y; ppe[c] = lo[c] > 0 ? ws[lo[c] - 1].y : 0x80000000u; }                      \
   }
-#define GAT_PRE_SIMPLE_L(Y) GAT_PRE_RANK_L(Y)
+#define GAT_PRE_SIMPLE_L(Y)                                                                                    \
+  _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lr[c] = l_rank[(Y)[c] & maskL];
 #define GAT_PRE_SIMPLE_G(Y) GAT_PRE_RANK_G(Y)
 #define GAT_PRE_TABLE_LL(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS(Y)
 #define GAT_PRE_TABLE_GL(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS(Y)
 #define GAT_PRE_TABLE_LG(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS2(Y)
 #define GAT_PRE_TABLE_GG(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS2(Y)
 #define GAT_ONE_SIMPLE(Y, C, JJ) GAT_STEP_SIMPLE((Y)[C], lr[C], JJ)
+#define GAT_ONE_SIMPLE_B(Y, C, JJ) GAT_STEP_SIMPLE_B((Y)[C], lr[C], JJ)
+#define GAT_ALIVE_ST (st != S_HALT)
+#define GAT_ALIVE_B (sL || sP || sO)
 #define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
   // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
-#define GAT_PLACE_LOOP(PRE, ONE)                                                                               \
+  // Two loops.  GAT_PLACE_LOOP: two chunk buffers, loads left to the compiler -- which, for a register loaded in one
+  // trip and used in the next, waits for EVERYTHING in flight (loads and stores share one in-order counter, vmcnt, and the
+  // flush above stores under a lane-dependent condition, so it cannot count): every chunk then exposes a round trip to
+  // memory.  The kernel has few waves (every tile of the batch is resident at once, 3-4 per SIMD) and cannot end before
+  // the serial chain of the longest unit's tile has: tools/place_scaling.py, config 2: 0.70 ms for 5 000 samples and
+  // 0.91 ms for 10 000 with this loop, 0.58 / 0.89 ms with the one below (the floor, 1 250 samples: 0.54 ms).
+  // GAT_PLACE_LOOP_PIPE, for the loops whose look-ups are all in LDS (k_place_pipe): four chunk buffers in registers the
+  // compiler does not manage (v96..v127: the kernel is compiled for 96), loads and waits written out by hand.  A chunk's
+  // loads are issued three chunks (24 rows) before it is worked on and waited for with vmcnt(24): the 24 loads issued
+  // after it may stay in flight (returns are in order; stores issued in between only make the wait stricter).  Every
+  // load is always issued (rows beyond the tile's end re-read its last chunk and are not used), so the count holds.
+  // (The same with the buffers as asm operands did not work: the compiler copies them around the loop's back edge while
+  // loads are on their way into them.)
+#define GAT_PIN_LOAD(R0, R1, R2, R3, R4, R5, R6, R7, ROW0)                                                     \
   {                                                                                                            \
-    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[c * kWave];                             \
+    const int r0_ = (int)(ROW0) < rows - kPlaceChunk ? (int)(ROW0) : rows - kPlaceChunk;                       \
+    const uint32_t* p_ = rp + (int64_t)r0_ * kWave;                                                            \
+    asm volatile("global_load_dword v" #R0 ", %0, off\n\tglobal_load_dword v" #R1 ", %0, off offset:256\n\t" \
+                 "global_load_dword v" #R2 ", %0, off offset:512\n\tglobal_load_dword v" #R3 ", %0, off offset:768\n\t" \
+                 "global_load_dword v" #R4 ", %0, off offset:1024\n\tglobal_load_dword v" #R5 ", %0, off offset:1280\n\t" \
+                 "global_load_dword v" #R6 ", %0, off offset:1536\n\tglobal_load_dword v" #R7 ", %0, off offset:1792" \
+                 :: "v"(p_) : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3, "v" #R4, "v" #R5, "v" #R6, "v" #R7); \
+  }
+#define GAT_PIN_TAKE(R0, R1, R2, R3, R4, R5, R6, R7)                                                           \
+  asm volatile("s_waitcnt vmcnt(24)\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R2 "\n\t" \
+               "v_mov_b32 %3, v" #R3 "\n\tv_mov_b32 %4, v" #R4 "\n\tv_mov_b32 %5, v" #R5 "\n\tv_mov_b32 %6, v" #R6 "\n\t" \
+               "v_mov_b32 %7, v" #R7                                                                            \
+               : "=v"(ya[0]), "=v"(ya[1]), "=v"(ya[2]), "=v"(ya[3]), "=v"(ya[4]), "=v"(ya[5]), "=v"(ya[6]), "=v"(ya[7]) \
+               :: "memory");
+#define GAT_PLACE_CHUNK(PRE, ONE, K)                                                                         \
+  PRE(ya)                                                                                                    \
+  _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + (K) * kPlaceChunk + c))  \
+  flush();
+#define GAT_PLACE_LOOP_PIPE(PRE, ONE, ALIVE)                                                                 \
+  {                                                                                                          \
+    static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
+    GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, 0)                                                      \
+    GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, kPlaceChunk)                                        \
+    GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, 2 * kPlaceChunk)                                    \
+    for (int j = 0; j < rows; j += 4 * kPlaceChunk) {                                                        \
+      if (__ballot(ALIVE) == 0) break;                                                                       \
+      GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
+      GAT_PLACE_CHUNK(PRE, ONE, 0)                                                                           \
+      if (j + 1 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
+      GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
+      GAT_PLACE_CHUNK(PRE, ONE, 1)                                                                           \
+      if (j + 2 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
+      GAT_PLACE_CHUNK(PRE, ONE, 2)                                                                           \
+      if (j + 3 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
+      GAT_PLACE_CHUNK(PRE, ONE, 3)                                                                           \
+    }                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* nothing on its way into a register at the end */\
+  }
+#define GAT_PLACE_LOOP(PRE, ONE, ALIVE)                                                                        \
+  {                                                                                                            \
+    const uint32_t* __restrict__ rq = rp;                                                                      \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rq[c * kWave];                             \
     for (int j = 0; j < rows; j += 2 * kPlaceChunk) {                                                          \
-      if (__ballot(st != S_HALT) == 0) break;                                                                  \
+      if (__ballot(ALIVE) == 0) break;                                                                         \
       const bool more_b = j + kPlaceChunk < rows;                                                              \
       if (more_b) {                                                                                            \
-        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rp[(kPlaceChunk + c) * kWave];         \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rq[(kPlaceChunk + c) * kWave];         \
       }                                                                                                        \
       PRE(ya)                                                                                                  \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + c))                    \
       flush();                                                                                                 \
-      if (!more_b || __ballot(st != S_HALT) == 0) break;                                                       \
+      if (!more_b || __ballot(ALIVE) == 0) break;                                                              \
       if (j + 2 * kPlaceChunk < rows) {                                                                        \
-        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rp[(2 * kPlaceChunk + c) * kWave];     \
+        _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rq[(2 * kPlaceChunk + c) * kWave];     \
       }                                                                                                        \
-      rp += 2 * kPlaceChunk * kWave;                                                                           \
+      rq += 2 * kPlaceChunk * kWave;                                                                           \
       PRE(yb)                                                                                                  \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb, c, (uint32_t)(j + kPlaceChunk + c))      \
       flush();                                                                                                 \
     }                                                                                                          \
   }
-  if (ALL_SIMPLE || (simple_shape && rank_lds)) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE)
-  else if constexpr (!ALL_SIMPLE) {
-    if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE)
+  if (simple_lds) {
+    if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    st = (sL || sP || sO) ? S_L : S_HALT;
+  } else if constexpr (!ALL_SIMPLE) {
+    if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE, GAT_ALIVE_ST)
     else if (ws_lds) {
-      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE)
+      if (rank_lds) { if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_ST) else GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_ST) } else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_ST)
     } else if constexpr (TREES) {
-      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE)
+      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_ST) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_ST)
     }
   }
 #undef GAT_PLACE_LOOP
+#undef GAT_PLACE_LOOP_PIPE
+#undef GAT_PLACE_CHUNK
+#undef GAT_PIN_TAKE
+#undef GAT_PIN_LOAD
 #undef GAT_ONE_TABLE
 #undef GAT_ONE_SIMPLE
+#undef GAT_ONE_SIMPLE_B
+#undef GAT_ALIVE_ST
+#undef GAT_ALIVE_B
+#undef GAT_STEP_SIMPLE_B
 #undef GAT_PRE_TABLE_GG
 #undef GAT_PRE_TABLE_LG
 #undef GAT_PRE_TABLE_GL
@@ -490,11 +617,21 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) {
 #undef GAT_STEP_TABLE
 #undef GAT_STEP_SIMPLE
   if (live) {
-    for (int i = nF; i < nS; ++i) out[i] = reinterpret_cast<const uint2*>(&l_out[(i >> 1) & 7][lane])[i & 1];   // what the last flush left
+    for (int i = nF; i < nS; ++i) out[i] = l_out[i & 15][lane];   // what the last flush left
     A.st[so] = make_int4(nS, rem, (st == S_HALT && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
                          (int)used);
     if (flag) atomicOr(A.flags, flag);
   }
+}
+
+template <int KIND, int MODE, int SMALL = 0>
+__global__ __launch_bounds__(64) void k_place(SamplerArgs A) { place_body<KIND, MODE, SMALL, false>(A); }
+
+// every unit's look-up tables in LDS (MODE 1, or MODE 0 with all rank and workspace tables within the LDS tables' sizes):
+// the rows pipelined through v96..v127 by hand
+template <int KIND, int MODE, int SMALL = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) void k_place_pipe(SamplerArgs A) {
+  place_body<KIND, MODE, SMALL, true>(A);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -344,6 +344,7 @@ struct gat_problem {
   bool split_ran = false;                // ... and the last sampler batch took it: the units' lists are in d_fslab
   const uint2* final_slab() const { return split_ran ? d_fslab.p : d_slab.p; }
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
+  uint32_t max_hist = 0;                 // longest length-rank table of an active unit
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
@@ -674,6 +675,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     max_hist = std::max(max_hist, U.hist_total);
   }
   P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
+  P->max_hist = max_hist;
   {
     // the split path pays when k_tail can take most units: SamplerAnnotator, lists the wave bucket sorts hold, workspaces
     // of up to kTailMaxWs segments
@@ -1058,9 +1060,16 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<1, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
-          if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          // (k_place_pipe: every look-up of every unit in LDS -- the rows prefetched by hand, see GAT_PLACE_LOOP_PIPE)
+          const bool pipe = !getenv("GAT_PLACE_NO_PIPE");
+          const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
+          if (mode == 1 && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && P->small_tables && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 0, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0 && P->small_tables) hipLaunchKernelGGL((gat::k_place<0, 0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && P->max_nws <= 64 && rank_fits && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 0, 2>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0 && P->max_nws <= 64) hipLaunchKernelGGL((gat::k_place<0, 0, 2>), gp, dim3(64), 0, ctx->stream, A);
+          else if (mode == 0 && rank_fits && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 0>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<0, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<0, 2>), gp, dim3(64), 0, ctx->stream, A);
         }

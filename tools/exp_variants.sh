@@ -1,0 +1,12 @@
+#!/bin/bash
+# timing experiments: builds of the library with parts of a kernel cut out (-DGAT_EXP_*; results are WRONG, only the
+# kernel times mean anything).  usage (GPU box): bash tools/exp_variants.sh "<-D flags>" ...
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+OUT=$R/gpurun_out/exp; mkdir -p $OUT
+i=0
+for flags in "$@"; do
+  i=$((i+1))
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags -o $OUT/lib_$i.so gat_amd/csrc/gat_mi355.hip || exit 1
+  GAT_LIB_PATH=$OUT/lib_$i.so python3 bench.py --no-cpu-baseline --extra "" --steps 5 --warmup 2 > $OUT/bench_$i.json 2>$OUT/err_$i.log
+  echo "== $flags"; python3 tools/show_bench.py $OUT/bench_$i.json
+done
