@@ -1709,7 +1709,10 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 // config 3 (1.80 vs 1.82 ms per 10 000 samples) and slower on the config-4 shape (54.9 vs 34.1 ms per 4 096 samples: with
 // 1 000 tracks only eight samples' accumulators fit beside a chunk, so a contig's 3.3 MB are staged 512 times).
 constexpr int kMergedSlots = 8;
-constexpr int kMergedThreads = 256;
+#ifndef GAT_MERGED_THREADS
+#define GAT_MERGED_THREADS 256
+#endif
+constexpr int kMergedThreads = GAT_MERGED_THREADS;
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int T = A.n_tracks;
