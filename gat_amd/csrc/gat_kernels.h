@@ -37,6 +37,8 @@ enum : int32_t {
   kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab
   kStatusAssert = 2,     // reference assert would fire (gat/Engine.pyx:645 sum()>0)
   kStatusTrimAssert = 4, // gat/SegmentList.pyx:560 sum() > size
+  kStatusContigLds = 8,  // k_contig: a contig's lists exceed the LDS the launch was given (sized for what is expected,
+                         // not for every unit at its capacity): host repeats the batch with the full size
 };
 
 struct SamplerArgs {
@@ -1331,6 +1333,11 @@ struct ContigArgs {
   const int32_t* patch;            // TailPatch records as words (layout: gat_tail.h), patch_stride words each
   int32_t patch_stride;
   uint32_t* ws_stat;               // per-unit statistics (k_finalize's job otherwise)
+  // one launch per size class of contigs: launch position p of this launch is contig order[base + p]
+  const int32_t* order;
+  int32_t base, count;
+  int32_t lds_cap;                 // segments the launch's LDS holds (not HUGE)
+  int32_t* flags;
 };
 
 // layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
@@ -1344,8 +1351,9 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   uint32_t* scratch = lds;                               // 513 words for the bucket sort
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
-  const int c = (int)(blockIdx.y + blockIdx.z * gridDim.y);      // (contigs beyond one grid dimension)
-  if (c >= A.n_contigs) return;
+  const int cp = (int)(blockIdx.y + blockIdx.z * gridDim.y);     // (contigs beyond one grid dimension)
+  if (cp >= A.count) return;
+  const int c = A.order[A.base + cp];
   uint2* out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
   uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + 520);
   int n = 0;
@@ -1369,6 +1377,10 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
       if (!my_patched) my_cnt = my_copy = A.unit_n[(int64_t)sidx * A.n_units + u];
     }
     const int my_dst = n + (int)(wave_incl_sum_u32((uint32_t)my_cnt, lane) - (uint32_t)my_cnt);
+    if (!HUGE && n + (int)wave_total_u32((uint32_t)my_cnt) > A.lds_cap) {      // (wave-uniform; nothing of this batch is kept)
+      if (lane == 0) atomicOr(A.flags, kStatusContigLds);
+      return;
+    }
     const uint2* __restrict__ base_final = A.slab_in + (int64_t)sidx * A.slab_stride;
     const uint2* __restrict__ base_merged = A.slab_merged != nullptr ? A.slab_merged + (int64_t)sidx * A.slab_stride : base_final;
     const uint64_t patched_mask = __ballot(my_patched);

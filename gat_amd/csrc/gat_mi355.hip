@@ -306,6 +306,10 @@ struct gat_problem {
   int cap_scale = 1;
   int64_t slab_stride = 0;
   int32_t max_unit_cap = 0, max_contig_cap = 0;
+  // k_contig: contigs by expected list length (largest first), size classes of that order, LDS sized for the expectation
+  std::vector<int32_t> h_contig_order, h_contig_need, h_contig_class_start;
+  DevBuf<int32_t> d_contig_order;
+  bool contig_tight = true;              // false after a batch whose lists did not fit: LDS for every unit at capacity
   int64_t n_seg_total = 0;               // input segments (for the algorithmic byte count)
   DevBuf<UnitDev> d_units;
   DevBuf<UnitDev> d_units_o;            // the active units' records in launch order (h_order), unit id in `pad`
@@ -485,6 +489,37 @@ static int layout_slab(gat_problem* P) {
   }
   if (off >= (int64_t)1 << 31) return GAT_ERR_CAPACITY;
   P->slab_stride = off > 0 ? off : 1;
+  {
+    // what a contig's list is expected to need in k_contig: its units' segments + a quarter (a unit's capacity adds 96
+    // slots of slack per unit: eight isochore units of fifty segments have 1 536 slots for ~400 segments)
+    P->h_contig_need.assign((size_t)P->n_contigs, 64);
+    for (int c = 0; c < P->n_contigs; ++c) {
+      int64_t need = 0, ccap = 0;
+      for (int ui = P->h_contig_unit_off[c]; ui < P->h_contig_unit_off[c + 1]; ++ui) {
+        const int u = P->h_contig_units[ui];
+        const int64_t n = (int64_t)P->h_units[u].hist_total;
+        need += n + n / 4;
+        ccap += P->h_units[u].slab_cap;
+      }
+      need = (need + 64 + 63) / 64 * 64;
+      if (getenv("GAT_TEST_SMALL_CAPS")) need = std::max<int64_t>(64, need / 4 / 64 * 64);      // tests: force the repeat
+      P->h_contig_need[c] = (int32_t)std::min<int64_t>(P->contig_tight ? need : ccap, std::max<int64_t>(64, ccap));
+    }
+    P->h_contig_order.resize((size_t)P->n_contigs);
+    for (int c = 0; c < P->n_contigs; ++c) P->h_contig_order[c] = c;
+    std::stable_sort(P->h_contig_order.begin(), P->h_contig_order.end(),
+                     [&](int32_t x, int32_t y) { return P->h_contig_need[x] > P->h_contig_need[y]; });
+    P->h_contig_class_start.clear();
+    int32_t first = 0;
+    for (int i = 0; i < P->n_contigs; ++i) {
+      const int32_t need = P->h_contig_need[P->h_contig_order[i]];
+      if (i == 0 || ((int64_t)need * 10 <= (int64_t)first * 7 && P->h_contig_class_start.size() < 6)) {
+        P->h_contig_class_start.push_back(i);
+        first = need;
+      }
+    }
+    P->h_contig_class_start.push_back(P->n_contigs);
+  }
   return GAT_OK;
 }
 
@@ -518,6 +553,11 @@ static int upload_layout(gat_ctx* ctx, gat_problem* P) {
     P->h_class_start.push_back(N);
   }
   HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
+  {
+    std::vector<int32_t> o = P->h_contig_order;
+    if (o.empty()) o.push_back(0);
+    HIPCHK(ctx, P->d_contig_order.upload(o, ctx->stream));
+  }
   HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
   HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx->stream));
   P->batch = 0;   // scratch must be re-sized
@@ -1260,15 +1300,27 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         B.patch = reinterpret_cast<const int32_t*>(P->d_patch.p);
         B.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
       }
-      size_t lds = (size_t)std::max(64, P->max_contig_cap) * 8 + 520 * 4;
+      const int need_max = P->h_contig_order.empty() ? 64 : P->h_contig_need[(size_t)P->h_contig_order[0]];
+      size_t lds = (size_t)std::max(64, need_max) * 8 + 520 * 4;
       const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
       if (huge_c) lds = 520 * 4;
       const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
       HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      const unsigned gcy = (unsigned)std::min(P->n_contigs, 32768), gcz = ((unsigned)P->n_contigs + gcy - 1) / gcy;
-      if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds, ctx->stream, B);
-      else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds, ctx->stream, B);
-      HIPCHK(ctx, hipGetLastError());
+      B.order = P->d_contig_order.p;
+      B.flags = P->d_flags.p;
+      // one launch per size class: LDS for the class's longest expected list (more waves per CU for the short contigs)
+      for (size_t k = 0; k + 1 < P->h_contig_class_start.size(); ++k) {
+        const int c0 = P->h_contig_class_start[k], c1 = P->h_contig_class_start[k + 1];
+        if (huge_c && k > 0) break;
+        B.base = huge_c ? 0 : c0;
+        B.count = huge_c ? P->n_contigs : c1 - c0;
+        B.lds_cap = huge_c ? 0 : std::max(64, P->h_contig_need[(size_t)P->h_contig_order[(size_t)c0]]);
+        const size_t lds_k = huge_c ? lds : (size_t)B.lds_cap * 8 + 520 * 4;
+        const unsigned gcy = (unsigned)std::min(B.count, 32768), gcz = ((unsigned)B.count + gcy - 1) / gcy;
+        if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
+        else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
+        HIPCHK(ctx, hipGetLastError());
+      }
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     if (!P->h_order.empty()) {
@@ -1295,6 +1347,14 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       return set_err(ctx, GAT_ERR_ASSERT, "sampler assertion failed on device (flags=%d): %s", flags,
                      (flags & gat::kStatusAssert) ? "sampled list has no overlap with the workspace (gat/Engine.pyx:645)"
                                                   : "trimming more than the total length (gat/SegmentList.pyx:560)");
+    if ((flags & gat::kStatusContigLds) && !(flags & gat::kStatusOverflow)) {
+      // a contig's lists were longer than expected: LDS for every unit at its capacity from now on, batch repeated
+      P->contig_tight = false;
+      if (layout_slab(P)) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
+      if ((rc = upload_layout(ctx, P))) return rc;
+      if (st) st->n_retried += nb * (int64_t)P->h_order.size();
+      return kRelayout;
+    }
     if (flags & gat::kStatusOverflow) {
       if (P->cap_scale >= 64) return set_err(ctx, GAT_ERR_CAPACITY, "sampler slab overflow even at 64x capacity");
       P->cap_scale *= 2;

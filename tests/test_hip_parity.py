@@ -302,6 +302,26 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     P.close()
 
 
+def test_contig_lists_longer_than_expected(ctx, monkeypatch):
+    """k_contig's LDS is sized for the lists a contig is expected to have, not for every unit at its capacity; a batch in
+    which a contig's lists do not fit is repeated with the full size (forced here by shrinking the expectation; the same
+    switch shrinks the slab regions, so the slab-overflow repeat runs in front of it)"""
+    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+    rs = np.random.RandomState(4242)
+    flat = _random_problem(rs, n_contigs=3, n_segs=500, n_tracks=2, isochores=True, dense=False)
+    counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    S = 20
+    want, wsamples = O.run_samples(flat, counters, 5, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 5, 0, S)
+    assert P.last_stats["n_retried"] > 0
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    seg, off = P.sample(5, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
 @pytest.mark.parametrize("seed", list(range(100, 164)))
 def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
     """random combinations of the knobs that select code paths -- segments per unit (register / bucket / counting
