@@ -760,11 +760,14 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       // Spread of the raw-output count of a stream: the NUMBER of placements until the unit's bases are reproduced varies
       // by cv(length) x sqrt(n) (a renewal count) and every placement costs e outputs -- that term dominates (measured on
       // config 2: 97 / 116 / 58 outputs for units of 778 / 444 / 166 segments = e x cv x sqrt(n)) -- plus the rejection
-      // noise v per placement.  7.5 sigma and the tail's few dozen outputs: a stream that runs out is redone from its seed
+      // noise v per placement.  5 to 7.5 sigma and the tail's few dozen outputs: a stream that runs out is redone from its seed
       // by ONE wave, placement by placement, and such a straggler (0.5 ms) is now longer than the rest of the sampler.
       const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
       const double var_n = P->sampler == GAT_SAMPLER_SEGMENTS ? 0.0 : len_cv2[(size_t)u] * e * e;
-      const double need = e * nplace * slack + 7.5 * std::sqrt(nplace * (v + 0.5 + var_n)) + 96.0;
+      // (the multiple follows what running out costs: ONE wave redoing the unit placement by placement -- 0.5 ms for 800
+      //  segments, a few dozen us for 50, where five sigma are plenty and the rows saved are a sixth of k_rng's work)
+      const double sigmas = std::min(7.5, std::max(5.0, 4.5 + nplace / 130.0));
+      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + 96.0;
       int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
