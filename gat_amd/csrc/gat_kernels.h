@@ -83,8 +83,16 @@ struct SamplerArgs {
   int32_t skip_stride;
   const uint32_t* todo_count; // split path: k_sampler works off the queue of units k_tail left alone (k_finalize fills it)
   const uint32_t* todo;       //   entries sidx * n_active + launch position
+  const int32_t* tb;          // long lists: k_tail_big's hand-over records (TailPatch words, skip_stride apart), or nullptr
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
 };
+
+// layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
+constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchPlaced = 2, kPatchNdraws = 3, kPatchNuns = 4, kPatchPad = 5, kPatchExtra = 6,
+              kPatchPos = 14, kPatchWords = 18;
+// k_tail_big's hand-over (state 2) keeps its loop state in the words a finished unit's extras would take
+constexpr int kTbTrueRemaining = kPatchPad, kTbNSampled = kPatchPos, kTbSampledAt = kPatchPos + 1, kTbPending = kPatchPos + 2,
+              kTbRemaining = kPatchPos + 3;
 
 // In-kernel stamps of the diagnostic build (tools/diag_sampler.sh): shares of a work unit's life per phase.  Stamps
 // fence the schedule, so that build's run time is not quoted; the product build compiles none of this.
@@ -963,6 +971,12 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       nS = pre.x;
       int4 pre2 = make_int4(0, 0, 0, 0);
       if (!HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[(int64_t)sidx * A.n_units + a];
+      const int32_t* __restrict__ R = nullptr;
+      if (BIG && !HUGE && A.tb != nullptr && pre2.w == 1) {
+        R = A.tb + ((int64_t)sidx * A.n_units + a) * A.skip_stride;
+        if (R[kPatchState] == 3) continue;                     // k_tail_big ran out of rows: the unit is redone from its seed
+        if (R[kPatchState] != 2) R = nullptr;
+      }
       if (pre2.w == 1) {
         // k_merge_big has done the first consolidation: the slab holds the merged list; its coverage and total
         // length come with it, and the pending length below makes the loop take them up at once
@@ -972,6 +986,20 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         total_known = (uint32_t)pre2.z;
         cov_valid = true;
         for (int i = lane; i < nU; i += kWave) seg[i] = out[i];
+        if (R != nullptr) {
+          // k_tail_big has run the placement rounds behind it: the merged list (unions applied in place), nE new segments
+          // that touch nothing (logged from the region's end backwards), and nS it placed but did not consolidate
+          const int nE = R[kPatchNExtra], nSp = R[kTbNSampled], at = R[kTbSampledAt];
+          for (int i = lane; i < nE; i += kWave) seg[nU + i] = out[cap - 1 - i];
+          for (int i = lane; i < nSp; i += kWave) seg[nU + nE + i] = out[at + i];
+          wave_sync();
+          for (int done = 0; done < nE; done += kWave) {
+            const int chunk = nE - done < kWave ? nE - done : kWave;
+            wave_insert_sorted(seg, nU + done, chunk, lane);         // (the next chunk stands right behind the grown list)
+          }
+          nU += nE;
+          nS = nSp;
+        }
       } else
       // (a list the counting sort will take straight from the slab need not be copied first)
       if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0) && !(nS > 512 && nS <= 1024))
@@ -984,6 +1012,17 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       rng.pre_base = rng.pre_j - (uint32_t)kWave;     // forces the first prefetch
       rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
       placed = (uint32_t)pre.x;
+      if (R != nullptr) {
+        // ... and the loop goes on where k_tail_big left it: at a consolidation whose bookkeeping (:601-605) is still to do
+        remaining = R[kTbRemaining];
+        pending = R[kTbPending];
+        true_remaining = R[kTbTrueRemaining];
+        nuns = R[kPatchNuns];
+        placed = (uint32_t)R[kPatchPlaced];
+        rng.ndraws = (uint32_t)R[kPatchNdraws];
+        rng.pre_j = rng.ndraws;
+        rng.pre_base = rng.pre_j - (uint32_t)kWave;
+      }
       wave_sync();
       GAT_PHASE(0)                                   // prologue: unit record, workspace, hand-off record, list into LDS
     } else {
@@ -1339,10 +1378,6 @@ struct ContigArgs {
   int32_t lds_cap;                 // segments the launch's LDS holds (not HUGE)
   int32_t* flags;
 };
-
-// layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
-constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchPlaced = 2, kPatchNdraws = 3, kPatchNuns = 4, kPatchExtra = 6,
-              kPatchPos = 14, kPatchWords = 18;
 
 // HUGE: a contig's list does not fit LDS; it is gathered, sorted and merged in its output region in global memory.
 template <bool HUGE>

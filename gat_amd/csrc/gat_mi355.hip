@@ -125,8 +125,8 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
 }
 
 // The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, 8-byte
-// entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two >= 8 x the group's mean length,
-// at most 32 768) are cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
+// entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two, see below, at most 32 768) are
+// cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
 // than `bound` bases; first[g] is the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a
 // segment starting in cell g begins.
 static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
@@ -145,8 +145,21 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
       const int64_t l = t * n_groups + c;
       for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) { total_len += annos[i].end - annos[i].start; ++cnt; }
     }
-    uint32_t bound = 1024;
-    while (cnt > 0 && (uint64_t)bound < 8 * (total_len / cnt) && bound < 32768u) bound <<= 1;
+    // the piece bound: a scan starts at the first entry that reaches into the segment's cell and passes everything up to
+    // the segment's end, so it walks over about (bound + segment length) / spacing entries, most of which ended before the
+    // segment began.  Twice the mean interval length or twice the mean spacing of the entries, whichever is larger (cutting
+    // finer than the spacing only adds entries): config-4 shape, 1 000 tracks, one entry per 300 bases: 30.8 -> 25.9 ms per
+    // 4 096 samples against the earlier 8 x mean length; config 3 (one per 3 000) keeps its bound.
+    const char* env_bf = getenv("GAT_MERGED_BOUND");
+    const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
+    uint64_t span = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      if (anno_off[l + 1] > anno_off[l]) span = std::max<uint64_t>(span, annos[anno_off[l + 1] - 1].end);
+    }
+    const uint64_t want = cnt > 0 ? std::max(bfac * (total_len / cnt), 2 * (span / cnt)) : 0;
+    uint32_t bound = 256;
+    while ((uint64_t)bound < want && bound < 32768u) bound <<= 1;
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
       for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
@@ -349,6 +362,7 @@ struct gat_problem {
   const uint2* final_slab() const { return split_ran ? d_fslab.p : d_slab.p; }
   int sampler_mode = 1;                  // 1: k_rng + k_place + k_sampler(resume); 0: k_sampler alone
   uint32_t max_hist = 0;                 // longest length-rank table of an active unit
+  bool long_lists = false;               // units beyond the wave's bucket sorts (k_merge_big, k_tail_big)
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
@@ -715,6 +729,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     max_hist = std::max(max_hist, U.hist_total);
   }
   P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
+  P->long_lists = max_hist + max_hist / 8 > 1024;
   P->max_hist = max_hist;
   {
     // the split path pays when k_tail can take most units: SamplerAnnotator, lists the wave bucket sorts hold, workspaces
@@ -866,6 +881,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
     HIPCHK(ctx, P->d_st2.alloc(ns));
+    if (!P->split_path && P->long_lists) HIPCHK(ctx, P->d_patch.alloc(ns));     // k_tail_big's hand-over records
     if (P->split_path) {
       HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
@@ -1178,6 +1194,18 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           }
           A.st2 = P->d_st2.p;                    // (k_sampler reads it for those units only: see n_long below)
           A.n_long = (int32_t)n_long;
+          if (!split && P->d_patch.p != nullptr && P->max_nws <= gat::kTailMaxWs && !getenv("GAT_NO_TAIL_BIG")) {
+            // the placement rounds behind that consolidation, one stream per lane; k_sampler resumes at the trim
+            gat::TailArgs TB;
+            TB.S = A;
+            TB.cum = nullptr; TB.patch = P->d_patch.p; TB.todo = nullptr; TB.todo_count = nullptr;
+            const unsigned gby = std::min(n_long, 32768u);
+            hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
+                               ctx->stream, TB);
+            HIPCHK(ctx, hipGetLastError());
+            A.tb = reinterpret_cast<const int32_t*>(P->d_patch.p);
+            A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+          }
         } else {
           // no workgroup pass: the wave's own counting sort, scratch behind the segment buffer if it fits
           while (nbk >= 1024 && (int64_t)(lds + (size_t)(nbk + 1) * 4) > ctx->max_lds) nbk >>= 1;

@@ -40,6 +40,7 @@ struct TailPatch {
   int32_t pos[kTailMaxExtra];          // merged-list elements in front of each
 };
 
+static_assert(offsetof(TailPatch, pad) == kPatchPad * 4 && offsetof(TailPatch, nuns) == kPatchNuns * 4, "TailPatch words");
 static_assert(sizeof(TailPatch) == kPatchWords * 4 && offsetof(TailPatch, extra) == kPatchExtra * 4 &&
               offsetof(TailPatch, pos) == kPatchPos * 4 && offsetof(TailPatch, placed) == kPatchPlaced * 4 &&
               offsetof(TailPatch, n_extra) == kPatchNExtra * 4 && offsetof(TailPatch, ndraws) == kPatchNdraws * 4,
@@ -422,6 +423,178 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   P->state = 1;
   // (the unit's statistics: its consumers may take the record as it is, without k_finalize)
   *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + Up->pad) * 4) = make_uint4(placed, rng.used, (uint32_t)nuns, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_tail_big: the placement rounds behind the first consolidation of a LONG list (k_merge_big's), one stream per lane.
+// Such a list needs ~n x coverage / 2 more segments (60 for 4 000 segments covering 3 % of their workspace), placed in
+// three to five rounds, and k_sampler paid every round with a handful of passes over the whole list by one wave (config-4
+// shape: 33 of 87 ms at 1.4 waves per CU).  Here a round costs a binary search per new segment:
+//   * a new segment that touches nothing is logged (from the end of the unit's slab region backwards),
+//   * one that touches exactly one segment (of the merged list, or a logged one) is united with it in place
+//     (merge(0) joins at start <= previous end, gat/SegmentList.pyx:756-816; the union touches nothing else, so the list
+//     stays what merge(0) of everything would give), coverage and total length move by the difference,
+//   * anything else -- an empty segment, one touching two neighbours -- ends the lane's work: the segments of the round
+//     not yet applied are handed on as "sampled since the last consolidation", which is what they are.
+// The lane stops at the consolidation after which the loop would trim or end (:601-626) -- with that consolidation's
+// bookkeeping still to do -- and k_sampler resumes there: merged list + log (inserted in one pass per 64) + loop state.
+__global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
+  __shared__ uint32_t l_ws[3 * kTailMaxWs];
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x;
+  const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_long) return;                           // (only the launch positions k_merge_big was given)
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int nws = Up->n_ws;
+  const int sidx = sb * kWave + lane;
+  const int64_t sa = (int64_t)(sidx < A.batch ? sidx : 0) * A.n_units + a;
+  TailPatch* P = T.patch + sa;
+  if (sidx < A.batch) P->state = 0;
+  if (nws > kTailMaxWs) return;                        // long workspace: k_sampler's (search trees)
+  const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
+  const int32_t ltotal = Up->ltotal;
+  const int cap = Up->slab_cap;
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  for (int i = lane; i < nws; i += kWave) {
+    const uint2 w = A.ws[Up->ws_off + i];
+    l_ws[i] = w.x; l_ws[kTailMaxWs + i] = w.y; l_ws[2 * kTailMaxWs + i] = A.ws_cdf[Up->ws_off + i];
+  }
+  __syncthreads();
+  if (sidx >= A.batch) return;
+  const int4 pre = A.st[sa];
+  const int4 c2 = A.st2[sa];
+  if (pre.z < 0 || c2.w != 1 || c2.x <= 0) return;     // not consolidated by k_merge_big: k_sampler's as before
+  uint2* U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  int nU = c2.x;
+  uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
+
+  TailRng rng;
+  rng.rows = (uint32_t)A.rng_rows[a];
+  rng.rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rng.rows * kWave + lane;
+  rng.used = (uint32_t)pre.w;
+  rng.out_of_rows = false;
+  rng.have = 0; rng.base = rng.used;
+
+  auto ws_overlap = [&](uint32_t s, uint32_t e) -> uint32_t {
+    uint32_t ov = 0;
+    for (int j = 0; j < nws; ++j) {
+      const uint32_t ws0 = l_ws[j], we0 = l_ws[kTailMaxWs + j];
+      const uint32_t lo = s > ws0 ? s : ws0, hi = e < we0 ? e : we0;
+      ov += hi > lo ? hi - lo : 0u;
+    }
+    return ov;
+  };
+  // merge(0) joins b to a (a.start <= b.start) when b.start <= a.end
+  auto touches = [](uint2 p, uint2 q) -> bool {
+    const bool p_first = p.x <= q.x;
+    const uint2 f = p_first ? p : q, g = p_first ? q : p;
+    return (int32_t)g.x <= (int32_t)f.y;
+  };
+
+  int nE = 0, nP = 0;          // logged segments U[cap - 1 - j]; placements of this round NOT applied: U[nU + j]
+  bool broken = false;         // a placement of this round could not be applied: the rest of the round is only recorded
+  uint32_t placed = (uint32_t)pre.x;
+  int32_t length = pre.z;
+  int32_t remaining = ltotal - (int32_t)cov, true_remaining = ltotal;
+  int nuns = 0;
+  if (true_remaining == remaining) nuns++; else true_remaining = remaining;           // :601-605, first consolidation
+  if (!(true_remaining > 0 && nuns < 20)) return;      // a trim or the end right away: k_sampler resumes as before (state 0)
+
+  bool handed = false;
+  for (int step = 0; step < 4096; ++step) {
+    // ---- sls.sample(length) (:279-343), as in k_tail
+    if (nU + nP + nE + 2 > cap) { atomicOr(A.flags, kStatusOverflow); return; }
+    const uint32_t p = tail_range(rng, ws_total - 1u);
+    int k = 0;
+    for (int j = 0; j < nws; ++j) k += ((int32_t)(l_ws[2 * kTailMaxWs + j] - p) < 0) ? 1 : 0;
+    k = k < nws ? k : nws - 1;
+    const uint32_t cs = l_ws[k], ce = l_ws[kTailMaxWs + k];
+    int32_t sampling_start = (int32_t)cs - length + 1;
+    if (k > 0) { const int32_t pe = (int32_t)l_ws[kTailMaxWs + k - 1]; sampling_start = pe > sampling_start ? pe : sampling_start; }
+    const uint32_t range = ce - 1u - (uint32_t)sampling_start;
+    const int32_t q = sampling_start + (int32_t)tail_range(rng, range);
+    if (rng.out_of_rows) break;
+    const uint2 x = make_uint2((uint32_t)(q > 0 ? q : 0), (uint32_t)(q + length));
+    const int32_t omin = (int32_t)ce < (int32_t)x.y ? (int32_t)ce : (int32_t)x.y;
+    const int32_t omax = (int32_t)cs > (int32_t)x.x ? (int32_t)cs : (int32_t)x.x;
+    const int32_t overlap = omin - omax > 0 ? omin - omax : 0;
+    placed++;
+    remaining -= overlap;
+    // The segment goes into the structure at once (every lane does the same work in every step; at the consolidation
+    // only the bookkeeping is left): where it stands in the merged list, what it touches there and in the log
+    bool applied = false;
+    if (!broken && x.x != x.y) {
+      int lo = 0, hi = nU;                                           // merged-list elements with start <= x.start
+      while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (U[mid].x <= x.x) lo = mid + 1; else hi = mid; }
+      const uint2 pv = lo > 0 ? U[lo - 1] : make_uint2(0u, 0u), nv = lo < nU ? U[lo] : make_uint2(0u, 0u);
+      const uint2 nn = lo + 1 < nU ? U[lo + 1] : make_uint2(0xffffffffu, 0xffffffffu);
+      const bool tl = lo > 0 && (int32_t)x.x <= (int32_t)pv.y;
+      const bool tr = lo < nU && (int32_t)nv.x <= (int32_t)x.y;
+      const bool tr2 = tr && lo + 1 < nU && (int32_t)nn.x <= (int32_t)x.y;
+      int nt = 0, tj = 0;                                            // logged segments it touches
+      for (int j0 = 0; j0 < nE; j0 += 4) {
+        uint2 e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = j0 + r < nE ? U[cap - 1 - (j0 + r)] : make_uint2(0xffffffffu, 0xffffffffu);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (j0 + r < nE && touches(e[r], x)) { nt++; tj = j0 + r; }
+      }
+      if (!(tl && tr) && !tr2 && nt <= 1 && !(nt == 1 && (tl || tr))) {
+        if (tl || tr || nt == 1) {
+          const int at = tl ? lo - 1 : (tr ? lo : cap - 1 - tj);
+          const uint2 o = U[at];
+          const uint2 u = make_uint2(o.x < x.x ? o.x : x.x, (int32_t)o.y > (int32_t)x.y ? o.y : x.y);
+          U[at] = u;
+          cov += ws_overlap(u.x, u.y) - ws_overlap(o.x, o.y);
+          total += (u.y - u.x) - (o.y - o.x);
+        } else {
+          U[cap - 1 - nE] = x;
+          nE++;
+          cov += ws_overlap(x.x, x.y);
+          total += x.y - x.x;
+        }
+        applied = true;
+      }
+    }
+    if (!applied) { broken = true; U[nU + nP] = x; nP++; }
+    // ---- hs.sample() (:413-435)
+    {
+      uint32_t r = 1;
+      if (hist_total > 1) r = 1u + tail_range(rng, hist_total - 2u);
+      uint32_t len_u = rank_len[r] * bucket;
+      if (bucket > 1) len_u += tail_range(rng, bucket - 1u);
+      length = (int32_t)len_u;
+      if (rng.out_of_rows) break;
+    }
+    // ---- consolidate (:582-606)
+    if (remaining <= length) {
+      const int32_t r_new = ltotal - (int32_t)cov;
+      const bool same = true_remaining == r_new;
+      const int32_t tr_new = same ? true_remaining : r_new;
+      const int nuns_new = nuns + (same ? 1 : 0);
+      if (broken || !(tr_new > 0 && nuns_new < 20)) {
+        // hand on at this consolidation: its bookkeeping is k_sampler's (it redoes it from true_remaining / nuns as they
+        // were), the segments not applied are its "sampled" ones
+        handed = true;
+        break;
+      }
+      true_remaining = tr_new; nuns = nuns_new; remaining = r_new;
+    }
+  }
+  const int hand_nS = nP, hand_at = nU;
+  if (!handed) { P->state = 3; return; }               // rows ran out (or the step limit): the unit is redone from its seed
+  A.st2[sa] = make_int4(nU, (int)cov, (int)total, 1);
+  int32_t* R = reinterpret_cast<int32_t*>(P);
+  R[kPatchNExtra] = nE;
+  R[kPatchPlaced] = (int32_t)placed;
+  R[kPatchNdraws] = (int32_t)rng.used;
+  R[kPatchNuns] = nuns;
+  R[kTbTrueRemaining] = true_remaining;
+  R[kTbNSampled] = hand_nS;
+  R[kTbSampledAt] = hand_at;
+  R[kTbPending] = length;
+  R[kTbRemaining] = remaining;
+  R[kPatchState] = 2;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

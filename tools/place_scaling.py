@@ -18,6 +18,6 @@ for S in sizes:
         st = P.last_stats
         if best is None or st["ms_place"] < best["ms_place"]:
             best = st
-    print("%s S=%6d  rng %.3f place %.3f consolidate %.3f tail %.3f count %.3f (main kernel %.3f) total %.3f ms" % (
-        name, S, best["ms_rng"], best["ms_place"], best["ms_merge"], best["ms_ktail"], best["ms_count"], best["ms_count_main"],
+    print("%s S=%6d  rng %.3f place %.3f consolidate %.3f behind-it %.3f count %.3f (main kernel %.3f) total %.3f ms" % (
+        name, S, best["ms_rng"], best["ms_place"], best["ms_merge"], best["ms_tail"], best["ms_count"], best["ms_count_main"],
         best["ms_total"]))
