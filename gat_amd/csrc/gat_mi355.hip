@@ -881,7 +881,10 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
     HIPCHK(ctx, P->d_st2.alloc(ns));
-    if (!P->split_path && P->long_lists) HIPCHK(ctx, P->d_patch.alloc(ns));     // k_tail_big's hand-over records
+    if (!P->split_path && P->long_lists) {                                      // k_tail_big's hand-over records
+      HIPCHK(ctx, P->d_patch.alloc(ns));
+      HIPCHK(ctx, hipMemsetAsync(P->d_patch.p, 0, ns * sizeof(gat::TailPatch), ctx->stream));
+    }
     if (P->split_path) {
       HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
@@ -1313,7 +1316,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       HIPCHK(ctx, hipGetLastError());
       if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[3], ctx->stream));
-      skip_ptr = A.skip;
+      skip_ptr = A.skip != nullptr ? A.skip : (A.tb != nullptr ? A.tb : nullptr);     // (n_tail_units: finished by k_tail / carried on by k_tail_big)
       skip_stride = A.skip_stride;
     }
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

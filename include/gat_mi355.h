@@ -98,7 +98,8 @@ typedef struct {
   int32_t count_kernel;         /* GAT_COUNT_KERNEL_* the call used for the overlap counters      */
   float ms_ktail;               /*   of ms_tail: k_tail (the loop's tail, one stream per lane)    */
   float ms_finalize;            /*   of ms_tail: k_finalize (merged list + extras -> final list)   */
-  int64_t n_tail_units;         /* work units finished by k_tail / k_finalize (the rest: k_sampler) */
+  int64_t n_tail_units;         /* work units finished by k_tail, or (long lists) carried through their placement rounds
+                                   by k_tail_big before k_sampler resumed them                        */
   int64_t lists_from_records;   /* != 0: no final unit lists were written; their consumer (k_contig or k_count_seg) took
                                    the merged lists and k_tail's records                              */
 } gat_stats;

@@ -297,9 +297,53 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     if case == "rows_run_out":
         assert st["n_full_units"] > 0
+    if case in ("large_units", "large_units_one_workspace_segment"):
+        # long lists: k_merge_big, then k_tail_big carries the units through their placement rounds
+        assert st["n_tail_units"] > 0.5 * S * flat["n_units"], st["n_tail_units"]
+        os.environ["GAT_NO_TAIL_BIG"] = "1"
+        try:
+            other = P.sample_and_count(counters, 99, 3, 3 + S)
+            assert P.last_stats["n_tail_units"] == 0
+        finally:
+            os.environ.pop("GAT_NO_TAIL_BIG")
+        for k in range(len(counters)):
+            assert np.array_equal(other[k], want[k])
     if case.startswith("slab_overflow_retry"):
         assert st["n_retried"] > 0
     P.close()
+
+
+def _long_list_case(ctx, seed):
+    """long lists (k_merge_big + k_tail_big + k_sampler's resume) at coverages from sparse to crowded: new segments that
+    touch nothing, touch one neighbour (united in place), touch several (handed back), rounds that end in a trim or not"""
+    import collections
+    from gat_amd import problem
+    rs = np.random.RandomState(seed)
+    contigs = collections.OrderedDict(("L%d" % i, int(rs.randint(400000, 4000000))) for i in range(int(rs.randint(1, 3))))
+    n_segs = int(rs.choice([1300, 2500, 5000]))
+    size = sum(contigs.values())
+    mean_len = max(2, int(size * float(rs.choice([0.005, 0.03, 0.1, 0.3])) / n_segs))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    annos = [("t0", synthetic.random_segments(contigs, 300, 2000, int(rs.randint(1 << 30))))]
+    ws = synthetic.workspace_ungapped(contigs, pieces=int(rs.choice([1, 1, 4])), gap=500)
+    flat = problem.flatten_arrays(segs, annos, ws, None, bucket_size=int(rs.choice([0, 1])), nbuckets=100000)
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S = 5
+    want, wsamples = O.run_samples(flat, counters, seed, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, seed, 0, S)
+    handed = P.last_stats["n_tail_units"]
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), (c, n_segs, mean_len)
+    seg, off = P.sample(seed, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+    return handed
+
+
+@pytest.mark.parametrize("seed", list(range(900, 912)))
+def test_long_lists_vs_oracle(ctx, seed):
+    _long_list_case(ctx, seed)
 
 
 def test_contig_lists_longer_than_expected(ctx, monkeypatch):

@@ -1,5 +1,5 @@
 """one-off sweep of the fuzz generator of tests/test_hip_parity.py over many seeds (GPU vs oracle, bit-exact);
-usage: tools/fuzz_sweep.py first_seed n_seeds [edge|merged]"""
+usage: tools/fuzz_sweep.py first_seed n_seeds [edge|merged|long]"""
 import importlib.util, os, sys, time
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, root)
@@ -21,6 +21,8 @@ ctx = _lib.Context(0)
 first, n = int(sys.argv[1]), int(sys.argv[2])
 edge = len(sys.argv) > 3 and sys.argv[3] == "edge"
 merged = len(sys.argv) > 3 and sys.argv[3] == "merged"
+long_lists = len(sys.argv) > 3 and sys.argv[3] == "long"
+handed = 0
 bad = 0
 outcomes = {}
 t0 = time.time()
@@ -31,6 +33,8 @@ for seed in range(first, first + n):
             for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED"):
                 os.environ.pop(k, None)
             m.test_merged_track_index_vs_oracle(ctx, seed, MP())
+        elif long_lists:
+            handed += m._long_list_case(ctx, seed)
         elif edge:
             r = m._edge_case(ctx, seed)
             outcomes[r] = outcomes.get(r, 0) + 1
@@ -39,4 +43,4 @@ for seed in range(first, first + n):
     except Exception as e:             # noqa: BLE001
         bad += 1
         print("seed %d: %s: %s" % (seed, type(e).__name__, str(e)[:300]))
-print("%d seeds, %d failures, %.1f s %s" % (n, bad, time.time() - t0, outcomes if edge else ""))
+print("%d seeds, %d failures, %.1f s %s" % (n, bad, time.time() - t0, outcomes if edge else ("units through k_tail_big: %d" % handed if long_lists else "")))
