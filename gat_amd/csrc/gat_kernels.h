@@ -985,7 +985,17 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         cov_known = (uint32_t)pre2.y;
         total_known = (uint32_t)pre2.z;
         cov_valid = true;
-        for (int i = lane; i < nU; i += kWave) seg[i] = out[i];
+        if (HUGE) { for (int i = lane; i < nU; i += kWave) seg[i] = out[i]; }
+        else {
+          // (eight rounds of loads in flight: a list of thousands, one wave, nothing else hides the latency)
+          for (int base = 0; base < nU; base += 8 * kWave) {
+            uint2 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + r * kWave + lane; v[r] = i < nU ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const int i = base + r * kWave + lane; if (i < nU) seg[i] = v[r]; }
+          }
+        }
         if (R != nullptr) {
           // k_tail_big has run the placement rounds behind it: the merged list (unions applied in place), nE new segments
           // that touch nothing (logged from the region's end backwards), and nS it placed but did not consolidate
@@ -1252,7 +1262,8 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     // ---- result = unintersected.merge(0).filter(workspace) (:639-646); pending sampled are dropped
     nout = 0;
     if (status == 0) {
-      if (dirty) nU = wave_merge0(seg, nU, lane);     // otherwise already merged by the last consolidation
+      // (after a trim the list holds [0, 0) placeholders; nothing touches that did not before -- a trim only shortens --
+      //  and the filter below drops what overlaps nothing, placeholders included: no merge(0) pass of its own)
       uint32_t total = 0;
       if (nws <= kWsLoopMax) {
         for (int base = 0; base < nU; base += kWave) {
