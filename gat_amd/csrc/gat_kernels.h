@@ -696,7 +696,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
     for (int k = tid; k < nws; k += kMergeThreads) { const uint2 w = ws[k]; wsl[k] = w.x; wsl[kWsTreeMin + k] = w.y; }
 
   // ---- counting sort by position bucket: src = slab, dst = LDS
-  constexpr int kB = 4;
+  constexpr int kB = 8;                                           // rounds of loads in flight (one block per CU: nothing else hides them)
   uint32_t lo = 0xffffffffu, hi = 0u;
   for (int base = 0; base < n; base += kB * kMergeThreads) {
     uint32_t x[kB];
@@ -810,12 +810,17 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   // ---- coverage of the merged list inside the workspace, and its total length
   uint32_t cov = 0, tot = 0;
   if (nws <= kWsTreeMin) {
-    for (int i = tid; i < count; i += kMergeThreads) {
-      const uint2 v = out[i];
-      tot += v.y - v.x;
-      for (int k = 0; k < nws; ++k) {
-        const uint32_t l2 = v.x > wsl[k] ? v.x : wsl[k], h2 = v.y < wsl[kWsTreeMin + k] ? v.y : wsl[kWsTreeMin + k];
-        cov += h2 > l2 ? h2 - l2 : 0u;
+    for (int base = 0; base < count; base += kB * kMergeThreads) {
+      uint2 v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < count ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        tot += v[q].y - v[q].x;
+        for (int k = 0; k < nws; ++k) {
+          const uint32_t l2 = v[q].x > wsl[k] ? v[q].x : wsl[k], h2 = v[q].y < wsl[kWsTreeMin + k] ? v[q].y : wsl[kWsTreeMin + k];
+          cov += h2 > l2 ? h2 - l2 : 0u;
+        }
       }
     }
   } else if constexpr (TREE) {
