@@ -847,7 +847,12 @@ def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
     flat = problem.flatten_arrays(segs, annos, ws, iso)
     counters = ["nucleotide-overlap", "nucleotide-density"]
     S = 6
-    want, _ = O.run_samples(flat, counters, 400 + seed, 1, 0, S)
+    try:
+        want, _ = O.run_samples(flat, counters, 400 + seed, 1, 0, S)
+    except ValueError:                                   # a segment longer than nbuckets * bucket_size
+        with pytest.raises(ValueError):
+            _lib.Problem(ctx, flat)
+        return
     P = _lib.Problem(ctx, flat)
     got = P.sample_and_count(counters, 400 + seed, 0, S)
     assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
