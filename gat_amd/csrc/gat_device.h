@@ -501,6 +501,53 @@ __device__ __forceinline__ bool wave_sort_bucket_global(uint2* dst, const uint2*
   return true;
 }
 
+// The same counting sort with the list in registers (E rounds of 64, all loaded in ONE round trip by the caller) instead
+// of three passes over the slab, each a round trip or two of its own: for a kernel lean enough to hold 2 E registers more.
+template <int E>
+__device__ __forceinline__ bool wave_sort_bucket_regs(uint2* dst, const uint2 (&v)[E], int n, uint32_t* scratch, int nb, int lane) {
+  uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (q * kWave + lane < n) { lo = v[q].x < lo ? v[q].x : lo; hi = v[q].x > hi ? v[q].x : hi; }
+  lo = wave_min_u32(lo); hi = wave_max_u32(hi);
+  const uint32_t span = hi - lo;
+  if (span == 0) return false;
+  const bool direct = span < (uint32_t)nb;
+  const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)nb << 32) / ((uint64_t)span + 1u));
+  wave_sync();
+  for (int i = lane; i <= nb; i += kWave) scratch[i] = 0;
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (q * kWave + lane < n) { const uint32_t d = v[q].x - lo; atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u); }
+  wave_sync();
+  const int per = nb / kWave;
+  uint32_t sum = 0, maxc = 0;
+  for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
+  uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
+  if (wave_max_u32(maxc) > 48u) return false;
+  for (int q = 0; q < per; ++q) { const uint32_t c = scratch[lane * per + q]; scratch[lane * per + q] = run; run += c; }
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (q * kWave + lane < n) {
+      const uint32_t d = v[q].x - lo;
+      dst[atomicAdd(&scratch[direct ? d : __umulhi(d, scale)], 1u)] = v[q];
+    }
+  wave_sync();
+  for (int b = lane; b < nb; b += kWave) {                          // scratch[b] is now the END of bucket b
+    const int e = (int)scratch[b], s0 = b ? (int)scratch[b - 1] : 0;
+    for (int i = s0 + 1; i < e; ++i) {
+      const uint2 x = dst[i];
+      int j = i - 1;
+      while (j >= s0 && dst[j].x > x.x) { dst[j + 1] = dst[j]; --j; }
+      dst[j + 1] = x;
+    }
+  }
+  wave_sync();
+  return true;
+}
+
 // bucket sort when possible (scratch available, list short enough), else the sorting network
 template <int MAXE = 8>
 __device__ __forceinline__ void wave_sort_fast(uint2* seg, int n, uint32_t* scratch, int lane) {

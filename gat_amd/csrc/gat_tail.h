@@ -82,9 +82,20 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
   constexpr int kWsRegMax = 64, kWsLoopMax = 32;
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
-  if (n > 512) {
+  if (n > 1024) {
     if (!wave_sort_bucket_global(seg, out, n, scratch, 512, lane)) {
       for (int i = lane; i < n; i += kWave) seg[i] = out[i];
+      wave_sort_auto(seg, n, lane);
+    }
+  } else if (n > 512) {
+    // 513..1 024 segments: the counting sort with the list in registers (one round trip instead of the six of the three
+    // passes over the slab; this kernel has the registers: the old k_sampler did not)
+    uint2 v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const int i = r * kWave + lane; v[r] = i < n ? out[i] : make_uint2(0u, 0u); }
+    if (!wave_sort_bucket_regs<16>(seg, v, n, scratch, 512, lane)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = v[r]; }
       wave_sort_auto(seg, n, lane);
     }
   } else {
