@@ -1271,17 +1271,24 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       //  and the filter below drops what overlaps nothing, placeholders included: no merge(0) pass of its own)
       uint32_t total = 0;
       if (nws <= kWsLoopMax) {
-        for (int base = 0; base < nU; base += kWave) {
-          const int i = base + lane;
-          bool keep = false;
-          uint2 v = make_uint2(0u, 0u);
-          if (i < nU) {
-            v = seg[i];
-            keep = ws_overlap_regs(W, v.x, v.y) > 0;
+        // (four rounds at a time: their LDS reads and workspace tests do not depend on one another, only the output
+        //  positions do -- a long list is worked on by one wave with little else on its SIMD to hide a round's latency)
+        for (int base = 0; base < nU; base += 4 * kWave) {
+          uint2 v[4];
+          bool keep[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = base + q * kWave + lane;
+            v[q] = i < nU ? seg[i] : make_uint2(0u, 0u);
           }
-          const uint64_t b = __ballot(keep);
-          if (keep) { fin[nout + __popcll(b & lanemask_lt(lane))] = v; total += v.y - v.x; }
-          nout += __popcll(b);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) keep[q] = base + q * kWave + lane < nU && ws_overlap_regs(W, v[q].x, v[q].y) > 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint64_t b = __ballot(keep[q]);
+            if (keep[q]) { fin[nout + __popcll(b & lanemask_lt(lane))] = v[q]; total += v[q].y - v[q].x; }
+            nout += __popcll(b);
+          }
         }
       } else if constexpr (TREE) {
         constexpr int R = 2;
