@@ -1807,7 +1807,6 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
-      uint2 z[kR];
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
@@ -1815,15 +1814,25 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }
+      // entries are fetched two at a time (16 bytes, one request to the L2 instead of two: the scan of a segment against
+      // 1 000 tracks passes eight entries, and the rate of those requests is what bounds the kernel); a contig's entries
+      // start at an even index and end with two sentinels
+      const uint4* __restrict__ Z2 = reinterpret_cast<const uint4*>(Z);
+      uint4 zz[kR];
 #pragma unroll
-      for (int r = 0; r < kR; ++r) z[r] = Z[k[r]];
+      for (int r = 0; r < kR; ++r) zz[r] = Z2[k[r] >> 1];
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
-        while (z[r].x < x[r].y) {                                    // the contig's sentinel start 0xffffffff ends the scan
-          const uint32_t ze = z[r].x + (z[r].y & 0xffffu);
-          const uint32_t lo = z[r].x > x[r].x ? z[r].x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
-          if (hi > lo) atomicAdd(&acc[z[r].y >> 16], hi - lo);
-          z[r] = Z[++k[r]];
+        uint32_t kk = k[r];
+        uint4 q = zz[r];
+        while (true) {
+          const uint2 e = (kk & 1u) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y);
+          if (!(e.x < x[r].y)) break;                                // the contig's sentinel start 0xffffffff ends the scan
+          const uint32_t ze = e.x + (e.y & 0xffffu);
+          const uint32_t lo = e.x > x[r].x ? e.x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
+          if (hi > lo) atomicAdd(&acc[e.y >> 16], hi - lo);
+          ++kk;
+          if (!(kk & 1u)) q = Z2[kk >> 1];
         }
       }
     }

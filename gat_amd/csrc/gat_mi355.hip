@@ -196,6 +196,8 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     }
     for (size_t i = 0; i < ne; ++i) hz.push_back(make_uint2(e[i].s, ((e[i].t & 0xffffu) << 16) | ((e[i].e - e[i].s) & 0xffffu)));
     hz.push_back(make_uint2(0xffffffffu, 0u));                      // ends every scan
+    hz.push_back(make_uint2(0xffffffffu, 0u));                      // (entries are read in pairs)
+    if (hz.size() & 1) hz.push_back(make_uint2(0xffffffffu, 0u));   // ... and the next contig starts at an even index
     hz_off[(size_t)c + 1] = (int64_t)hz.size();
     hf_off[(size_t)c + 1] = (int64_t)hf.size();
   }
