@@ -654,7 +654,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) void k_pla
 // clean merged list (st2) and goes straight to the tail.  Lists the counting sort declines (clustered keys) are left
 // to k_sampler's own sort.
 constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 words, padded to 16 bytes)
-constexpr int kMergeThreads = 256;
+#ifndef GAT_MERGE_THREADS
+#define GAT_MERGE_THREADS 512
+#endif
+constexpr int kMergeThreads = GAT_MERGE_THREADS;
 constexpr int kMergeWaves = kMergeThreads / kWave;
 
 __device__ __forceinline__ uint32_t block_reduce_u32(uint32_t v, uint32_t* red, int tid, bool want_max, bool want_min) {
