@@ -982,6 +982,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       const int32_t* __restrict__ R = nullptr;
       if (BIG && !HUGE && A.tb != nullptr && pre2.w == 1) {
         R = A.tb + ((int64_t)sidx * A.n_units + a) * A.skip_stride;
+        if (R[kPatchState] == 1) return;                       // k_resume_big has finished the unit
         if (R[kPatchState] == 3) continue;                     // k_tail_big ran out of rows: the unit is redone from its seed
         if (R[kPatchState] != 2) R = nullptr;
       }

@@ -1208,6 +1208,11 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
                                ctx->stream, TB);
             HIPCHK(ctx, hipGetLastError());
+            if (!getenv("GAT_NO_RESUME_BIG")) {
+              // ... and the rest of the unit -- log inserted, trim, final filter -- with the list where it is
+              hipLaunchKernelGGL(gat::k_resume_big, dim3((unsigned)nb, gby, (n_long + gby - 1) / gby), dim3(64), 0, ctx->stream, TB);
+              HIPCHK(ctx, hipGetLastError());
+            }
             A.tb = reinterpret_cast<const int32_t*>(P->d_patch.p);
             A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
           }

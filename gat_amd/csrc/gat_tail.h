@@ -609,6 +609,216 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_resume_big: what is left of a long list's unit behind k_tail_big -- the log inserted, the consolidation's bookkeeping,
+// the overshoot trim(s), the final filter -- one wave per unit with the list where it is, in the slab.  k_sampler does the
+// same with the list in LDS, which for lists of thousands means one or two waves per CU and every 64-element round of
+// every pass an exposed latency (9.5 of 44 ms on the config-4 shape).  Here every pass runs eight rounds of loads at a
+// time and the occupancy is what registers allow.  Whatever does not fit (segments k_tail_big could not apply, a log
+// beyond 128 entries, workspaces beyond the register loop, rows running out) is left to k_sampler as before (record state
+// 2), or handed to it for a redo from the seed (state 3).  A finished unit is marked state 1.
+__global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
+  __shared__ int32_t l_cs[2 * kWave];
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x;
+  const int sidx = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  if (a >= A.n_long) return;
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  int32_t* R = reinterpret_cast<int32_t*>(T.patch + sa);
+  if (R[kPatchState] != 2) return;
+  const int nE = R[kPatchNExtra];
+  const int nws = Up->n_ws;
+  constexpr int kWsLoopMax = 32;
+  if (R[kTbNSampled] > 0 || nE > 2 * kWave || nws > kWsLoopMax) return;
+  const int4 c2 = A.st2[sa];
+  int nU = c2.x;
+  uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
+  const int32_t ltotal = Up->ltotal;
+  int32_t true_remaining = R[kTbTrueRemaining];
+  int nuns = R[kPatchNuns];
+  {
+    // the bookkeeping of the consolidation k_tail_big stopped at (:601-605)
+    const int32_t remaining = ltotal - (int32_t)cov;
+    if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+  }
+  if (true_remaining > 0 && nuns < 20) return;          // (k_tail_big goes on in that case: cannot be; k_sampler's anyway)
+  const int u = Up->pad;
+  const int cap = Up->slab_cap;
+  const uint32_t hist_total = Up->hist_total, bucket = Up->bucket;
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  const WsRegs W = ws_load(A.ws + Up->ws_off, A.ws_cdf + Up->ws_off, nws, lane);
+  uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
+
+  // ---- the log (nE <= 128 segments that touch nothing, unsorted) into the merged list, in place from the back
+  if (nE > 0) {
+    uint2 e[2];
+    int cu[2], rk[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = h * kWave + lane;
+      e[h] = j < nE ? out[cap - 1 - j] : make_uint2(0xffffffffu, 0xffffffffu);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                                   // list elements with start <= the new segment's
+      int lo = 0, hi = (h * kWave + lane < nE) ? nU : 0;
+      while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (out[mid].x <= e[h].x) lo = mid + 1; else hi = mid; }
+      cu[h] = lo;
+      rk[h] = 0;
+    }
+    for (int j = 0; j < kWave; ++j) {                               // rank among the new ones: by start, then by log index
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)e[g].x, j);
+        const int jj = g * kWave + j;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int me = h * kWave + lane;
+          rk[h] += (jj < nE && (sj < e[h].x || (sj == e[h].x && jj < me))) ? 1 : 0;
+        }
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) l_cs[rk[h]] = cu[h];
+    wave_sync();
+    const int cs0 = lane < nE ? l_cs[lane] : 0x7fffffff, cs1 = kWave + lane < nE ? l_cs[kWave + lane] : 0x7fffffff;
+    constexpr int kB = 8;
+    for (int top = ((nU - 1) >> 6) << 6; top >= 0; top -= kB * kWave) {
+      uint2 v[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = top - q * kWave + lane; v[q] = (i >= 0 && i < nU && top - q * kWave >= 0) ? out[i] : make_uint2(0u, 0u); }
+      int sh[kB];
+      bool nothing_below = false;
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const int base = top - q * kWave;
+        const int i = base + lane;
+        const int below = __popcll(__ballot(cs0 < base + 1)) + __popcll(__ballot(cs1 < base + 1));
+        const int upto = __popcll(__ballot(cs0 <= base + kWave - 1)) + __popcll(__ballot(cs1 <= base + kWave - 1));
+        int s2 = below;
+        for (int j = below; j < upto; ++j) s2 += l_cs[j] <= i ? 1 : 0;
+        sh[q] = (base >= 0 && i < nU) ? s2 : 0;
+        if (base >= 0 && upto == 0) nothing_below = true;           // nothing goes in at or before this block
+      }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = top - q * kWave + lane; if (sh[q] > 0) out[i + sh[q]] = v[q]; }
+      if (nothing_below) break;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) out[cu[h] + rk[h]] = e[h];
+    nU += nE;
+    wave_sync();                                                    // (the list is read again below: stores done)
+  }
+
+  WaveRng rng;
+  rng.mt = nullptr;
+  rng.use_pre = true; rng.exhausted = false; rng.ndraws = (uint32_t)R[kPatchNdraws]; rng.pos = 0; rng.rbuf = 0;
+  rng.pre_rows = (uint32_t)A.rng_rows[a];
+  rng.pre_j = rng.ndraws;
+  rng.pre_base = rng.pre_j - (uint32_t)kWave;
+  rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
+  bool redo = false, trim_assert = false;
+  while (true_remaining != 0 && nuns < 20) {
+    if (true_remaining > 0) { redo = true; break; }                 // (a trim leaves remaining <= 0: cannot be)
+    // ---- overshoot: trim (:608-626), as in k_sampler, the list in the slab
+    const uint32_t p = rng_range(rng, total - 1u, lane);
+    int k = 0;
+    {
+      uint32_t run = 0;
+      bool found = false;
+      constexpr int kB = 8;
+      for (int base0 = 0; base0 < nU && !found; base0 += kB * kWave) {
+        uint2 v[kB];
+#pragma unroll
+        for (int q = 0; q < kB; ++q) { const int i = base0 + q * kWave + lane; v[q] = i < nU ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+        for (int q = 0; q < kB; ++q) {
+          if (found) continue;
+          const int i = base0 + q * kWave + lane;
+          const uint32_t incl = run + wave_incl_sum_u32(v[q].y - v[q].x, lane);
+          const bool ge = i < nU && (int32_t)(incl - 1u - p) >= 0;  // cdf[i] = incl - 1; leftmost i with (int)(cdf[i] - p) >= 0
+          const uint64_t b = __ballot(ge);
+          if (b != 0) { k = base0 + q * kWave + (int)__builtin_ctzll(b); found = true; }
+          run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+        }
+      }
+    }
+    const uint2 chosen = out[k];
+    (void)rng_range(rng, chosen.y - 1u - chosen.x, lane);           // position inside the segment: only its index matters
+    const uint32_t forward = rng_range(rng, 1u, lane);              // numpy.random.randint(0, 2)
+    int32_t s = -true_remaining;
+    if (rng.exhausted) { redo = true; break; }
+    if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { trim_assert = true; break; }
+    uint32_t removed = 0;                                           // workspace bases taken away by the trim (lane 0)
+    if (lane == 0) {
+      int idx = k;
+      while (s > 0) {
+        const uint2 v = out[idx];
+        const int32_t l = (int32_t)v.y - (int32_t)v.x;
+        uint32_t ra, rb;
+        if (l < s) { out[idx] = make_uint2(0u, 0u); s -= l; ra = v.x; rb = v.y; }
+        else {
+          if (forward) { out[idx] = make_uint2(v.x + (uint32_t)s, v.y); ra = v.x; rb = v.x + (uint32_t)s; }
+          else { out[idx] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
+          s = 0;
+        }
+        if (rb > ra) removed += ws_overlap_regs(W, ra, rb);
+        if (forward) { idx++; if (idx == nU) idx = 0; }
+        else { idx--; if (idx < 0) idx = nU - 1; }
+      }
+    }
+    cov -= (uint32_t)__builtin_amdgcn_readfirstlane((int)removed);
+    total -= (uint32_t)(-true_remaining);
+    wave_sync();
+    true_remaining = 1;
+    // ---- hs.sample() (:413-435) and the consolidation with nothing new (:582-606)
+    {
+      uint32_t r = 1;
+      if (hist_total > 1) r = 1u + rng_range(rng, hist_total - 2u, lane);
+      if (bucket > 1) (void)rng_range(rng, bucket - 1u, lane);
+      (void)rank_len; (void)r;                                      // (any length >= 1 >= remaining (<= 0): only the draws count)
+      if (rng.exhausted) { redo = true; break; }
+    }
+    const int32_t remaining = ltotal - (int32_t)cov;
+    if (true_remaining == remaining) nuns++; else true_remaining = remaining;
+  }
+  if (redo) { if (lane == 0) R[kPatchState] = 3; return; }
+  const int64_t so = (int64_t)sidx * A.n_units + u;
+  if (trim_assert) {
+    if (lane == 0) { A.unit_n[so] = 0; atomicOr(A.flags, kStatusTrimAssert); R[kPatchState] = 1; }
+    return;
+  }
+  // ---- result = unintersected.merge(0).filter(workspace) (:639-646): placeholders and segments outside the workspace
+  // dropped, compacted in place (forward: a round's output never passes its input)
+  int nout = 0;
+  uint32_t tsum = 0;
+  {
+    constexpr int kB = 8;
+    for (int base0 = 0; base0 < nU; base0 += kB * kWave) {
+      uint2 v[kB];
+      bool keep[kB];
+#pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = base0 + q * kWave + lane; v[q] = i < nU ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+      for (int q = 0; q < kB; ++q) keep[q] = base0 + q * kWave + lane < nU && ws_overlap_regs(W, v[q].x, v[q].y) > 0;
+#pragma unroll
+      for (int q = 0; q < kB; ++q) {
+        const uint64_t b = __ballot(keep[q]);
+        if (keep[q]) { out[nout + __popcll(b & lanemask_lt(lane))] = v[q]; tsum += v[q].y - v[q].x; }
+        nout += __popcll(b);
+      }
+    }
+  }
+  tsum = wave_total_u32(tsum);
+  if (lane == 0) {
+    A.unit_n[so] = tsum > 0 ? nout : 0;
+    if (!(tsum > 0)) atomicOr(A.flags, kStatusAssert);
+    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4((uint32_t)R[kPatchPlaced], rng.ndraws, (uint32_t)nuns, 0u);
+    R[kPatchState] = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // k_finalize: result = unintersected.merge(0).filter(workspace) (gat/Engine.pyx:639-646) from the merged list and
 // k_tail's record, written OUT OF PLACE into the second slab (the extras shift what is behind them: in place every
 // element would have to be held until everything in front of it is written).  Units k_tail left alone are queued for

@@ -61,8 +61,9 @@ def test_config_workloads_vs_oracle(ctx, name):
         assert np.array_equal(seg, wsamples[0]), name
         assert (want[0] != 0).any()              # the comparison is not about zeros
         # the kernels these shapes normally do not take: k_place with compiler-managed loads (instead of k_place_pipe), and
-        # on the long lists of the config-4 shape k_sampler running the placement rounds itself (instead of k_tail_big)
-        for knob in ("GAT_PLACE_NO_PIPE", "GAT_NO_TAIL_BIG"):
+        # on the long lists of the config-4 shape k_sampler running the placement rounds itself (instead of k_tail_big) / finishing
+        # the units itself (instead of k_resume_big)
+        for knob in ("GAT_PLACE_NO_PIPE", "GAT_NO_TAIL_BIG", "GAT_NO_RESUME_BIG"):
             os.environ[knob] = "1"
             try:
                 again = P.sample_and_count(counters, seed, begin, begin + S)

@@ -308,6 +308,15 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
             os.environ.pop("GAT_NO_TAIL_BIG")
         for k in range(len(counters)):
             assert np.array_equal(other[k], want[k])
+        os.environ["GAT_NO_RESUME_BIG"] = "1"            # ... and k_sampler, not k_resume_big, finishing them
+        try:
+            other = P.sample_and_count(counters, 99, 3, 3 + S)
+            seg2, off2 = P.sample(99, 3, 3 + S)
+        finally:
+            os.environ.pop("GAT_NO_RESUME_BIG")
+        for k in range(len(counters)):
+            assert np.array_equal(other[k], want[k])
+        assert np.array_equal(off2, wsamples[1]) and np.array_equal(seg2, wsamples[0])
     if case.startswith("slab_overflow_retry"):
         assert st["n_retried"] > 0
     P.close()
