@@ -700,17 +700,16 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
 
   // ---- counting sort by position bucket: src = slab, dst = LDS
   constexpr int kB = 8;                                           // rounds of loads in flight (one block per CU: nothing else hides them)
-  uint32_t lo = 0xffffffffu, hi = 0u;
-  for (int base = 0; base < n; base += kB * kMergeThreads) {
-    uint32_t x[kB];
-#pragma unroll
-    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; x[q] = i < n ? out[i].x : 0u; }
-#pragma unroll
-    for (int q = 0; q < kB; ++q)
-      if (base + q * kMergeThreads + tid < n) { lo = x[q] < lo ? x[q] : lo; hi = x[q] > hi ? x[q] : hi; }
+  // the range of the starts from the unit's workspace instead of a pass over the list: a placed segment starts at
+  // max(0, q) with q >= workspace start - length + 1 and q < workspace end (gat/Engine.pyx:318-331); the buckets only
+  // have to be monotone in the start
+  uint32_t lo, hi;
+  {
+    const uint32_t max_len = A.rank_len[Up->rank_off + Up->hist_total] * Up->bucket + Up->bucket;
+    const uint32_t w0 = ws[0].x, w1 = ws[nws - 1].y;
+    lo = w0 > max_len ? w0 - max_len : 0u;
+    hi = w1;
   }
-  lo = block_reduce_u32(lo, red, tid, false, true);
-  hi = block_reduce_u32(hi, red, tid, true, false);
   const uint32_t span = hi - lo;
   if (span == 0) return;
   int nb = 1024;
