@@ -54,7 +54,7 @@ def _device_stats_wanted(n_values):
 
 
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
-                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None):
+                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None, mt_state=None):
     """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
 
     segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
@@ -64,6 +64,8 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
     stat_vals: {counter name: {annotation: value}} -- the values whose p-value will be asked for (observed, or
     observed / reference fold); given them, large matrices get their statistics on the device (gat_null_stats) and the
     result carries `.stats[counter index][annotation]` for AnnotatorResult.
+    mt_state: the reference's own stream (run(reference_stream=True)): the samples are drawn from this ONE MT19937
+    state (_lib.mt19937_seed), which is advanced in place; one GPU, no sharding.
     Returns ([ {annotation: array of num_samples} per counter ] like the reference, number of work
     units), or (None, 0) for an empty workspace.  If torch.distributed is initialised, samples are
     sharded over the ranks and the count matrix is all-gathered (RCCL)."""
@@ -109,7 +111,14 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
 
     try:
         begin, end = distributed.shard_range(num_samples, rank, world)
-        if world > 1 and backend == "nccl":
+        if mt_state is not None:
+            if world > 1:
+                raise NotImplementedError("reference_stream: one stream is one GPU (the samples depend on each other)")
+            if samples_outfile is not None:
+                raise NotImplementedError("reference_stream: the sampled lists are not kept (counts only)")
+            local = P.sample_and_count_serial(names, mt_state, num_samples)
+            begin, end = 0, num_samples
+        elif world > 1 and backend == "nccl":
             # the shard's matrix stays on the device: one RCCL all-gather of device memory, one read-back
             import torch
             per = distributed.padded_shard(num_samples, world)
@@ -171,7 +180,9 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
 
     kwargs: num_samples, pseudo_count, reference, output_counts_pattern, output_samples_pattern
     (as in the reference) and random_seed (base of the per-unit streams; default: drawn from numpy's
-    global RandomState, so numpy.random.seed() makes a run reproducible).  num_threads is accepted
+    global RandomState, so numpy.random.seed() makes a run reproducible).  reference_stream=True: random_seed seeds ONE
+    stream for the whole run, as the reference's gat-run.py --random-seed does (same numbers as an unpatched reference;
+    one wave's speed).  num_threads is accepted
     and ignored (the GPU replaces the process pool)."""
     num_samples = kwargs.get("num_samples", 10000)
     pseudo_count = kwargs.get("pseudo_count", 1.0)
@@ -179,6 +190,7 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     output_counts_pattern = kwargs.get("output_counts_pattern", None)
     output_samples_pattern = kwargs.get("output_samples_pattern", None)
     seed = kwargs.get("random_seed", None)
+    reference_stream = bool(kwargs.get("reference_stream", False))
     rank, world, _ = _dist_state()
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 32))
@@ -191,6 +203,12 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     conditional = getattr(workspace_generator, "is_conditional", False)
     if not isinstance(sampler, (SamplerAnnotator, SamplerSegments)):
         raise NotImplementedError("only SamplerAnnotator and SamplerSegments run on the GPU path")
+    mt_state = None
+    if reference_stream:
+        # the reference's own stream: numpy.random.seed(seed) once (scripts/gat-run.py:267-271), every work unit of every
+        # segment track drawing from it in order -- an unpatched reference's table, number for number, at one stream's speed
+        from . import _lib
+        mt_state = _lib.mt19937_seed(seed)
 
     observed_counts = [computeCounts(counter=c, aggregator=sum, segments=segments, annotations=annotations,
                                      workspace=workspace, workspace_generator=workspace_generator) for c in counters]
@@ -209,7 +227,7 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                 for annotation in annotations.tracks:
                     ra, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples,
                                                 seed, samples_outfile=outf, workspace_generator=workspace_generator,
-                                                only_tracks=[annotation])
+                                                only_tracks=[annotation], mt_state=mt_state)
                     for k in range(len(counters)):
                         r[k][annotation] = ra[k][annotation]
                     seed = (seed + num_samples * n_units) & 0xFFFFFFFF
@@ -225,7 +243,8 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                         v = v / f if f > 0 else v
                     stat_vals[c.name][annotation] = v
             r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
-                                       samples_outfile=outf, workspace_generator=workspace_generator, stat_vals=stat_vals)
+                                       samples_outfile=outf, workspace_generator=workspace_generator, stat_vals=stat_vals,
+                                       mt_state=mt_state)
             seed = (seed + num_samples * n_units) & 0xFFFFFFFF    # next track: disjoint unit streams
         if outf:
             outf.close()
@@ -350,6 +369,10 @@ def buildParser(usage=None):
                       "this value, so its sampled columns are statistically equal to, not identical with, the ones printed here "
                       "(observed counts, sizes and densities are identical); with the per-unit seeding patched into the "
                       "reference the tables are byte-identical (tests/golden/make_goldens.py)")
+    g.add_option("--reference-stream", dest="reference_stream", action="store_true",
+                 help="(not in the reference) draw every sample from ONE stream seeded with --random-seed, in the reference's "
+                      "order: the table of an unpatched reference run with the same seed, number for number.  One stream is one "
+                      "chain of dependent draws: a single GPU wave runs it (about 60 us per work unit of 400 segments)")
     g.add_option("--truncate-segments-to-workspace", dest="truncate_segments_to_workspace", action="store_true")
     g.add_option("--truncate-workspace-to-annotations", dest="truncate_workspace_to_annotations", action="store_true")
     g.add_option("--restrict-workspace", dest="restrict_workspace", action="store_true")
@@ -372,7 +395,7 @@ def buildParser(usage=None):
                         output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",
                         overlapping_annotations=False, pseudo_count=1.0, pvalue_method="empirical", qvalue_method="BH",
                         qvalue_lambda=None, qvalue_pi0_method="smoother",
-                        random_seed=None, restrict_workspace=False, sampler="annotator", segment_files=[],
+                        random_seed=None, reference_stream=False, restrict_workspace=False, sampler="annotator", segment_files=[],
                         truncate_segments_to_workspace=False, truncate_workspace_to_annotations=False,
                         conditional="unconditional", conditional_extension=None, conditional_expansion=None,
                         workspace_files=[], device=0, loglevel=1, stdout=None, stdlog=None)
@@ -413,4 +436,5 @@ def fromSegments(options, args=None):
     return run(segments, annotations, workspace, sampler, counters, workspace_generator=workspace_generator,
                num_samples=options.num_samples, output_counts_pattern=options.output_counts_pattern,
                output_samples_pattern=options.output_samples_pattern, pseudo_count=options.pseudo_count,
-               num_threads=options.num_threads, random_seed=options.random_seed)
+               num_threads=options.num_threads, random_seed=options.random_seed,
+               reference_stream=getattr(options, "reference_stream", False))

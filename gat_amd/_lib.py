@@ -30,7 +30,17 @@ SYMBOLS = [
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
+    "gat_sample_and_count_serial", "gat_mt19937_seed",
 ]
+
+MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
+
+
+def mt19937_seed(seed):
+    """the state numpy.random.seed(seed) leaves for an integer seed (624 words + position 624)"""
+    st = np.zeros(MT_STATE_WORDS, dtype=np.uint32)
+    lib().gat_mt19937_seed(int(seed) & 0xFFFFFFFF, _p(st))
+    return st
 
 
 COUNT_KERNELS = {0: "none", 1: "k_count_seg", 2: "k_count_swap", 3: "k_count_merged"}
@@ -125,6 +135,10 @@ def lib():
     L.gat_problem_destroy.argtypes = [vp]
     L.gat_sample_and_count.restype = C.c_int
     L.gat_sample_and_count.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp, C.POINTER(Stats)]
+    L.gat_sample_and_count_serial.restype = C.c_int
+    L.gat_sample_and_count_serial.argtypes = [vp, vp, vp, C.c_int, vp, i64, vp, C.POINTER(Stats)]
+    L.gat_mt19937_seed.restype = None
+    L.gat_mt19937_seed.argtypes = [u32, vp]
     L.gat_sample.restype = C.c_int
     L.gat_sample.argtypes = [vp, vp, u32, i64, i64, vp, i64, vp, C.POINTER(Stats)]
     L.gat_sample_units.restype = C.c_int
@@ -328,6 +342,27 @@ class Problem(object):
                 self.ctx.d2h(host, dev)
         finally:
             self.ctx.free(dev)
+        return [host[k].view(np.float64).copy() if c == "nucleotide-density" else host[k].copy()
+                for k, c in enumerate(counters)]
+
+    def sample_and_count_serial(self, counters, mt_state, n_samples):
+        """samples 0 .. n_samples-1 drawn from ONE MT19937 stream in the reference's order (an unpatched gat-run.py
+        --random-seed): mt_state (mt19937_seed(seed), or what an earlier call left) is advanced in place.  Returns the
+        count matrices like sample_and_count."""
+        assert mt_state.dtype == np.uint32 and mt_state.size == MT_STATE_WORDS and mt_state.flags["C_CONTIGUOUS"]
+        ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
+        ns = int(n_samples)
+        dev = self.ctx.alloc(max(1, len(counters) * self.n_tracks * ns) * 8)
+        st = Stats()
+        try:
+            _check(lib().gat_sample_and_count_serial(self.ctx._h, self._h, _p(ids), len(ids), _p(mt_state), ns,
+                                                     C.c_void_p(dev), C.byref(st)), self.ctx._h)
+            host = np.zeros((len(counters), self.n_tracks, ns), dtype=np.int64)
+            if host.size:
+                self.ctx.d2h(host, dev)
+        finally:
+            self.ctx.free(dev)
+        self.last_stats = st.asdict()
         return [host[k].view(np.float64).copy() if c == "nucleotide-density" else host[k].copy()
                 for k, c in enumerate(counters)]
 

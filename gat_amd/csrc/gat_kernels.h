@@ -84,6 +84,9 @@ struct SamplerArgs {
   const uint32_t* todo_count; // split path: k_sampler works off the queue of units k_tail left alone (k_finalize fills it)
   const uint32_t* todo;       //   entries sidx * n_active + launch position
   const int32_t* tb;          // long lists: k_tail_big's hand-over records (TailPatch words, skip_stride apart), or nullptr
+  // the reference's own stream (k_serial): ONE MT19937 state for the whole run, 624 words + the position
+  uint32_t* serial_state;
+  const int32_t* unit_pos;    // unit id -> launch position, -1: inactive (k_serial walks the units in the reference's order)
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
 };
 
@@ -868,7 +871,8 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
 // WPE: waves per SIMD the register budget is set for: 4 (LDS allows no more for lists of hundreds of segments), or 5 for
 // problems whose lists are so short that registers, not LDS, decide how many waves a CU holds.
 template <int KIND, bool BIG, bool TREE, bool HUGE>
-__device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sidx, const int a, uint32_t* lds, const int lane) {
+__device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sidx, const int a, uint32_t* lds, const int lane,
+                                             WaveRng* serial = nullptr) {
   uint32_t* mt = lds;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int u = Up->pad;
@@ -932,7 +936,8 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     } else {
       WaveRng rng;
       rng.mt = mt;
-      rng_seed(rng, seed, lane);
+      if (serial != nullptr) { rng = *serial; rng.ndraws = 0; }     // (k_serial: the run's one stream goes on)
+      else rng_seed(rng, seed, lane);
       rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
       full_units = 1;
       const int target = Up->n_target;
@@ -955,6 +960,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       }
       placed = (uint32_t)nout;
       ndraws = rng.ndraws;
+      if (serial != nullptr) *serial = rng;
     }
     if (lane == 0) {
       A.unit_n[so] = status ? 0 : nout;
@@ -1044,7 +1050,8 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       wave_sync();
       GAT_PHASE(0)                                   // prologue: unit record, workspace, hand-off record, list into LDS
     } else {
-      rng_seed(rng, seed, lane);
+      if (serial != nullptr) { rng = *serial; rng.mt = mt; rng.ndraws = 0; }      // (k_serial: the run's one stream goes on)
+      else rng_seed(rng, seed, lane);
       rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
       full_units = 1;
     }
@@ -1169,7 +1176,32 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         if (true_remaining == remaining) nuns++; else true_remaining = remaining;
         // the reference still draws a position here (:628) before its loop test fails; the draws and
         // the segment are discarded and the unit's stream ends, so nothing observable depends on them
-        if (!(true_remaining != 0 && nuns < 20)) break;
+        if (!(true_remaining != 0 && nuns < 20)) {
+          if (serial != nullptr) {
+            // (the run's one stream goes on behind this unit: the draws of that discarded position are consumed -- on both
+            //  ways out, nothing left to place or twenty rounds without progress; a negative true_remaining cannot stand
+            //  here: it only equals `remaining` right behind a trim, which sets it to 1)
+            const uint32_t p_ = rng_range(rng, ws_total - 1u, lane);
+            int k_;
+            uint2 ch_;
+            int32_t pe_ = 0;
+            if (ws_in_regs) {
+              const uint64_t b_ = __ballot(lane < nws && (int32_t)(W.cdf - p_) >= 0);
+              k_ = (int)__builtin_ctzll(b_);
+              ch_.x = (uint32_t)__builtin_amdgcn_readlane((int)W.start, k_);
+              ch_.y = (uint32_t)__builtin_amdgcn_readlane((int)W.end, k_);
+              if (k_ > 0) pe_ = __builtin_amdgcn_readlane((int)W.end, k_ - 1);
+            } else {
+              k_ = ws_bisect(p_);
+              ch_ = ws[k_];
+              if (k_ > 0) pe_ = (int32_t)ws[k_ - 1].y;
+            }
+            int32_t ss_ = (int32_t)ch_.x - length + 1;
+            if (k_ > 0) ss_ = pe_ > ss_ ? pe_ : ss_;
+            (void)rng_range(rng, ch_.y - 1u - (uint32_t)ss_, lane);
+          }
+          break;
+        }
       }
 
       // ---- overshoot: trim (:608-626)
@@ -1264,6 +1296,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       GAT_PHASE(6)
     }
     ndraws = rng.ndraws;
+    if (serial != nullptr) *serial = rng;
     GAT_PHASE(6)
     if (rng.use_pre && rng.exhausted) continue;       // rows ran out: redo this unit from its seed
 
@@ -1351,6 +1384,43 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
 }
 
 // sums the per-work-unit statistics: one atomic per block instead of one per work unit
+// k_serial: the reference's OWN random stream -- numpy.random.seed(seed) once (scripts/gat-run.py:267-271), then every
+// (sample, unit) in the order of gat/__init__.py:531-541 drawing from that one MT19937 -- so that `gat-run.py
+// --random-seed=N` of an unpatched reference can be reproduced table for table.  One stream is one chain: ONE wave runs
+// the whole batch, unit after unit, with the sampler code of k_sampler in its stand-alone form (slow by construction --
+// about 60 us per unit of 400 segments -- and still some thirty times the reference's engine).  The state (624 words +
+// position) comes from and goes back to global memory, so batches, segment tracks and calls continue each other.
+template <int KIND, bool BIG, bool TREE, bool HUGE>
+__global__ __launch_bounds__(64) void k_serial(SamplerArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const int lane = threadIdx.x;
+  uint32_t* mt = lds;
+  for (int i = lane; i < kMtN; i += kWave) mt[i] = A.serial_state[i];
+  WaveRng rng;
+  rng.mt = mt;
+  rng.pos = (int)A.serial_state[kMtN];
+  rng.ndraws = 0;
+  rng.use_pre = false; rng.exhausted = false;
+  rng.pre = nullptr; rng.pre_j = 0; rng.pre_rows = 0; rng.pre_base = 0;
+  wave_sync();
+  rng.rbuf = 0;
+  if (rng.pos < kMtN && (rng.pos & (kWave - 1)) != 0) {           // inside a block of 64 outputs: its tempered words
+    const int i = (rng.pos & ~(kWave - 1)) + lane;
+    rng.rbuf = mt_temper(mt[i < kMtN ? i : kMtN - 1]);
+  }
+  for (int s = 0; s < A.batch; ++s) {
+    for (int u = 0; u < A.n_units; ++u) {
+      const int a = A.unit_pos[u];
+      if (a < 0) continue;                                          // (gat/__init__.py:536-538: no segments or no workspace)
+      sampler_unit<KIND, BIG, TREE, HUGE>(A, s, a, lds, lane, &rng);
+      wave_sync();
+    }
+  }
+  wave_sync();
+  for (int i = lane; i < kMtN; i += kWave) A.serial_state[i] = mt[i];
+  if (lane == 0) A.serial_state[kMtN] = (uint32_t)rng.pos;
+}
+
 __global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict__ ws_stat, int64_t n,
                                                       unsigned long long* __restrict__ stat,
                                                       const int32_t* __restrict__ skip, int skip_stride) {

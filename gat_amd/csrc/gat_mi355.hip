@@ -355,6 +355,7 @@ struct gat_problem {
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
   DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
+  DevBuf<uint32_t> d_serial;             // gat_sample_and_count_serial: the MT19937 state (and its copy at the batch's start)
   DevBuf<int32_t> d_unit_pos;            // unit id -> launch position (k_contig reads k_tail's records by it)
   bool patched_contigs = false;          // the last batch skipped k_finalize: k_contig took (merged list, record)
   bool patched_counts = false;           // ... k_count_seg takes (merged list, record)
@@ -1081,8 +1082,10 @@ constexpr int kRelayout = 1;
 static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed);
 // defer: only enqueue (the caller adds the count kernels behind, synchronises once and calls finish_sampler_batch)
 // records_ok: the consumer is k_count_seg alone, which reads (merged list, k_tail's record): no k_finalize
+// serial_state: the run's ONE MT19937 state on the device (k_serial: the reference's own stream) instead of the per-unit streams
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
-                             gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false) {
+                             gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false,
+                             uint32_t* serial_state = nullptr) {
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -1095,6 +1098,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     const int32_t* skip_ptr = nullptr;
     int skip_stride = 0;
     if (!P->h_order.empty()) {
+      const int smode = serial_state != nullptr ? 0 : P->sampler_mode;
       gat::SamplerArgs A;
       memset(&A, 0, sizeof(A));
       A.units = P->d_units.p; A.units_o = P->d_units_o.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
@@ -1114,7 +1118,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       const unsigned n_act = (unsigned)P->h_order.size();
       const unsigned gy = std::min(n_act, 32768u), gz = (n_act + gy - 1) / std::max(gy, 1u);
       A.n_active = (int32_t)n_act;
-      if (P->sampler_mode) {
+      if (smode) {
         // lane-parallel front end: the scratch was sized for P->batch samples, tiles are laid out for that
         const int64_t nsb_alloc = (P->batch + 63) / 64;
         const unsigned nsb = (unsigned)((nb + 63) / 64);
@@ -1149,7 +1153,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[1], ctx->stream));
       }
-      ctx->k_recorded = timed && P->sampler_mode;
+      ctx->k_recorded = timed && smode;
       size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
       // SamplerSegments never holds a list; a SamplerAnnotator list beyond LDS is worked on in the slab (HUGE variant)
       const bool huge = P->sampler != GAT_SAMPLER_SEGMENTS && ((int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr);
@@ -1160,7 +1164,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       for (int32_t u : P->h_order) max_work = std::max(max_work, P->h_units[u].hist_total);
       A.st2 = nullptr;
       // the split path (k_consolidate / k_merge_big + k_tail + k_finalize in front of k_sampler); lists beyond LDS: old path
-      const bool split = P->split_path && P->sampler_mode && !huge;
+      const bool split = P->split_path && smode && !huge;
       unsigned n_long_big = 0;                  // launch positions k_merge_big was given
       bool long_lists = false;                  // k_sampler<BIG>: the code for lists beyond the bucket sorts
       if (!huge && max_work + max_work / 8 > 1024) {
@@ -1172,7 +1176,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         const size_t lds_m = (size_t)2 * P->max_unit_cap * 4 + (size_t)(nbk + 1) * 4;
         unsigned n_long = 0;
         for (int32_t u : P->h_order) { const uint32_t w = P->h_units[u].hist_total; if (w + w / 8 > 1024) ++n_long; else break; }
-        if (P->sampler_mode && P->sampler != GAT_SAMPLER_SEGMENTS && (int64_t)lds_m + 1024 <= ctx->max_lds && n_long > 0 &&
+        if (smode && P->sampler != GAT_SAMPLER_SEGMENTS && (int64_t)lds_m + 1024 <= ctx->max_lds && n_long > 0 &&
             !getenv("GAT_NO_MERGE_BIG")) {
           gat::SamplerArgs M = A;
           M.st2 = P->d_st2.p;
@@ -1306,7 +1310,28 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         }
       };
       const bool list_in_lds = !huge && P->sampler != GAT_SAMPLER_SEGMENTS;
-      if (split) {
+      if (serial_state != nullptr) {
+        // the reference's own stream: one wave, every (sample, unit) of the batch in order
+        gat::SamplerArgs K = A;
+        K.serial_state = serial_state;
+        K.unit_pos = P->d_unit_pos.p;
+        const int sv = variant == 8 ? 0 : variant;
+        const void* kf = sv == 0 ? (const void*)gat::k_serial<0, false, false, false> : sv == 1 ? (const void*)gat::k_serial<0, false, true, false>
+                       : sv == 2 ? (const void*)gat::k_serial<0, true, false, false> : sv == 3 ? (const void*)gat::k_serial<0, true, true, false>
+                       : sv == 4 ? (const void*)gat::k_serial<1, false, false, false> : sv == 5 ? (const void*)gat::k_serial<1, false, true, false>
+                       : sv == 6 ? (const void*)gat::k_serial<0, false, false, true> : (const void*)gat::k_serial<0, false, true, true>;
+        HIPCHK(ctx, hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        switch (sv) {
+          case 0: hipLaunchKernelGGL((gat::k_serial<0, false, false, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 1: hipLaunchKernelGGL((gat::k_serial<0, false, true, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 2: hipLaunchKernelGGL((gat::k_serial<0, true, false, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 3: hipLaunchKernelGGL((gat::k_serial<0, true, true, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 4: hipLaunchKernelGGL((gat::k_serial<1, false, false, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 5: hipLaunchKernelGGL((gat::k_serial<1, false, true, false>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          case 6: hipLaunchKernelGGL((gat::k_serial<0, false, false, true>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+          default: hipLaunchKernelGGL((gat::k_serial<0, false, true, true>), dim3(1), dim3(64), lds, ctx->stream, K); break;
+        }
+      } else if (split) {
         launch_sampler(dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)), lds, A);      // off the queue
       } else if (list_in_lds && A.big_buckets == 0 && P->h_class_start.size() > 2) {
         // one launch per size class: LDS for the class's longest list
@@ -1476,9 +1501,33 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
   }
 }
 
+static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                 uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
+                                 gat_stats* stats, uint32_t* state_host);
+
 extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
                                     uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
                                     gat_stats* stats) {
+  return sample_and_count_impl(ctx, P, counter_ids, n_counters, seed, sample_begin, sample_end, counts_dev, stats, nullptr);
+}
+
+extern "C" int gat_sample_and_count_serial(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                           uint32_t* mt_state, int64_t n_samples, void* counts_dev, gat_stats* stats) {
+  if (!mt_state) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: NULL state");
+  if (mt_state[GAT_MT_STATE_WORDS - 1] > 624u) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: position %u > 624", mt_state[GAT_MT_STATE_WORDS - 1]);
+  return sample_and_count_impl(ctx, P, counter_ids, n_counters, 0u, 0, n_samples, counts_dev, stats, mt_state);
+}
+
+extern "C" void gat_mt19937_seed(uint32_t seed, uint32_t* mt_state) {
+  // numpy.random.seed(int): init_genrand (numpy/random/src/mt19937/mt19937.c: mt19937_seed), position = 624
+  uint32_t x = seed;
+  for (int i = 0; i < 624; ++i) { mt_state[i] = x; x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1); }
+  mt_state[624] = 624u;
+}
+
+static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                 uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
+                                 gat_stats* stats, uint32_t* state_host) {
   if (!ctx || !P || !counts_dev || (n_counters > 0 && !counter_ids)) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count: NULL argument");
   if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1492,10 +1541,19 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
   memset(&local, 0, sizeof(local));
   const int64_t S = sample_end - sample_begin;
   HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+  uint32_t* d_state = nullptr;
+  if (state_host != nullptr) {
+    // the run's one stream: its state lives on the device over the batches (a copy restores it when a batch is repeated)
+    if (P->d_serial.n < 2 * (size_t)GAT_MT_STATE_WORDS) HIPCHK(ctx, P->d_serial.alloc(2 * (size_t)GAT_MT_STATE_WORDS));
+    d_state = P->d_serial.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_state, state_host, GAT_MT_STATE_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
   int64_t done = 0;
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
+    if (d_state != nullptr)
+      HIPCHK(ctx, hipMemcpyAsync(d_state + GAT_MT_STATE_WORDS, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
     int swap_capx = 0;
     if (P->swap_capx) {
       const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
@@ -1504,7 +1562,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
     const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
                             count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx) == GAT_COUNT_KERNEL_SEG;
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok))) return rc;   // (enqueued only)
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok, d_state))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
@@ -1520,7 +1578,11 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     // ONE synchronisation per batch: the sampler's status word is read behind the count kernels (which ran on whatever
     // an overflowed unit left -- harmless, the batch is redone with doubled regions)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) continue;
+    if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) {
+      if (d_state != nullptr)        // (the repeated batch draws from where this one began)
+        HIPCHK(ctx, hipMemcpyAsync(d_state, d_state + GAT_MT_STATE_WORDS, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      continue;
+    }
     if (rc) return rc;
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]));
@@ -1533,6 +1595,7 @@ extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t*
     done += nb;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+  if (d_state != nullptr) HIPCHK(ctx, hipMemcpyAsync(state_host, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));

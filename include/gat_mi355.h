@@ -181,6 +181,19 @@ int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                     const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
                     const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
 
+/* ---- the reference's own random stream ---------------------------------------------------
+ * scripts/gat-run.py:267-271 seeds numpy's global generator ONCE and every (sample, unit) of the run -- in the order of
+ * gat/__init__.py:531-541, segment track after segment track -- draws from that one MT19937.  gat_sample_and_count's
+ * per-unit streams are what makes the samples independent work; this entry reproduces an unpatched reference instead,
+ * table for table, at the speed of one stream: one wave runs the samples [0, n_samples) one after the other.
+ * mt_state: GAT_MT_STATE_WORDS words, the 624 state words + the position (numpy's `pos`, 624 after seeding); read at
+ * entry, written back at return, so that calls (batches, segment tracks) continue each other.  gat_mt19937_seed fills
+ * it as numpy.random.seed(seed) does for an integer seed.  Counts as in gat_sample_and_count with sample_begin 0. */
+#define GAT_MT_STATE_WORDS 625
+void gat_mt19937_seed(uint32_t seed, uint32_t* mt_state);
+int gat_sample_and_count_serial(gat_ctx* ctx, gat_problem* prob, const int32_t* counter_ids, int n_counters,
+                                uint32_t* mt_state, int64_t n_samples, void* counts_dev, gat_stats* stats);
+
 /* ---- null-distribution statistics on the device -----------------------------------------
  * The numbers AnnotatorResult takes from a row of sampled counts (makeEnrichmentStatistics / getTwoSidedPValue,
  * gat/Engine.pyx:1635-1718, :1543-1576), computed from the count matrix where gat_sample_and_count left it:

@@ -822,8 +822,41 @@ def g7_workspaces():
     print("G7 workspace generators: %d cases, %d segment ops" % (len(cases), len(ops)))
 
 
+def g5u_cli_unpatched():
+    """tables of the reference's gat-run.py AS IT IS -- numpy.random.seed(--random-seed) once, one stream for the whole run
+    (scripts/gat-run.py:267-271) -- on the G5 inputs: what gat-run.py --reference-stream of this repository has to print"""
+    import importlib.util
+    cli_dir = os.path.join(HERE, "cli")
+    spec = importlib.util.spec_from_file_location("gat_run_ref_u", os.path.join(os.path.dirname(gat.__file__), "..", "scripts", "gat-run.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases = collections.OrderedDict([
+        ("reference_stream_default", ["--num-samples=40", "--random-seed=31"]),
+        ("reference_stream_tracks_isochores", ["--num-samples=25", "--random-seed=32", "--with-segment-tracks",
+                                               "--isochores=%s" % os.path.join(cli_dir, "isochores.bed"), "--order=track",
+                                               "--counter=segment-overlap"]),
+        ("reference_stream_density", ["--num-samples=30", "--random-seed=33", "--counter=nucleotide-density",
+                                      "--truncate-segments-to-workspace", "--order=annotation"]),
+    ])
+    for name, extra in cases.items():
+        out = os.path.join(cli_dir, "expected_%s.tsv" % name)
+        argv = ["gat-run.py", "--segments=%s" % os.path.join(cli_dir, "segments.bed"),
+                "--annotations=%s" % os.path.join(cli_dir, "annotations.bed"),
+                "--workspace=%s" % os.path.join(cli_dir, "workspace.bed"),
+                "--stdout=%s" % out, "--log=%s" % os.path.join(cli_dir, "ref.log")] + extra
+        mod.main(argv)
+        lines = [l for l in open(out) if not l.startswith("#")]
+        with open(out, "w") as f:
+            f.writelines(lines)
+        print("G5u cli %s: %d rows" % (name, len(lines) - 1))
+    with open(os.path.join(cli_dir, "cases_reference_stream.json"), "w") as f:
+        json.dump(dict((k, [x.replace(cli_dir + os.sep, "") for x in v]) for k, v in cases.items()), f, indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5u", "g6", "g7", "g8"]
+    if "g5u" in which:
+        g5u_cli_unpatched()
     if "g1" in which:
         g1_algebra()
     if "g2" in which:

@@ -240,6 +240,11 @@ def test_run_api_rows_match_reference(ctx):
         k = [str(c) for c in z["counters"]].index(r.counter)
         a = [str(t) for t in z["track_names"]].index(r.annotation)
         assert r.observed == z["observed"][k, a]
+    # ... and with the reference's own stream (one MT19937 for the whole run): the rows of the UNPATCHED reference
+    results0 = gat_amd.run(segments, annotations, workspaces["collapsed"], gat_amd.SamplerAnnotator(bucket_size=0),
+                           counters, gat_amd.UnconditionalWorkspace(), num_samples=int(z["num_samples"]),
+                           random_seed=int(z["seed"]), reference_stream=True)
+    assert [str(r) for r in results0] == [str(x) for x in z["rows_mode0"]]
 
 
 def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
@@ -353,6 +358,34 @@ def _long_list_case(ctx, seed):
 @pytest.mark.parametrize("seed", list(range(900, 912)))
 def test_long_lists_vs_oracle(ctx, seed):
     _long_list_case(ctx, seed)
+
+
+@pytest.mark.parametrize("name", ["config1", "config2_s12", "dense", "density_ungapped", "long_segments", "small_contigs",
+                                  "small_isochores", "small_isochores_sampler_segments", "small_isochores_truncated"])
+def test_reference_stream_matches_the_unpatched_reference(ctx, name):
+    """gat_sample_and_count_serial: ONE MT19937 stream for the whole run, seeded as numpy.random.seed(seed), every
+    (sample, unit) in the reference's order -- the count matrices the reference's real gat.run produced WITHOUT the
+    per-unit re-seeding (counts_mode0 of the goldens), number for number; and the state carries over calls."""
+    z = np.load(os.path.join(G, "run_%s.npz" % name), allow_pickle=True)
+    flat = dict((k, z[k]) for k in ("n_units", "segs", "seg_off", "ws", "ws_off", "unit_contig", "n_contigs", "merge_contigs",
+                                   "n_tracks", "annos", "anno_off", "cws_nseg", "bucket_size", "nbuckets", "sampler"))
+    counters = [str(c) for c in z["counters"]]
+    S = int(z["num_samples"])
+    want = z["counts_mode0"]
+    P = _lib.Problem(ctx, flat)
+    state = _lib.mt19937_seed(int(z["seed"]))
+    got = P.sample_and_count_serial(counters, state, S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(np.asarray(got[k], dtype=np.float64), np.asarray(want[k], dtype=np.float64)), (name, c)
+    # the oracle's mode 0 agrees (it is what pins the oracle to the reference), and two calls continue each other
+    owant, _ = O.run_samples(flat, counters, int(z["seed"]), 0, 0, S)
+    state = _lib.mt19937_seed(int(z["seed"]))
+    cut = S // 3 + 1
+    a = P.sample_and_count_serial(counters, state, cut)
+    b = P.sample_and_count_serial(counters, state, S - cut)
+    for k in range(len(counters)):
+        assert np.array_equal(np.concatenate([a[k], b[k]], axis=1), owant[k]), (name, counters[k])
+    P.close()
 
 
 def test_contig_lists_longer_than_expected(ctx, monkeypatch):
@@ -476,6 +509,21 @@ def test_cli_table_matches_reference(ctx, tmp_path):
                 "--log=%s" % str(tmp_path / "log")] + extra
         assert mod.main(argv) == 0
         got = [l for l in open(out) if not l.startswith("#")]
+        want = [l for l in open(os.path.join(cli, "expected_%s.tsv" % name)) if not l.startswith("#")]
+        assert got == want, name
+
+
+def test_cli_reference_stream_matches_the_unpatched_reference(ctx, tmp_path):
+    """gat-run.py --reference-stream: the tables the reference's own gat-run.py prints WITHOUT any patch (one numpy stream
+    seeded with --random-seed for the whole run: tests/golden/make_goldens.py g5u), byte for byte -- two segment tracks
+    and isochores (the stream carries over tracks and units), the density counter with truncation"""
+    cli = os.path.join(G, "cli")
+    cases = json.load(open(os.path.join(cli, "cases_reference_stream.json")))
+    for name, extra in cases.items():
+        extra = [x.replace("--isochores=", "--isochores=%s%s" % (cli, os.sep)) for x in extra]
+        got = _run_cli(tmp_path, name, ["--segments=%s" % os.path.join(cli, "segments.bed"),
+                                        "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+                                        "--workspace=%s" % os.path.join(cli, "workspace.bed"), "--reference-stream"] + extra)
         want = [l for l in open(os.path.join(cli, "expected_%s.tsv" % name)) if not l.startswith("#")]
         assert got == want, name
 
