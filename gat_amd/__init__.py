@@ -372,7 +372,7 @@ def buildParser(usage=None):
     g.add_option("--reference-stream", dest="reference_stream", action="store_true",
                  help="(not in the reference) draw every sample from ONE stream seeded with --random-seed, in the reference's "
                       "order: the table of an unpatched reference run with the same seed, number for number.  One stream is one "
-                      "chain of dependent draws: a single GPU wave runs it (about 60 us per work unit of 400 segments)")
+                      "chain of dependent draws: a single GPU wave runs it (0.4 ms per work unit of 400 segments)")
     g.add_option("--truncate-segments-to-workspace", dest="truncate_segments_to_workspace", action="store_true")
     g.add_option("--truncate-workspace-to-annotations", dest="truncate_workspace_to_annotations", action="store_true")
     g.add_option("--restrict-workspace", dest="restrict_workspace", action="store_true")

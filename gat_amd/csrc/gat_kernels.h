@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
 // (sample, unit) in the order of gat/__init__.py:531-541 drawing from that one MT19937 -- so that `gat-run.py
 // --random-seed=N` of an unpatched reference can be reproduced table for table.  One stream is one chain: ONE wave runs
 // the whole batch, unit after unit, with the sampler code of k_sampler in its stand-alone form (slow by construction --
-// about 60 us per unit of 400 segments -- and still some thirty times the reference's engine).  The state (624 words +
+// 0.4 ms per unit of 400 segments, 106 samples/s on config 2 -- and still five times the reference's engine).  The state (624 words +
 // position) comes from and goes back to global memory, so batches, segment tracks and calls continue each other.
 template <int KIND, bool BIG, bool TREE, bool HUGE>
 __global__ __launch_bounds__(64) void k_serial(SamplerArgs A) {
