@@ -1856,6 +1856,8 @@ constexpr int kMergedSlots = 8;
 #define GAT_MERGED_THREADS 256
 #endif
 constexpr int kMergedThreads = GAT_MERGED_THREADS;
+// PATCH (as in k_count_seg): a unit k_tail finished is read as merged list + the record's extras, no k_finalize.
+template <bool PATCH>
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int T = A.n_tracks;
@@ -1873,9 +1875,22 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   const int nidx = A.n_index[c], coff = A.c_off[c];
   for (int t = lane; t < T; t += kWave) acc[t] = 0u;
   const int s_end = min(A.n_samples, (grp + 1) * SG);
+  const int upos = PATCH ? A.unit_pos[nidx] : -1;
   for (int s = grp * SG + wave; s < s_end; s += kMergedThreads / kWave) {
-    const int n = A.n_arr[(int64_t)s * A.n_stride + nidx];
+    int n = A.n_arr[(int64_t)s * A.n_stride + nidx];
     const uint2* __restrict__ X = A.seg + (int64_t)s * A.seg_stride + coff;
+    int nU = n;
+    const uint2* __restrict__ Rex = X;
+    if (PATCH && upos >= 0) {
+      const int64_t sa = (int64_t)s * A.n_units + upos;
+      const int32_t* __restrict__ R = A.patch + sa * A.patch_stride;
+      if (R[kPatchState] == 1) {
+        nU = A.st2[sa].x;
+        n = nU + R[kPatchNExtra];
+        X = A.seg_merged + (int64_t)s * A.seg_stride + coff;
+        Rex = reinterpret_cast<const uint2*>(R + kPatchExtra) - nU;
+      }
+    }
     constexpr int kR = 4;                                            // segments per lane whose look-ups are in flight together
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
@@ -1883,7 +1898,8 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
-        x[r] = i < n ? X[i] : make_uint2(0u, 0u);                    // (an empty segment meets nothing: start < 0 never holds)
+        // (an empty segment -- padding, or what a trim emptied -- meets nothing: start < 0 never holds)
+        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }

@@ -302,8 +302,13 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
   HIPCHK(ctx, A.end.upload(he, ctx->stream));
   HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
   HIPCHK(ctx, A.off.upload(A.h_off, ctx->stream));
+  // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
+  // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
+  // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
   const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
-  if (n_groups > 0 && n_tracks >= (env_mm ? atoi(env_mm) : 4)) {
+  const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
+  const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+  if (n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
     int rc = build_merged(ctx, A, annos, anno_off, n_tracks, n_groups);
     if (rc) return rc;
   }
@@ -986,9 +991,11 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       const size_t need = (size_t)A.n_contigs * (size_t)A.n_tracks * (size_t)A.n_samples;
       if (part.n < need) HIPCHK(ctx, part.alloc(need));
       A.part = part.p;
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
-      hipLaunchKernelGGL(gat::k_count_merged, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
+      if (A.seg_merged != nullptr) hipLaunchKernelGGL(gat::k_count_merged<true>, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
+      else hipLaunchKernelGGL(gat::k_count_merged<false>, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
       ctx->main_recorded = true;
@@ -1560,8 +1567,9 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
       if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
     }
     // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
+    const int route = count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx);
     const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
-                            count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx) == GAT_COUNT_KERNEL_SEG;
+                            (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok, d_state))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
