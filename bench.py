@@ -238,8 +238,8 @@ class Workload(object):
                             "see l2_GBps / l2_frac_of_peak and hbm_measured_GBps")
             roof["lookups_per_s"] = len(flat["segs"]) * S / count_s if count_s > 0 else 0.0
         prof, src = counters_profile(self.name, S) if self.args.scale == 1.0 else (None, None)
-        if prof:
-            k = prof.get("count_kernel", prof)
+        k = (prof or {}).get("count_kernel")
+        if k and "fetch_kib_per_launch" in k and "write_kib_per_launch" in k:
             traffic = (2.0 * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
             roof["traffic"] = traffic
             roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; " \

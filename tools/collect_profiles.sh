@@ -2,6 +2,8 @@
 # rocprofv3 summaries behind DESIGN.md / bench.py's roofline, one BASELINE shape at a time: kernel-trace stats, then the
 # counters in separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; no --pmc together with
 # trace domains other than --kernel-trace).  usage (GPU box): bash tools/collect_profiles.sh <round tag> [config:samples ...]
+# (gpurun merges what this writes into the local gpurun_out/ next to what earlier calls left there: remove the local
+#  gpurun_out/prof_<tag> first, or tools/summarize_profiles.py sums the counters of old and new kernels alike)
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

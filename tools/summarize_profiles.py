@@ -83,7 +83,7 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
                 out.write("   %-28s %16.1f GB/s (2 x FETCH + WRITE over the average launch)\n" % ("hbm_rate", rec["hbm_GBps"]))
             per_kernel[n] = rec
     if S is not None:
-        count = [n for n in per_kernel if "k_count_merged(" in n or "k_count_seg<" in n or "k_count_swap" in n]
+        count = [n for n in per_kernel if ("k_count_merged" in n and "finish" not in n) or "k_count_seg<" in n or "k_count_swap" in n]
         entry = {"kernels": per_kernel}
         if count:
             main = max(count, key=lambda n: per_kernel[n].get("avg_ns") or 0)
