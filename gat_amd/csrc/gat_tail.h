@@ -1,4 +1,5 @@
-// gat_tail.h -- SamplerAnnotator.sample behind k_place as three lean kernels (the split path of the sampler).
+// gat_tail.h -- SamplerAnnotator.sample behind k_place as lean kernels: the split path of the sampler (k_consolidate,
+// k_tail, k_finalize) and its counterpart for long lists behind k_merge_big (k_tail_big, k_resume_big).
 //
 // k_sampler runs the rest of gat/Engine.pyx:572-646 with one WAVE per (sample, unit): a third of its time is the first
 // consolidation -- lane-parallel work over the whole list -- and the rest is the loop's tail: a handful of draws, two or
@@ -11,12 +12,16 @@
 //                  and nothing else; leaves the merged list in the slab with its running lengths (cum).
 //   k_tail         one LANE per (sample, unit), like k_place: the tail of the loop as a per-lane state machine whose list
 //                  accesses are binary searches in the merged list (L2): new segments that touch nothing become "extras",
-//                  the overshoot trim becomes (where it starts, direction, segments removed whole, bases off the next).
+//                  the overshoot trim is applied to the list where it is (it is the last thing that happens to it).
 //                  Whatever does not fit that shape -- a new segment touching a neighbour, a second trim, more than four
 //                  new segments, a long workspace -- is left, untouched, to k_sampler, which resumes from the merged list.
 //   k_finalize     one wave per (sample, unit): merged list (trimmed in place by k_tail) + extras, placeholders dropped
 //                  (:639-646), the unit's list written where its consumers expect it.  No LDS.  Not run when the
-//                  consumer takes (merged list, extras) as they are: k_contig, k_count_seg<.., PATCH>.
+//                  consumer takes (merged list, extras) as they are: k_contig, k_count_seg / k_count_merged<.., PATCH>.
+//   k_tail_big     one LANE per (sample, unit) of a LONG list: the placement rounds behind k_merge_big's consolidation;
+//                  new segments are logged or united in place with the one segment they touch.
+//   k_resume_big   one wave per such unit: the log into the list, the trim(s), the final filter, the list in the slab
+//                  (no list in LDS: as many waves per CU as registers allow).
 //
 // Results are those of k_sampler (and of the reference) bit for bit: every branch below cites the line it restates.
 #pragma once
