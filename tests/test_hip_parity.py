@@ -388,6 +388,35 @@ def test_reference_stream_matches_the_unpatched_reference(ctx, name):
     P.close()
 
 
+@pytest.mark.parametrize("seed", list(range(40, 52)))
+def test_reference_stream_random_problems_vs_oracle(ctx, seed, monkeypatch):
+    """the one-stream mode on random problems (isochores, dense units, several contigs and tracks, long lists, slab
+    overflow and its repeat from the batch's stream position) against the oracle's mode 0 -- the mode that pins the oracle
+    to the reference -- and a run cut into three calls against the same run in one"""
+    rs = np.random.RandomState(seed)
+    if seed % 4 == 3:
+        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+    if seed % 6 == 5:
+        flat = _big_problem(rs, 1500, 3, n_contigs=1)
+    else:
+        flat = _random_problem(rs, n_contigs=int(rs.randint(1, 5)), n_segs=int(rs.randint(20, 500)),
+                               n_tracks=int(rs.randint(1, 4)), isochores=bool(seed % 2), dense=(seed % 3 == 0))
+    counters = list(_lib.COUNTER_IDS.keys())
+    S = 14
+    want, _ = O.run_samples(flat, counters, 900 + seed, 0, 0, S)
+    P = _lib.Problem(ctx, flat)
+    state = _lib.mt19937_seed(900 + seed)
+    got = P.sample_and_count_serial(counters, state, S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    state2 = _lib.mt19937_seed(900 + seed)
+    parts = [P.sample_and_count_serial(counters, state2, n) for n in (3, 1, S - 4)]
+    assert np.array_equal(state, state2)
+    for k in range(len(counters)):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=1), want[k])
+    P.close()
+
+
 def test_contig_lists_longer_than_expected(ctx, monkeypatch):
     """k_contig's LDS is sized for the lists a contig is expected to have, not for every unit at its capacity; a batch in
     which a contig's lists do not fit is repeated with the full size (forced here by shrinking the expectation; the same
