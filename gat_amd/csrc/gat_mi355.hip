@@ -19,6 +19,9 @@
 #include <climits>
 #include <string>
 #include <vector>
+#include <thread>
+#include <chrono>
+#include <atomic>
 
 #include "../../include/gat_mi355.h"
 #define GAT_NUM_COUNTERS_DEV 6
@@ -124,6 +127,20 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
   return GAT_OK;
 }
 
+// host threads for the per-list / per-contig preparation of gat_problem_create (GAT_HOST_THREADS, default min(16, cores))
+template <typename F>
+static void parallel_for(int64_t n, F body) {
+  const char* env_t = getenv("GAT_HOST_THREADS");
+  unsigned nthreads = env_t ? (unsigned)std::max(1, atoi(env_t)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  nthreads = (unsigned)std::min<int64_t>(nthreads, std::max<int64_t>(1, n));
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i); };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+}
+
 // The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, 8-byte
 // entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two, see below, at most 32 768) are
 // cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
@@ -132,14 +149,20 @@ static int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char*
 static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
                         int32_t n_groups) {
   if (n_tracks > 65535) return GAT_OK;                              // (track ids are 16 bits: such problems keep the per-track kernel)
-  std::vector<uint2> hz;
-  std::vector<uint32_t> hf;
   std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
   std::vector<int32_t> h_shift((size_t)n_groups, 0), h_cells((size_t)n_groups, 1);
   struct Ent { uint32_t s, e, t; };
-  std::vector<Ent> e;
-  for (int c = 0; c < n_groups; ++c) {
-    e.clear();
+  // a contig's index is built by itself (collect, sort, grid): the contigs are dealt to host threads -- sorting 10^7 entries
+  // on one core made gat_problem_create 0.9 s on the config-4 shape
+  std::vector<std::vector<uint2>> cz((size_t)n_groups);
+  std::vector<std::vector<uint32_t>> cf((size_t)n_groups);
+  std::vector<int> c_err((size_t)n_groups, 0);
+  const char* env_bf = getenv("GAT_MERGED_BOUND");
+  const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
+  auto build_one = [&](int c) {
+    std::vector<Ent> e;
+    std::vector<uint2>& hz = cz[(size_t)c];
+    std::vector<uint32_t>& hf = cf[(size_t)c];
     uint64_t total_len = 0, cnt = 0;
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
@@ -150,8 +173,6 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     // segment began.  Twice the mean interval length or twice the mean spacing of the entries, whichever is larger (cutting
     // finer than the spacing only adds entries): config-4 shape, 1 000 tracks, one entry per 300 bases: 30.8 -> 25.9 ms per
     // 4 096 samples against the earlier 8 x mean length; config 3 (one per 3 000) keeps its bound.
-    const char* env_bf = getenv("GAT_MERGED_BOUND");
-    const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
     uint64_t span = 0;
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
@@ -160,6 +181,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     const uint64_t want = cnt > 0 ? std::max(bfac * (total_len / cnt), 2 * (span / cnt)) : 0;
     uint32_t bound = 256;
     while ((uint64_t)bound < want && bound < 32768u) bound <<= 1;
+    e.reserve((size_t)cnt + (size_t)cnt / 4);
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
       for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
@@ -171,7 +193,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     }
     std::sort(e.begin(), e.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
     const size_t ne = e.size();
-    if (ne >= 0xfffffff0ull) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
+    if (ne >= 0xfffffff0ull) { c_err[(size_t)c] = 1; return; }
     const uint32_t max_start = ne ? e[ne - 1].s : 0u;
     int64_t target = 64;
     while (target < (int64_t)(ne / 2)) target <<= 1;                // about two entries per cell
@@ -180,26 +202,36 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     const int64_t cells = ((int64_t)max_start >> sh) + 1;
     h_shift[(size_t)c] = sh;
     h_cells[(size_t)c] = (int32_t)cells;
-    const size_t fo = hf.size();
-    hf.resize(fo + (size_t)cells);
+    hf.resize((size_t)cells);
     {
       size_t k = 0;                                                 // first entry starting at or behind the cell's start
       for (int64_t g = 0; g < cells; ++g) {
         const uint64_t cs = (uint64_t)g << sh;
         while (k < ne && (uint64_t)e[k].s < cs) ++k;
-        hf[fo + (size_t)g] = (uint32_t)k;
+        hf[(size_t)g] = (uint32_t)k;
       }
       for (size_t i = 0; i < ne; ++i) {                             // ... or an earlier one that reaches past it
         for (int64_t g = ((int64_t)e[i].s >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].e; ++g)
-          if ((uint32_t)i < hf[fo + (size_t)g]) hf[fo + (size_t)g] = (uint32_t)i;
+          if ((uint32_t)i < hf[(size_t)g]) hf[(size_t)g] = (uint32_t)i;
       }
     }
+    hz.reserve(ne + 3);
     for (size_t i = 0; i < ne; ++i) hz.push_back(make_uint2(e[i].s, ((e[i].t & 0xffffu) << 16) | ((e[i].e - e[i].s) & 0xffffu)));
     hz.push_back(make_uint2(0xffffffffu, 0u));                      // ends every scan
     hz.push_back(make_uint2(0xffffffffu, 0u));                      // (entries are read in pairs)
     if (hz.size() & 1) hz.push_back(make_uint2(0xffffffffu, 0u));   // ... and the next contig starts at an even index
+  };
+  parallel_for(n_groups, [&](int64_t c) { build_one((int)c); });
+  std::vector<uint2> hz;
+  std::vector<uint32_t> hf;
+  for (int c = 0; c < n_groups; ++c) {
+    if (c_err[(size_t)c]) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
+    hz.insert(hz.end(), cz[(size_t)c].begin(), cz[(size_t)c].end());
+    hf.insert(hf.end(), cf[(size_t)c].begin(), cf[(size_t)c].end());
     hz_off[(size_t)c + 1] = (int64_t)hz.size();
     hf_off[(size_t)c + 1] = (int64_t)hf.size();
+    std::vector<uint2>().swap(cz[(size_t)c]);
+    std::vector<uint32_t>().swap(cf[(size_t)c]);
   }
   HIPCHK(ctx, A.mz.upload(hz, ctx->stream));
   HIPCHK(ctx, A.mfirst.upload(hf, ctx->stream));
@@ -249,13 +281,21 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
     int rc = check_list(ctx, annos + o, m, "annotation", l);
     if (rc) return rc;
     A.max_m = std::max(A.max_m, m);
-    uint32_t cum = 0;
-    for (int64_t i = 0; i < m; ++i) {
-      hs[(size_t)(o + i)] = annos[o + i].start;
-      he[(size_t)(o + i)] = annos[o + i].end;
-      hc[(size_t)(o + i)] = cum;
-      cum += annos[o + i].end - annos[o + i].start;
-    }
+  }
+  {
+    constexpr int64_t kBlock = 256;                                 // lists per task
+    parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
+      for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        uint32_t cum = 0;
+        for (int64_t i = 0; i < m; ++i) {
+          hs[(size_t)(o + i)] = annos[o + i].start;
+          he[(size_t)(o + i)] = annos[o + i].end;
+          hc[(size_t)(o + i)] = cum;
+          cum += annos[o + i].end - annos[o + i].start;
+        }
+      }
+    });
   }
   // per group (contig) a uniform grid over the start coordinates, about one start per cell:
   // grid[g] = #starts < (g << shift); the count kernels look a position up instead of bisecting
@@ -282,17 +322,22 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
   }
   for (int64_t l = 0; l < n_lists; ++l) h_goff[(size_t)l + 1] = h_goff[(size_t)l] + h_cells[(size_t)(l % n_groups)] + 1;
   std::vector<uint32_t> hg((size_t)h_goff[(size_t)n_lists]);
-  for (int64_t l = 0; l < n_lists; ++l) {
-    const int c = (int)(l % n_groups);
-    const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
-    const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
-    uint32_t* g = hg.data() + h_goff[(size_t)l];
-    int64_t k = 0;
-    for (int cell = 0; cell <= cells; ++cell) {
-      const uint64_t bound = (uint64_t)cell << sh;
-      while (k < m && (uint64_t)annos[o + k].start < bound) ++k;
-      g[cell] = (uint32_t)(cell == cells ? m : k);
-    }
+  {
+    constexpr int64_t kBlock = 256;
+    parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
+      for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+        const int c = (int)(l % n_groups);
+        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
+        uint32_t* g = hg.data() + h_goff[(size_t)l];
+        int64_t k = 0;
+        for (int cell = 0; cell <= cells; ++cell) {
+          const uint64_t bound = (uint64_t)cell << sh;
+          while (k < m && (uint64_t)annos[o + k].start < bound) ++k;
+          g[cell] = (uint32_t)(cell == cells ? m : k);
+        }
+      }
+    });
   }
   HIPCHK(ctx, A.grid.upload(hg, ctx->stream));
   HIPCHK(ctx, A.goff.upload(h_goff, ctx->stream));
@@ -309,8 +354,11 @@ static int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const
   const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
   const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
   if (n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = build_merged(ctx, A, annos, anno_off, n_tracks, n_groups);
     if (rc) return rc;
+    if (getenv("GAT_TIME_CREATE"))
+      fprintf(stderr, "[gat] build_merged %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
   return GAT_OK;
 }
@@ -819,7 +867,11 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
   int rc = upload_layout(ctx, P.get());
   if (rc) return rc;
+  const auto t_annos = std::chrono::steady_clock::now();
   rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs);
+  if (getenv("GAT_TIME_CREATE"))
+    fprintf(stderr, "[gat] build_annos (incl. build_merged) %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_annos).count());
   if (rc) return rc;
   {
     // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
