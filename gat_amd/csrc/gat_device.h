@@ -8,11 +8,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gat_types.h"
 
 namespace gat {
 
-constexpr int kWave = 64;
-constexpr int kMtN = 624;
 constexpr int kMtM = 397;
 constexpr int kMtLdsWords = 640;   // 624 state words, padded so the segment buffer stays 16-B aligned
 
@@ -671,8 +670,7 @@ __device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, i
 // l.  A search reads ONE node per level (four 16-byte loads) and counts its keys below the target:
 // 4 dependent round trips for a 50 000-segment workspace where a binary search makes 16.  The pad
 // value is never below any target, and a target above every key walks down the last nodes.
-constexpr int kWsTreeMin = 32;      // workspaces with more segments get trees (the shorter ones are searched in registers)
-constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so that the geometry stays in scalar registers
+// (kWsTreeMin, kWsTreeLevels: gat_types.h)
 struct WsTreeGeom {                 // wave-uniform, derived from the number of keys
   int nlev;
   int off[kWsTreeLevels];           // first word of the level

@@ -14,32 +14,7 @@
 
 namespace gat {
 
-// per isochore unit, everything SamplerAnnotator.sample derives from (segments, workspace) before
-// its loop (gat/Engine.pyx:543-565), hoisted to problem creation.
-struct UnitDev {
-  int32_t n_ws;         // workspace segments of the unit
-  int32_t ws_off;       // offset into ws / ws_cdf
-  int32_t tree_start_off;  // offset into ws_tree of the search tree over the workspace starts (-1: short workspace)
-  int32_t tree_cdf_off;    // ... over the cumulated lengths
-  uint32_t hist_total;  // HistogramSampler.total_size == number of working segments
-  uint32_t bucket;      // bucket size (after the bucket_size==0 rule, gat/SegmentList.pyx:1164)
-  uint32_t ws_total;    // SegmentListSampler.total_size == workspace bases
-  int32_t ltotal;       // bases to reproduce (gat/Engine.pyx:550-552)
-  int32_t slab_off;     // offset of the unit's output region inside a sample's slab
-  int32_t slab_cap;     // capacity of that region == LDS buffer capacity used for the unit
-  int32_t contig;
-  int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
-  int32_t n_target;     // SamplerSegments: len(segments) placements (gat/Engine.pyx:726)
-  int32_t pad;          // units_o: the unit id
-};
-
-enum : int32_t {
-  kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab
-  kStatusAssert = 2,     // reference assert would fire (gat/Engine.pyx:645 sum()>0)
-  kStatusTrimAssert = 4, // gat/SegmentList.pyx:560 sum() > size
-  kStatusContigLds = 8,  // k_contig: a contig's lists exceed the LDS the launch was given (sized for what is expected,
-                         // not for every unit at its capacity): host repeats the batch with the full size
-};
+// (UnitDev and the kStatus* bits: gat_types.h)
 
 struct SamplerArgs {
   const UnitDev* units;
@@ -222,8 +197,7 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
 // outputs (masked value > range) leave the state unchanged -- exactly numpy's masked rejection.
 // A lane halts when `remaining <= length` (:582): the pending length, the number of outputs
 // consumed and `remaining` are handed to k_sampler, which consolidates and finishes the unit.
-constexpr int kPlaceWsLds = 256;      // workspace segments kept in LDS (16 B each)
-constexpr int kPlaceRankLds = 1024;   // length-rank table entries kept in LDS
+// (kPlaceWsLds = 256 workspace segments and kPlaceRankLds = 1024 length-rank entries kept in LDS: gat_types.h)
 constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
 // MODE (chosen by the host from the units' shapes, so that the common problems run a lean kernel): 1 every unit is of
@@ -1851,7 +1825,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 // every wave advancing a cursor through its samples' sorted lists, look-ups in LDS).  It is bit-exact and no faster on
 // config 3 (1.80 vs 1.82 ms per 10 000 samples) and slower on the config-4 shape (54.9 vs 34.1 ms per 4 096 samples: with
 // 1 000 tracks only eight samples' accumulators fit beside a chunk, so a contig's 3.3 MB are staged 512 times).
-constexpr int kMergedSlots = 8;
+// (kMergedSlots: gat_types.h)
 #ifndef GAT_MERGED_THREADS
 #define GAT_MERGED_THREADS 256
 #endif

@@ -1,0 +1,641 @@
+// gat_prep.hip -- problem creation: what the reference does once per (segments, workspace) pair before sampling starts
+// (gat/Engine.pyx:543-565: filter, ltotal, length histogram, both sampler CDFs -- hoisted out of the per-sample loop),
+// the layout of the per-sample slab, and the look-up tables of the count kernels (SoA + position grids, the merged
+// index).  Host code only: nothing here launches a kernel or computes a sample.
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <map>
+#include <memory>
+
+#include "gat_host.h"
+
+int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx) {
+  for (int64_t i = 0; i < n; ++i) {
+    if (s[i].start >= s[i].end)
+      return set_err(ctx, GAT_ERR_ASSERT, "%s list %lld is not normalized: empty/invalid segment %u-%u", what,
+                     (long long)idx, s[i].start, s[i].end);
+    if (s[i].end >= 0x80000000u)
+      return set_err(ctx, GAT_ERR_ARG, "%s list %lld: coordinate %u >= 2^31 not supported", what, (long long)idx, s[i].end);
+    if (i > 0 && s[i - 1].end > s[i].start)
+      return set_err(ctx, GAT_ERR_ASSERT, "%s list %lld is not normalized: %u-%u overlaps/precedes %u-%u", what,
+                     (long long)idx, s[i - 1].start, s[i - 1].end, s[i].start, s[i].end);
+  }
+  return GAT_OK;
+}
+
+// The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, 8-byte
+// entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two, see below, at most 32 768) are
+// cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
+// than `bound` bases; first[g] is the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a
+// segment starting in cell g begins.
+static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
+                        int32_t n_groups) {
+  if (n_tracks > 65535) return GAT_OK;                              // (track ids are 16 bits: such problems keep the per-track kernel)
+  std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
+  std::vector<int32_t> h_shift((size_t)n_groups, 0), h_cells((size_t)n_groups, 1);
+  struct Ent { uint32_t s, e, t; };
+  // a contig's index is built by itself (collect, sort, grid): the contigs are dealt to host threads -- sorting 10^7 entries
+  // on one core made gat_problem_create 0.9 s on the config-4 shape
+  std::vector<std::vector<uint2>> cz((size_t)n_groups);
+  std::vector<std::vector<uint32_t>> cf((size_t)n_groups);
+  std::vector<int> c_err((size_t)n_groups, 0);
+  const char* env_bf = getenv("GAT_MERGED_BOUND");
+  const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
+  auto build_one = [&](int c) {
+    std::vector<Ent> e;
+    std::vector<uint2>& hz = cz[(size_t)c];
+    std::vector<uint32_t>& hf = cf[(size_t)c];
+    uint64_t total_len = 0, cnt = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) { total_len += annos[i].end - annos[i].start; ++cnt; }
+    }
+    // the piece bound: a scan starts at the first entry that reaches into the segment's cell and passes everything up to
+    // the segment's end, so it walks over about (bound + segment length) / spacing entries, most of which ended before the
+    // segment began.  Twice the mean interval length or twice the mean spacing of the entries, whichever is larger (cutting
+    // finer than the spacing only adds entries): config-4 shape, 1 000 tracks, one entry per 300 bases: 30.8 -> 25.9 ms per
+    // 4 096 samples against the earlier 8 x mean length; config 3 (one per 3 000) keeps its bound.
+    uint64_t span = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      if (anno_off[l + 1] > anno_off[l]) span = std::max<uint64_t>(span, annos[anno_off[l + 1] - 1].end);
+    }
+    const uint64_t want = cnt > 0 ? std::max(bfac * (total_len / cnt), 2 * (span / cnt)) : 0;
+    uint32_t bound = 256;
+    while ((uint64_t)bound < want && bound < 32768u) bound <<= 1;
+    e.reserve((size_t)cnt + (size_t)cnt / 4);
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c;
+      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
+        uint32_t s0 = annos[i].start;
+        const uint32_t e0 = annos[i].end;
+        while (e0 - s0 > bound) { e.push_back(Ent{s0, s0 + bound, (uint32_t)t}); s0 += bound; }
+        e.push_back(Ent{s0, e0, (uint32_t)t});
+      }
+    }
+    std::sort(e.begin(), e.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
+    const size_t ne = e.size();
+    if (ne >= 0xfffffff0ull) { c_err[(size_t)c] = 1; return; }
+    const uint32_t max_start = ne ? e[ne - 1].s : 0u;
+    int64_t target = 64;
+    while (target < (int64_t)(ne / 2)) target <<= 1;                // about two entries per cell
+    int sh = 0;
+    while (((int64_t)max_start >> sh) + 1 > target) ++sh;
+    const int64_t cells = ((int64_t)max_start >> sh) + 1;
+    h_shift[(size_t)c] = sh;
+    h_cells[(size_t)c] = (int32_t)cells;
+    hf.resize((size_t)cells);
+    {
+      size_t k = 0;                                                 // first entry starting at or behind the cell's start
+      for (int64_t g = 0; g < cells; ++g) {
+        const uint64_t cs = (uint64_t)g << sh;
+        while (k < ne && (uint64_t)e[k].s < cs) ++k;
+        hf[(size_t)g] = (uint32_t)k;
+      }
+      for (size_t i = 0; i < ne; ++i) {                             // ... or an earlier one that reaches past it
+        for (int64_t g = ((int64_t)e[i].s >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].e; ++g)
+          if ((uint32_t)i < hf[(size_t)g]) hf[(size_t)g] = (uint32_t)i;
+      }
+    }
+    hz.reserve(ne + 3);
+    for (size_t i = 0; i < ne; ++i) hz.push_back(make_uint2(e[i].s, ((e[i].t & 0xffffu) << 16) | ((e[i].e - e[i].s) & 0xffffu)));
+    hz.push_back(make_uint2(0xffffffffu, 0u));                      // ends every scan
+    hz.push_back(make_uint2(0xffffffffu, 0u));                      // (entries are read in pairs)
+    if (hz.size() & 1) hz.push_back(make_uint2(0xffffffffu, 0u));   // ... and the next contig starts at an even index
+  };
+  parallel_for(n_groups, [&](int64_t c) { build_one((int)c); });
+  std::vector<uint2> hz;
+  std::vector<uint32_t> hf;
+  for (int c = 0; c < n_groups; ++c) {
+    if (c_err[(size_t)c]) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
+    hz.insert(hz.end(), cz[(size_t)c].begin(), cz[(size_t)c].end());
+    hf.insert(hf.end(), cf[(size_t)c].begin(), cf[(size_t)c].end());
+    hz_off[(size_t)c + 1] = (int64_t)hz.size();
+    hf_off[(size_t)c + 1] = (int64_t)hf.size();
+    std::vector<uint2>().swap(cz[(size_t)c]);
+    std::vector<uint32_t>().swap(cf[(size_t)c]);
+  }
+  HIPCHK(ctx, A.mz.upload(hz, ctx->stream));
+  HIPCHK(ctx, A.mfirst.upload(hf, ctx->stream));
+  HIPCHK(ctx, A.mz_off.upload(hz_off, ctx->stream));
+  HIPCHK(ctx, A.mf_off.upload(hf_off, ctx->stream));
+  HIPCHK(ctx, A.m_shift.upload(h_shift, ctx->stream));
+  HIPCHK(ctx, A.m_cells.upload(h_cells, ctx->stream));
+  {
+    // the groups dealt to the eight XCD slots of k_count_merged: largest first, each to the slot with the least so far
+    std::vector<std::pair<int64_t, int>> w;
+    for (int c = 0; c < n_groups; ++c) w.push_back(std::make_pair(hz_off[(size_t)c + 1] - hz_off[(size_t)c], c));
+    std::sort(w.begin(), w.end(), [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) {
+      return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    std::vector<std::vector<int32_t>> slots((size_t)gat::kMergedSlots);
+    std::vector<int64_t> load((size_t)gat::kMergedSlots, 0);
+    for (auto& x : w) {
+      size_t best = 0;
+      for (size_t k = 1; k < load.size(); ++k) if (load[k] < load[best]) best = k;
+      slots[best].push_back(x.second);
+      load[best] += x.first;
+    }
+    std::vector<int32_t> so((size_t)gat::kMergedSlots + 1, 0), sc;
+    A.max_slot_contigs = 0;
+    for (size_t k = 0; k < slots.size(); ++k) {
+      for (int32_t c : slots[k]) sc.push_back(c);
+      so[k + 1] = (int32_t)sc.size();
+      A.max_slot_contigs = std::max<int>(A.max_slot_contigs, (int)slots[k].size());
+    }
+    if (sc.empty()) sc.push_back(0);
+    HIPCHK(ctx, A.m_slot_off.upload(so, ctx->stream));
+    HIPCHK(ctx, A.m_slot_contigs.upload(sc, ctx->stream));
+  }
+  A.has_merged = true;
+  A.merged_entries = (int64_t)hz.size();
+  return GAT_OK;
+}
+
+int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists,
+                       int32_t n_groups) {
+  const int64_t total = anno_off[n_lists];
+  std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
+  A.h_off.assign(anno_off, anno_off + n_lists + 1);
+  A.max_m = 0;
+  A.total = total;
+  for (int64_t l = 0; l < n_lists; ++l) {
+    const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+    int rc = check_list(ctx, annos + o, m, "annotation", l);
+    if (rc) return rc;
+    A.max_m = std::max(A.max_m, m);
+  }
+  {
+    constexpr int64_t kBlock = 256;                                 // lists per task
+    parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
+      for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        uint32_t cum = 0;
+        for (int64_t i = 0; i < m; ++i) {
+          hs[(size_t)(o + i)] = annos[o + i].start;
+          he[(size_t)(o + i)] = annos[o + i].end;
+          hc[(size_t)(o + i)] = cum;
+          cum += annos[o + i].end - annos[o + i].start;
+        }
+      }
+    });
+  }
+  // per group (contig) a uniform grid over the start coordinates, about one start per cell:
+  // grid[g] = #starts < (g << shift); the count kernels look a position up instead of bisecting
+  const int64_t n_tracks = n_groups > 0 ? n_lists / n_groups : 0;
+  std::vector<int32_t> h_shift((size_t)std::max(1, n_groups), 0), h_cells((size_t)std::max(1, n_groups), 1);
+  std::vector<int64_t> h_goff((size_t)n_lists + 1, 0);
+  A.max_cells = 1;
+  for (int c = 0; c < n_groups; ++c) {
+    uint32_t max_start = 0;
+    int64_t mc = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {
+      const int64_t l = t * n_groups + c, o = anno_off[l], m = anno_off[l + 1] - o;
+      mc = std::max(mc, m);
+      if (m > 0) max_start = std::max(max_start, annos[o + m - 1].start);
+    }
+    int64_t target = 16;
+    while (target < mc) target <<= 1;
+    { const char* env_g = getenv("GAT_GRID_FACTOR"); target *= env_g ? atoi(env_g) : 2; }   // about one start per two cells (measured best of 1, 2, 4, 8)
+    int sh = 0;
+    while (((int64_t)max_start >> sh) + 1 > target) ++sh;
+    h_shift[(size_t)c] = sh;
+    h_cells[(size_t)c] = (int32_t)(((int64_t)max_start >> sh) + 1);
+    A.max_cells = std::max<int64_t>(A.max_cells, h_cells[(size_t)c]);
+  }
+  for (int64_t l = 0; l < n_lists; ++l) h_goff[(size_t)l + 1] = h_goff[(size_t)l] + h_cells[(size_t)(l % n_groups)] + 1;
+  std::vector<uint32_t> hg((size_t)h_goff[(size_t)n_lists]);
+  {
+    constexpr int64_t kBlock = 256;
+    parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
+      for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+        const int c = (int)(l % n_groups);
+        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
+        uint32_t* g = hg.data() + h_goff[(size_t)l];
+        int64_t k = 0;
+        for (int cell = 0; cell <= cells; ++cell) {
+          const uint64_t bound = (uint64_t)cell << sh;
+          while (k < m && (uint64_t)annos[o + k].start < bound) ++k;
+          g[cell] = (uint32_t)(cell == cells ? m : k);
+        }
+      }
+    });
+  }
+  HIPCHK(ctx, A.grid.upload(hg, ctx->stream));
+  HIPCHK(ctx, A.goff.upload(h_goff, ctx->stream));
+  HIPCHK(ctx, A.shift.upload(h_shift, ctx->stream));
+  HIPCHK(ctx, A.cells.upload(h_cells, ctx->stream));
+  HIPCHK(ctx, A.start.upload(hs, ctx->stream));
+  HIPCHK(ctx, A.end.upload(he, ctx->stream));
+  HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
+  HIPCHK(ctx, A.off.upload(A.h_off, ctx->stream));
+  // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
+  // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
+  // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
+  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
+  const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+  if (n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = build_merged(ctx, A, annos, anno_off, n_tracks, n_groups);
+    if (rc) return rc;
+    if (getenv("GAT_TIME_CREATE"))
+      fprintf(stderr, "[gat] build_merged %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side hoisted setup of one unit (gat/Engine.pyx:543-565)
+static uint32_t host_overlap(const gat_segment* w, int64_t nw, uint32_t s, uint32_t e) {
+  // bases of [s,e) inside the normalized list w
+  uint32_t ov = 0;
+  const gat_segment* it = std::lower_bound(w, w + nw, s, [](const gat_segment& a, uint32_t v) { return a.end <= v; });
+  for (; it != w + nw && it->start < e; ++it) ov += std::min(e, it->end) - std::max(s, it->start);
+  return ov;
+}
+
+static int32_t cap_for(int64_t n) {
+  int64_t c = n + n / 4 + 96;
+  if (getenv("GAT_TEST_SMALL_CAPS")) c = n / 2 + 8;      // tests: force the overflow / retry path
+  c = (c + 63) / 64 * 64;
+  return (int32_t)c;
+}
+
+int layout_slab(gat_problem* P) {
+  // regions in contig-major order so that a contig's units are adjacent (k_contig output region)
+  int64_t off = 0;
+  P->max_unit_cap = 0;
+  P->max_contig_cap = 0;
+  for (int c = 0; c < P->n_contigs; ++c) {
+    P->h_contig_slab_off[c] = (int32_t)off;
+    int64_t ccap = 0;
+    for (int ui = P->h_contig_unit_off[c]; ui < P->h_contig_unit_off[c + 1]; ++ui) {
+      const int u = P->h_contig_units[ui];
+      UnitDev& U = P->h_units[u];
+      const int64_t cap = (int64_t)P->h_base_cap[u] * P->cap_scale;
+      U.slab_off = (int32_t)off;
+      U.slab_cap = (int32_t)cap;
+      off += cap;
+      ccap += cap;
+      P->max_unit_cap = std::max<int32_t>(P->max_unit_cap, (int32_t)cap);
+    }
+    P->max_contig_cap = std::max<int32_t>(P->max_contig_cap, (int32_t)ccap);
+    if (!P->merge_contigs) {
+      const int u = P->h_contig_units[P->h_contig_unit_off[c]];
+      P->h_count_c_off[c] = P->h_units[u].slab_off;
+      P->h_count_n_index[c] = u;
+    } else {
+      P->h_count_c_off[c] = P->h_contig_slab_off[c];
+      P->h_count_n_index[c] = c;
+    }
+  }
+  if (off >= (int64_t)1 << 31) return GAT_ERR_CAPACITY;
+  P->slab_stride = off > 0 ? off : 1;
+  {
+    // what a contig's list is expected to need in k_contig: its units' segments + a quarter (a unit's capacity adds 96
+    // slots of slack per unit: eight isochore units of fifty segments have 1 536 slots for ~400 segments)
+    P->h_contig_need.assign((size_t)P->n_contigs, 64);
+    for (int c = 0; c < P->n_contigs; ++c) {
+      int64_t need = 0, ccap = 0;
+      for (int ui = P->h_contig_unit_off[c]; ui < P->h_contig_unit_off[c + 1]; ++ui) {
+        const int u = P->h_contig_units[ui];
+        const int64_t n = (int64_t)P->h_units[u].hist_total;
+        need += n + n / 4;
+        ccap += P->h_units[u].slab_cap;
+      }
+      need = (need + 64 + 63) / 64 * 64;
+      if (getenv("GAT_TEST_SMALL_CAPS")) need = std::max<int64_t>(64, need / 4 / 64 * 64);      // tests: force the repeat
+      P->h_contig_need[c] = (int32_t)std::min<int64_t>(P->contig_tight ? need : ccap, std::max<int64_t>(64, ccap));
+    }
+    P->h_contig_order.resize((size_t)P->n_contigs);
+    for (int c = 0; c < P->n_contigs; ++c) P->h_contig_order[c] = c;
+    std::stable_sort(P->h_contig_order.begin(), P->h_contig_order.end(),
+                     [&](int32_t x, int32_t y) { return P->h_contig_need[x] > P->h_contig_need[y]; });
+    P->h_contig_class_start.clear();
+    int32_t first = 0;
+    for (int i = 0; i < P->n_contigs; ++i) {
+      const int32_t need = P->h_contig_need[P->h_contig_order[i]];
+      if (i == 0 || ((int64_t)need * 10 <= (int64_t)first * 7 && P->h_contig_class_start.size() < 6)) {
+        P->h_contig_class_start.push_back(i);
+        first = need;
+      }
+    }
+    P->h_contig_class_start.push_back(P->n_contigs);
+  }
+  return GAT_OK;
+}
+
+int upload_layout(gat_ctx* ctx, gat_problem* P) {
+  HIPCHK(ctx, P->d_units.upload(P->h_units, ctx->stream));
+  {
+    // a wave finds its unit with one load (units_o[blockIdx.y]) instead of order[] -> units[]
+    std::vector<UnitDev> o;
+    o.reserve(P->h_order.size());
+    for (int32_t u : P->h_order) { UnitDev x = P->h_units[(size_t)u]; x.pad = u; o.push_back(x); }
+    if (o.empty()) o.push_back(UnitDev{});
+    HIPCHK(ctx, P->d_units_o.upload(o, ctx->stream));
+  }
+  {
+    // size classes of the launch order (largest unit first, capacities do not grow): a new class where the capacity has
+    // dropped to 70 % of the class's first, at most six.  The wave-per-unit kernels keep a unit's list in LDS, their
+    // speed follows the waves a CU holds, and the dynamic LDS of a launch is one number: sized for the longest list of
+    // the PROBLEM, the config-4 shape ran ONE wave per CU (81 KB for chr1's 8 000 segments, 13 KB for chr21's).
+    P->h_class_start.clear();
+    const int N = (int)P->h_order.size();
+    int32_t first_cap = 0;
+    const char* env_c = getenv("GAT_SIZE_CLASSES");
+    const int max_classes = env_c ? std::max(1, atoi(env_c)) : 6;
+    for (int i = 0; i < N; ++i) {
+      const int32_t cap = P->h_units[(size_t)P->h_order[(size_t)i]].slab_cap;
+      if (i == 0 || ((int64_t)cap * 10 <= (int64_t)first_cap * 7 && (int)P->h_class_start.size() < max_classes)) {
+        P->h_class_start.push_back(i);
+        first_cap = cap;
+      }
+    }
+    P->h_class_start.push_back(N);
+  }
+  HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
+  {
+    std::vector<int32_t> o = P->h_contig_order;
+    if (o.empty()) o.push_back(0);
+    HIPCHK(ctx, P->d_contig_order.upload(o, ctx->stream));
+  }
+  HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
+  HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx->stream));
+  P->batch = 0;   // scratch must be re-sized
+  return GAT_OK;
+}
+
+extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_problem** out) {
+  if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (d->n_units < 0 || d->n_contigs < 0 || d->n_tracks < 0 || d->nbuckets <= 0)
+    return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: negative size / nbuckets <= 0");
+  std::unique_ptr<gat_problem> P(new gat_problem());
+  P->ctx = ctx;
+  P->n_units = d->n_units;
+  P->n_contigs = d->n_contigs;
+  P->n_tracks = d->n_tracks;
+  P->merge_contigs = d->merge_contigs ? 1 : 0;
+  if (d->sampler != GAT_SAMPLER_ANNOTATOR && d->sampler != GAT_SAMPLER_SEGMENTS)
+    return set_err(ctx, GAT_ERR_ARG, "unknown sampler %d", d->sampler);
+  P->sampler = d->sampler;
+  P->h_units.resize((size_t)d->n_units);
+  P->h_base_cap.assign((size_t)d->n_units, 0);
+  P->h_cws_nseg.assign(d->cws_nseg, d->cws_nseg + d->n_contigs);
+
+  std::vector<uint2> h_ws;
+  std::vector<uint32_t> h_ws_cdf, h_rank_len, h_ws_tree;
+  std::vector<std::pair<int64_t, int32_t>> work;   // (working segments, unit)
+  std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
+  std::vector<double> len_cv2((size_t)std::max(1, d->n_units), 0.0);
+
+  for (int u = 0; u < d->n_units; ++u) {
+    UnitDev& U = P->h_units[u];
+    memset(&U, 0, sizeof(U));
+    const gat_segment* us = d->segs + d->seg_off[u];
+    const int64_t nus = d->seg_off[u + 1] - d->seg_off[u];
+    const gat_segment* uw = d->ws + d->ws_off[u];
+    const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+    const int c = d->unit_contig[u];
+    U.contig = c;
+    P->n_seg_total += nus;
+    const bool skipped = (nus == 0 || nuw == 0);     // gat/__init__.py:536-538
+    if (c >= d->n_contigs || (c < 0 && !skipped))
+      return set_err(ctx, GAT_ERR_ARG, "unit %d: contig index %d invalid (skipped units carry -1)", u, c);
+    if (skipped) continue;
+    if (c < 0) return set_err(ctx, GAT_ERR_ARG, "unit %d is not skipped by computeSample but has contig -1", u);
+    per_contig[(size_t)c].push_back(u);
+    int rc;
+    if ((rc = check_list(ctx, us, nus, "segment", u))) return rc;     // gat/Engine.pyx:535
+    if ((rc = check_list(ctx, uw, nuw, "workspace", u))) return rc;   // gat/Engine.pyx:536
+    // working = segments.filter(workspace); ltotal = working.intersect(workspace).sum()
+    uint32_t ltotal = 0, maxlen = 0;
+    int64_t nwork = 0;
+    std::vector<uint32_t> lens;
+    lens.reserve((size_t)nus);
+    for (int64_t i = 0; i < nus; ++i) {
+      const uint32_t ov = host_overlap(uw, nuw, us[i].start, us[i].end);
+      if (ov == 0) continue;
+      ltotal += ov;
+      const uint32_t l = us[i].end - us[i].start;
+      lens.push_back(l);
+      maxlen = std::max(maxlen, l);
+      nwork++;
+    }
+    if (nwork == 0) continue;          // sample() returns an empty list, no RNG use (gat/Engine.pyx:545-546)
+    // getLengthDistribution (gat/SegmentList.pyx:1148-1184)
+    int64_t bucket = d->bucket_size;
+    if (bucket == 0) bucket = (int64_t)std::ceil((double)(int32_t)maxlen / (double)d->nbuckets);
+    std::map<uint32_t, uint32_t> hist;
+    for (uint32_t l : lens) {
+      const int64_t i = ((int64_t)l + bucket - 1) / bucket;
+      if (i >= d->nbuckets)
+        return set_err(ctx, GAT_ERR_VALUE, "unit %d: segment of length %u too large: increase nbuckets (%d) or bucket_size (%lld)",
+                       u, l, d->nbuckets, (long long)bucket);
+      hist[(uint32_t)i] += 1;
+    }
+    uint32_t cum = 0;
+    U.rank_off = (int32_t)h_rank_len.size();
+    h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
+    for (auto& kv : hist) {
+      cum += kv.second;
+      for (uint32_t q = 0; q < kv.second; ++q) h_rank_len.push_back(kv.first);   // ranks (cum-count, cum]
+    }
+    U.hist_total = cum;
+    U.bucket = (uint32_t)bucket;
+    {
+      double m1 = 0, m2 = 0;                               // squared coefficient of variation of the lengths drawn
+      for (uint32_t l : lens) { m1 += (double)l; m2 += (double)l * (double)l; }
+      m1 /= (double)lens.size(); m2 /= (double)lens.size();
+      len_cv2[(size_t)u] = m1 > 0 ? std::max(0.0, m2 / (m1 * m1) - 1.0) : 0.0;
+    }
+    // SegmentListSampler(workspace) (gat/Engine.pyx:261-277)
+    U.n_ws = (int32_t)nuw;
+    U.ws_off = (int32_t)h_ws.size();
+    uint32_t tot = 0;
+    for (int64_t i = 0; i < nuw; ++i) {
+      tot += uw[i].end - uw[i].start;
+      h_ws.push_back(make_uint2(uw[i].start, uw[i].end));
+      h_ws_cdf.push_back(tot - 1u);
+    }
+    U.ws_total = tot;
+    // long workspaces: 16-ary search trees (gat_device.h, WsTree) over the starts and over the cumulated lengths
+    U.tree_start_off = -1;
+    U.tree_cdf_off = -1;
+    if (nuw > ((int64_t)1 << (4 * gat::kWsTreeLevels)))
+      return set_err(ctx, GAT_ERR_CAPACITY, "unit %d: %lld workspace segments (> %lld)", u, (long long)nuw,
+                     (long long)((int64_t)1 << (4 * gat::kWsTreeLevels)));
+    if (nuw > gat::kWsTreeMin) {
+      auto build = [&](auto key, uint32_t pad) {
+        const int32_t off = (int32_t)h_ws_tree.size();
+        std::vector<uint32_t> level((size_t)nuw);
+        for (int64_t i = 0; i < nuw; ++i) level[(size_t)i] = key(i);
+        for (;;) {
+          const size_t n = level.size(), nodes = (n + 15) / 16;
+          h_ws_tree.insert(h_ws_tree.end(), level.begin(), level.end());
+          h_ws_tree.insert(h_ws_tree.end(), nodes * 16 - n, pad);
+          if (n <= 16) break;
+          std::vector<uint32_t> up(nodes);
+          for (size_t j = 0; j < nodes; ++j) up[j] = level[std::min(16 * j + 15, n - 1)];   // largest key of node j
+          level.swap(up);
+        }
+        return off;
+      };
+      U.tree_start_off = build([&](int64_t i) { return uw[i].start; }, 0xffffffffu);
+      const size_t base = h_ws_cdf.size() - (size_t)nuw;
+      U.tree_cdf_off = build([&](int64_t i) { return h_ws_cdf[base + (size_t)i]; }, 0x7fffffffu);
+    }
+    U.ltotal = (int32_t)ltotal;
+    U.n_target = (int32_t)nus;                       // SamplerSegments places len(segments) segments
+    P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(nwork, nus) : nwork);
+    work.push_back(std::make_pair(nwork, (int32_t)u));
+  }
+  // contig -> units (reference order)
+  P->h_contig_unit_off.assign((size_t)d->n_contigs + 1, 0);
+  for (int c = 0; c < d->n_contigs; ++c) {
+    if (per_contig[(size_t)c].empty())
+      return set_err(ctx, GAT_ERR_ARG, "contig %d has no unit: contigs must be those of the non-skipped units", c);
+    if (!P->merge_contigs && per_contig[(size_t)c].size() != 1)
+      return set_err(ctx, GAT_ERR_ARG, "contig %d has %zu units but keys carry no isochore (merge_contigs=0)", c, per_contig[(size_t)c].size());
+    for (int32_t u : per_contig[(size_t)c]) P->h_contig_units.push_back(u);
+    P->h_contig_unit_off[(size_t)c + 1] = (int32_t)P->h_contig_units.size();
+  }
+  std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int32_t>& a, const std::pair<int64_t, int32_t>& b) {
+    return a.first != b.first ? a.first > b.first : a.second < b.second;
+  });
+  for (auto& w : work) P->h_order.push_back(w.second);
+  P->all_simple = !P->h_order.empty();
+  uint32_t max_hist = 0;
+  for (int32_t u : P->h_order) {
+    const UnitDev& U = P->h_units[(size_t)u];
+    const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
+    const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
+    if (!degenerate && !simple) P->all_simple = false;
+    P->max_nws = std::max(P->max_nws, U.n_ws);
+    max_hist = std::max(max_hist, U.hist_total);
+  }
+  P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
+  P->long_lists = max_hist + max_hist / 8 > 1024;
+  P->max_hist = max_hist;
+  {
+    // the split path pays when k_tail can take most units: SamplerAnnotator, lists the wave bucket sorts hold, workspaces
+    // of up to kTailMaxWs segments
+    size_t small_ws = 0;
+    for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs) ++small_ws;
+    // (long lists: their tail places dozens of segments, not the handful k_tail keeps aside -- 0.2 % finished there on the
+    //  config-4 shape -- so those problems stay with k_merge_big + k_sampler)
+    P->split_path = P->sampler == GAT_SAMPLER_ANNOTATOR && !P->h_order.empty() && 2 * small_ws >= P->h_order.size() &&
+                    max_hist + max_hist / 8 <= 1024 && !getenv("GAT_NO_SPLIT");
+  }
+  // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
+  // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
+  // are redone by k_sampler from their seed.
+  {
+    const char* env = getenv("GAT_SAMPLER_MODE");
+    if (env && !strcmp(env, "wave")) P->sampler_mode = 0;
+    auto expect = [](uint64_t range) {
+      if (range == 0) return 0.0;
+      uint64_t m = range; m |= m >> 1; m |= m >> 2; m |= m >> 4; m |= m >> 8; m |= m >> 16; m |= m >> 32;
+      return (double)(m + 1) / (double)(range + 1);
+    };
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[u];
+      // offset draw: range = chosen workspace segment + sampled length - 2, weighted by how often a segment
+      // is chosen (its share of the workspace) and taken at the mean working-segment length
+      const gat_segment* uw = d->ws + d->ws_off[u];
+      const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+      const double mean_len = U.hist_total ? (double)(uint32_t)U.ltotal / (double)U.hist_total : 1.0;
+      double e = 0.0, v = 0.0;
+      for (int64_t k = 0; k < nuw; ++k) {
+        const double wl = (double)(uw[k].end - uw[k].start);
+        const double p = expect((uint64_t)(wl + mean_len)) ;
+        e += wl / (double)U.ws_total * p;
+      }
+      auto addvar = [&](double ex) { if (ex > 0) v += (ex - 1.0) * ex; };   // geometric: var = (1-p)/p^2 = ex(ex-1)
+      addvar(e);
+      if (U.hist_total > 2) { const double x = expect((uint64_t)U.hist_total - 2); e += x; addvar(x); }
+      if (U.bucket > 1) { const double x = expect((uint64_t)U.bucket - 1); e += x; addvar(x); }
+      if (U.ws_total > 1) { const double x = expect((uint64_t)U.ws_total - 1); e += x; addvar(x); }
+      const char* env_sl = getenv("GAT_RNG_SLACK");
+      const double slack = env_sl ? atof(env_sl) : 1.0;
+      // Spread of the raw-output count of a stream: the NUMBER of placements until the unit's bases are reproduced varies
+      // by cv(length) x sqrt(n) (a renewal count) and every placement costs e outputs -- that term dominates (measured on
+      // config 2: 97 / 116 / 58 outputs for units of 778 / 444 / 166 segments = e x cv x sqrt(n)) -- plus the rejection
+      // noise v per placement.  5 to 7.5 sigma and the tail's few dozen outputs: a stream that runs out is redone from its seed
+      // by ONE wave, placement by placement, and such a straggler (0.5 ms) is now longer than the rest of the sampler.
+      const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
+      const double var_n = P->sampler == GAT_SAMPLER_SEGMENTS ? 0.0 : len_cv2[(size_t)u] * e * e;
+      // (the multiple follows what running out costs: ONE wave redoing the unit placement by placement -- 0.5 ms for 800
+      //  segments, a few dozen us for 50, where five sigma are plenty and the rows saved are a sixth of k_rng's work)
+      const double sigmas = std::min(7.5, std::max(5.0, 4.5 + nplace / 130.0));
+      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + 96.0;
+      int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
+      rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
+      P->h_rng_rows.push_back((int32_t)rows);
+      P->rng_rows_total += rows;
+    }
+  }
+  P->h_contig_slab_off.assign((size_t)d->n_contigs, 0);
+  P->h_count_c_off.assign((size_t)d->n_contigs, 0);
+  P->h_count_n_index.assign((size_t)d->n_contigs, 0);
+  if (layout_slab(P.get())) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
+
+  HIPCHK(ctx, P->d_order.upload(P->h_order, ctx->stream));
+  {
+    std::vector<int32_t> pos((size_t)std::max(1, d->n_units), -1);
+    for (size_t a = 0; a < P->h_order.size(); ++a) pos[(size_t)P->h_order[a]] = (int32_t)a;
+    HIPCHK(ctx, P->d_unit_pos.upload(pos, ctx->stream));
+  }
+  HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx->stream));
+  HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx->stream));
+  HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
+  HIPCHK(ctx, P->d_ws.upload(h_ws, ctx->stream));
+  HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx->stream));
+  if (h_ws_tree.empty()) h_ws_tree.assign(16, 0u);
+  HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx->stream));
+  HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx->stream));
+  HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
+  int rc = upload_layout(ctx, P.get());
+  if (rc) return rc;
+  const auto t_annos = std::chrono::steady_clock::now();
+  rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs);
+  if (getenv("GAT_TIME_CREATE"))
+    fprintf(stderr, "[gat] build_annos (incl. build_merged) %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_annos).count());
+  if (rc) return rc;
+  {
+    // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
+    const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
+    const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->annos.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
+    const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
+    const size_t lds_need = (size_t)3 * capx * 4 + (8192 + 1) * 4;
+    (void)lds_need; (void)capx;
+    if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
+  }
+  HIPCHK(ctx, P->d_flags.alloc(1));
+  HIPCHK(ctx, P->d_stat.alloc(8));
+  *out = P.release();
+  return GAT_OK;
+}
+
+extern "C" void gat_problem_destroy(gat_problem* p) {
+  if (!p) return;
+  if (p->ctx) (void)hipSetDevice(p->ctx->device);
+  delete p;
+}
+
+extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,
+                                int64_t* slab, int64_t* bytes) {
+  if (!p) return set_err(nullptr, GAT_ERR_ARG, "NULL problem");
+  if (n_units) *n_units = p->n_units;
+  if (n_contigs) *n_contigs = p->n_contigs;
+  if (n_tracks) *n_tracks = p->n_tracks;
+  if (slab) *slab = p->slab_stride;
+  // B_sample = 8*sum n' + 8*sum_a sum_c m + 8*A, with n' ~ n input segments
+  if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->annos.total + 8 * (int64_t)p->n_tracks;
+  return GAT_OK;
+}

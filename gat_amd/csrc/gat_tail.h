@@ -31,7 +31,7 @@
 namespace gat {
 
 constexpr int kTailMaxExtra = 4;      // new segments k_tail keeps aside per unit
-constexpr int kTailMaxWs = 64;        // workspace segments k_tail scans linearly (wave-uniform loop)
+// (kTailMaxWs = 64 workspace segments k_tail scans linearly: gat_types.h)
 constexpr int kTailMaxWalk = 6;       // segments an overshoot trim may touch
 constexpr int kTailRows = 8;          // random rows fetched at a time
 

@@ -1,0 +1,47 @@
+// gat_types.h -- the records and constants the host side of libgat_mi355.so shares with the kernels: what a host
+// translation unit that launches nothing (gat_prep.hip: problem creation, annotation tables) needs to know, without the
+// kernels themselves.  Included by gat_device.h / gat_kernels.h / gat_tail.h, which own everything else.
+#pragma once
+#include <stdint.h>
+
+namespace gat {
+
+constexpr int kWave = 64;
+constexpr int kMtN = 624;
+
+constexpr int kWsTreeMin = 32;      // workspaces with more segments get trees (the shorter ones are searched in registers)
+constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so that the geometry stays in scalar registers
+
+constexpr int kPlaceWsLds = 256;      // k_place: workspace segments kept in LDS (16 B each)
+constexpr int kPlaceRankLds = 1024;   // k_place: length-rank table entries kept in LDS
+constexpr int kTailMaxWs = 64;        // workspace segments k_tail scans linearly (wave-uniform loop)
+constexpr int kMergedSlots = 8;       // k_count_merged: contigs are dealt to this many slots (blockIdx % 8: the XCD stride)
+
+// per isochore unit, everything SamplerAnnotator.sample derives from (segments, workspace) before
+// its loop (gat/Engine.pyx:543-565), hoisted to problem creation.
+struct UnitDev {
+  int32_t n_ws;         // workspace segments of the unit
+  int32_t ws_off;       // offset into ws / ws_cdf
+  int32_t tree_start_off;  // offset into ws_tree of the search tree over the workspace starts (-1: short workspace)
+  int32_t tree_cdf_off;    // ... over the cumulated lengths
+  uint32_t hist_total;  // HistogramSampler.total_size == number of working segments
+  uint32_t bucket;      // bucket size (after the bucket_size==0 rule, gat/SegmentList.pyx:1164)
+  uint32_t ws_total;    // SegmentListSampler.total_size == workspace bases
+  int32_t ltotal;       // bases to reproduce (gat/Engine.pyx:550-552)
+  int32_t slab_off;     // offset of the unit's output region inside a sample's slab
+  int32_t slab_cap;     // capacity of that region == LDS buffer capacity used for the unit
+  int32_t contig;
+  int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
+  int32_t n_target;     // SamplerSegments: len(segments) placements (gat/Engine.pyx:726)
+  int32_t pad;          // units_o: the unit id
+};
+
+enum : int32_t {
+  kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab
+  kStatusAssert = 2,     // reference assert would fire (gat/Engine.pyx:645 sum()>0)
+  kStatusTrimAssert = 4, // gat/SegmentList.pyx:560 sum() > size
+  kStatusContigLds = 8,  // k_contig: a contig's lists exceed the LDS the launch was given (sized for what is expected,
+                         // not for every unit at its capacity): host repeats the batch with the full size
+};
+
+}  // namespace gat

@@ -6,7 +6,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 TAG=$1; shift
 OUT=$R/gpurun_out/diag_$TAG; mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -pthread -fPIC -shared -DGAT_DIAG -o $OUT/libgat_mi355_diag.so gat_amd/csrc/gat_mi355.hip || exit 1
+make -C gat_amd/csrc -s -j2 EXTRA=-DGAT_DIAG BUILD=$OUT/build OUT=$OUT/libgat_mi355_diag.so || exit 1
 rm -f $OUT/phases.jsonl
 GAT_LIB_PATH=$OUT/libgat_mi355_diag.so GAT_DIAG_OUT=$OUT/phases.jsonl python3 bench.py --no-cpu-baseline --extra "" --steps 2 --warmup 1 "$@" > $OUT/bench.log 2>&1
 python3 - $OUT/phases.jsonl <<'PY'

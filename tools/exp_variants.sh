@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/exp; mkdir -p $OUT
 i=0
 for flags in "$@"; do
   i=$((i+1))
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -pthread -fPIC -shared $flags -o $OUT/lib_$i.so gat_amd/csrc/gat_mi355.hip || exit 1
+  make -C gat_amd/csrc -s -j2 EXTRA="$flags" BUILD=$OUT/build_$i OUT=$OUT/lib_$i.so || exit 1
   GAT_LIB_PATH=$OUT/lib_$i.so python3 bench.py --no-cpu-baseline --extra "${EXP_EXTRA:-}" --steps 5 --warmup 2 > $OUT/bench_$i.json 2>$OUT/err_$i.log
   echo "== $flags"; python3 tools/show_bench.py $OUT/bench_$i.json
 done
