@@ -11,7 +11,7 @@ from . import intervals, problem, synthetic            # noqa: F401
 from . import io as IO                                   # noqa: F401
 from . import stats as Stats                             # noqa: F401
 from .engine import (SegmentList, PositionList, IntervalDictionary, IntervalCollection, Sampler, SamplerAnnotator, SamplerSegments,  # noqa: F401
-                     Counter, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
+                     Counter, computeCountsAll, overlap_sizes, CounterNucleotideOverlap, CounterNucleotideDensity, CounterSegmentOverlap,
                      CounterSegmentMidpointOverlap, CounterAnnotationOverlap, CounterAnnotationMidpointOverlap,
                      UnconditionalWorkspace, ConditionalWorkspaceCooccurance, ConditionalWorkspaceCentered,
                      ConditionalWorkspaceAnnotationCentered, ConditionalWorkspaceSegmentCentered, computeCounts, AnnotatorResult, AnnotatorResultExtended,
@@ -43,18 +43,77 @@ def _dist_state():
     return 0, 1, None
 
 
+_NUMPY_MODEL_OK = None
+
+
+def _numpy_summation_model_holds():
+    """gat_null_stats restates the order in which numpy.mean / numpy.std add up a contiguous float64 array (gat_stats.h:
+    chunks of 8 192 elements, each summed pairwise down to blocks of at most 128 with eight running sums, the chunk sums
+    added left to right).  That order belongs to the numpy at hand, not to the reference: it is checked once per process
+    on arrays whose sums depend on it, and a numpy that adds differently gets its statistics from numpy itself."""
+    global _NUMPY_MODEL_OK
+    if _NUMPY_MODEL_OK is not None:
+        return _NUMPY_MODEL_OK
+
+    def block(a):                                   # n <= 128
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for x in a:
+                r = r + x
+            return r
+        r = list(a[:8])
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = r[j] + a[i + j]
+            i += 8
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        while i < n:
+            res = res + a[i]
+            i += 1
+        return res
+
+    def pairwise(a):
+        if len(a) <= 128:
+            return block(a)
+        n2 = len(a) // 2
+        n2 -= n2 % 8
+        return pairwise(a[:n2]) + pairwise(a[n2:])
+
+    ok = True
+    rs = np.random.RandomState(20261002)
+    for n in (7, 100, 1000, 8192 + 331):
+        a = rs.random_sample(n) * 1e5
+        al = a.tolist()
+        total = None
+        for i in range(0, n, 8192):
+            p = pairwise(al[i:i + 8192])
+            total = p if total is None else total + p
+        m = total / n
+        dev = [(x - m) * (x - m) for x in al]
+        total = None
+        for i in range(0, n, 8192):
+            p = pairwise(dev[i:i + 8192])
+            total = p if total is None else total + p
+        ok = ok and m == float(np.mean(a)) and float(np.sqrt(total / n)) == float(np.std(a))
+    _NUMPY_MODEL_OK = bool(ok)
+    return _NUMPY_MODEL_OK
+
+
 def _device_stats_wanted(n_values):
-    """null-distribution statistics on the device (gat_null_stats) for large count matrices: the host needs about 2 ms
-    per row of 100 000 samples.  GAT_DEVICE_STATS=1 / 0 forces / forbids it."""
+    """null-distribution statistics on the device (gat_null_stats) whenever the count matrix is there anyway: the host
+    needs 0.1 ms (10 000 samples) to 2 ms (100 000) per row for them.  GAT_DEVICE_STATS=1 / 0 forces / forbids it;
+    otherwise it is used when this numpy sums the way the kernel restates (_numpy_summation_model_holds)."""
     import os
     env = os.environ.get("GAT_DEVICE_STATS")
     if env is not None:
         return env not in ("0", "")
-    return n_values >= 2000000
+    return n_values > 0 and _numpy_summation_model_holds()
 
 
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
-                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None, mt_state=None):
+                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None, mt_state=None, _aflat=None):
     """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
 
     segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
@@ -84,13 +143,16 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
     tracks = list(annotations.tracks) if only_tracks is None else list(only_tracks)
     count_workspace = None
     if workspace_generator is not None and type(workspace_generator) is not UnconditionalWorkspace:
-        count_workspace = workspace.asArrays()
+        count_workspace = workspace
         annos = annotations[tracks[0]] if only_tracks is not None else None
         segs, _, workspace = workspace_generator(segs, annos, workspace)
-    flat = problem.flatten_units(segs.asArrays(), workspace.asArrays(),
-                                 [(t, annotations[t].asArrays()) for t in tracks],
-                                 getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000),
-                                 count_workspace=count_workspace)
+    bucket_size, nbuckets = getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000)
+    flat = problem.flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size, nbuckets, count_workspace=count_workspace,
+                                        _aflat=_aflat if only_tracks is None else None)
+    if flat is None:
+        flat = problem.flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) for t in tracks],
+                                     bucket_size, nbuckets,
+                                     count_workspace=None if count_workspace is None else count_workspace.asArrays())
     flat["sampler"] = getattr(sampler, "kind", 0)
     names = [c.name for c in counters]
     if flat["n_contigs"] == 0:
@@ -123,12 +185,16 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
             import torch
             per = distributed.padded_shard(num_samples, world)
             dev = torch.device("cuda", ctx.device)
+            # (the context runs on a stream of its own: what torch enqueues -- the fills, the collective, the re-ordering of the
+            #  gathered blocks -- is ordered against it by hand, both ways)
             shard = torch.zeros((len(names), len(tracks), end - begin), dtype=torch.int64, device=dev)
-            P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())
+            torch.cuda.current_stream(dev).synchronize()              # the fill has landed before the kernels write
+            P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())   # (returns after its stream has drained)
             stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
             stack_t[:, :, :end - begin] = shard
             full_t = distributed.allgather_counts(stack_t, num_samples)
             if want_stats:
+                torch.cuda.current_stream(dev).synchronize()          # gathered and re-ordered before k_null_stats reads
                 stats = device_stats(full_t.data_ptr())
             full = full_t.cpu().numpy()
             local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
@@ -139,11 +205,11 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
             try:
                 P.sample_and_count_device(names, seed, 0, num_samples, dev)
                 stats = device_stats(dev)
-                host = np.zeros((len(names), len(tracks), num_samples), dtype=np.int64)
+                host = np.empty((len(names), len(tracks), num_samples), dtype=np.int64)
                 ctx.d2h(host, dev)
             finally:
                 ctx.free(dev)
-            local = [host[k].view(np.float64).copy() if n == "nucleotide-density" else host[k].copy() for k, n in enumerate(names)]
+            local = [host[k].view(np.float64) if n == "nucleotide-density" else host[k] for k, n in enumerate(names)]
         else:
             local = P.sample_and_count(names, seed, begin, end)
             if world > 1:
@@ -210,8 +276,9 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
         from . import _lib
         mt_state = _lib.mt19937_seed(seed)
 
-    observed_counts = [computeCounts(counter=c, aggregator=sum, segments=segments, annotations=annotations,
-                                     workspace=workspace, workspace_generator=workspace_generator) for c in counters]
+    observed_counts = computeCountsAll(counters, sum, segments, annotations, workspace, workspace_generator)
+    # the annotations as one array (IntervalCollection._flat), looked over once for the whole run
+    aflat = annotations._flat(list(annotations.tracks)) if len(annotations) else None
     sampled_counts = {}
     for track in segments.tracks:
         outf = None
@@ -244,7 +311,7 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                     stat_vals[c.name][annotation] = v
             r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
                                        samples_outfile=outf, workspace_generator=workspace_generator, stat_vals=stat_vals,
-                                       mt_state=mt_state)
+                                       mt_state=mt_state, _aflat=aflat)
             seed = (seed + num_samples * n_units) & 0xFFFFFFFF    # next track: disjoint unit streams
         if outf:
             outf.close()
@@ -255,6 +322,10 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     annotator_results = []
     sizes = {}                       # (counts, sum) per dictionary object: the same track / workspace recur in every row
     keep = []                        # ... and the objects stay alive so that their ids stay theirs
+    overlaps = {}                    # the intersections' sizes, every annotation of a segment track in one call
+    if type(workspace_generator) is UnconditionalWorkspace:      # (the rows see the dictionaries themselves)
+        for track in sampled_counts:
+            overlaps[track] = overlap_sizes(segments[track], annotations, _aflat=aflat)
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
         for track, r in observed_count.items():
             if track not in sampled_counts:
@@ -273,7 +344,8 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
                     samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
                     annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
                     pseudo_count=pseudo_count, _sizes=sizes,
-                    _stats=dev_stats[counter_id][annotation] if dev_stats else None))
+                    _stats=dev_stats[counter_id][annotation] if dev_stats else None,
+                    _overlap=overlaps[track].get(annotation) if overlaps.get(track) else None))
     if output_counts_pattern and rank == 0:               # (every rank holds the gathered matrix: one writer)
         for counter in counters:
             with open(re.sub("%s", counter.name, output_counts_pattern), "w") as outfile:

@@ -28,7 +28,7 @@ SYMBOLS = [
     "gat_ctx_create", "gat_ctx_destroy", "gat_last_error", "gat_version", "gat_ctx_synchronize",
     "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
-    "gat_count_lists", "gat_problem_info",
+    "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed",
 ]
@@ -67,6 +67,9 @@ class ProblemDesc(C.Structure):
         ("bucket_size", C.c_uint32),
         ("nbuckets", C.c_int32),
         ("sampler", C.c_int32),
+        ("n_anno_lists", C.c_int64),
+        ("anno_end", C.c_void_p),
+        ("anno_group", C.c_void_p),
     ]
 
 
@@ -92,6 +95,8 @@ class Stats(C.Structure):
         ("ms_finalize", C.c_float),
         ("n_tail_units", C.c_int64),
         ("lists_from_records", C.c_int64),
+        ("n_index_entries", C.c_int64),
+        ("n_index_lookups", C.c_int64),
     ]
 
     def asdict(self):
@@ -145,6 +150,10 @@ def lib():
     L.gat_sample_units.argtypes = [vp, vp, u32, i64, i64, vp, i64, vp, C.POINTER(Stats)]
     L.gat_count_lists.restype = C.c_int
     L.gat_count_lists.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, i32, vp, i32, vp]
+    L.gat_count_list_ranges.restype = C.c_int
+    L.gat_count_list_ranges.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, vp, i32, vp, i32, vp]
+    L.gat_intersection_sizes.restype = C.c_int
+    L.gat_intersection_sizes.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
     L.gat_problem_info.restype = C.c_int
     L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.gat_null_stats.restype = C.c_int
@@ -223,8 +232,9 @@ class Context(object):
         out[:, 1] = np.sqrt(out[:, 1] / l)                # numpy.std's last two steps (sum of squares from the device)
         return out
 
-    def count_lists(self, counters, lists, list_off, n_lists, annos, anno_off, n_tracks, ws_nseg, n_groups):
-        """Counter*(list, annotation, workspace) for n_lists x n_groups lists (observed counts)."""
+    def count_lists(self, counters, lists, list_off, n_lists, annos, anno_off, n_tracks, ws_nseg, n_groups, anno_end=None):
+        """Counter*(list, annotation, workspace) for n_lists x n_groups lists (observed counts).  anno_end given: the
+        annotation lists are the ranges annos[anno_off[l]:anno_end[l]] (gat_count_list_ranges), else anno_off is a CSR."""
         ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
         lists = np.ascontiguousarray(lists, dtype=SEG)
         annos = np.ascontiguousarray(annos, dtype=SEG)
@@ -232,10 +242,32 @@ class Context(object):
         anno_off = np.ascontiguousarray(anno_off, dtype=np.int64)
         ws_nseg = np.ascontiguousarray(ws_nseg, dtype=np.int64)
         out = np.zeros((len(ids), n_tracks, n_lists), dtype=np.int64)
-        _check(lib().gat_count_lists(self._h, _p(ids), len(ids), _p(lists), _p(list_off), n_lists, _p(annos),
-                                     _p(anno_off), n_tracks, _p(ws_nseg), n_groups, _p(out)), self._h)
+        if anno_end is None:
+            _check(lib().gat_count_lists(self._h, _p(ids), len(ids), _p(lists), _p(list_off), n_lists, _p(annos),
+                                         _p(anno_off), n_tracks, _p(ws_nseg), n_groups, _p(out)), self._h)
+        else:
+            anno_end = np.ascontiguousarray(anno_end, dtype=np.int64)
+            assert len(anno_off) == len(anno_end) == n_tracks * n_groups
+            _check(lib().gat_count_list_ranges(self._h, _p(ids), len(ids), _p(lists), _p(list_off), n_lists, _p(annos),
+                                               _p(anno_off), _p(anno_end), n_tracks, _p(ws_nseg), n_groups, _p(out)), self._h)
         return [out[k].view(np.float64).copy() if c == "nucleotide-density" else out[k].copy()
                 for k, c in enumerate(counters)]
+
+
+def intersection_sizes(a, a_off, b, b_begin, b_end, n_tracks):
+    """(pairs, bases) per track of b: segments and bases of the intersection of the dictionary a (len(a_off) - 1 normalized
+    lists) with each of n_tracks dictionaries given as ranges of b (gat_intersection_sizes: the overlap_* columns)."""
+    a = np.ascontiguousarray(a, dtype=SEG)
+    b = np.ascontiguousarray(b, dtype=SEG)
+    a_off = np.ascontiguousarray(a_off, dtype=np.int64)
+    b_begin = np.ascontiguousarray(b_begin, dtype=np.int64)
+    b_end = np.ascontiguousarray(b_end, dtype=np.int64)
+    n_groups = len(a_off) - 1
+    assert len(b_begin) == len(b_end) == n_tracks * n_groups
+    pairs = np.zeros(n_tracks, dtype=np.int64)
+    bases = np.zeros(n_tracks, dtype=np.int64)
+    _check(lib().gat_intersection_sizes(_p(a), _p(a_off), n_groups, _p(b), _p(b_begin), _p(b_end), n_tracks, _p(pairs), _p(bases)))
+    return pairs, bases
 
 
 COMM_ID_BYTES = 128
@@ -297,7 +329,15 @@ class Problem(object):
         d.nbuckets = int(flat.get("nbuckets", 100000))
         d.sampler = int(flat.get("sampler", 0))
         assert len(keep["seg_off"]) == d.n_units + 1 and len(keep["ws_off"]) == d.n_units + 1
-        assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1 and len(keep["cws_nseg"]) == d.n_contigs
+        assert len(keep["cws_nseg"]) == d.n_contigs
+        if flat.get("anno_group") is not None:
+            # the annotation lists as the host holds them (one per track and key), grouped into contigs by the library
+            d.n_anno_lists = len(flat["anno_group"])
+            d.anno_group = arr("anno_group", np.int32)
+            d.anno_end = arr("anno_end", np.int64)
+            assert len(keep["anno_off"]) == len(keep["anno_end"]) == d.n_anno_lists
+        else:
+            assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1
         self.n_units, self.n_contigs, self.n_tracks = d.n_units, d.n_contigs, d.n_tracks
         self._h = C.c_void_p()
         _check(lib().gat_problem_create(ctx._h, C.byref(d), C.byref(self._h)), ctx._h)
@@ -337,13 +377,12 @@ class Problem(object):
         dev = self.ctx.alloc(nslots * 8)
         try:
             self.sample_and_count_device(counters, seed, sample_begin, sample_end, dev)
-            host = np.zeros((len(counters), self.n_tracks, ns), dtype=np.int64)
+            host = np.empty((len(counters), self.n_tracks, ns), dtype=np.int64)
             if host.size:
                 self.ctx.d2h(host, dev)
         finally:
             self.ctx.free(dev)
-        return [host[k].view(np.float64).copy() if c == "nucleotide-density" else host[k].copy()
-                for k, c in enumerate(counters)]
+        return [host[k].view(np.float64) if c == "nucleotide-density" else host[k] for k, c in enumerate(counters)]
 
     def sample_and_count_serial(self, counters, mt_state, n_samples):
         """samples 0 .. n_samples-1 drawn from ONE MT19937 stream in the reference's order (an unpatched gat-run.py

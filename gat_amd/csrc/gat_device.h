@@ -22,7 +22,11 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 // LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering; the workgroup is a single wave (launch_bounds 64).
+#ifdef GAT_EXP_WAVE_SYNC_LDS
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+#endif
 
 // the same between the lanes of one wave inside a workgroup of several waves that do not run in step (no barrier may be
 // used): LDS operations of a wave execute in order; wait for them and keep the compiler from moving accesses across

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,8 +39,12 @@ struct gat_ctx {
   bool t_recorded = false;
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};    // around the count phase
   // status word and statistics of a sampler batch, copied behind its kernels and read after the batch's ONE synchronisation
+  std::vector<std::pair<void*, size_t>> user_allocs;   // gat_dev_alloc'ed blocks and their sizes (back to the pool at gat_dev_free)
+  void* h_stage = nullptr;                      // pinned staging buffer of gat_memcpy_d2h (grows; pageable targets are filled from it)
+  size_t h_stage_bytes = 0;
   int32_t* h_flags = nullptr;                   // pinned
   unsigned long long* h_stat = nullptr;         // pinned, 8 words
+  unsigned long long* h_mstat = nullptr;        // pinned, 512 words: k_count_merged's traffic counters of a call
   std::string err;
   int max_lds = 65536;
 };
@@ -63,24 +68,72 @@ inline int set_err(gat_ctx* ctx, int code, const char* fmt, ...) {
                      __FILE__, __LINE__);                                                          \
   } while (0)
 
+// Every copy between host and device goes through the context's pinned buffer, in pieces of at most kStagePiece bytes:
+// a copy from or to pageable memory makes the runtime pin and unpin the caller's pages around it, and every such change
+// of the device's page tables stalled the next operation on the device by 25-30 ms once gigabytes were mapped
+// (gat_amd.run() on config 3: the memsets behind gat_problem_create, the read-back behind gat_null_stats).  Synchronous:
+// both return when the bytes have arrived.
+constexpr size_t kStagePiece = (size_t)64 << 20;
+inline hipError_t ctx_stage(gat_ctx* ctx, size_t bytes) {
+  if (ctx->h_stage_bytes >= bytes) return hipSuccess;
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  ctx->h_stage = nullptr;
+  ctx->h_stage_bytes = 0;
+  size_t want = (size_t)1 << 20;
+  while (want < bytes) want <<= 1;
+  hipError_t e = hipHostMalloc(&ctx->h_stage, want, hipHostMallocDefault);
+  if (e == hipSuccess) ctx->h_stage_bytes = want;
+  return e;
+}
+inline hipError_t staged_h2d(gat_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  for (size_t o = 0; o < bytes; o += kStagePiece) {
+    const size_t n = std::min(kStagePiece, bytes - o);
+    hipError_t e = ctx_stage(ctx, n);
+    if (e != hipSuccess) return e;
+    memcpy(ctx->h_stage, (const char*)src_host + o, n);
+    if ((e = hipMemcpyAsync((char*)dst_dev + o, ctx->h_stage, n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+inline hipError_t staged_d2h(gat_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  for (size_t o = 0; o < bytes; o += kStagePiece) {
+    const size_t n = std::min(kStagePiece, bytes - o);
+    hipError_t e = ctx_stage(ctx, n);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(ctx->h_stage, (const char*)src_dev + o, n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
+    memcpy((char*)dst_host + o, ctx->h_stage, n);
+  }
+  return hipSuccess;
+}
+
+// Device memory of the size of a problem's scratch (gigabytes) costs milliseconds to map and to unmap, and hipFree waits
+// for the device: blocks of a megabyte and more go back to a process-wide pool per device instead and are handed out again
+// to the next request they fit (a host that creates one problem per segment track, or per run, asks for the same sizes
+// again and again).  gat_prep.hip.
+hipError_t dev_pool_alloc(void** out, size_t bytes);
+void dev_pool_free(void* p, size_t bytes);
+size_t dev_pool_held();            // bytes the pool of the current device holds back (free memory as far as a problem cares)
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t bytes = 0;                 // (kept so that a buffer of a type this translation unit only knows by name can be released)
   ~DevBuf() { release(); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  void release() { if (p) { dev_pool_free(p, bytes); p = nullptr; n = 0; bytes = 0; } }
   hipError_t alloc(size_t count) {
     release();
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e == hipSuccess) n = count;
+    hipError_t e = dev_pool_alloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) { n = count; bytes = count * sizeof(T); }
     return e;
   }
-  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+  hipError_t upload(const std::vector<T>& h, gat_ctx* ctx) {
     hipError_t e = alloc(h.size());
     if (e != hipSuccess) return e;
-    if (!h.empty()) e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (!h.empty()) e = staged_h2d(ctx, p, h.data(), h.size() * sizeof(T));
     return e;
   }
 };
@@ -102,6 +155,19 @@ struct AnnoDev {
   int64_t max_m = 0;
   int64_t max_cells = 0;
   int64_t total = 0;
+};
+
+// wall-clock stamps of problem creation (GAT_TIME_CREATE=1; tools/time_create.py)
+struct PrepTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PrepTimer() : on(getenv("GAT_TIME_CREATE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gat] %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
 };
 
 int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx);
@@ -149,6 +215,7 @@ struct gat_problem {
   DevBuf<uint2> d_slab, d_cslab;
   DevBuf<int32_t> d_unit_n, d_contig_n, d_flags;
   DevBuf<unsigned long long> d_stat;
+  DevBuf<unsigned long long> d_mstat;    // k_count_merged: 256 pairs {index entries read, segments looked up} (CountArgs::mstat)
   // lane-parallel front end (k_rng + k_place)
   std::vector<int32_t> h_rng_rows;       // per active index: raw outputs generated per stream
   std::vector<int64_t> h_rng_off;
@@ -183,6 +250,7 @@ struct gat_problem {
 };
 
 // gat_prep.hip
-int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists, int32_t n_groups);
+int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
+                int32_t n_groups, bool want_merged, bool checked);
 int layout_slab(gat_problem* P);
 int upload_layout(gat_ctx* ctx, gat_problem* P);

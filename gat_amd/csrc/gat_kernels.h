@@ -1583,6 +1583,8 @@ struct CountArgs {
   const int32_t* m_cells;     // n_contigs
   const int32_t* m_slot_off;  // kMergedSlots+1: the contigs of an XCD slot are m_slot_contigs[m_slot_off[x] .. m_slot_off[x+1])
   const int32_t* m_slot_contigs;
+  unsigned long long* mstat;  // k_count_merged's own traffic, for the byte model of its roofline: 256 pairs {index entries read,
+                              // sample segments looked up}, a wave adds to pair blockIdx % 256 once per sample (nullptr: not kept)
   // split path without k_finalize (k_count_seg<.., PATCH>; contig == unit): a unit k_tail finished is read as (merged
   // list in seg_merged, k_tail's record), any other from seg as usual
   const uint2* seg_merged;
@@ -1866,6 +1868,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       }
     }
     constexpr int kR = 4;                                            // segments per lane whose look-ups are in flight together
+    uint32_t n_ent = 0;                                              // index entries this lane read (the one that ended a scan too)
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
@@ -1897,6 +1900,14 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           ++kk;
           if (!(kk & 1u)) q = Z2[kk >> 1];
         }
+        n_ent += kk - k[r] + 1u;
+      }
+    }
+    if (A.mstat != nullptr) {
+      const uint32_t tot = wave_total_u32(n_ent);
+      if (lane == 0) {
+        atomicAdd(&A.mstat[2 * (blockIdx.x & 255u)], (unsigned long long)tot);
+        atomicAdd(&A.mstat[2 * (blockIdx.x & 255u) + 1], (unsigned long long)(n > 0 ? n : 0));
       }
     }
     wave_fence();

@@ -73,6 +73,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev_cnt) HIPCHK(ctx, hipEventCreate(&ev));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_mstat, 512 * 8, hipHostMallocDefault));
   *out = ctx;
   return GAT_OK;
 }
@@ -85,8 +86,10 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_t) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_cnt) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
+  if (ctx->h_mstat) (void)hipHostFree(ctx->h_mstat);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -100,31 +103,40 @@ extern "C" int gat_ctx_synchronize(gat_ctx* ctx) {
 extern "C" int gat_dev_alloc(gat_ctx* ctx, void** out, size_t bytes) {
   if (!ctx || !out) return set_err(ctx, GAT_ERR_ARG, "gat_dev_alloc: NULL argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMalloc(out, bytes ? bytes : 1));
+  if (bytes == 0) bytes = 1;
+  HIPCHK(ctx, dev_pool_alloc(out, bytes));
+  ctx->user_allocs.push_back(std::make_pair(*out, bytes));
   return GAT_OK;
 }
 extern "C" int gat_dev_free(gat_ctx* ctx, void* p) {
   if (!ctx) return set_err(ctx, GAT_ERR_ARG, "gat_dev_free: NULL ctx");
+  if (!p) return GAT_OK;
+  for (size_t i = 0; i < ctx->user_allocs.size(); ++i)
+    if (ctx->user_allocs[i].first == p) {
+      // (the caller may free right behind work it enqueued on the context's stream: a pooled block must be idle)
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      dev_pool_free(p, ctx->user_allocs[i].second);
+      ctx->user_allocs.erase(ctx->user_allocs.begin() + (long)i);
+      return GAT_OK;
+    }
   HIPCHK(ctx, hipFree(p));
   return GAT_OK;
 }
 extern "C" int gat_memcpy_d2h(gat_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return set_err(ctx, GAT_ERR_ARG, "NULL ctx");
-  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, staged_d2h(ctx, dst, src, bytes));
   return GAT_OK;
 }
 extern "C" int gat_memcpy_h2d(gat_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return set_err(ctx, GAT_ERR_ARG, "NULL ctx");
-  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, staged_h2d(ctx, dst, src, bytes));
   return GAT_OK;
 }
-
 
 // ------------------------------------------------------------------------------------------
 static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->batch >= want) return GAT_OK;
+  PrepTimer tm;
   const char* env = getenv("GAT_SLAB_BYTES");
   // a batch as large as a tenth of the 288 GB takes: the lane-per-stream kernels have a fixed floor per launch (the serial
   // chain of the longest unit's tile), so fewer, larger batches are faster (config 3, 10 000 samples: 9.7 ms in two
@@ -132,7 +144,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   double budget = env ? atof(env) : 30.0 * 1024 * 1024 * 1024;
   if (!env) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.6 * (double)free_b);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.6 * (double)(free_b + dev_pool_held()));
   }
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
                              (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
@@ -140,11 +152,13 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
+  tm.lap("  scratch: budget");
   HIPCHK(ctx, P->d_slab.alloc((size_t)(b * P->slab_stride)));
   if (P->merge_contigs) HIPCHK(ctx, P->d_cslab.alloc((size_t)(b * P->slab_stride)));
   HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
   HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
   HIPCHK(ctx, P->d_ws_stat.alloc((size_t)(b * std::max(1, P->n_units)) * 4));
+  tm.lap("  scratch: slab, counts");
   HIPCHK(ctx, hipMemsetAsync(P->d_unit_n.p, 0, (size_t)(b * std::max(1, P->n_units)) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(b * std::max(1, P->n_contigs)) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(P->d_ws_stat.p, 0, (size_t)(b * std::max(1, P->n_units)) * 16, ctx->stream));
@@ -152,7 +166,12 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     const int64_t nsb = (b + 63) / 64;
     P->h_rng_off.assign(P->h_order.size() + 1, 0);
     for (size_t a = 0; a < P->h_order.size(); ++a) P->h_rng_off[a + 1] = P->h_rng_off[a] + nsb * (int64_t)P->h_rng_rows[a] * 64;
-    HIPCHK(ctx, P->d_rng_off.upload(P->h_rng_off, ctx->stream));
+    tm.lap("  scratch: memsets enqueued");
+    if (tm.on) { (void)hipStreamSynchronize(ctx->stream); tm.lap("  scratch: (timing only) memsets done"); }
+    HIPCHK(ctx, P->d_rng_off.alloc(P->h_rng_off.size()));
+    tm.lap("  scratch: rng offsets alloc");
+    HIPCHK(ctx, staged_h2d(ctx, P->d_rng_off.p, P->h_rng_off.data(), P->h_rng_off.size() * 8));
+    tm.lap("  scratch: rng offsets up");
     HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
@@ -170,6 +189,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     }
   }
   P->batch = b;
+  tm.lap("scratch for the batch");
   return GAT_OK;
 }
 
@@ -709,7 +729,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       // shares of a k_sampler work unit's life per phase, summed over the batch (tools/diag_sampler.sh)
       const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
       std::vector<unsigned long long> h(nd);
-      HIPCHK(ctx, hipMemcpy(h.data(), P->d_diag.p, nd * 8, hipMemcpyDeviceToHost));
+      HIPCHK(ctx, staged_d2h(ctx, h.data(), P->d_diag.p, nd * 8));
       double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (size_t i = 0; i < nd; ++i) sum[i & 7] += (double)h[i];
       if (FILE* f = fopen(fn, "a")) {
@@ -815,14 +835,17 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
   gat_stats local;
   memset(&local, 0, sizeof(local));
   const int64_t S = sample_end - sample_begin;
+  PrepTimer tm;
   HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
   uint32_t* d_state = nullptr;
   if (state_host != nullptr) {
     // the run's one stream: its state lives on the device over the batches (a copy restores it when a batch is repeated)
     if (P->d_serial.n < 2 * (size_t)GAT_MT_STATE_WORDS) HIPCHK(ctx, P->d_serial.alloc(2 * (size_t)GAT_MT_STATE_WORDS));
     d_state = P->d_serial.p;
-    HIPCHK(ctx, hipMemcpyAsync(d_state, state_host, GAT_MT_STATE_WORDS * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, staged_h2d(ctx, d_state, state_host, GAT_MT_STATE_WORDS * 4));
   }
+  if (P->d_mstat.n < 512) HIPCHK(ctx, P->d_mstat.alloc(512));
+  HIPCHK(ctx, hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream));
   int64_t done = 0;
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
@@ -845,15 +868,18 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     A.out = (int64_t*)counts_dev;
     A.out_stride = S;
     A.out_begin = done;
+    A.mstat = P->d_mstat.p;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     ctx->main_recorded = false;
     ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
     if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+    tm.lap("batch enqueued");
     // ONE synchronisation per batch: the sampler's status word is read behind the count kernels (which ran on whatever
     // an overflowed unit left -- harmless, the batch is redone with doubled regions)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    tm.lap("batch synchronised");
     if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) {
       if (d_state != nullptr)        // (the repeated batch draws from where this one began)
         HIPCHK(ctx, hipMemcpyAsync(d_state, d_state + GAT_MT_STATE_WORDS, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -871,8 +897,10 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     done += nb;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  if (d_state != nullptr) HIPCHK(ctx, hipMemcpyAsync(state_host, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (d_state != nullptr) HIPCHK(ctx, staged_d2h(ctx, state_host, d_state, GAT_MT_STATE_WORDS * 4));
+  for (int i = 0; i < 256; ++i) { local.n_index_entries += (int64_t)ctx->h_mstat[2 * i]; local.n_index_lookups += (int64_t)ctx->h_mstat[2 * i + 1]; }
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
   local.ms_total = ms;
@@ -921,9 +949,8 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
     const int nstride = from_contigs ? P->n_contigs : P->n_units;
     h_slab.resize((size_t)(nb * P->slab_stride));
     h_n.resize((size_t)(nb * std::max(1, nstride)));
-    HIPCHK(ctx, hipMemcpyAsync(h_slab.data(), src, h_slab.size() * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(h_n.data(), nsrc, h_n.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, staged_d2h(ctx, h_slab.data(), src, h_slab.size() * sizeof(uint2)));
+    HIPCHK(ctx, staged_d2h(ctx, h_n.data(), nsrc, h_n.size() * 4));
     for (int64_t i = 0; i < nb; ++i) {
       for (int c = 0; c < C; ++c) {
         // (units that computeSample skips keep n == 0: their entries are never written and were zeroed at allocation)
@@ -944,18 +971,21 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
   return GAT_OK;
 }
 
-extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
-                               const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
-                               const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
-                               const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
-  if (!ctx || !list_off || !anno_off || !counts_host || (n_groups > 0 && !ws_nseg))
+static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                            const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                            const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                            const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
+  if (!ctx || !list_off || !anno_begin || !anno_end || !counts_host || (n_groups > 0 && !ws_nseg))
     return set_err(ctx, GAT_ERR_ARG, "gat_count_lists: NULL argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Counters C;
   int rc = parse_counters(ctx, counter_ids, n_counters, C);
   if (rc) return rc;
   AnnoDev A;
-  if ((rc = build_annos(ctx, A, annos, anno_off, (int64_t)n_tracks * n_groups, n_groups))) return rc;
+  // (the merged index pays when many lists are counted against it; for a handful -- the observed counts of a run's
+  //  segment tracks -- building it costs more than the per-track kernel's extra look-ups)
+  const bool want_merged = n_lists >= 16 || getenv("GAT_COUNT_LISTS_MERGED") != nullptr;
+  if ((rc = build_annos(ctx, A, annos, anno_begin, anno_end, (int64_t)n_tracks * n_groups, n_groups, want_merged, false))) return rc;
   for (int64_t l = 0; l < n_lists * n_groups; ++l)
     if ((rc = check_list(ctx, lists + list_off[l], list_off[l + 1] - list_off[l], "segment", l))) return rc;
   const int64_t total = list_off[n_lists * n_groups];
@@ -965,39 +995,57 @@ extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_c
   DevBuf<int32_t> d_c_off, d_n, d_index;
   DevBuf<int64_t> d_nseg, d_out;
   DevBuf<uint32_t> d_part;
-  HIPCHK(ctx, d_seg.upload(h_seg, ctx->stream));
+  HIPCHK(ctx, d_seg.upload(h_seg, ctx));
   std::vector<int64_t> h_nseg(ws_nseg, ws_nseg + n_groups);
-  HIPCHK(ctx, d_nseg.upload(h_nseg, ctx->stream));
+  HIPCHK(ctx, d_nseg.upload(h_nseg, ctx));
   const size_t nslots = (size_t)n_counters * n_tracks * n_lists;
   HIPCHK(ctx, d_out.alloc(nslots));
   HIPCHK(ctx, hipMemsetAsync(d_out.p, 0, std::max<size_t>(1, nslots) * 8, ctx->stream));
   std::vector<int32_t> h_index((size_t)n_groups);
   for (int g = 0; g < n_groups; ++g) h_index[(size_t)g] = g;
-  HIPCHK(ctx, d_index.upload(h_index, ctx->stream));
+  HIPCHK(ctx, d_index.upload(h_index, ctx));
+  // the group offsets and lengths of every list, uploaded once; one launch per list (they differ from list to list)
+  std::vector<int32_t> h_c_off((size_t)std::max<int64_t>(1, n_lists * n_groups)), h_n((size_t)std::max<int64_t>(1, n_lists * n_groups));
   for (int64_t l = 0; l < n_lists; ++l) {
-    // one launch per list: group offsets differ from list to list
-    std::vector<int32_t> h_c_off((size_t)n_groups), h_n((size_t)n_groups);
     const int64_t base = list_off[l * n_groups];
     for (int g = 0; g < n_groups; ++g) {
-      h_c_off[(size_t)g] = (int32_t)(list_off[l * n_groups + g] - base);
-      h_n[(size_t)g] = (int32_t)(list_off[l * n_groups + g + 1] - list_off[l * n_groups + g]);
+      h_c_off[(size_t)(l * n_groups + g)] = (int32_t)(list_off[l * n_groups + g] - base);
+      h_n[(size_t)(l * n_groups + g)] = (int32_t)(list_off[l * n_groups + g + 1] - list_off[l * n_groups + g]);
     }
-    HIPCHK(ctx, d_c_off.upload(h_c_off, ctx->stream));
-    HIPCHK(ctx, d_n.upload(h_n, ctx->stream));
+  }
+  HIPCHK(ctx, d_c_off.upload(h_c_off, ctx));
+  HIPCHK(ctx, d_n.upload(h_n, ctx));
+  for (int64_t l = 0; l < n_lists; ++l) {
+    const int64_t base = list_off[l * n_groups];
     gat::CountArgs K;
     memset(&K, 0, sizeof(K));
-    K.seg = d_seg.p + base; K.seg_stride = 0; K.c_off = d_c_off.p;
-    K.n_arr = d_n.p; K.n_stride = 0; K.n_index = d_index.p;
+    K.seg = d_seg.p + base; K.seg_stride = 0; K.c_off = d_c_off.p + l * n_groups;
+    K.n_arr = d_n.p + l * n_groups; K.n_stride = 0; K.n_index = d_index.p;
     K.cws_nseg = d_nseg.p; K.n_contigs = n_groups; K.n_tracks = n_tracks; K.n_samples = 1;
     K.out = d_out.p; K.out_stride = n_lists; K.out_begin = l;
     int32_t longest = 0;
-    for (int g = 0; g < n_groups; ++g) longest = std::max(longest, h_n[(size_t)g]);
+    for (int g = 0; g < n_groups; ++g) longest = std::max(longest, h_n[(size_t)(l * n_groups + g)]);
     if ((rc = launch_count(ctx, A, C, K, d_part, 0, longest))) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
-  HIPCHK(ctx, hipMemcpyAsync(counts_host, d_out.p, nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, staged_d2h(ctx, counts_host, d_out.p, nslots * 8));
   return GAT_OK;
+}
+
+extern "C" int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                               const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                               const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
+                               const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
+  if (!anno_off) return set_err(ctx, GAT_ERR_ARG, "gat_count_lists: NULL argument");
+  return count_lists_impl(ctx, counter_ids, n_counters, lists, list_off, n_lists, annos, anno_off, anno_off + 1, n_tracks, ws_nseg,
+                          n_groups, counts_host);
+}
+
+extern "C" int gat_count_list_ranges(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                                     const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                                     const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                                     const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
+  return count_lists_impl(ctx, counter_ids, n_counters, lists, list_off, n_lists, annos, anno_begin, anno_end, n_tracks, ws_nseg,
+                          n_groups, counts_host);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1118,11 +1166,11 @@ extern "C" int gat_null_stats(gat_ctx* ctx, const void* counts_dev, int64_t n_ro
   DevBuf<uint8_t> d_dbl;
   DevBuf<double> d_vals, d_out;
   if (leaf_off.empty()) { leaf_off.push_back(0); leaf_len.push_back(0); prog.push_back(0); }
-  HIPCHK(ctx, d_off.upload(leaf_off, ctx->stream));
-  HIPCHK(ctx, d_len.upload(leaf_len, ctx->stream));
-  HIPCHK(ctx, d_prog.upload(prog, ctx->stream));
-  HIPCHK(ctx, d_dbl.upload(std::vector<uint8_t>(is_double_host, is_double_host + n_rows), ctx->stream));
-  HIPCHK(ctx, d_vals.upload(std::vector<double>(vals_host, vals_host + n_rows), ctx->stream));
+  HIPCHK(ctx, d_off.upload(leaf_off, ctx));
+  HIPCHK(ctx, d_len.upload(leaf_len, ctx));
+  HIPCHK(ctx, d_prog.upload(prog, ctx));
+  HIPCHK(ctx, d_dbl.upload(std::vector<uint8_t>(is_double_host, is_double_host + n_rows), ctx));
+  HIPCHK(ctx, d_vals.upload(std::vector<double>(vals_host, vals_host + n_rows), ctx));
   HIPCHK(ctx, d_out.alloc((size_t)n_rows * 8));
   gat::StatsArgs A;
   A.counts = (const int64_t*)counts_dev; A.row_stride = n_samples; A.n_rows = (int32_t)n_rows; A.S = (int32_t)n_samples;
@@ -1139,7 +1187,6 @@ extern "C" int gat_null_stats(gat_ctx* ctx, const void* counts_dev, int64_t n_ro
     hipLaunchKernelGGL(gat::k_null_stats, dim3((unsigned)nr), dim3(gat::kStatsThreads), lds, ctx->stream, B);
     HIPCHK(ctx, hipGetLastError());
   }
-  HIPCHK(ctx, hipMemcpyAsync(out_host, d_out.p, (size_t)n_rows * 64, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, staged_d2h(ctx, out_host, d_out.p, (size_t)n_rows * 64));
   return GAT_OK;
 }

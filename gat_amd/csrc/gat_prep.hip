@@ -8,7 +8,102 @@
 #include <map>
 #include <memory>
 
+#include <mutex>
+
 #include "gat_host.h"
+
+// ------------------------------------------------------------------------------------------
+// the device-memory pool behind DevBuf (gat_host.h)
+namespace {
+struct PoolBlock { void* p; size_t bytes; };
+struct DevPool { std::vector<PoolBlock> blocks; size_t held = 0; };
+std::mutex g_pool_mutex;
+std::map<int, DevPool> g_pools;
+constexpr size_t kPoolMinBytes = (size_t)1 << 20;
+size_t pool_limit() {
+  static const size_t limit = [] {
+    const char* env = getenv("GAT_POOL_BYTES");
+    return env ? (size_t)atof(env) : (size_t)64 << 30;
+  }();
+  return limit;
+}
+}  // namespace
+
+// small requests are rounded up to a power of two so that the next one of that class finds the block again: in the
+// steady state of a host that creates problem after problem NOTHING reaches hipMalloc / hipFree -- every one of those calls
+// changes the device's page tables, and the first operation on the device after such a change was seen to wait 25-30 ms
+// when gigabytes are mapped (gat_amd.run() on config 3: the memsets behind gat_problem_create, the read-back behind
+// gat_null_stats)
+static size_t pool_class(size_t bytes) {
+  if (bytes >= kPoolMinBytes) return bytes;
+  size_t c = 512;
+  while (c < bytes) c <<= 1;
+  return c;
+}
+
+hipError_t dev_pool_alloc(void** out, size_t bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const size_t want = pool_class(bytes);
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevPool& P = g_pools[dev];
+    size_t best = P.blocks.size();
+    for (size_t i = 0; i < P.blocks.size(); ++i) {                  // the smallest block that fits without wasting a quarter
+      const size_t have = P.blocks[i].bytes;
+      const bool fits = want < kPoolMinBytes ? have == want : (have >= want && have <= want + want / 4 + kPoolMinBytes);
+      if (fits && (best == P.blocks.size() || have < P.blocks[best].bytes)) best = i;
+    }
+    if (best != P.blocks.size()) {
+      *out = P.blocks[best].p;
+      P.held -= P.blocks[best].bytes;
+      P.blocks[best] = P.blocks.back();
+      P.blocks.pop_back();
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess) {
+    // out of memory with blocks held back: give them to the driver and ask again
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevPool& P = g_pools[dev];
+    if (!P.blocks.empty()) {
+      (void)hipGetLastError();
+      for (auto& b : P.blocks) (void)hipFree(b.p);
+      P.blocks.clear();
+      P.held = 0;
+      e = hipMalloc(out, want);
+    }
+  }
+  return e;
+}
+
+// (a large block comes back under the size it was handed out for -- at most a quarter below its own -- so it may shrink in
+//  the books; the driver frees what it allocated)
+void dev_pool_free(void* p, size_t bytes) {
+  if (!p) return;
+  const size_t cls = pool_class(bytes);
+  hipPointerAttribute_t attr;
+  int dev = 0;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device; else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DevPool& P = g_pools[dev];
+    if (P.held + cls <= pool_limit() && P.blocks.size() < 4096) {
+      P.blocks.push_back(PoolBlock{p, cls});
+      P.held += cls;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+
+size_t dev_pool_held() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  return g_pools[dev].held;
+}
 
 int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx) {
   for (int64_t i = 0; i < n; ++i) {
@@ -24,60 +119,87 @@ int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, 
   return GAT_OK;
 }
 
+// stable LSD radix sort of 64-bit keys by their upper 32 bits (three passes of 11 / 11 / 10 bits); tmp is scratch
+static void radix_sort_hi32(std::vector<uint64_t>& v, std::vector<uint64_t>& tmp) {
+  const size_t n = v.size();
+  if (n < 2) return;
+  if (n < 512) { std::stable_sort(v.begin(), v.end(), [](uint64_t a, uint64_t b) { return (a >> 32) < (b >> 32); }); return; }
+  tmp.resize(n);
+  uint64_t* src = v.data();
+  uint64_t* dst = tmp.data();
+  uint32_t top = 0;
+  for (size_t i = 0; i < n; ++i) top |= (uint32_t)(src[i] >> 32);
+  static const int kShift[3] = {32, 43, 54}, kBits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass > 0 && (top >> (kShift[pass] - 32)) == 0) break;       // no key has a bit up there
+    const int sh = kShift[pass];
+    const uint32_t mask = (1u << kBits[pass]) - 1u;
+    uint32_t cnt[2049];
+    memset(cnt, 0, sizeof(cnt));
+    for (size_t i = 0; i < n; ++i) cnt[((src[i] >> sh) & mask) + 1]++;
+    for (uint32_t k = 0; k < mask + 1u; ++k) cnt[k + 1] += cnt[k];
+    for (size_t i = 0; i < n; ++i) dst[cnt[(src[i] >> sh) & mask]++] = src[i];
+    std::swap(src, dst);
+  }
+  if (src != v.data()) memcpy(v.data(), src, n * sizeof(uint64_t));
+}
+
 // The merged index of k_count_merged: per group (contig) the intervals of ALL tracks in one list sorted by start, 8-byte
 // entries {start, length:16 | track:16}.  Intervals longer than `bound` (a power of two, see below, at most 32 768) are
 // cut into pieces -- an overlap sum does not change -- so that no entry keeps a scan alive over more
 // than `bound` bases; first[g] is the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a
 // segment starting in cell g begins.
-static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_tracks,
-                        int32_t n_groups) {
+static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend,
+                        int64_t n_tracks, int32_t n_groups) {
   if (n_tracks > 65535) return GAT_OK;                              // (track ids are 16 bits: such problems keep the per-track kernel)
+  PrepTimer tm;
   std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
   std::vector<int32_t> h_shift((size_t)n_groups, 0), h_cells((size_t)n_groups, 1);
-  struct Ent { uint32_t s, e, t; };
   // a contig's index is built by itself (collect, sort, grid): the contigs are dealt to host threads -- sorting 10^7 entries
-  // on one core made gat_problem_create 0.9 s on the config-4 shape
-  std::vector<std::vector<uint2>> cz((size_t)n_groups);
+  // on one core made gat_problem_create 0.9 s on the config-4 shape.  An entry is one 64-bit key, start in the upper half,
+  // (track << 16 | length) in the lower: collected track by track and sorted by a STABLE radix sort on the start, equal
+  // starts stay in track order
+  std::vector<std::vector<uint64_t>> ck((size_t)n_groups);
   std::vector<std::vector<uint32_t>> cf((size_t)n_groups);
   std::vector<int> c_err((size_t)n_groups, 0);
   const char* env_bf = getenv("GAT_MERGED_BOUND");
   const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
   auto build_one = [&](int c) {
-    std::vector<Ent> e;
-    std::vector<uint2>& hz = cz[(size_t)c];
+    std::vector<uint64_t>& e = ck[(size_t)c];
+    std::vector<uint64_t> tmp;
     std::vector<uint32_t>& hf = cf[(size_t)c];
-    uint64_t total_len = 0, cnt = 0;
+    uint64_t total_len = 0, cnt = 0, span = 0;
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
-      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) { total_len += annos[i].end - annos[i].start; ++cnt; }
+      for (int64_t i = lbeg[l]; i < lend[l]; ++i) total_len += annos[i].end - annos[i].start;
+      cnt += (uint64_t)(lend[l] - lbeg[l]);
+      if (lend[l] > lbeg[l]) span = std::max<uint64_t>(span, annos[lend[l] - 1].end);
     }
     // the piece bound: a scan starts at the first entry that reaches into the segment's cell and passes everything up to
     // the segment's end, so it walks over about (bound + segment length) / spacing entries, most of which ended before the
     // segment began.  Twice the mean interval length or twice the mean spacing of the entries, whichever is larger (cutting
     // finer than the spacing only adds entries): config-4 shape, 1 000 tracks, one entry per 300 bases: 30.8 -> 25.9 ms per
     // 4 096 samples against the earlier 8 x mean length; config 3 (one per 3 000) keeps its bound.
-    uint64_t span = 0;
-    for (int64_t t = 0; t < n_tracks; ++t) {
-      const int64_t l = t * n_groups + c;
-      if (anno_off[l + 1] > anno_off[l]) span = std::max<uint64_t>(span, annos[anno_off[l + 1] - 1].end);
-    }
     const uint64_t want = cnt > 0 ? std::max(bfac * (total_len / cnt), 2 * (span / cnt)) : 0;
     uint32_t bound = 256;
     while ((uint64_t)bound < want && bound < 32768u) bound <<= 1;
-    e.reserve((size_t)cnt + (size_t)cnt / 4);
+    e.reserve((size_t)cnt + (size_t)cnt / 4 + 4);
     for (int64_t t = 0; t < n_tracks; ++t) {
       const int64_t l = t * n_groups + c;
-      for (int64_t i = anno_off[l]; i < anno_off[l + 1]; ++i) {
+      const uint64_t tt = (uint64_t)t << 16;
+      for (int64_t i = lbeg[l]; i < lend[l]; ++i) {
         uint32_t s0 = annos[i].start;
         const uint32_t e0 = annos[i].end;
-        while (e0 - s0 > bound) { e.push_back(Ent{s0, s0 + bound, (uint32_t)t}); s0 += bound; }
-        e.push_back(Ent{s0, e0, (uint32_t)t});
+        while (e0 - s0 > bound) { e.push_back(((uint64_t)s0 << 32) | tt | (uint64_t)bound); s0 += bound; }
+        e.push_back(((uint64_t)s0 << 32) | tt | (uint64_t)(e0 - s0));
       }
     }
-    std::sort(e.begin(), e.end(), [](const Ent& a, const Ent& b) { return a.s != b.s ? a.s < b.s : a.t < b.t; });
+    radix_sort_hi32(e, tmp);
     const size_t ne = e.size();
     if (ne >= 0xfffffff0ull) { c_err[(size_t)c] = 1; return; }
-    const uint32_t max_start = ne ? e[ne - 1].s : 0u;
+    auto st_of = [&](size_t i) { return (uint32_t)(e[i] >> 32); };
+    auto en_of = [&](size_t i) { return (uint32_t)(e[i] >> 32) + (uint32_t)(e[i] & 0xffffu); };
+    const uint32_t max_start = ne ? st_of(ne - 1) : 0u;
     int64_t target = 64;
     while (target < (int64_t)(ne / 2)) target <<= 1;                // about two entries per cell
     int sh = 0;
@@ -90,38 +212,43 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
       size_t k = 0;                                                 // first entry starting at or behind the cell's start
       for (int64_t g = 0; g < cells; ++g) {
         const uint64_t cs = (uint64_t)g << sh;
-        while (k < ne && (uint64_t)e[k].s < cs) ++k;
+        while (k < ne && (uint64_t)st_of(k) < cs) ++k;
         hf[(size_t)g] = (uint32_t)k;
       }
       for (size_t i = 0; i < ne; ++i) {                             // ... or an earlier one that reaches past it
-        for (int64_t g = ((int64_t)e[i].s >> sh) + 1; g < cells && ((uint64_t)g << sh) < (uint64_t)e[i].e; ++g)
+        const uint64_t en = en_of(i);
+        for (int64_t g = ((int64_t)st_of(i) >> sh) + 1; g < cells && ((uint64_t)g << sh) < en; ++g)
           if ((uint32_t)i < hf[(size_t)g]) hf[(size_t)g] = (uint32_t)i;
       }
     }
-    hz.reserve(ne + 3);
-    for (size_t i = 0; i < ne; ++i) hz.push_back(make_uint2(e[i].s, ((e[i].t & 0xffffu) << 16) | ((e[i].e - e[i].s) & 0xffffu)));
-    hz.push_back(make_uint2(0xffffffffu, 0u));                      // ends every scan
-    hz.push_back(make_uint2(0xffffffffu, 0u));                      // (entries are read in pairs)
-    if (hz.size() & 1) hz.push_back(make_uint2(0xffffffffu, 0u));   // ... and the next contig starts at an even index
+    // the device reads an entry as uint2 {start, track << 16 | length}: the two halves of the key the other way round
+    for (size_t i = 0; i < ne; ++i) e[i] = (e[i] >> 32) | (e[i] << 32);
+    e.push_back(0xffffffffull);                                     // {0xffffffff, 0} ends every scan
+    e.push_back(0xffffffffull);                                     // (entries are read in pairs)
+    if (e.size() & 1) e.push_back(0xffffffffull);                   // ... and the next contig starts at an even index
   };
   parallel_for(n_groups, [&](int64_t c) { build_one((int)c); });
-  std::vector<uint2> hz;
-  std::vector<uint32_t> hf;
+  tm.lap("  merged index: per contig");
   for (int c = 0; c < n_groups; ++c) {
     if (c_err[(size_t)c]) return set_err(ctx, GAT_ERR_CAPACITY, "group %d: more than 2^32 annotation intervals", c);
-    hz.insert(hz.end(), cz[(size_t)c].begin(), cz[(size_t)c].end());
-    hf.insert(hf.end(), cf[(size_t)c].begin(), cf[(size_t)c].end());
-    hz_off[(size_t)c + 1] = (int64_t)hz.size();
-    hf_off[(size_t)c + 1] = (int64_t)hf.size();
-    std::vector<uint2>().swap(cz[(size_t)c]);
-    std::vector<uint32_t>().swap(cf[(size_t)c]);
+    hz_off[(size_t)c + 1] = hz_off[(size_t)c] + (int64_t)ck[(size_t)c].size();
+    hf_off[(size_t)c + 1] = hf_off[(size_t)c] + (int64_t)cf[(size_t)c].size();
   }
-  HIPCHK(ctx, A.mz.upload(hz, ctx->stream));
-  HIPCHK(ctx, A.mfirst.upload(hf, ctx->stream));
-  HIPCHK(ctx, A.mz_off.upload(hz_off, ctx->stream));
-  HIPCHK(ctx, A.mf_off.upload(hf_off, ctx->stream));
-  HIPCHK(ctx, A.m_shift.upload(h_shift, ctx->stream));
-  HIPCHK(ctx, A.m_cells.upload(h_cells, ctx->stream));
+  static_assert(sizeof(uint2) == sizeof(uint64_t), "index entries");
+  std::vector<uint2> hz((size_t)hz_off[(size_t)n_groups]);
+  std::vector<uint32_t> hf((size_t)hf_off[(size_t)n_groups]);
+  parallel_for(n_groups, [&](int64_t c) {
+    if (!ck[(size_t)c].empty()) memcpy(hz.data() + hz_off[(size_t)c], ck[(size_t)c].data(), ck[(size_t)c].size() * 8);
+    if (!cf[(size_t)c].empty()) memcpy(hf.data() + hf_off[(size_t)c], cf[(size_t)c].data(), cf[(size_t)c].size() * 4);
+    std::vector<uint64_t>().swap(ck[(size_t)c]);
+    std::vector<uint32_t>().swap(cf[(size_t)c]);
+  });
+  HIPCHK(ctx, A.mz.upload(hz, ctx));
+  HIPCHK(ctx, A.mfirst.upload(hf, ctx));
+  HIPCHK(ctx, A.mz_off.upload(hz_off, ctx));
+  HIPCHK(ctx, A.mf_off.upload(hf_off, ctx));
+  HIPCHK(ctx, A.m_shift.upload(h_shift, ctx));
+  HIPCHK(ctx, A.m_cells.upload(h_cells, ctx));
   {
     // the groups dealt to the eight XCD slots of k_count_merged: largest first, each to the slot with the least so far
     std::vector<std::pair<int64_t, int>> w;
@@ -144,38 +271,64 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
       A.max_slot_contigs = std::max<int>(A.max_slot_contigs, (int)slots[k].size());
     }
     if (sc.empty()) sc.push_back(0);
-    HIPCHK(ctx, A.m_slot_off.upload(so, ctx->stream));
-    HIPCHK(ctx, A.m_slot_contigs.upload(sc, ctx->stream));
+    HIPCHK(ctx, A.m_slot_off.upload(so, ctx));
+    HIPCHK(ctx, A.m_slot_contigs.upload(sc, ctx));
   }
   A.has_merged = true;
   A.merged_entries = (int64_t)hz.size();
+  tm.lap("  merged index: gather + upload");
   return GAT_OK;
 }
 
-int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* anno_off, int64_t n_lists,
-                       int32_t n_groups) {
-  const int64_t total = anno_off[n_lists];
-  std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
-  A.h_off.assign(anno_off, anno_off + n_lists + 1);
+// The annotation tables of the count kernels.  n_lists = n_tracks * n_groups lists, list l = annos[lbeg[l] .. lend[l])
+// (a CSR array passes off and off + 1); checked: whether the lists have to be verified normalized (the ones the library
+// merged itself are).  want_merged: build the merged index when the problem's shape asks for it (see below).
+int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
+                int32_t n_groups, bool want_merged, bool checked) {
+  PrepTimer tm;
+  A.h_off.assign((size_t)n_lists + 1, 0);
   A.max_m = 0;
-  A.total = total;
   for (int64_t l = 0; l < n_lists; ++l) {
-    const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
-    int rc = check_list(ctx, annos + o, m, "annotation", l);
-    if (rc) return rc;
+    const int64_t m = lend[l] - lbeg[l];
+    if (m < 0) return set_err(ctx, GAT_ERR_ARG, "annotation list %lld: negative length", (long long)l);
+    A.h_off[(size_t)l + 1] = A.h_off[(size_t)l] + m;
     A.max_m = std::max(A.max_m, m);
   }
+  const int64_t total = A.h_off[(size_t)n_lists];
+  A.total = total;
+  if (!checked) {
+    constexpr int64_t kBlock = 256;                                 // lists per task
+    const int64_t nblocks = (n_lists + kBlock - 1) / kBlock;
+    std::vector<int64_t> bad((size_t)std::max<int64_t>(1, nblocks), -1);
+    parallel_for(nblocks, [&](int64_t b) {
+      for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+        const gat_segment* s = annos + lbeg[l];
+        const int64_t m = lend[l] - lbeg[l];
+        bool ok = true;
+        for (int64_t i = 0; i < m && ok; ++i)
+          ok = s[i].start < s[i].end && s[i].end < 0x80000000u && (i == 0 || s[i - 1].end <= s[i].start);
+        if (!ok) { bad[(size_t)b] = l; return; }
+      }
+    });
+    for (int64_t b = 0; b < nblocks; ++b)
+      if (bad[(size_t)b] >= 0) {                                     // the first offender, with the reference's message
+        const int64_t l = bad[(size_t)b];
+        return check_list(ctx, annos + lbeg[l], lend[l] - lbeg[l], "annotation", l);
+      }
+  }
+  std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
   {
     constexpr int64_t kBlock = 256;                                 // lists per task
     parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
       for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
-        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        const gat_segment* s = annos + lbeg[l];
+        const int64_t o = A.h_off[(size_t)l], m = lend[l] - lbeg[l];
         uint32_t cum = 0;
         for (int64_t i = 0; i < m; ++i) {
-          hs[(size_t)(o + i)] = annos[o + i].start;
-          he[(size_t)(o + i)] = annos[o + i].end;
+          hs[(size_t)(o + i)] = s[i].start;
+          he[(size_t)(o + i)] = s[i].end;
           hc[(size_t)(o + i)] = cum;
-          cum += annos[o + i].end - annos[o + i].start;
+          cum += s[i].end - s[i].start;
         }
       }
     });
@@ -186,17 +339,19 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   std::vector<int32_t> h_shift((size_t)std::max(1, n_groups), 0), h_cells((size_t)std::max(1, n_groups), 1);
   std::vector<int64_t> h_goff((size_t)n_lists + 1, 0);
   A.max_cells = 1;
+  const char* env_g = getenv("GAT_GRID_FACTOR");
+  const int gfac = env_g ? atoi(env_g) : 2;                        // about one start per two cells (measured best of 1, 2, 4, 8)
   for (int c = 0; c < n_groups; ++c) {
     uint32_t max_start = 0;
     int64_t mc = 0;
     for (int64_t t = 0; t < n_tracks; ++t) {
-      const int64_t l = t * n_groups + c, o = anno_off[l], m = anno_off[l + 1] - o;
+      const int64_t l = t * n_groups + c, m = lend[l] - lbeg[l];
       mc = std::max(mc, m);
-      if (m > 0) max_start = std::max(max_start, annos[o + m - 1].start);
+      if (m > 0) max_start = std::max(max_start, annos[lend[l] - 1].start);
     }
     int64_t target = 16;
     while (target < mc) target <<= 1;
-    { const char* env_g = getenv("GAT_GRID_FACTOR"); target *= env_g ? atoi(env_g) : 2; }   // about one start per two cells (measured best of 1, 2, 4, 8)
+    target *= gfac;
     int sh = 0;
     while (((int64_t)max_start >> sh) + 1 > target) ++sh;
     h_shift[(size_t)c] = sh;
@@ -210,39 +365,114 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
     parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
       for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
         const int c = (int)(l % n_groups);
-        const int64_t o = anno_off[l], m = anno_off[l + 1] - o;
+        const gat_segment* s = annos + lbeg[l];
+        const int64_t m = lend[l] - lbeg[l];
         const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
         uint32_t* g = hg.data() + h_goff[(size_t)l];
         int64_t k = 0;
         for (int cell = 0; cell <= cells; ++cell) {
           const uint64_t bound = (uint64_t)cell << sh;
-          while (k < m && (uint64_t)annos[o + k].start < bound) ++k;
+          while (k < m && (uint64_t)s[k].start < bound) ++k;
           g[cell] = (uint32_t)(cell == cells ? m : k);
         }
       }
     });
   }
-  HIPCHK(ctx, A.grid.upload(hg, ctx->stream));
-  HIPCHK(ctx, A.goff.upload(h_goff, ctx->stream));
-  HIPCHK(ctx, A.shift.upload(h_shift, ctx->stream));
-  HIPCHK(ctx, A.cells.upload(h_cells, ctx->stream));
-  HIPCHK(ctx, A.start.upload(hs, ctx->stream));
-  HIPCHK(ctx, A.end.upload(he, ctx->stream));
-  HIPCHK(ctx, A.cumx.upload(hc, ctx->stream));
-  HIPCHK(ctx, A.off.upload(A.h_off, ctx->stream));
+  tm.lap("  annotation tables: SoA + grids");
+  HIPCHK(ctx, A.grid.upload(hg, ctx));
+  HIPCHK(ctx, A.goff.upload(h_goff, ctx));
+  HIPCHK(ctx, A.shift.upload(h_shift, ctx));
+  HIPCHK(ctx, A.cells.upload(h_cells, ctx));
+  HIPCHK(ctx, A.start.upload(hs, ctx));
+  HIPCHK(ctx, A.end.upload(he, ctx));
+  HIPCHK(ctx, A.cumx.upload(hc, ctx));
+  HIPCHK(ctx, A.off.upload(A.h_off, ctx));
+  tm.lap("  annotation tables: upload");
   // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
   // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
   // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
   const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
   const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
   const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
-  if (n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = build_merged(ctx, A, annos, anno_off, n_tracks, n_groups);
+  if (want_merged && n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
+    int rc = build_merged(ctx, A, annos, lbeg, lend, n_tracks, n_groups);
     if (rc) return rc;
-    if (getenv("GAT_TIME_CREATE"))
-      fprintf(stderr, "[gat] build_merged %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
+  return GAT_OK;
+}
+
+// The contig-level annotation lists from lists that carry a group id (gat_problem_desc::anno_group): what
+// computeSample's contig_annotations are (gat/__init__.py:716-718: annotations ... fromIsochores(), i.e.
+// IntervalDictionary.fromIsochores, gat/Engine.pyx:2857-2876): the lists of a (track, contig) concatenated and -- when
+// the keys carry isochores -- sorted and merge(0)d (gat/SegmentList.pyx:756-816: empty segments dropped, a segment starting
+// at or before the running end joins it); without isochores a key IS its contig and the list passes through (a later
+// list of the same group replaces an earlier one, as the dictionary assignment does).  Groups are built by host threads
+// into buf; list g = buf[gbeg[g] .. gend[g]).
+static int group_annotations(gat_ctx* ctx, const gat_problem_desc* d, std::vector<gat_segment>& buf, std::vector<int64_t>& gbeg,
+                             std::vector<int64_t>& gend) {
+  const int64_t n_groups = (int64_t)d->n_tracks * d->n_contigs, nl = d->n_anno_lists;
+  std::vector<int64_t> cnt((size_t)n_groups + 1, 0), size((size_t)n_groups + 1, 0);
+  for (int64_t l = 0; l < nl; ++l) {
+    const int32_t g = d->anno_group[l];
+    if (g < -1 || g >= n_groups) return set_err(ctx, GAT_ERR_ARG, "annotation list %lld: group %d out of range", (long long)l, g);
+    const int64_t b = d->anno_off[l], e = d->anno_end ? d->anno_end[l] : d->anno_off[l + 1];
+    if (e < b) return set_err(ctx, GAT_ERR_ARG, "annotation list %lld: negative length", (long long)l);
+    if (g < 0) continue;
+    cnt[(size_t)g + 1]++;
+    size[(size_t)g + 1] += d->merge_contigs ? e - b : std::max<int64_t>(size[(size_t)g + 1], e - b) - size[(size_t)g + 1];
+  }
+  for (int64_t g = 0; g < n_groups; ++g) { cnt[(size_t)g + 1] += cnt[(size_t)g]; size[(size_t)g + 1] += size[(size_t)g]; }
+  std::vector<int64_t> member((size_t)cnt[(size_t)n_groups]), cur(cnt.begin(), cnt.end() - 1);
+  for (int64_t l = 0; l < nl; ++l) if (d->anno_group[l] >= 0) member[(size_t)cur[(size_t)d->anno_group[l]]++] = l;
+  buf.resize((size_t)size[(size_t)n_groups]);
+  gbeg.assign(size.begin(), size.end() - 1);
+  gend = gbeg;
+  constexpr int64_t kBlock = 64;                                    // groups per task
+  const int64_t nblocks = (n_groups + kBlock - 1) / kBlock;
+  std::vector<int64_t> bad((size_t)std::max<int64_t>(1, nblocks), -1);
+  parallel_for(nblocks, [&](int64_t blk) {
+    std::vector<uint64_t> keys;
+    for (int64_t g = blk * kBlock; g < std::min(n_groups, (blk + 1) * kBlock); ++g) {
+      gat_segment* out = buf.data() + gbeg[(size_t)g];
+      const int64_t m0 = cnt[(size_t)g], m1 = cnt[(size_t)g + 1];
+      if (m1 == m0) continue;
+      auto lb = [&](int64_t l) { return d->anno_off[l]; };
+      auto le = [&](int64_t l) { return d->anno_end ? d->anno_end[l] : d->anno_off[l + 1]; };
+      if (!d->merge_contigs) {
+        const int64_t l = member[(size_t)(m1 - 1)];                  // new[isochore] = segmentlist: the last one stays
+        const int64_t n = le(l) - lb(l);
+        if (n > 0) memcpy(out, d->annos + lb(l), (size_t)n * sizeof(gat_segment));
+        gend[(size_t)g] = gbeg[(size_t)g] + n;
+        continue;
+      }
+      // concatenate, sort by start (one member, or members that follow one another, are sorted already), merge(0)
+      keys.clear();
+      bool sorted = true;
+      uint32_t last = 0;
+      for (int64_t q = m0; q < m1; ++q) {
+        const int64_t l = member[(size_t)q];
+        for (int64_t i = lb(l); i < le(l); ++i) {
+          const gat_segment x = d->annos[i];
+          if (x.start > x.end || x.end >= 0x80000000u) { bad[(size_t)blk] = l; return; }
+          if (x.start == x.end) continue;                            // merge() drops empty segments
+          sorted = sorted && x.start >= last;
+          last = x.start;
+          keys.push_back(((uint64_t)x.start << 32) | x.end);
+        }
+      }
+      if (!sorted) std::sort(keys.begin(), keys.end());
+      int64_t n = 0;
+      for (size_t i = 0; i < keys.size(); ++i) {
+        const uint32_t s0 = (uint32_t)(keys[i] >> 32), e0 = (uint32_t)keys[i];
+        if (n > 0 && s0 <= out[n - 1].end) { if (e0 > out[n - 1].end) out[n - 1].end = e0; }
+        else { out[n].start = s0; out[n].end = e0; ++n; }
+      }
+      gend[(size_t)g] = gbeg[(size_t)g] + n;
+    }
+  });
+  for (int64_t b = 0; b < nblocks; ++b)
+    if (bad[(size_t)b] >= 0)
+      return set_err(ctx, GAT_ERR_ARG, "annotation list %lld: segment with start > end or a coordinate >= 2^31", (long long)bad[(size_t)b]);
   return GAT_OK;
 }
 
@@ -328,14 +558,14 @@ int layout_slab(gat_problem* P) {
 }
 
 int upload_layout(gat_ctx* ctx, gat_problem* P) {
-  HIPCHK(ctx, P->d_units.upload(P->h_units, ctx->stream));
+  HIPCHK(ctx, P->d_units.upload(P->h_units, ctx));
   {
     // a wave finds its unit with one load (units_o[blockIdx.y]) instead of order[] -> units[]
     std::vector<UnitDev> o;
     o.reserve(P->h_order.size());
     for (int32_t u : P->h_order) { UnitDev x = P->h_units[(size_t)u]; x.pad = u; o.push_back(x); }
     if (o.empty()) o.push_back(UnitDev{});
-    HIPCHK(ctx, P->d_units_o.upload(o, ctx->stream));
+    HIPCHK(ctx, P->d_units_o.upload(o, ctx));
   }
   {
     // size classes of the launch order (largest unit first, capacities do not grow): a new class where the capacity has
@@ -356,14 +586,14 @@ int upload_layout(gat_ctx* ctx, gat_problem* P) {
     }
     P->h_class_start.push_back(N);
   }
-  HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx->stream));
+  HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx));
   {
     std::vector<int32_t> o = P->h_contig_order;
     if (o.empty()) o.push_back(0);
-    HIPCHK(ctx, P->d_contig_order.upload(o, ctx->stream));
+    HIPCHK(ctx, P->d_contig_order.upload(o, ctx));
   }
-  HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx->stream));
-  HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx->stream));
+  HIPCHK(ctx, P->d_count_c_off.upload(P->h_count_c_off, ctx));
+  HIPCHK(ctx, P->d_count_n_index.upload(P->h_count_n_index, ctx));
   P->batch = 0;   // scratch must be re-sized
   return GAT_OK;
 }
@@ -374,6 +604,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (d->n_units < 0 || d->n_contigs < 0 || d->n_tracks < 0 || d->nbuckets <= 0)
     return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: negative size / nbuckets <= 0");
+  PrepTimer tm;
   std::unique_ptr<gat_problem> P(new gat_problem());
   P->ctx = ctx;
   P->n_units = d->n_units;
@@ -584,29 +815,37 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   P->h_count_n_index.assign((size_t)d->n_contigs, 0);
   if (layout_slab(P.get())) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments");
 
-  HIPCHK(ctx, P->d_order.upload(P->h_order, ctx->stream));
+  HIPCHK(ctx, P->d_order.upload(P->h_order, ctx));
   {
     std::vector<int32_t> pos((size_t)std::max(1, d->n_units), -1);
     for (size_t a = 0; a < P->h_order.size(); ++a) pos[(size_t)P->h_order[a]] = (int32_t)a;
-    HIPCHK(ctx, P->d_unit_pos.upload(pos, ctx->stream));
+    HIPCHK(ctx, P->d_unit_pos.upload(pos, ctx));
   }
-  HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx->stream));
-  HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx->stream));
-  HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx->stream));
-  HIPCHK(ctx, P->d_ws.upload(h_ws, ctx->stream));
-  HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx->stream));
+  HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx));
+  HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx));
+  HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx));
+  HIPCHK(ctx, P->d_ws.upload(h_ws, ctx));
+  HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx));
   if (h_ws_tree.empty()) h_ws_tree.assign(16, 0u);
-  HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx->stream));
-  HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx->stream));
-  HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx->stream));
+  HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx));
+  HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx));
+  HIPCHK(ctx, P->d_cws_nseg.upload(P->h_cws_nseg, ctx));
   int rc = upload_layout(ctx, P.get());
   if (rc) return rc;
-  const auto t_annos = std::chrono::steady_clock::now();
-  rc = build_annos(ctx, P->annos, d->annos, d->anno_off, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs);
-  if (getenv("GAT_TIME_CREATE"))
-    fprintf(stderr, "[gat] build_annos (incl. build_merged) %.1f ms\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_annos).count());
+  tm.lap("units, layout, their uploads");
+  if (d->anno_group != nullptr) {
+    // lists with a group id each: the library forms the contig-level lists itself (fromIsochores)
+    std::vector<gat_segment> buf;
+    std::vector<int64_t> gbeg, gend;
+    if ((rc = group_annotations(ctx, d, buf, gbeg, gend))) return rc;
+    tm.lap("annotations grouped by contig");
+    rc = build_annos(ctx, P->annos, buf.data(), gbeg.data(), gend.data(), (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true,
+                     d->merge_contigs != 0);
+  } else {
+    rc = build_annos(ctx, P->annos, d->annos, d->anno_off, d->anno_off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false);
+  }
   if (rc) return rc;
+  tm.lap("annotation tables (total)");
   {
     // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
     const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
@@ -624,7 +863,10 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
 
 extern "C" void gat_problem_destroy(gat_problem* p) {
   if (!p) return;
-  if (p->ctx) (void)hipSetDevice(p->ctx->device);
+  if (p->ctx) {
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);      // its blocks go back to the pool: nothing may still be running on them
+  }
   delete p;
 }
 
@@ -637,5 +879,37 @@ extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t*
   if (slab) *slab = p->slab_stride;
   // B_sample = 8*sum n' + 8*sum_a sum_c m + 8*A, with n' ~ n input segments
   if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->annos.total + 8 * (int64_t)p->n_tracks;
+  return GAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sizes of dictionary intersections for the overlap_* columns of the result rows (AnnotatorResultExtended.__init__,
+// gat/Engine.pyx:1911-1928): one merge-join per (track, group) pair of normalized lists, as SegmentList.intersect walks
+// them (gat/SegmentList.pyx:1469-1549: one output segment per overlapping pair), summed per track.  Input statistics on
+// host threads; nothing of a sample passes here.
+extern "C" int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off, int32_t n_groups,
+                                      const gat_segment* b, const int64_t* b_begin, const int64_t* b_end, int32_t n_tracks,
+                                      int64_t* pairs_out, int64_t* bases_out) {
+  if (!a_off || !b_begin || !b_end || !pairs_out || !bases_out || n_groups < 0 || n_tracks < 0)
+    return set_err(nullptr, GAT_ERR_ARG, "gat_intersection_sizes: bad argument");
+  parallel_for(n_tracks, [&](int64_t t) {
+    int64_t pairs = 0, bases = 0;
+    for (int32_t g = 0; g < n_groups; ++g) {
+      const gat_segment* x = a + a_off[g];
+      const int64_t nx = a_off[g + 1] - a_off[g];
+      const gat_segment* y = b + b_begin[t * n_groups + g];
+      const int64_t ny = b_end[t * n_groups + g] - b_begin[t * n_groups + g];
+      uint32_t sum = 0;                                              // SegmentList.sum(): a Position (uint32) accumulator per list
+      int64_t i = 0, j = 0;
+      while (i < nx && j < ny) {
+        const uint32_t lo = std::max(x[i].start, y[j].start), hi = std::min(x[i].end, y[j].end);
+        if (hi > lo) { ++pairs; sum += hi - lo; }
+        if (x[i].end < y[j].end) ++i; else if (y[j].end < x[i].end) ++j; else { ++i; ++j; }
+      }
+      bases += (int64_t)sum;
+    }
+    pairs_out[t] = pairs;
+    bases_out[t] = bases;
+  });
   return GAT_OK;
 }

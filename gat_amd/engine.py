@@ -8,6 +8,7 @@ libgat_mi355.so -- see gat_amd/__init__.py:run and gat_amd/_lib.py.  There is no
 """
 import collections
 import math
+import operator
 
 import numpy as np
 
@@ -60,6 +61,8 @@ class SegmentList(object):
     """list of half-open (start, end) uint32 segments (gat/SegmentList.pyx:146).
 
     "normalized" = sorted by start, non-overlapping, no empty segments."""
+
+    is_points = False
 
     def __init__(self, allocate=0, clone=None, iter=None, normalize=False, array=None):  # noqa: A002
         self.isNormalized = 1
@@ -338,12 +341,116 @@ class PositionList(SegmentList):
 
 
 # ------------------------------------------------------------------------------------------------
+class _DictFlat(object):
+    """the lists of an IntervalDictionary in ONE array: list i (key keys[i]) = data[off[i]:off[i + 1]], and the lists hold
+    exactly those views (`arrays`), which is how a later look finds out whether a list was replaced since.  A run over an
+    isochore-partitioned collection touches 10^4 small lists; every pass over them that makes a numpy call per list costs
+    more than the sampling on the device, so the passes work on this form (IntervalDictionary._flat)."""
+    __slots__ = ("data", "off", "keys", "arrays", "index")
+
+    def __init__(self, data, off, keys, arrays):
+        self.data, self.off, self.keys, self.arrays = data, off, keys, arrays
+        self.index = None
+
+    def position(self, key):
+        if self.index is None:
+            self.index = dict((k, i) for i, k in enumerate(self.keys))
+        return self.index.get(key, -1)
+
+    def ranges(self, target_keys, base=0):
+        """(begin, end) of the lists of `target_keys` in `data` (+ base); a key this dictionary lacks gives (0, 0)"""
+        if target_keys == self.keys:
+            return self.off[:-1] + base, self.off[1:] + base
+        pos = np.fromiter((self.position(k) for k in target_keys), dtype=np.int64, count=len(target_keys))
+        have = pos >= 0
+        p = np.where(have, pos, 0)
+        return np.where(have, self.off[p] + base, 0), np.where(have, self.off[p + 1] + base, 0)
+
+
+_GET_A = operator.attrgetter("_a")
+_GET_NORMALIZED = operator.attrgetter("isNormalized")
+_GET_POINTS = operator.attrgetter("is_points")
+
+
+class _IsochorePrep(object):
+    """the isochore classes of a toIsochores call, for all contigs at once: their segments in coordinates
+    (contig number << 32) + position, sorted by start, each with its class.  valid: every class list is a normalized
+    SegmentList and no two segments overlap (isochores partition a contig) -- what the vectorised split relies on.  Shared
+    by the dictionaries of a collection (IntervalCollection.toIsochores)."""
+
+    def __init__(self, tracks):
+        self.ids = {}
+        self.valid = len(tracks) >= 1
+        starts, ends, labels = [], [], []
+        for k, (_, vv) in enumerate(tracks):
+            if not isinstance(vv, IntervalDictionary) or vv._has_points() or not vv._all_normalized():
+                self.valid = False
+                return
+            f = vv._flat()
+            if len(f.data) == 0:
+                continue
+            cid = np.fromiter((self.contig_id(c) for c in f.keys), dtype=np.int64, count=len(f.keys))
+            hi = np.repeat(cid << 32, np.diff(f.off))
+            starts.append(hi + f.data["start"])
+            ends.append(hi + f.data["end"])
+            labels.append(np.full(len(f.data), k, dtype=np.int64))
+        if starts:
+            b_s, b_e, lab = np.concatenate(starts), np.concatenate(ends), np.concatenate(labels)
+            order = np.argsort(b_s, kind="stable")
+            self.b_start, self.b_end, self.label = b_s[order], b_e[order], lab[order]
+            if bool(np.any(self.b_start >= self.b_end)) or bool(np.any(self.b_end[:-1] > self.b_start[1:])):
+                self.valid = False
+        else:
+            self.b_start = self.b_end = self.label = np.empty(0, dtype=np.int64)
+
+    def contig_id(self, contig):
+        i = self.ids.get(contig)
+        if i is None:
+            i = self.ids[contig] = len(self.ids)
+        return i
+
+
+def _new_list(array, like):
+    """a list of `like`'s class and flag around `array` (what clone() + a replacing operation leave)"""
+    s = like.__class__.__new__(like.__class__)
+    s._a = array
+    s.isNormalized = like.isNormalized
+    return s
+
+
 class IntervalDictionary(object):
     """key (contig or contig.isochore) -> SegmentList (gat/Engine.pyx:2741)."""
 
     def __init__(self, name=None):
         self.intervals = collections.defaultdict(SegmentList)
         self.name = name
+        self._flat_cache = None
+
+    def _flat(self):
+        """the lists as one array (_DictFlat); built once and found again as long as no list was replaced, added or removed"""
+        f = self._flat_cache
+        d = self.intervals
+        if f is not None and len(f.arrays) == len(d) and all(map(operator.is_, map(_GET_A, d.values()), f.arrays)) \
+                and list(d.keys()) == f.keys:
+            return f
+        vals = list(d.values())
+        arrays = [v._a for v in vals]
+        off = np.zeros(len(arrays) + 1, dtype=np.int64)
+        if arrays:
+            np.cumsum(np.fromiter((len(a) for a in arrays), dtype=np.int64, count=len(arrays)), out=off[1:])
+        data = np.concatenate(arrays) if off[-1] else iv.EMPTY.copy()
+        o = off.tolist()
+        views = [data[o[i]:o[i + 1]] for i in range(len(arrays))]
+        for v, w in zip(vals, views):
+            v._a = w                                   # same content; from now on the list IS its slice of `data`
+        f = self._flat_cache = _DictFlat(data, off, list(d.keys()), views)
+        return f
+
+    def _all_normalized(self):
+        return all(map(_GET_NORMALIZED, self.intervals.values()))
+
+    def _has_points(self):
+        return any(map(_GET_POINTS, self.intervals.values()))
 
     def __len__(self):
         return len(self.intervals)
@@ -370,10 +477,18 @@ class IntervalDictionary(object):
         self.intervals[contig] = segmentlist
 
     def sum(self):  # noqa: A003
-        return sum(x.sum() for x in self.intervals.values())
+        if len(self.intervals) < 16 or self._has_points():
+            return sum(x.sum() for x in self.intervals.values())
+        # SegmentList.sum() list by list (a uint32 accumulator each, gat/SegmentList.pyx:1607), then Python's sum
+        f = self._flat()
+        run = np.zeros(len(f.data) + 1, dtype=np.int64)
+        np.cumsum(f.data["end"].astype(np.int64) - f.data["start"], out=run[1:])
+        return int(((run[f.off[1:]] - run[f.off[:-1]]) & 0xFFFFFFFF).sum())
 
     def counts(self):
-        return sum(len(x) for x in self.intervals.values())
+        if len(self.intervals) < 16:
+            return sum(len(x) for x in self.intervals.values())
+        return int(self._flat().off[-1])
 
     def clone(self):
         r = IntervalDictionary(self.name)
@@ -460,66 +575,96 @@ class IntervalDictionary(object):
             return np.where(k > 0, cum[k] - (b_e[last] - np.minimum(x, b_e[last])), 0)
         return npairs, int((below(a_e) - below(a_s)).sum())
 
-    def toIsochores(self, isochores, truncate=False):
-        """gat/Engine.pyx:2837-2855."""
-        for contig in list(self.intervals.keys()):
+    def toIsochores(self, isochores, truncate=False, _prep=None):
+        """gat/Engine.pyx:2837-2855: every list split by the isochore tracks, key `contig.isochore`.  One vectorised pass
+        over the whole dictionary when the isochore classes do not overlap one another (they partition the contigs);
+        otherwise list by list as the reference does, assertions included."""
+        contigs = list(self.intervals.keys())
+        tracks = list(isochores.items())
+        for _, other_vv in tracks:
+            for contig in contigs:
+                other_vv[contig]                       # (a dictionary look-up inserts the missing key, as the reference's does)
+        if self._to_isochores_flat(contigs, tracks, truncate, _prep if _prep is not None else _IsochorePrep(tracks)):
+            return
+        for contig in contigs:
             segmentlist = self.intervals[contig]
-            others = [(other_track, other_vv[contig]) for other_track, other_vv in isochores.items()]
-            split = self._split_by_classes(segmentlist, [o for _, o in others], truncate)
-            for k, (other_track, other) in enumerate(others):
+            for other_track, other_vv in tracks:
                 newlist = segmentlist.clone()
-                if split is not None:
-                    newlist._a = split[k]
-                elif truncate:
-                    newlist.intersect(other)
+                if truncate:
+                    newlist.intersect(other_vv[contig])
                 else:
-                    newlist.filter(other)
+                    newlist.filter(other_vv[contig])
                 self.intervals["%s.%s" % (contig, other_track)] = newlist
             del self.intervals[contig]
 
-    @staticmethod
-    def _split_by_classes(segmentlist, classes, truncate):
-        """segmentlist.intersect(c) (or .filter(c)) for every list c of `classes` in ONE pass over their union, when the
-        classes do not overlap one another (isochores partition a contig) -- the loop above makes a handful of numpy calls
-        per (track, contig, class) triple, 20 000 triples for 100 tracks.  None when the shortcut does not apply (the
-        loop then does what the reference does, assertions included)."""
-        if getattr(segmentlist, "is_points", False) or len(classes) < 2:
-            return None
-        if truncate and not segmentlist.isNormalized:
-            return None
-        if any(getattr(c, "is_points", False) or not c.isNormalized for c in classes):
-            return None
-        a = segmentlist._a
-        sizes = [len(c._a) for c in classes]
-        if len(a) == 0 or sum(sizes) == 0:
-            return None
-        b = np.concatenate([c._a for c in classes])
-        label = np.repeat(np.arange(len(classes)), sizes)
-        order = np.argsort(b["start"], kind="stable")
-        b, label = b[order], label[order]
-        if not bool(np.all(b["end"][:-1] <= b["start"][1:])) or not iv.is_normalized(a):
-            return None
-        j0 = np.searchsorted(b["end"], a["start"], side="right")
-        j1 = np.maximum(np.searchsorted(b["start"], a["end"], side="left"), j0)
-        cnt = j1 - j0
-        n = int(cnt.sum())
-        ai = np.repeat(np.arange(len(a)), cnt)
-        bi = np.repeat(j0, cnt) + (np.arange(n) - np.repeat(np.cumsum(cnt) - cnt, cnt))
-        cls = label[bi]
-        out = []
-        if truncate:
-            pieces = iv.make(np.maximum(a["start"][ai], b["start"][bi]), np.minimum(a["end"][ai], b["end"][bi]))
-            for k in range(len(classes)):
-                out.append(pieces[cls == k] if sizes[k] else iv.EMPTY.copy())
+    def _to_isochores_flat(self, contigs, tracks, truncate, prep):
+        """toIsochores for all lists and classes at once, in coordinates (contig number << 32) + position: the classes'
+        segments B sorted by start, for every segment of this dictionary the range of B it overlaps, one piece (truncate)
+        or one copy per class touched (filter), the pieces brought into (contig, class) order.  False when the shortcut does
+        not apply."""
+        if not prep.valid or not contigs or self._has_points():
+            return False
+        if truncate and not self._all_normalized():
+            return False
+        f = self._flat()
+        a = f.data
+        na, nk, K = len(a), len(contigs), len(tracks)
+        lens = np.diff(f.off)
+        rank = np.repeat(np.arange(nk, dtype=np.int64), lens)                 # list (contig position) of every segment
+        if na:
+            # normalized list by list (what SegmentList.check asks for): the shortcut reads the lists as sorted and disjoint
+            if bool(np.any(a["start"] >= a["end"])):
+                return False
+            inner = np.ones(na, dtype=bool)
+            inner[f.off[1:-1][f.off[1:-1] < na]] = False                      # the first segment of a list has no predecessor
+            if na > 1 and bool(np.any((a["end"][:-1] > a["start"][1:]) & inner[1:])):
+                return False
+        cid = np.fromiter((prep.contig_id(c) for c in contigs), dtype=np.int64, count=nk)
+        hi = np.repeat(cid << 32, lens)
+        a_s = hi + a["start"]
+        a_e = hi + a["end"]
+        b_s, b_e, label = prep.b_start, prep.b_end, prep.label
+        if na and len(b_s):
+            j0 = np.searchsorted(b_e, a_s, side="right")
+            j1 = np.maximum(np.searchsorted(b_s, a_e, side="left"), j0)
+            cnt = j1 - j0
+            n = int(cnt.sum())
+            ai = np.repeat(np.arange(na, dtype=np.int64), cnt)
+            bi = np.repeat(j0, cnt) + (np.arange(n, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+            cls = label[bi]
         else:
-            for k in range(len(classes)):
-                if not sizes[k]:
-                    out.append(iv.EMPTY.copy())
-                    continue
-                hit = np.zeros(len(a), dtype=bool)
-                hit[ai[cls == k]] = True
-                out.append(a[hit].copy())
-        return out
+            ai = bi = cls = np.empty(0, dtype=np.int64)
+        if truncate:
+            src = ai
+            gid = rank[ai] * K + cls
+            order = np.argsort(gid, kind="stable")                            # within a group: segment order = position order
+            out = iv.make((np.maximum(a_s[ai], b_s[bi]) & 0xFFFFFFFF)[order], (np.minimum(a_e[ai], b_e[bi]) & 0xFFFFFFFF)[order])
+        else:
+            hit = np.zeros(na * K, dtype=bool)
+            hit[ai * K + cls] = True
+            idx = np.flatnonzero(hit)                                         # (segment, class) pairs, each once
+            src = idx // K
+            gid = rank[src] * K + (idx - src * K)
+            order = np.argsort(gid, kind="stable")
+            out = a[src[order]]
+        off = np.zeros(nk * K + 1, dtype=np.int64)
+        np.cumsum(np.bincount(gid, minlength=nk * K), out=off[1:])
+        o = off.tolist()
+        olds = [self.intervals[c] for c in contigs]
+        keys, views = [], []
+        self.intervals.clear()
+        g = 0
+        for old, contig in zip(olds, contigs):
+            for other_track, _ in tracks:
+                key = "%s.%s" % (contig, other_track)
+                w = out[o[g]:o[g + 1]]
+                self.intervals[key] = _new_list(w, old)
+                keys.append(key)
+                views.append(w)
+                g += 1
+        if len(keys) == len(self.intervals):                                  # (no two (contig, class) pairs share a key)
+            self._flat_cache = _DictFlat(out, off, keys, views)
+        return True
 
     def fromIsochores(self):
         """gat/Engine.pyx:2857-2876."""
@@ -550,6 +695,26 @@ class IntervalCollection(object):
     def __init__(self, name=None):
         self.intervals = collections.defaultdict(IntervalDictionary)
         self.name = name
+        self._flat_cache = None
+
+    def _flat(self, tracks=None, _have=None):
+        """(data, bases, flats): the lists of the dictionaries of `tracks` (default: all) in ONE array -- dictionary t's
+        flat form (IntervalDictionary._flat) starts at bases[t].  Kept while the dictionaries' own flat forms stay.
+        _have: what an earlier call with the same tracks returned, from a caller that knows nothing was touched since (one
+        run() looks at the annotations several times; finding 10^4 lists unchanged costs a millisecond each time)."""
+        if _have is not None:
+            return _have
+        tracks = list(self.intervals.keys()) if tracks is None else list(tracks)
+        flats = [self.intervals[t]._flat() for t in tracks]
+        c = self._flat_cache
+        if c is not None and len(c[2]) == len(flats) and all(x is y for x, y in zip(c[2], flats)):
+            return c
+        bases = np.zeros(len(flats) + 1, dtype=np.int64)
+        if flats:
+            np.cumsum([len(f.data) for f in flats], out=bases[1:])
+        data = np.concatenate([f.data for f in flats]) if bases[-1] else iv.EMPTY.copy()
+        c = self._flat_cache = (data, bases, flats)
+        return c
 
     def setName(self, name):
         self.name = name
@@ -619,7 +784,7 @@ class IntervalCollection(object):
                 vv[contig] = p
 
     def hasPositions(self):
-        return any(getattr(s, "is_points", False) for vv in self.intervals.values() for s in vv.intervals.values())
+        return any(vv._has_points() for vv in self.intervals.values())
 
     def merge(self, delete=False):
         merged = IntervalDictionary()
@@ -665,8 +830,15 @@ class IntervalCollection(object):
             vv.filter(other)
 
     def toIsochores(self, isochores, truncate=False):
+        prep = None
         for vv in self.intervals.values():
-            vv.toIsochores(isochores, truncate)
+            if prep is None:
+                # (the classes are the same for every track; a look-up of a contig they lack only adds an empty list)
+                for _, other_vv in isochores.items():
+                    for contig in list(vv.keys()):
+                        other_vv[contig]
+                prep = _IsochorePrep(list(isochores.items()))
+            vv.toIsochores(isochores, truncate, _prep=prep)
 
     def fromIsochores(self):
         for vv in self.intervals.values():
@@ -880,28 +1052,70 @@ class ConditionalWorkspaceSegmentCentered(ConditionalWorkspaceCentered):
 def computeCounts(counter, aggregator, segments, annotations, workspace, workspace_generator, append=False):
     """observed counts for all track x annotation pairs (gat/Engine.pyx:2164-2204): ONE device call over all
     (segment track, isochore) x (annotation, isochore) lists."""
-    counts = collections.defaultdict(lambda: collections.defaultdict(float))
+    return computeCountsAll([counter], aggregator, segments, annotations, workspace, workspace_generator)[0]
+
+
+def computeCountsAll(counters, aggregator, segments, annotations, workspace, workspace_generator=None):
+    """computeCounts for several counters at once: the lists cross to the device once, every counter is evaluated by
+    the same launch (gat_count_list_ranges).  Returns one {track: {annotation: count}} per counter."""
     if aggregator is not sum:
         raise NotImplementedError("only aggregator=sum is supported")
+    all_counts = [collections.defaultdict(lambda: collections.defaultdict(float)) for _ in counters]
     isochores = list(workspace.keys())
     ctx = get_context()
     tracks = list(annotations.tracks)
     seg_tracks = list(segments.tracks)
-    if not seg_tracks or not tracks:
-        return counts
-    if counter.name not in POINT_COUNTERS and annotations.hasPositions():
+    if not seg_tracks or not tracks or not counters:
+        return all_counts
+    if annotations.hasPositions() and any(c.name not in POINT_COUNTERS for c in counters):
         raise _points_type_error("annotations")              # gat/Engine.pyx:2200: counter(SegmentList, PositionList, ..)
-    lists = [segments[t][i].asArray() for t in seg_tracks for i in isochores]
-    annos = [annotations[a][i].asArray() for a in tracks for i in isochores]
-    lcat, loff = _problem._cat(lists)
-    acat, aoff = _problem._cat(annos)
+    # the reference looks every (track, isochore) up (segments[track][isochore], :2196-2200): a dictionary that lacks the
+    # key gains an empty list
+    for coll, names in ((segments, seg_tracks), (annotations, tracks)):
+        for t in names:
+            d = coll[t]
+            if list(d.keys()) != isochores:
+                for i in isochores:
+                    d[i]
+    sdata, sbases, sflats = segments._flat(seg_tracks)
+    lb, le = zip(*[f.ranges(isochores, base) for f, base in zip(sflats, sbases)])
+    lb, le = np.concatenate(lb), np.concatenate(le)
+    if len(lb) and bool(np.all(lb[1:] == le[:-1])) and lb[0] == 0:
+        lcat, loff = sdata, np.append(lb, le[-1])
+    else:
+        lcat, loff = _problem._cat([sdata[b:e] for b, e in zip(lb.tolist(), le.tolist())])
+    adata, abases, aflats = annotations._flat(tracks)
+    ab, ae = zip(*[f.ranges(isochores, base) for f, base in zip(aflats, abases)])
     ws_nseg = [len(workspace[i]) for i in isochores]
-    r = ctx.count_lists([counter.name], lcat, loff, len(seg_tracks), acat, aoff, len(tracks), ws_nseg, len(isochores))[0]
-    for l, track in enumerate(seg_tracks):
-        for a, annotation in enumerate(tracks):
-            v = r[a, l]
-            counts[track][annotation] = float(v) if counter.name == "nucleotide-density" else int(v)
-    return counts
+    names = [c.name for c in counters]
+    r = ctx.count_lists(names, lcat, loff, len(seg_tracks), adata, np.concatenate(ab), len(tracks), ws_nseg, len(isochores),
+                        anno_end=np.concatenate(ae))
+    for k, name in enumerate(names):
+        vals = r[k].tolist()                                 # [annotation][segment track]: Python floats / ints
+        counts = all_counts[k]
+        for l, track in enumerate(seg_tracks):
+            per = counts[track]
+            for a_i, annotation in enumerate(tracks):
+                per[annotation] = vals[a_i][l]
+    return all_counts
+
+
+def overlap_sizes(track_segments, annotations, tracks=None, _aflat=None):
+    """{annotation track: (segments, bases)} of `track_segments.clone().intersect(annotations[track])` for every track at
+    once (gat_intersection_sizes): the overlap_* columns of the result rows (gat/Engine.pyx:1911-1928).  None when a list
+    is not a normalized SegmentList (the row then takes the list-by-list path, which raises as the reference does)."""
+    tracks = list(annotations.tracks) if tracks is None else list(tracks)
+    if not tracks or track_segments._has_points() or not track_segments._all_normalized():
+        return None
+    for t in tracks:
+        d = annotations[t]
+        if d is track_segments or d._has_points() or not d._all_normalized():
+            return None
+    fs = track_segments._flat()
+    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
+    bb, be = zip(*[f.ranges(fs.keys, base) for f, base in zip(aflats, abases)])
+    pairs, bases = _lib.intersection_sizes(fs.data, fs.off, adata, np.concatenate(bb), np.concatenate(be), len(tracks))
+    return dict((t, (int(p), int(b))) for t, p, b in zip(tracks, pairs.tolist(), bases.tolist()))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1038,7 +1252,9 @@ class AnnotatorResultExtended(AnnotatorResult):
         "percent_overlap_nsegments_annotation", "percent_overlap_size_annotation"]
 
     def __init__(self, track, annotation, counter, observed, samples, track_segments, annotation_segments,
-                 workspace, reference=None, pseudo_count=1.0, _sizes=None, _stats=None):
+                 workspace, reference=None, pseudo_count=1.0, _sizes=None, _stats=None, _overlap=None):
+        """_overlap: (segments, bases) of the intersection of the two dictionaries when the caller has them already
+        (overlap_sizes: every annotation of a run in one call)."""
         AnnotatorResult.__init__(self, track, annotation, counter, observed, samples, reference=reference,
                                  pseudo_count=pseudo_count, _stats=_stats)
         sizes = _sizes if _sizes is not None else {}
@@ -1050,8 +1266,9 @@ class AnnotatorResultExtended(AnnotatorResult):
             return sizes[key]
         self.track_nsegments, self.track_size = cached(track_segments)
         self.annotation_nsegments, self.annotation_size = cached(annotation_segments)
-        stats = (track_segments.intersect_stats(annotation_segments, _cache=sizes)
-                 if hasattr(track_segments, "intersect_stats") else None)
+        stats = _overlap
+        if stats is None and hasattr(track_segments, "intersect_stats"):
+            stats = track_segments.intersect_stats(annotation_segments, _cache=sizes)
         if stats is None:
             overlap = track_segments.clone()
             try:

@@ -105,6 +105,65 @@ def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000, 
                 bucket_size=int(bucket_size), nbuckets=int(nbuckets))
 
 
+def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nbuckets=100000, count_workspace=None, _aflat=None):
+    """flatten_units from the host classes themselves (IntervalDictionary / IntervalCollection, gat_amd/engine.py) without a
+    numpy call per list: segments and workspace per unit from the dictionaries' flat forms, and the annotation lists
+    handed over as they are -- one per (track, key), each with the contig it belongs to -- for the library to form the
+    contig-level lists (gat_problem_desc::anno_group; IntervalDictionary.fromIsochores on its host threads).  Same result as
+    flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) ...]); None when the shortcut
+    does not apply (a track mixing keys with and without isochores)."""
+    fs, fw = segs._flat(), workspace._flat()
+    units = fs.keys
+    seg_len = np.diff(fs.off)
+    wb, we = fw.ranges(units)
+    ws_len = we - wb
+    unit_contig, contigs, contig_index = [], [], {}
+    dotted_any = plain_any = False
+    for u, ns, nw in zip(units, seg_len.tolist(), ws_len.tolist()):
+        contig, dotted = split_key(u)
+        dotted_any |= dotted
+        plain_any |= not dotted
+        if ns == 0 or nw == 0:                      # gat/__init__.py:536-538
+            unit_contig.append(-1)
+            continue
+        if contig not in contig_index:
+            contig_index[contig] = len(contigs)
+            contigs.append(contig)
+        unit_contig.append(contig_index[contig])
+    if dotted_any and plain_any:
+        raise ValueError("mixing keys with and without isochores is not supported")
+    merge = 1 if dotted_any else 0
+    if fw.keys == units:
+        ws_cat, ws_off = fw.data, fw.off
+    else:
+        ws_cat, ws_off = _cat([fw.data[b:e] for b, e in zip(wb.tolist(), we.tolist())])
+    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
+    n_contigs = len(contigs)
+    groups, begins, ends = [], [], []
+    last_keys, last_group = None, None
+    for t, (f, base) in enumerate(zip(aflats, abases.tolist())):
+        if f.keys is not last_keys and f.keys != last_keys:
+            g, dotted_t = [], False
+            for k in f.keys:
+                contig, dotted = split_key(k)
+                dotted_t |= dotted
+                g.append(contig_index.get(contig, -1))
+            if f.keys and dotted_t != bool(merge) and len(f.data):
+                return None                          # this track's fromIsochores would not do what the segments' does
+            last_keys, last_group = f.keys, np.array(g, dtype=np.int64)
+        groups.append(np.where(last_group >= 0, last_group + t * n_contigs, -1))
+        begins.append(f.off[:-1] + base)
+        ends.append(f.off[1:] + base)
+    contig_workspace = from_isochores((workspace if count_workspace is None else count_workspace).asArrays())
+    cat = (lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dtype=dt))
+    return dict(n_units=len(units), unit_names=list(units), segs=fs.data, seg_off=fs.off, ws=ws_cat, ws_off=ws_off,
+                unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=n_contigs, contig_names=list(contigs),
+                merge_contigs=merge, n_tracks=len(tracks), track_names=list(tracks),
+                annos=adata, anno_off=cat(begins, np.int64), anno_end=cat(ends, np.int64), anno_group=cat(groups, np.int32),
+                cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
+                bucket_size=int(bucket_size), nbuckets=int(nbuckets))
+
+
 def apply_isochores(segments, annotations, workspace, isochores=None, truncate_segments=False):
     """the array form of IO.applyIsochores (gat/IO.py:188-248).
 

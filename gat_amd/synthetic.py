@@ -147,6 +147,37 @@ def config(name, scale=1.0):
     raise ValueError("unknown config %r" % name)
 
 
+def as_collections(cfg):
+    """the inputs of a configuration as the host classes gat_amd.run() takes (what gat-run.py's fromSegments builds from
+    BED files, gat/IO.py:88-248): (segments, annotations, workspace) with the isochores applied.  Returns them with the
+    seconds the isochore split took."""
+    import time
+    import gat_amd
+
+    def coll(tracks):
+        c = gat_amd.IntervalCollection()
+        for t, per in tracks:
+            for contig, a in per.items():
+                s = gat_amd.SegmentList(array=a)
+                s.isNormalized = 1
+                c.add(t, contig, s)
+        return c
+
+    segments = coll([("merged", cfg["segments"])])
+    annotations = coll(cfg["annotations"])
+    workspaces = coll([("ws", cfg["workspace"])])
+    workspaces.collapse()
+    workspaces.restrict("collapsed")
+    t0 = time.perf_counter()
+    if cfg["isochores"]:
+        isochores = coll(list(cfg["isochores"].items()))
+        isochores.intersect(workspaces["collapsed"])
+        workspaces.toIsochores(isochores, truncate=True)
+        annotations.toIsochores(isochores, truncate=True)
+        segments.toIsochores(isochores, truncate=False)
+    return segments, annotations, workspaces["collapsed"], time.perf_counter() - t0
+
+
 def small_genome():
     """4 small contigs, gapped workspace, 3 isochore classes, 3 annotation tracks; one (contig, isochore)
     unit without segments and one contig without annotations in track t1 (golden run_small_*)."""

@@ -75,6 +75,15 @@ typedef struct {
   uint32_t bucket_size;         /* SamplerAnnotator(bucket_size, nbuckets): gat/Engine.pyx:498  */
   int32_t nbuckets;
   int32_t sampler;              /* GAT_SAMPLER_ANNOTATOR (gat/Engine.pyx:445) or GAT_SAMPLER_SEGMENTS (:653) */
+  /* Optional (all 0 / NULL: annos / anno_off are the [track][contig] lists above).  With anno_group set, the caller hands
+   * over the annotation lists as it holds them -- one per (track, isochore key), the `annotations` argument of
+   * UnconditionalSampler.sample (gat/__init__.py:704) -- and the library forms computeSample's contig_annotations itself
+   * (gat/__init__.py:716-718 -> IntervalDictionary.fromIsochores, gat/Engine.pyx:2857-2876: the lists of a contig
+   * concatenated and, when merge_contigs, sorted and merge(0)d), on host threads: */
+  int64_t n_anno_lists;         /* number of lists; list l = annos[anno_off[l] .. anno_end[l])                       */
+  const int64_t* anno_end;      /* n_anno_lists, or NULL: anno_off has n_anno_lists + 1 entries (CSR)                 */
+  const int32_t* anno_group;    /* n_anno_lists: track * n_contigs + contig of the list's key, or -1 (its contig has   */
+                                /* no unit that computeSample samples: the counters never see it)                      */
 } gat_problem_desc;
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
@@ -102,6 +111,8 @@ typedef struct {
                                    by k_tail_big before k_sampler resumed them                        */
   int64_t lists_from_records;   /* != 0: no final unit lists were written; their consumer (k_contig or k_count_seg) took
                                    the merged lists and k_tail's records                              */
+  int64_t n_index_entries;      /* k_count_merged: entries of the merged index its scans read (8 bytes each), and ...   */
+  int64_t n_index_lookups;      /*   ... the sample segments it looked up: what the kernel's byte model is made of       */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0
@@ -180,6 +191,25 @@ int gat_count_lists(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                     const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
                     const gat_segment* annos, const int64_t* anno_off, int32_t n_tracks,
                     const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
+
+/* The same with the annotation lists given as ranges of one array: list (track t, group g) =
+ * annos[anno_begin[t * n_groups + g] .. anno_end[t * n_groups + g]) -- what a host that keeps every dictionary's lists
+ * in one array passes without copying them into group order. */
+int gat_count_list_ranges(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                          const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                          const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                          const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
+
+/* Sizes of the intersection of two interval dictionaries, for the overlap_* columns of a result row: replaces
+ * `overlap = track_segments.clone(); overlap.intersect(annotation_segments); overlap.counts(), overlap.sum()`
+ * (AnnotatorResultExtended.__init__, gat/Engine.pyx:1911-1928; SegmentList.intersect, gat/SegmentList.pyx:1469-1549).
+ * Host arithmetic on the INPUTS of a run (one merge-join per pair of lists, on host threads); no sample passes here.
+ * a: n_groups normalized lists (CSR a_off); b: n_tracks * n_groups normalized lists as ranges of one array, list
+ * (t, g) = b[b_begin[t * n_groups + g] .. b_end[..]).  Per track t: pairs_out[t] = number of overlapping (a, b) segment
+ * pairs over all groups (= segments of the intersection), bases_out[t] = their total overlap. */
+int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off, int32_t n_groups,
+                           const gat_segment* b, const int64_t* b_begin, const int64_t* b_end, int32_t n_tracks,
+                           int64_t* pairs_out, int64_t* bases_out);
 
 /* ---- the reference's own random stream ---------------------------------------------------
  * scripts/gat-run.py:267-271 seeds numpy's global generator ONCE and every (sample, unit) of the run -- in the order of
