@@ -15,11 +15,18 @@ JSON line.  With N > 1 every rank takes its own contiguous range of sample ids (
 ONE RCCL all-gather of the per-sample count matrix, and rank 0 reads the gathered matrix back.
 
 Prints one JSON line (rank 0): metric/value per the driver contract plus
-  roofline     : the overlap-count kernel: algorithmic bytes / kernel time measured with HIP events in
-                 this run, next to what the counters of the committed rocprofv3 passes say (HBM bytes, VALU issue)
-  kernels      : per-kernel time of the step (HIP events on the launch stream)
-  configs      : the same for config3 / config5 / config4 shapes
-  cpu_baseline : the CPU oracle (oracle/gat_oracle.c, a port of the reference) timed on this host
+  roofline       : the overlap-count kernel: algorithmic bytes / kernel time measured with HIP events in this run.  For
+                   k_count_seg the bytes are SURVEY.md 8d's contract; k_count_merged never moves those (it looks a sample
+                   segment up once in an index of all tracks), so its bytes are what it does move, counted by the kernel
+                   itself: segments once + index entries read + grid look-ups + partials (contract number kept beside)
+  kernels        : per-kernel time of the step (HIP events on the launch stream)
+  sustained      : the same step repeated for at least a second behind the driver's K steps (mean, min, max over repeats)
+  configs        : the same for config3 / config5 / config4 shapes
+  strong_scaling : the metric's own job -- 10 000 samples in all -- cut into N shards: at N = 1 the time of one shard's
+                   call for N = 1, 2, 4, 8 (what each of N GPUs would run; no collective), under --gpus N the job itself
+  api            : gat_amd.run() end to end (the drop-in seam: observed counts, problem creation, sampling + counting,
+                   statistics, result rows) on config2 and config3, 10 000 samples
+  cpu_baseline   : the CPU oracle (oracle/gat_oracle.c, a port of the reference) timed on this host
 """
 import argparse
 import json
@@ -52,7 +59,11 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--extra", default="config3,config5,config4",
                     help="further BASELINE shapes measured in the same run and reported under 'configs' ('' = none)")
-    ap.add_argument("--extra-steps", type=int, default=4)
+    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the sustained loop per shape (0 = none)")
+    ap.add_argument("--no-api", action="store_true", help="skip the gat_amd.run() block")
+    ap.add_argument("--dump-counts", default=None, help="rank 0 saves the gathered count matrix of the last step (tests)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="scale interval counts (debugging only)")
@@ -144,7 +155,10 @@ class Workload(object):
         self.counters = [args.counter or cfg["counter"]]
         self.flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
         self.dev = torch.device("cuda", dev_index)
-        self.ctx = _lib.Context(dev_index, stream=torch.cuda.current_stream().cuda_stream)
+        # ONE stream for the library's kernels, the collective and the read-back: a torch stream of its own (the default
+        # stream's handle is 0, which the library reads as "make a private stream")
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.ctx = _lib.Context(dev_index, stream=self.stream.cuda_stream)
         self.P = _lib.Problem(self.ctx, self.flat)
         self.info = self.P.info()
         K, A = len(self.counters), self.flat["n_tracks"]
@@ -153,60 +167,99 @@ class Workload(object):
         # the matrix a host consumer gets: pinned, filled inside the timed region (rank 0 holds all ranks' columns)
         self.host = torch.empty((world * K, A, S), dtype=torch.int64, pin_memory=True) if rank == 0 else None
 
-    def step(self, i):
-        import torch.distributed as dist
-        # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
-        begin = (i * self.world + self.rank) * self.S
-        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts.data_ptr())
-        src = self.counts
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.counts)
-            src = self.gathered
-        if self.host is not None:
-            self.host.copy_(src, non_blocking=True)
-        return st
-
-    def measure(self, steps, warmup):
+    def step(self, i, begin=None):
         import torch
         import torch.distributed as dist
-        world, dev = self.world, self.dev
-        for i in range(warmup):
-            self.step(i)
+        # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
+        if begin is None:
+            begin = (i * self.world + self.rank) * self.S
+        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts.data_ptr())
+        with torch.cuda.stream(self.stream):
+            src = self.counts
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.gathered, self.counts)
+                src = self.gathered
+            if self.host is not None:
+                self.host.copy_(src, non_blocking=True)
+        return st
+
+    KEYS = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
+            "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_tail_units",
+            "n_index_entries", "n_index_lookups")
+
+    def timed(self, steps, first_step, acc=None):
+        """`steps` steps bracketed by barrier + synchronize on both sides; seconds, the MAX over the ranks"""
+        import torch
+        import torch.distributed as dist
         torch.cuda.synchronize()
-        if world > 1:
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        keys = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
-                "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_tail_units")
-        acc = dict((k, 0.0) for k in keys)
         for i in range(steps):
-            st = self.step(warmup + i)
-            for k in keys:
-                acc[k] += st.get(k, 0.0)
-            acc["count_kernel"] = st.get("count_kernel", 1)
+            st = self.step(first_step + i)
+            if acc is not None:
+                for k in self.KEYS:
+                    acc[k] += st.get(k, 0.0)
+                acc["count_kernel"] = st.get("count_kernel", 1)
         torch.cuda.synchronize()
-        if world > 1:
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
+        return dt
+
+    def measure(self, steps, warmup, sustain_s=0.0):
+        import torch
+        import torch.distributed as dist
+        world = self.world
+        for i in range(warmup):
+            self.step(i)
+        acc = dict((k, 0.0) for k in self.KEYS)
+        dt = self.timed(steps, warmup, acc)
+        # the same step for at least `sustain_s` seconds more, in repeats of about a quarter of that (every rank runs the
+        # same number of steps: rank 0's estimate is broadcast)
+        sustained = None
+        if sustain_s > 0:
+            per = max(1, int(round(0.25 * sustain_s / max(dt / steps, 1e-6))))
+            if world > 1:
+                t = torch.tensor([per], dtype=torch.int64, device=self.dev)
+                dist.broadcast(t, src=0)
+                per = int(t.item())
+            rates, total_t, total_n, nxt = [], 0.0, 0, warmup + steps
+            while total_t < sustain_s and len(rates) < 64:
+                d = self.timed(per, nxt)
+                nxt += per
+                rates.append(self.S * per * world / d)
+                total_t += d
+                total_n += per
+                if world > 1:                              # (all ranks leave the loop together)
+                    t = torch.tensor([total_t], dtype=torch.float64, device=self.dev)
+                    dist.broadcast(t, src=0)
+                    total_t = float(t.item())
+            sustained = {"value": self.S * total_n * world / total_t, "unit": "samples/s", "seconds": total_t, "steps": total_n,
+                         "repeats": len(rates), "min": min(rates), "max": max(rates)}
         # the one collective of the path, timed by itself after the timed region (the split the report shows per N)
         allgather = None
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
             t1 = time.perf_counter()
-            for _ in range(5):
-                dist.all_gather_into_tensor(self.gathered, self.counts)
+            with torch.cuda.stream(self.stream):
+                for _ in range(5):
+                    dist.all_gather_into_tensor(self.gathered, self.counts)
             torch.cuda.synchronize()
             allgather = {"avg_ms": (time.perf_counter() - t1) / 5 * 1e3, "bytes_per_rank": int(self.counts.numel() * 8),
                          "collective": "RCCL all_gather_into_tensor", "backend": dist.get_backend(),
                          "world_size": dist.get_world_size()}
-        return self.report(steps, warmup, dt, acc, allgather)
+        out = self.report(steps, warmup, dt, acc, allgather)
+        if sustained is not None:
+            out["sustained"] = sustained
+        return out
 
     def report(self, steps, warmup, dt, acc, allgather):
         S, world, flat, info = self.S, self.world, self.flat, self.info
@@ -232,15 +285,39 @@ class Workload(object):
                 "note": "achieved/frac follow the SURVEY 8d contract (every annotation interval charged once per sample); "
                         "the kernel serves annotations from LDS / L2, so real HBM traffic is lower: see hbm_measured_GBps"}
         if merged:
-            roof["note"] = ("achieved/frac are the SURVEY 8d contract's number and exceed the HBM peak: k_count_merged looks every "
-                            "sample segment up ONCE in a merged index of all tracks instead of reading every track's intervals, so "
-                            "the contract's bytes are never moved; what bounds it is the rate at which the L2s serve 8-byte gathers: "
-                            "see l2_GBps / l2_frac_of_peak and hbm_measured_GBps")
-            roof["lookups_per_s"] = len(flat["segs"]) * S / count_s if count_s > 0 else 0.0
+            # k_count_merged looks every sample segment up ONCE in a merged index of all tracks; the contract's bytes (every
+            # annotation interval once per sample) are never moved.  Its algorithmic bytes are what the algorithm does move,
+            # counted by the kernel itself (gat_stats n_index_lookups / n_index_entries): per sample segment 8 bytes of the
+            # segment + 4 of its grid cell + 8 per index entry its scan reads, and the partial sums it leaves per
+            # (contig, sample, track), 4 bytes each
+            lookups, entries = acc["n_index_lookups"] / steps, acc["n_index_entries"] / steps
+            moved = 12.0 * lookups + 8.0 * entries + 4.0 * flat["n_contigs"] * A * S
+            roof["contract_bytes_per_launch"] = bytes_per_sample * S
+            roof["contract_GBps"] = achieved
+            roof["algorithmic_bytes_per_launch"] = moved
+            roof["algorithmic_bytes_per_sample"] = moved / max(1, S)
+            roof["index_entries_per_lookup"] = entries / max(1.0, lookups)
+            achieved = moved / count_s / 1e9 if count_s > 0 else 0.0
+            roof["achieved"], roof["frac"] = achieved, achieved / HBM_PEAK_GBPS
+            roof["note"] = ("bound by the rate at which the L2s serve its gathers (l2_request_frac), not by HBM: achieved/frac = the "
+                            "bytes the algorithm moves (segments once + grid cells + index entries read + partials, counted by "
+                            "the kernel) / kernel time against the HBM peak; contract_GBps is SURVEY 8d's figure (every "
+                            "annotation interval charged once per sample), which this algorithm never moves")
+            roof["lookups_per_s"] = lookups / count_s if count_s > 0 else 0.0
+            # one L2 request per segment load (16 lanes x 8 B = a 128-byte line), per grid cell and per PAIR of entries;
+            # against the 34.5 TB/s / 128 B = 270 requests per ns the L2s deliver (MI355X_MICROARCH.md, L2)
+            reqs = lookups / 16.0 + lookups + (entries / 2.0 + 0.5 * lookups)
+            # (an upper bound: lanes of one load that fall into the same line are one request -- sorted segments often do)
+            roof["l2_requests_per_launch_model"] = reqs
+            roof["l2_request_frac"] = min(1.0, reqs / count_s / (34500.0e9 / 128.0)) if count_s > 0 else 0.0
         prof, src = counters_profile(self.name, S) if self.args.scale == 1.0 else (None, None)
         k = (prof or {}).get("count_kernel")
         if k and "fetch_kib_per_launch" in k and "write_kib_per_launch" in k:
-            traffic = (2.0 * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
+            # FETCH_SIZE counts half the bytes of wide coalesced streaming reads on gfx950 (MI355X_MICROARCH.md, HBM);
+            # a gather-bound kernel's narrow requests are uncalibrated: x2 only for the streaming kernel
+            fx = 1.0 if merged else 2.0
+            roof["fetch_factor"] = fx
+            traffic = (fx * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
             roof["traffic"] = traffic
             roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; " \
                                      "not re-measured in this run)" % src
@@ -295,6 +372,76 @@ class Workload(object):
         self.ctx.close()
 
 
+STRONG_TOTAL = 10000            # the metric's job: 10k simulations
+
+
+def strong_scaling(args, dev_index, rank, world):
+    """The metric's own job -- STRONG_TOTAL samples in all -- cut over N GPUs (gat/__init__.py:681-700: the reference cuts
+    its samples over pool workers).  world == 1: one GPU runs what EACH of N GPUs would run for N = 1, 2, 4, 8 (a call of
+    STRONG_TOTAL / N samples + its read-back), which bounds the job from below: N GPUs finish no earlier than one shard's call
+    (the all-gather comes on top).  world > 1: the job itself -- every rank its shard, one all-gather, read-back."""
+    import torch
+    out = {"samples_total": STRONG_TOTAL, "scaling": "strong"}
+    for name in ("config2", "config3"):
+        rows = {}
+        for n in ([world] if world > 1 else [1, 2, 4, 8]):
+            shard = -(-STRONG_TOTAL // n)
+            torch.cuda.empty_cache()
+            E = Workload(name, shard, args, dev_index, rank, world)
+            r = E.measure(20, 3)
+            E.close()
+            del E
+            k = r["kernels"]
+            rows["n%d" % n] = {"n_gpus": n, "samples_per_gpu": shard, "ms_per_job": r["ms_per_step"],
+                               "value": STRONG_TOTAL / (r["ms_per_step"] / 1e3), "unit": "samples/s",
+                               "measured_on": "%d GPU(s)" % world,
+                               "kernels_ms": {"k_rng": k["k_rng_ms"], "k_place": k["k_place_ms"], "k_merge": k["k_merge_ms"],
+                                              "k_tail": k["k_tail_ms"], "k_contig": k["k_contig_ms"], "count": k["count_phase_ms"]},
+                               "allgather_ms": (r["allgather"] or {}).get("avg_ms")}
+        out[name] = rows
+    if world == 1:
+        out["note"] = ("one GPU running a shard of STRONG_TOTAL / N samples: what N GPUs would each do, without the all-gather; "
+                       "the floor at small shards is k_place's serial chain over the longest unit's tile (DESIGN.md)")
+    return out
+
+
+def api_block(args, repeats=5):
+    """gat_amd.run() -- the reference's gat.run() seam (gat/__init__.py:855-1088) -- end to end on config2 and config3 with
+    10 000 samples: observed counts, problem creation (inputs cross PCIe), sampling + counting, null-distribution
+    statistics, the 24-column result rows.  Wall clock of the call, median of `repeats` after one warm-up call."""
+    import gc
+    import gat_amd
+    from gat_amd import synthetic
+    out = {"seam": "gat_amd.run(segments, annotations, workspace, sampler, counters, workspace_generator, num_samples=10000)"}
+    for name in ("config2", "config3"):
+        cfg = synthetic.config(name)
+        t0 = time.perf_counter()
+        segments, annotations, workspace, t_iso = synthetic.as_collections(cfg)
+        t_inputs = time.perf_counter() - t0
+        counters = [gat_amd.COUNTERS[cfg["counter"]]()]
+
+        def call():
+            t = time.perf_counter()
+            rows = gat_amd.run(segments, annotations, workspace, gat_amd.SamplerAnnotator(bucket_size=1, nbuckets=100000), counters,
+                               gat_amd.UnconditionalWorkspace(), num_samples=10000, random_seed=args.seed)
+            return time.perf_counter() - t, len(rows)
+        call()
+        gc.collect()
+        gc.disable()
+        try:
+            ts = sorted(call()[0] for _ in range(repeats))
+        finally:
+            gc.enable()
+        n_rows = call()[1]
+        med = ts[len(ts) // 2]
+        out[name] = {"ms_per_run": med * 1e3, "min_ms": ts[0] * 1e3, "max_ms": ts[-1] * 1e3, "repeats": repeats,
+                     "samples_per_s": 10000 / med, "result_rows": n_rows, "num_samples": 10000,
+                     "inputs_ms": t_inputs * 1e3, "isochore_split_ms": t_iso * 1e3,
+                     "includes": "computeCounts (observed), gat_problem_create, gat_sample_and_count, gat_null_stats, D2H of the "
+                                 "count matrix, AnnotatorResultExtended rows; excludes building the collections (inputs_ms)"}
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -325,14 +472,27 @@ def main():
 
     cfg_samples = synthetic.CONFIG_SAMPLES[args.config]
     W = Workload(args.config, args.samples or cfg_samples, args, dev_index, rank, world)
-    main_out = W.measure(args.steps, args.warmup)
+    main_out = W.measure(args.steps, args.warmup, args.sustain_seconds)
     out = {"metric": METRIC, "value": main_out["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
-    for k in ("config", "roofline", "kernels", "sampler", "allgather"):
-        out[k] = main_out[k]
+    for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained"):
+        if k in main_out:
+            out[k] = main_out[k]
+    if "sustained" in main_out:
+        out["sustained_value"] = main_out["sustained"]["value"]
     if world > 1:
-        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        devs = [None] * world
+        dist.all_gather_object(devs, (socket.gethostname(), torch.cuda.current_device(),
+                                      str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", dev_index))))
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "devices": [list(d) for d in devs], "one_gpu_per_rank": len(set(devs)) == world}
+    if args.dump_counts and rank == 0:
+        import numpy as np
+        torch.cuda.synchronize()
+        last = args.warmup + args.steps - 1 + (main_out.get("sustained") or {}).get("steps", 0)
+        np.savez(args.dump_counts, counts=W.host.numpy(), samples_per_rank=W.S, world=world, seed=args.seed,
+                 first_sample=last * world * W.S)
     if rank == 0 and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(W.flat, W.counters, args.seed, args.cpu_seconds)
         if args.config in REFERENCE_CYTHON:
@@ -346,13 +506,17 @@ def main():
     for name in [x for x in args.extra.split(",") if x and x != args.config]:
         torch.cuda.empty_cache()
         E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world)
-        r = E.measure(max(1, args.extra_steps), 1)
+        r = E.measure(max(1, args.extra_steps), 2, args.sustain_seconds)
         r["n_gpus"] = world
         extras[name] = r
         E.close()
         del E
     if extras:
         out["configs"] = extras
+    if not args.no_strong and args.scale == 1.0:
+        out["strong_scaling"] = strong_scaling(args, dev_index, rank, world)
+    if not args.no_api and world == 1 and args.scale == 1.0:
+        out["api"] = api_block(args)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -326,6 +326,15 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     if type(workspace_generator) is UnconditionalWorkspace:      # (the rows see the dictionaries themselves)
         for track in sampled_counts:
             overlaps[track] = overlap_sizes(segments[track], annotations, _aflat=aflat)
+        if aflat is not None and len(aflat[2]) >= 16 and not annotations.hasPositions():
+            # (counts, sum) of every annotation dictionary in one pass over the collection's array: list sums as
+            # SegmentList.sum() forms them (a uint32 accumulator each), added up per dictionary
+            data, bases, flats = aflat
+            run_ = np.zeros(len(data) + 1, dtype=np.int64)
+            np.cumsum(data["end"].astype(np.int64) - data["start"], out=run_[1:])
+            for t, f, base in zip(annotations.tracks, flats, bases.tolist()):
+                per = (run_[f.off[1:] + base] - run_[f.off[:-1] + base]) & 0xFFFFFFFF
+                sizes[id(annotations[t])] = (int(f.off[-1]), int(per.sum()))
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
         for track, r in observed_count.items():
             if track not in sampled_counts:

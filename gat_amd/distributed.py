@@ -40,11 +40,19 @@ def allgather_counts(local, n_total, group=None):
 
 
 def gather_numpy(local_np, n_total, group=None):
-    """numpy convenience wrapper (CPU tensors; used by the host API when results are already on
-    the host and by the gloo tests)."""
+    """numpy convenience wrapper for a matrix that is on the HOST already (gloo ranks; the gloo tests).  Under RCCL the
+    count matrix never takes this way: gat_amd.sample_counts leaves the shard on the device, gathers device memory
+    (allgather_counts) and reads the gathered matrix back once; a host matrix handed in under an nccl group is gathered
+    through a gloo group of the same ranks instead of a round trip over the device."""
     import torch
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(local_np))
-    if dist.is_initialized() and dist.get_backend(group) == "nccl":     # RCCL moves device memory only
-        return allgather_counts(t.cuda(), n_total, group).cpu().numpy()
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+        global _HOST_GROUP
+        if _HOST_GROUP is None:
+            _HOST_GROUP = dist.new_group(backend="gloo")         # (collective: every rank gets here together)
+        return allgather_counts(t, n_total, _HOST_GROUP).numpy()
     return allgather_counts(t, n_total, group).numpy()
+
+
+_HOST_GROUP = None

@@ -64,3 +64,35 @@ def test_shard_ranges_cover_everything():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert all(e - b <= distributed.padded_shard(n, w) for b, e in r)
+
+
+def _worker_ragged(rank, world, port, S, path):
+    import torch.distributed as dist
+    from gat_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    begin, end = distributed.shard_range(S, rank, world)
+    per = distributed.padded_shard(S, world)
+    # slot (k, a, s) of the whole matrix holds a number that names it; a rank fills its own columns
+    stack = np.zeros((2, 3, per), dtype=np.int64)
+    for k in range(2):
+        for a in range(3):
+            stack[k, a, :end - begin] = (k * 3 + a) * 1000 + np.arange(begin, end)
+    full = distributed.gather_numpy(stack, S)
+    np.save(os.path.join(path, "ragged%d.npy" % rank), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_shards(tmp_path):
+    """the node's shape -- eight ranks -- with 37 samples: shards of 5, the last of 2, ranks past the end of nothing; every rank
+    must end up with every column in sample order."""
+    S, world = 37, 8
+    mp.spawn(_worker_ragged, args=(world, _free_port(), S, str(tmp_path)), nprocs=world, join=True)
+    want = np.zeros((2, 3, S), dtype=np.int64)
+    for k in range(2):
+        for a in range(3):
+            want[k, a] = (k * 3 + a) * 1000 + np.arange(S)
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "ragged%d.npy" % r)), want), r

@@ -106,3 +106,109 @@ def test_c_abi_allgather_counts_single_rank():
         ctx.free(b)
         comm.close()
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# RCCL with more than one rank: these run the moment a box shows two GPUs (the boxes this suite usually sees have one,
+# where RCCL refuses two ranks on a device and the tests above stand in with gloo).
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+needs_two_gpus = pytest.mark.skipif(_n_gpus() < 2, reason="RCCL with two ranks needs two GPUs")
+
+
+def _worker_c_abi(rank, world, uid, path):
+    from gat_amd import _lib
+    ctx = _lib.Context(rank)                              # one GPU per rank
+    comm = _lib.Comm(ctx, world, rank, uid)
+    n = 2 * 3 * 11                                        # [counter][track][shard] slots of this rank
+    src = (np.arange(n, dtype=np.int64) + 1) * (rank + 1) * 7 - 5
+    a, b = ctx.alloc(n * 8), ctx.alloc(world * n * 8)
+    try:
+        _lib._check(_lib.lib().gat_memcpy_h2d(ctx._h, a, src.ctypes.data, n * 8), ctx._h)
+        comm.allgather_counts(a, b, n)
+        out = np.zeros(world * n, dtype=np.int64)
+        ctx.d2h(out, b)
+        np.save(os.path.join(path, "abi%d.npy" % rank), out)
+    finally:
+        ctx.free(a)
+        ctx.free(b)
+        comm.close()
+        ctx.close()
+
+
+@needs_two_gpus
+def test_c_abi_allgather_counts_two_ranks(tmp_path):
+    """gat_comm_create + gat_allgather_counts over RCCL, two ranks on two GPUs, no torch.distributed: every rank ends up with
+    rank r's block at r * n_slots."""
+    from gat_amd import _lib
+    uid = _lib.comm_unique_id()                           # (rank 0's call in a real host; the bytes travel by argument here)
+    mp.spawn(_worker_c_abi, args=(2, uid, str(tmp_path)), nprocs=2, join=True)
+    n = 2 * 3 * 11
+    want = np.concatenate([(np.arange(n, dtype=np.int64) + 1) * (r + 1) * 7 - 5 for r in range(2)])
+    for r in range(2):
+        assert np.array_equal(np.load(str(tmp_path / ("abi%d.npy" % r))), want), r
+
+
+def _worker_nccl(rank, world, port, path, seed, device_stats):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = str(rank)
+    os.environ["GAT_DEVICE_STATS"] = "1" if device_stats else "0"
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    rows = _run(37, seed)
+    with open(os.path.join(path, "nccl_rows%d.txt" % rank), "w") as f:
+        f.write("\n".join(rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("device_stats", [True, False])
+def test_run_under_nccl_equals_single_process(tmp_path, device_stats):
+    """gat_amd.run() under the nccl backend (= RCCL): two ranks, one GPU each, shard the samples, all-gather the device
+    matrix, take the statistics from it (on the device, or with numpy) and print the rows one process prints."""
+    mp.spawn(_worker_nccl, args=(2, _free_port(), str(tmp_path), 5, device_stats), nprocs=2, join=True)
+    r0 = open(str(tmp_path / "nccl_rows0.txt")).read().split("\n")
+    r1 = open(str(tmp_path / "nccl_rows1.txt")).read().split("\n")
+    assert r0 == r1 and len(r0) == 9
+    os.environ["GAT_DEVICE_STATS"] = "0"
+    try:
+        assert r0 == _run(37, 5)
+    finally:
+        del os.environ["GAT_DEVICE_STATS"]
+
+
+@needs_two_gpus
+def test_bench_two_gpus_over_rccl(tmp_path):
+    """bench.py --gpus 2 as the driver launches it: backend nccl, one GPU per rank, and the gathered matrix of the last
+    step equal to the oracle's columns for those sample ids."""
+    import json
+    import subprocess
+    import sys
+    from gat_amd import problem, synthetic
+    from oracle import oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                    "GAT_BENCH_SHARE_GPU"))
+    dump = str(tmp_path / "counts.npz")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "64",
+           "--extra", "", "--no-strong", "--sustain-seconds", "0", "--dump-counts", dump]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["distributed"]["backend"] == "nccl" and out["distributed"]["world_size"] == 2
+    assert out["distributed"]["one_gpu_per_rank"] and len(set(map(tuple, out["distributed"]["devices"]))) == 2
+    z = np.load(dump)
+    cfg = synthetic.config("config2")
+    flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
+    first, S = int(z["first_sample"]), int(z["samples_per_rank"])
+    want, _ = O.run_samples(flat, ["nucleotide-overlap"], int(z["seed"]), 1, first, first + 2 * S)
+    got = z["counts"]                                     # [rank * K + k][track][sample of the rank's shard]
+    for rk in range(2):
+        assert np.array_equal(got[rk], want[0][:, rk * S:(rk + 1) * S]), rk

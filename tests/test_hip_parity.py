@@ -728,7 +728,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--samples", "2000", "--extra", ""]
+           "--warmup", "1", "--samples", "2000", "--extra", "", "--no-strong", "--sustain-seconds", "0.2"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -736,7 +736,8 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["allgather"]["bytes_per_rank"] == 2000 * 8
-    assert "cpu_baseline" not in out                      # reported at N = 1 only
+    assert "cpu_baseline" not in out and "api" not in out # reported at N = 1 only
+    assert out["sustained"]["seconds"] >= 0.2 and out["sustained"]["min"] <= out["sustained_value"] <= out["sustained"]["max"]
 
 
 def test_bench_starts_its_own_ranks():
@@ -748,14 +749,17 @@ def test_bench_starts_its_own_ranks():
     env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))
     env["GAT_BENCH_SHARE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples",
-           "1000", "--extra", "config1", "--extra-steps", "1"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+           "1000", "--extra", "config1", "--extra-steps", "1", "--sustain-seconds", "0"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["value"] > 0
     assert out["configs"]["config1"]["value"] > 0 and out["configs"]["config1"]["n_gpus"] == 2
+    # the metric's own job (10 000 samples in all) cut over the two ranks
+    st = out["strong_scaling"]
+    assert st["samples_total"] == 10000 and st["config2"]["n2"]["samples_per_gpu"] == 5000 and st["config3"]["n2"]["value"] > 0
 
 
 def test_cli_overlap_stats_match_reference(ctx, tmp_path):

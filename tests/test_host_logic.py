@@ -434,3 +434,128 @@ def test_numpy_summation_model():
         assert m == float(np.mean(a)), n
         v = np_sum([(x - m) * (x - m) for x in al]) / n
         assert float(np.sqrt(v)) == float(np.std(a)), n
+
+
+def _coll(tracks):
+    import gat_amd
+    c = gat_amd.IntervalCollection()
+    for t, per in tracks:
+        for contig, a in per.items():
+            s = gat_amd.SegmentList(array=a)
+            s.isNormalized = 1
+            c.add(t, contig, s)
+    return c
+
+
+def test_to_isochores_one_pass_equals_list_by_list():
+    """IntervalDictionary.toIsochores (gat/Engine.pyx:2837-2855) as one vectorised pass over the dictionary against the
+    list-by-list form of the reference: random tracks with missing contigs, empty lists, 1-4 isochore classes with and
+    without gaps, truncate and filter; keys, lists, flags, sums, and the flat form it leaves behind."""
+    import collections
+    from gat_amd import engine, intervals as iv
+    rs = np.random.RandomState(5)
+
+    def rand_list(n, size):
+        s = np.sort(rs.randint(0, size, n))
+        return iv.normalize(iv.make(s, s + rs.randint(1, 50, n)))
+
+    for trial in range(60):
+        contigs = ["c%d" % i for i in range(rs.randint(1, 5))]
+        K = rs.randint(1, 5)
+        block = rs.randint(20, 200)
+        iso = []
+        for k in range(K):
+            per = collections.OrderedDict()
+            for c in contigs:
+                if rs.rand() < 0.2:
+                    continue
+                st = np.arange(k * block, 3000, K * block)
+                per[c] = iv.make(st, st + block - (rs.randint(0, 3) if rs.rand() < .5 else 0))
+            iso.append(("iso%d" % k, per))
+        tr = []
+        for t in range(3):
+            per = collections.OrderedDict()
+            for c in contigs + ["zz"]:
+                if rs.rand() < 0.3:
+                    continue
+                per[c] = rand_list(rs.randint(0, 40), 3200)
+            tr.append(("t%d" % t, per))
+        for truncate in (True, False):
+            A, B = _coll(tr), _coll(tr)
+            A.toIsochores(_coll(iso), truncate)
+            orig = engine.IntervalDictionary._to_isochores_flat
+            engine.IntervalDictionary._to_isochores_flat = lambda *a, **k: False
+            try:
+                B.toIsochores(_coll(iso), truncate)
+            finally:
+                engine.IntervalDictionary._to_isochores_flat = orig
+            for t in A.tracks:
+                assert list(A[t].keys()) == list(B[t].keys())
+                for k in A[t].keys():
+                    assert np.array_equal(A[t][k].asArray(), B[t][k].asArray()), (trial, truncate, t, k)
+                    assert A[t][k].isNormalized == B[t][k].isNormalized
+                assert A[t].sum() == B[t].sum() and A[t].counts() == B[t].counts()
+                assert A[t]._flat() is A[t]._flat()
+    # overlapping classes are not a partition: the shortcut steps aside and the result is still the reference's
+    seg = [("t", collections.OrderedDict([("c0", iv.make([10, 100], [60, 180]))]))]
+    iso2 = [("a", collections.OrderedDict([("c0", iv.make([0], [120]))])), ("b", collections.OrderedDict([("c0", iv.make([50], [200]))]))]
+    A = _coll(seg)
+    A.toIsochores(_coll(iso2), True)
+    assert A["t"]["c0.a"].asList() == [(10, 60), (100, 120)] and A["t"]["c0.b"].asList() == [(50, 60), (100, 180)]
+
+
+def test_flat_form_follows_the_lists():
+    """IntervalDictionary._flat: one array for all lists, found again while nothing changed, rebuilt when a list is replaced,
+    added or removed; sum() / counts() through it equal the per-list ones."""
+    import collections
+    import gat_amd
+    from gat_amd import intervals as iv
+    per = collections.OrderedDict(("k%d" % i, iv.make(np.arange(i) * 10, np.arange(i) * 10 + 3)) for i in range(20))
+    d = _coll([("t", per)])["t"]
+    f = d._flat()
+    assert f is d._flat() and f.keys == list(per.keys()) and len(f.data) == sum(range(20))
+    assert d.sum() == 3 * sum(range(20)) and d.counts() == sum(range(20))
+    for i, k in enumerate(per):
+        assert np.array_equal(d[k].asArray(), per[k]) and np.array_equal(f.data[f.off[i]:f.off[i + 1]], per[k])
+    d["k3"].merge(7)                                    # [0,3) [10,13) [20,23) become one: the list has a new array
+    g = d._flat()
+    assert g is not f and len(g.data) == sum(range(20)) - 2 and d.counts() == len(g.data)
+    d["new"] = gat_amd.SegmentList(iter=[(1, 2)], normalize=True)
+    assert d._flat().keys[-1] == "new" and d.counts() == len(g.data) + 1
+    del d["k19"]
+    assert "k19" not in d._flat().keys
+    b, e = d._flat().ranges(["k5", "nope", "k2"], base=100)
+    assert (e - b).tolist() == [5, 0, 2] and b[0] == 100 + d._flat().off[d._flat().position("k5")]
+
+
+def test_flatten_dictionaries_equals_flatten_units():
+    """problem.flatten_dictionaries (the host classes' flat forms + annotation lists handed over with a group id each)
+    describes the same problem as problem.flatten_units on the arrays: identical units, contigs, workspaces, and --
+    grouping the lists as the library does (gat_prep.hip: group_annotations) -- identical contig-level annotations."""
+    from gat_amd import intervals as iv, problem, synthetic
+    _, cfg = synthetic.small_genome()
+    segments, annotations, workspace, _ = synthetic.as_collections(cfg)
+    segs = segments["merged"]
+    tracks = list(annotations.tracks)
+    new = problem.flatten_dictionaries(segs, workspace, annotations, tracks, 1, 1000)
+    old = problem.flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) for t in tracks], 1, 1000)
+    for k in ("n_units", "n_contigs", "merge_contigs", "n_tracks", "unit_names", "contig_names", "bucket_size", "nbuckets"):
+        assert old[k] == new[k], k
+    for k in ("segs", "seg_off", "ws", "ws_off", "unit_contig", "cws_nseg"):
+        assert np.array_equal(old[k], new[k]), k
+    assert len(new["anno_group"]) == len(new["anno_off"]) == len(new["anno_end"])
+    C = new["n_contigs"]
+    for g in range(new["n_tracks"] * C):
+        members = np.flatnonzero(new["anno_group"] == g)
+        parts = [new["annos"][new["anno_off"][l]:new["anno_end"][l]] for l in members]
+        got = iv.merge(np.concatenate(parts), 0) if parts else iv.EMPTY
+        assert np.array_equal(got, old["annos"][old["anno_off"][g]:old["anno_off"][g + 1]]), g
+    # lists of contigs without an active unit carry -1
+    assert (new["anno_group"] == -1).sum() == sum(1 for t in tracks for k in annotations[t].keys()
+                                                  if problem.split_key(k)[0] not in new["contig_names"])
+
+
+def test_numpy_summation_self_check():
+    """the run-time form of test_numpy_summation_model: what decides whether gat_null_stats may stand in for numpy"""
+    import gat_amd
+    assert gat_amd._numpy_summation_model_holds() is True
