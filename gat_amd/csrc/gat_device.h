@@ -22,11 +22,15 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 
 // LDS hand-off between lanes of ONE wave: LDS operations of a wave execute in order, so only the
 // compiler has to be kept from reordering; the workgroup is a single wave (launch_bounds 64).
-#ifdef GAT_EXP_WAVE_SYNC_LDS
-__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
-#endif
+// MEM = false: the data handed between the lanes is in LDS -- wait for the wave's LDS operations, nothing else; loads from
+// global memory the wave has in flight stay in flight (a __syncthreads() here -- s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+// -- drained them at every step of a sort or merge).  MEM = true: the list itself lives in global memory (the HUGE
+// variants of k_sampler / k_contig, k_resume_big): the full form, as before.
+template <bool MEM = false>
+__device__ __forceinline__ void wave_sync() {
+  if constexpr (MEM) __syncthreads();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 // the same between the lanes of one wave inside a workgroup of several waves that do not run in step (no barrier may be
 // used): LDS operations of a wave execute in order; wait for them and keep the compiler from moving accesses across
@@ -230,12 +234,13 @@ __device__ __forceinline__ void cmpex(uint2* seg, int i, int j) {
   const uint2 a = seg[i], b = seg[j];
   if (b.x < a.x) { seg[i] = b; seg[j] = a; }
 }
+template <bool MEM = false>
 __device__ __forceinline__ void wave_sort_by_start(uint2* seg, int n, int lane) {
   if (n < 2) return;
   int lP = 1;
   while ((1 << lP) < n) ++lP;
   const int half_total = 1 << (lP - 1);
-  wave_sync();
+  wave_sync<MEM>();
   for (int lk = 1; lk <= lP; ++lk) {
     // flip step: i and its mirror image inside blocks of k = 2^lk
     const int hmask = (1 << (lk - 1)) - 1;
@@ -244,14 +249,14 @@ __device__ __forceinline__ void wave_sort_by_start(uint2* seg, int n, int lane) 
       const int i = base + off, j = base + ((1 << lk) - 1 - off);
       if (j < n) cmpex(seg, i, j);
     }
-    wave_sync();
+    wave_sync<MEM>();
     for (int ld = lk - 2; ld >= 0; --ld) {
       const int dmask = (1 << ld) - 1;
       for (int t = lane; t < half_total; t += kWave) {
         const int i = ((t >> ld) << (ld + 1)) + (t & dmask), j = i + (1 << ld);
         if (j < n) cmpex(seg, i, j);
       }
-      wave_sync();
+      wave_sync<MEM>();
     }
   }
 }
@@ -298,10 +303,10 @@ template <int E>
 __device__ __forceinline__ void sort_disperse_below64(uint32_t (&ks)[E], uint32_t (&ke)[E], int ld_from, int lane) {
   for (int ld = ld_from; ld >= 0; --ld) sort_stage_lanes<E>(ks, ke, 1 << ld, ld, lane);
 }
-template <int E>
+template <int E, bool MEM = false>
 __device__ __forceinline__ void wave_sort_regs(uint2* seg, int n, int lane) {
   uint32_t ks[E], ke[E];
-  wave_sync();
+  wave_sync<MEM>();
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = r * kWave + lane;
@@ -340,16 +345,17 @@ __device__ __forceinline__ void wave_sort_regs(uint2* seg, int n, int lane) {
     const int i = r * kWave + lane;
     if (i < n) seg[i] = make_uint2(ks[r], ke[r]);
   }
-  wave_sync();
+  wave_sync<MEM>();
 }
 // The sort behind the bucket sort: up to a wave's worth in registers, longer lists through the in-LDS network.
 // It only runs for short lists, clustered keys and units redone from their seed, and it is kept SMALL on purpose:
 // the register networks for 2..16 elements per lane tripled the kernel beyond the instruction cache, which cost
 // the common path more than they saved here.
+template <bool MEM = false>
 __device__ __forceinline__ void wave_sort_auto(uint2* seg, int n, int lane) {
   if (n < 2) return;
-  if (n <= 64) wave_sort_regs<1>(seg, n, lane);
-  else wave_sort_by_start(seg, n, lane);
+  if (n <= 64) wave_sort_regs<1, MEM>(seg, n, lane);
+  else wave_sort_by_start<MEM>(seg, n, lane);
 }
 
 // Sort by start for keys that are spread over a range (placed segments are): 512 buckets by
@@ -358,11 +364,11 @@ __device__ __forceinline__ void wave_sort_auto(uint2* seg, int n, int lane) {
 // index.  ~10x fewer instructions than the sorting network.  Returns false (nothing written) when
 // the keys are too clustered (a bucket with more than 16 members, or all starts equal); the caller
 // then uses the network.  scratch: 513 words of LDS.
-template <int E>
+template <int E, bool MEM = false>
 __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* scratch, int lane) {
   constexpr int NB = 512, PER = NB / kWave;
   uint32_t ks[E], ke[E];
-  wave_sync();
+  wave_sync<MEM>();
   uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -376,7 +382,7 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
   const bool direct = span < (uint32_t)NB;                       // fewer positions than buckets
   const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)NB << 32) / ((uint64_t)span + 1u));
   for (int i = lane; i <= NB; i += kWave) scratch[i] = 0;
-  wave_sync();
+  wave_sync<MEM>();
   uint32_t bk[E], slot[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -388,7 +394,7 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
       slot[r] = atomicAdd(&scratch[bk[r]], 1u);
     }
   }
-  wave_sync();
+  wave_sync<MEM>();
   // exclusive prefix over the bucket counts: lane owns PER consecutive buckets
   uint32_t c[PER], sum = 0, maxc = 0;
 #pragma unroll
@@ -396,11 +402,11 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
   uint32_t run = wave_incl_sum_u32(sum, lane) - sum;
   maxc = wave_max_u32(maxc);
   if (maxc > 16u) return false;
-  wave_sync();
+  wave_sync<MEM>();
 #pragma unroll
   for (int q = 0; q < PER; ++q) { scratch[lane * PER + q] = run; run += c[q]; }
   if (lane == kWave - 1) scratch[NB] = run;
-  wave_sync();
+  wave_sync<MEM>();
   uint32_t base[E], cnt[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
@@ -408,7 +414,7 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
     base[r] = 0; cnt[r] = 0;
     if (i < n) { base[r] = scratch[bk[r]]; cnt[r] = scratch[bk[r] + 1] - base[r]; seg[base[r] + slot[r]] = make_uint2(ks[r], ke[r]); }
   }
-  wave_sync();
+  wave_sync<MEM>();
   uint32_t rank[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) rank[r] = 0;
@@ -421,13 +427,13 @@ __device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* sc
       }
     }
   }
-  wave_sync();
+  wave_sync<MEM>();
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = r * kWave + lane;
     if (i < n) seg[base[r] + rank[r]] = make_uint2(ks[r], ke[r]);
   }
-  wave_sync();
+  wave_sync<MEM>();
   return true;
 }
 // Counting sort by position bucket for long lists whose unsorted source is still in global memory
@@ -552,29 +558,30 @@ __device__ __forceinline__ bool wave_sort_bucket_regs(uint2* dst, const uint2 (&
 }
 
 // bucket sort when possible (scratch available, list short enough), else the sorting network
-template <int MAXE = 8>
+template <int MAXE = 8, bool MEM = false>
 __device__ __forceinline__ void wave_sort_fast(uint2* seg, int n, uint32_t* scratch, int lane) {
   if (n < 2) return;
   bool done = false;
   if (scratch != nullptr && n > 64) {
-    if (n <= 256) done = wave_sort_bucket<4>(seg, n, scratch, lane);
-    else if (n <= 512) done = wave_sort_bucket<8>(seg, n, scratch, lane);
+    if (n <= 256) done = wave_sort_bucket<4, MEM>(seg, n, scratch, lane);
+    else if (n <= 512) done = wave_sort_bucket<8, MEM>(seg, n, scratch, lane);
     // (k_sampler, MAXE = 8: the first consolidation sorts longer lists straight from the slab, wave_sort_bucket_global;
     //  a later full sort of such a list -- after a trim with many new segments -- is rare and takes the network)
-    else if (MAXE >= 16 && n <= 1024) done = wave_sort_bucket<16>(seg, n, scratch, lane);
+    else if (MAXE >= 16 && n <= 1024) done = wave_sort_bucket<16, MEM>(seg, n, scratch, lane);
   }
-  if (!done) wave_sort_auto(seg, n, lane);
+  if (!done) wave_sort_auto<MEM>(seg, n, lane);
 }
 
 // SegmentList.merge(0) (gat/SegmentList.pyx:756-816) on a list already sorted by start (empty
 // segments anywhere are skipped, as the reference skips them): in place, 64 elements per step.
 // head[i] = first non-empty, or int32(start) - 0 > running max end; the previous group's end is
 // the running max seen just before the next head.  Returns the new length.
+template <bool MEM = false>
 __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
   int count = 0;
   int32_t carry = INT32_MIN;
   bool any = false;
-  wave_sync();
+  wave_sync<MEM>();
   for (int base = 0; base < n; base += kWave) {
     const int i = base + lane;
     uint32_t s = 0, e = 0;
@@ -592,7 +599,7 @@ __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
     const bool head = valid && (!prev_valid || (int32_t)s > excl);
     const uint64_t hb = __ballot(head);
     const int pos = count + __popcll(hb & lanemask_lt(lane));
-    wave_sync();
+    wave_sync<MEM>();
     if (head) {
       seg[pos].x = s;
       if (pos > 0) seg[pos - 1].y = (uint32_t)excl;
@@ -600,10 +607,10 @@ __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
     count += __popcll(hb);
     carry = __builtin_amdgcn_readlane(incl, kWave - 1);
     any = any || (vb != 0);
-    wave_sync();
+    wave_sync<MEM>();
   }
   if (count > 0 && lane == 0) seg[count - 1].y = (uint32_t)carry;
-  wave_sync();
+  wave_sync<MEM>();
   return count;
 }
 
@@ -613,8 +620,9 @@ __device__ __forceinline__ int wave_merge0(uint2* seg, int n, int lane) {
 // the number of elements of the other list that sort before it; the old list is shifted in
 // place from its last 64-row backwards (shifts are monotone and <= nS, so nothing unread is
 // overwritten) and rows in front of the first insertion point are not touched.
+template <bool MEM = false>
 __device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, int lane) {
-  wave_sync();
+  wave_sync<MEM>();
   uint2 nv = make_uint2(0xffffffffu, 0xffffffffu);
   if (lane < nS) nv = seg[nU + lane];
   int nrank = 0;
@@ -659,13 +667,13 @@ __device__ __forceinline__ void wave_insert_sorted(uint2* seg, int nU, int nS, i
       sh += cj <= i ? 1 : 0;
     }
     sh = ok ? sh : 0;
-    wave_sync();
+    wave_sync<MEM>();
     if (sh > 0) seg[i + sh] = v;
-    wave_sync();
+    wave_sync<MEM>();
     if (upto == 0) break;                                                  // nothing goes in at or before this block
   }
   if (lane < nS) seg[newpos] = nv;
-  wave_sync();
+  wave_sync<MEM>();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -990,10 +990,10 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
           const int nE = R[kPatchNExtra], nSp = R[kTbNSampled], at = R[kTbSampledAt];
           for (int i = lane; i < nE; i += kWave) seg[nU + i] = out[cap - 1 - i];
           for (int i = lane; i < nSp; i += kWave) seg[nU + nE + i] = out[at + i];
-          wave_sync();
+          wave_sync<HUGE>();
           for (int done = 0; done < nE; done += kWave) {
             const int chunk = nE - done < kWave ? nE - done : kWave;
-            wave_insert_sorted(seg, nU + done, chunk, lane);         // (the next chunk stands right behind the grown list)
+            wave_insert_sorted<HUGE>(seg, nU + done, chunk, lane);         // (the next chunk stands right behind the grown list)
           }
           nU += nE;
           nS = nSp;
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         rng.pre_j = rng.ndraws;
         rng.pre_base = rng.pre_j - (uint32_t)kWave;
       }
-      wave_sync();
+      wave_sync<HUGE>();
       GAT_PHASE(0)                                   // prologue: unit record, workspace, hand-off record, list into LDS
     } else {
       if (serial != nullptr) { rng = *serial; rng.mt = mt; rng.ndraws = 0; }      // (k_serial: the run's one stream goes on)
@@ -1066,7 +1066,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
           const bool touch_prev = pcount > 0 && (int32_t)xs <= (int32_t)rfl(pv.y);
           const bool touch_next = pcount < nU && (int32_t)rfl(nv.x) <= (int32_t)xe;
           if (xs != xe && !touch_prev && !touch_next) {
-            wave_insert_sorted(seg, nU, 1, lane);
+            wave_insert_sorted<HUGE>(seg, nU, 1, lane);
             nU += 1;
             nS = 0;
             cov = cov_known + (nws <= kWsLoopMax ? ws_overlap_regs(W, xs, xe) : ws_overlap1(xs, xe));
@@ -1082,9 +1082,9 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             // ready for the few new segments to be inserted
             uint2 moved = make_uint2(0u, 0u);
             if (lane < nS) moved = seg[nU + lane];
-            const int kept = wave_merge0(seg, nU, lane);
+            const int kept = wave_merge0<HUGE>(seg, nU, lane);
             if (lane < nS) seg[kept + lane] = moved;
-            wave_sync();
+            wave_sync<HUGE>();
             nU = kept;
             dirty = false;
           }
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             uint32_t* big = reinterpret_cast<uint32_t*>(seg + A.lds_cap);
             if (!wave_sort_bucket_global(seg, out, n, big, nb, lane)) {
               for (int i = lane; i < n; i += kWave) seg[i] = out[i];
-              wave_sort_by_start(seg, n, lane);
+              wave_sort_by_start<HUGE>(seg, n, lane);
             }
           } else if (!HUGE && resume && nU == 0 && !dirty && n > 512 && n <= 1024 && n == pre.x) {
             // 513..1024 segments, still where k_place wrote them: the same counting sort with 512 buckets (the bucket sort
@@ -1104,19 +1104,19 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             // every wave of the kernel spills: 128 VGPRs + 76 bytes of scratch against 106 without)
             if (!wave_sort_bucket_global(seg, out, n, mt, 512, lane)) {
               for (int i = lane; i < n; i += kWave) seg[i] = out[i];
-              wave_sort_auto(seg, n, lane);
+              wave_sort_auto<HUGE>(seg, n, lane);
             }
           } else if (BIG && nU > 0 && !dirty && n > 1024 && nS <= 1024) {
             // a long clean list and some new segments: insert them 64 at a time (a pass over the list each) rather than
             // sort everything with the network (thousands of passes)
             for (int done = 0; done < nS; done += kWave)
-              wave_insert_sorted(seg, nU + done, nS - done < kWave ? nS - done : kWave, lane);
+              wave_insert_sorted<HUGE>(seg, nU + done, nS - done < kWave ? nS - done : kWave, lane);
           } else
-          if (nU == 0 || nS > kWave || dirty) wave_sort_fast(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
+          if (nU == 0 || nS > kWave || dirty) wave_sort_fast<8, HUGE>(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)
-          else if (nS > 0) wave_insert_sorted(seg, nU, nS, lane);         // same order, few new segments
+          else if (nS > 0) wave_insert_sorted<HUGE>(seg, nU, nS, lane);         // same order, few new segments
           GAT_PHASE(1)                               // sort / insert
-          nU = wave_merge0(seg, n, lane);
+          nU = wave_merge0<HUGE>(seg, n, lane);
           GAT_PHASE(2)                               // merge(0)
           nS = 0;
           dirty = false;
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         if (rng.exhausted) break;
         if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { status |= kStatusTrimAssert; break; }
         // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597); _getInsertionPoint(pos,pos+1) == k
-        wave_sync();
+        wave_sync<HUGE>();
         uint32_t removed = 0;                      // workspace bases taken away by the trim (lane 0)
         if (lane == 0) {
           int idx = k;
@@ -1226,7 +1226,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
         }
         cov_known -= rfl(removed);
         total_known -= (uint32_t)(-true_remaining);      // trim_ends removes exactly that many bases
-        wave_sync();
+        wave_sync<HUGE>();
         dirty = true;
         true_remaining = 1;
         GAT_PHASE(5)                                 // overshoot trim
@@ -1348,7 +1348,7 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
     for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
       const uint32_t e = A.todo[w];
       sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)(e / (uint32_t)A.n_active), (int)(e % (uint32_t)A.n_active), lds, lane);
-      wave_sync();
+      wave_sync<HUGE>();
     }
     return;
   }
@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(64) void k_serial(SamplerArgs A) {
       const int a = A.unit_pos[u];
       if (a < 0) continue;                                          // (gat/__init__.py:536-538: no segments or no workspace)
       sampler_unit<KIND, BIG, TREE, HUGE>(A, s, a, lds, lane, &rng);
-      wave_sync();
+      wave_sync<HUGE>();
     }
   }
   wave_sync();
@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     if (patched_mask != 0) {
       // one lane per finished unit: its extras behind the merged list (k_tail has applied the trim to both; the order
       // inside the contig's list does not matter: it is sorted below, and merge(0) drops the emptied segments)
-      wave_sync();
+      wave_sync<HUGE>();
       if (my_patched) {
         const int nU = my_copy, nE = my_patch[kPatchNExtra];
 #pragma unroll
@@ -1523,12 +1523,12 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
         *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + u) * 4) =
             make_uint4((uint32_t)my_patch[kPatchPlaced], (uint32_t)my_patch[kPatchNdraws], (uint32_t)my_patch[kPatchNuns], 0u);
       }
-      wave_sync();
+      wave_sync<HUGE>();
     }
     n += (int)wave_total_u32((uint32_t)my_cnt);
   }
-  wave_sort_fast<16>(seg, n, scratch, lane);
-  n = wave_merge0(seg, n, lane);
+  wave_sort_fast<16, HUGE>(seg, n, scratch, lane);
+  n = wave_merge0<HUGE>(seg, n, lane);
   if (!HUGE)
     for (int i = lane; i < n; i += kWave) out[i] = seg[i];
   if (lane == 0) {

@@ -682,10 +682,10 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
         }
       }
     }
-    wave_sync();
+    wave_sync<true>();
 #pragma unroll
     for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) l_cs[rk[h]] = cu[h];
-    wave_sync();
+    wave_sync<true>();
     const int cs0 = lane < nE ? l_cs[lane] : 0x7fffffff, cs1 = kWave + lane < nE ? l_cs[kWave + lane] : 0x7fffffff;
     constexpr int kB = 8;
     for (int top = ((nU - 1) >> 6) << 6; top >= 0; top -= kB * kWave) {
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) out[cu[h] + rk[h]] = e[h];
     nU += nE;
-    wave_sync();                                                    // (the list is read again below: stores done)
+    wave_sync<true>();                                                    // (the list is read again below: stores done)
   }
 
   WaveRng rng;
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     }
     cov -= (uint32_t)__builtin_amdgcn_readfirstlane((int)removed);
     total -= (uint32_t)(-true_remaining);
-    wave_sync();
+    wave_sync<true>();
     true_remaining = 1;
     // ---- hs.sample() (:413-435) and the consolidation with nothing new (:582-606)
     {

@@ -1053,3 +1053,65 @@ def test_device_null_stats_golden_and_run(ctx, monkeypatch):
                 assert getattr(devr, key) == c[key], key
     monkeypatch.setenv("GAT_DEVICE_STATS", "1")
     test_run_api_rows_match_reference(ctx)
+
+
+@pytest.mark.parametrize("with_isochores", [True, False])
+def test_grouped_annotation_lists_equal_contig_lists(ctx, with_isochores):
+    """gat_problem_desc::anno_group: the annotation lists handed over one per (track, key) with a group id each -- the
+    library forms the contig-level lists (IntervalDictionary.fromIsochores, gat/Engine.pyx:2857-2876) on its host threads --
+    against the same problem described with the contig-level lists made by the host (problem.flatten_units), and both
+    against the oracle: all six counters, isochore keys (concatenate, sort, merge(0)) and plain keys (pass through)."""
+    from gat_amd import problem, synthetic
+    _, cfg = synthetic.small_genome()
+    if not with_isochores:
+        cfg["isochores"] = None
+    segments, annotations, workspace, _ = synthetic.as_collections(cfg)
+    if not with_isochores:
+        for coll in (segments, annotations):             # gat/IO.py:243-248 without isochores
+            for t in coll.tracks:
+                for c in list(coll[t].keys()):
+                    if c in workspace:
+                        coll[t][c].intersect(workspace[c])
+                    else:
+                        del coll[t][c]
+    segs = segments["merged"]
+    tracks = list(annotations.tracks)
+    new = problem.flatten_dictionaries(segs, workspace, annotations, tracks, 1, 1000)
+    old = problem.flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) for t in tracks], 1, 1000)
+    assert new is not None and new["merge_contigs"] == (1 if with_isochores else 0)
+    counters = list(_lib.COUNTER_IDS.keys())
+    Pn, Po = _lib.Problem(ctx, new), _lib.Problem(ctx, old)
+    got_n = Pn.sample_and_count(counters, 77, 3, 19)
+    got_o = Po.sample_and_count(counters, 77, 3, 19)
+    want, _ = O.run_samples(old, counters, 77, 1, 3, 19)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got_n[k], got_o[k]), c
+        assert np.array_equal(got_n[k], want[k]), c
+    Pn.close()
+    Po.close()
+
+
+def test_count_list_ranges_equals_csr(ctx):
+    """gat_count_list_ranges: the annotation lists as ranges of one array, in any order and with gaps, against the CSR form"""
+    rs = np.random.RandomState(19)
+    n_groups, n_tracks, n_lists = 4, 5, 2
+    mk = lambda n, w: np.array(O.normalize([(int(a), int(a + b)) for a, b in zip(rs.randint(0, 60000, n), rs.randint(1, w, n))]), dtype=_lib.SEG)  # noqa: E731
+    lists = [mk(70, 300) for _ in range(n_lists * n_groups)]
+    annos = [mk(50, 900) if i % 7 else mk(0, 2) for i in range(n_tracks * n_groups)]
+    off = lambda ls: np.concatenate([[0], np.cumsum([len(x) for x in ls])]).astype(np.int64)  # noqa: E731
+    ws_nseg = [3, 1, 7, 2]
+    counters = list(_lib.COUNTER_IDS.keys())
+    want = ctx.count_lists(counters, np.concatenate(lists), off(lists), n_lists, np.concatenate(annos), off(annos), n_tracks, ws_nseg, n_groups)
+    order = rs.permutation(len(annos))                   # the array holds the lists in another order, with filler between
+    filler = mk(5, 10)
+    pieces, begin, end, pos = [], np.zeros(len(annos), np.int64), np.zeros(len(annos), np.int64), 0
+    for i in order:
+        pieces.append(filler)
+        pos += len(filler)
+        begin[i], end[i] = pos, pos + len(annos[i])
+        pieces.append(annos[i])
+        pos += len(annos[i])
+    got = ctx.count_lists(counters, np.concatenate(lists), off(lists), n_lists, np.concatenate(pieces), begin, n_tracks, ws_nseg, n_groups,
+                          anno_end=end)
+    for k in range(len(counters)):
+        assert np.array_equal(got[k], want[k]), counters[k]

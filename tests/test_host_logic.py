@@ -559,3 +559,28 @@ def test_numpy_summation_self_check():
     """the run-time form of test_numpy_summation_model: what decides whether gat_null_stats may stand in for numpy"""
     import gat_amd
     assert gat_amd._numpy_summation_model_holds() is True
+
+
+def test_intersection_sizes_equal_the_intersections():
+    """gat_intersection_sizes (the overlap_* columns, gat/Engine.pyx:1911-1928) against intersect() list by list"""
+    from gat_amd import _lib, intervals as iv
+    rs = np.random.RandomState(23)
+
+    def mk(n):
+        s = np.sort(rs.randint(0, 5000, n))
+        return iv.normalize(iv.make(s, s + rs.randint(1, 40, n)))
+    n_groups, n_tracks = 5, 4
+    a = [mk(rs.randint(0, 60)) for _ in range(n_groups)]
+    b = [mk(rs.randint(0, 90)) for _ in range(n_tracks * n_groups)]
+    a[2] = iv.EMPTY.copy()
+    off = lambda ls: np.concatenate([[0], np.cumsum([len(x) for x in ls])]).astype(np.int64)  # noqa: E731
+    bo = off(b)
+    pairs, bases = _lib.intersection_sizes(np.concatenate(a), off(a), np.concatenate(b), bo[:-1], bo[1:], n_tracks)
+    for t in range(n_tracks):
+        inter = [iv.intersect(a[g], b[t * n_groups + g]) for g in range(n_groups)]
+        assert pairs[t] == sum(len(x) for x in inter) and bases[t] == sum(iv.total(x) for x in inter)
+    # touching segments do not intersect; identical ones do, once
+    x = iv.make([0, 10, 30], [10, 20, 40])
+    y = iv.make([10, 30], [15, 40])
+    p, s = _lib.intersection_sizes(x, [0, 3], y, [0], [2], 1)
+    assert (int(p[0]), int(s[0])) == (2, 15)
