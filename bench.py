@@ -42,9 +42,10 @@ sys.path.insert(0, ROOT)
 METRIC = "Monte Carlo samples/sec + bit-exact p-values, 10k sims, hg19-sized workspace"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # ... 6.29 TB/s measured with a float4 copy
-# samples per GPU per step of the extra shapes: config3 = its own 10 000; config5 / config4 are 8-GPU jobs of
-# 125 000 / 12 500 samples per GPU, measured here over one call's worth
-EXTRA_SAMPLES = {"config3": 10000, "config5": 16384, "config4": 4096}
+# samples per GPU per step of the extra shapes: config3 = its own 10 000; config4 is an 8-GPU job of 12 500 samples per
+# GPU: a rank's whole shard per step (the library cuts it into batches that fit its scratch budget); config5 (125 000 per
+# GPU) is measured over one call of 16 384
+EXTRA_SAMPLES = {"config3": 10000, "config5": 16384, "config4": 12500}
 # the reference itself (Cython engine, one core, build container) -- it cannot travel
 REFERENCE_CYTHON = {"config2": 19.1}
 
@@ -59,7 +60,7 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--extra", default="config3,config5,config4",
                     help="further BASELINE shapes measured in the same run and reported under 'configs' ('' = none)")
-    ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of the extra shapes (config4: a quarter of it)")
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the sustained loop per shape (0 = none)")
     ap.add_argument("--no-api", action="store_true", help="skip the gat_amd.run() block")
     ap.add_argument("--dump-counts", default=None, help="rank 0 saves the gathered count matrix of the last step (tests)")
@@ -185,7 +186,7 @@ class Workload(object):
 
     KEYS = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
             "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_tail_units",
-            "n_index_entries", "n_index_lookups")
+            "n_index_entries", "n_index_lookups", "n_batches", "ms_total")
 
     def timed(self, steps, first_step, acc=None):
         """`steps` steps bracketed by barrier + synchronize on both sides; seconds, the MAX over the ranks"""
@@ -304,9 +305,12 @@ class Workload(object):
                             "the kernel) / kernel time against the HBM peak; contract_GBps is SURVEY 8d's figure (every "
                             "annotation interval charged once per sample), which this algorithm never moves")
             roof["lookups_per_s"] = lookups / count_s if count_s > 0 else 0.0
-            # one L2 request per segment load (16 lanes x 8 B = a 128-byte line), per grid cell and per PAIR of entries;
-            # against the 34.5 TB/s / 128 B = 270 requests per ns the L2s deliver (MI355X_MICROARCH.md, L2)
-            reqs = lookups / 16.0 + lookups + (entries / 2.0 + 0.5 * lookups)
+            # one L2 request per segment load (16 lanes x 8 B = a 128-byte line), per grid cell and per 64-byte BLOCK of
+            # eight entries (n_index_entries counts whole blocks); against the 34.5 TB/s / 128 B = 270 requests per ns the
+            # L2s deliver (MI355X_MICROARCH.md, L2)
+            # (scans that pass few entries fetch them in pairs, one request per pair: entries_per_lookup says which)
+            per_req = 8.0 if entries / max(1.0, lookups) >= 8.0 else 2.0
+            reqs = lookups / 16.0 + lookups + entries / per_req + (0.5 * lookups if per_req == 2.0 else 0.0)
             # (an upper bound: lanes of one load that fall into the same line are one request -- sorted segments often do)
             roof["l2_requests_per_launch_model"] = reqs
             roof["l2_request_frac"] = min(1.0, reqs / count_s / (34500.0e9 / 128.0)) if count_s > 0 else 0.0
@@ -362,6 +366,9 @@ class Workload(object):
                         "contig_kernel_avg_ms": acc["ms_contig"] / steps,
                         "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
                         "units_finished_by_k_tail": acc["n_tail_units"],
+                        "batches_per_step": acc["n_batches"] / steps,
+                        # wall time of a step against what its kernels took on the stream (HIP events around the call)
+                        "stream_ms_per_step": acc["ms_total"] / steps,
                         "work_units": S * steps * flat["n_units"]},
             "allgather": allgather,
         }
@@ -506,7 +513,8 @@ def main():
     for name in [x for x in args.extra.split(",") if x and x != args.config]:
         torch.cuda.empty_cache()
         E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world)
-        r = E.measure(max(1, args.extra_steps), 2, args.sustain_seconds)
+        # (a config-4 step is a rank's whole shard, about 0.1 s: a quarter of the steps)
+        r = E.measure(max(1, args.extra_steps // 4 if name == "config4" else args.extra_steps), 2, args.sustain_seconds)
         r["n_gpus"] = world
         extras[name] = r
         E.close()

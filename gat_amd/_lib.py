@@ -97,6 +97,7 @@ class Stats(C.Structure):
         ("lists_from_records", C.c_int64),
         ("n_index_entries", C.c_int64),
         ("n_index_lookups", C.c_int64),
+        ("n_batches", C.c_int64),
     ]
 
     def asdict(self):
@@ -188,8 +189,15 @@ class Context(object):
     """one HIP device + stream (gat_ctx)."""
 
     def __init__(self, device=0, stream=None):
+        """stream: a hipStream_t handle to run on (e.g. torch.cuda.Stream(...).cuda_stream); None: the context makes a
+        private non-blocking stream; 0 -- the handle torch reports for its DEFAULT stream -- means that stream (it is
+        passed on as hipStreamLegacy: a NULL handle is the C ABI's "make a private stream")."""
         self._h = C.c_void_p()
-        _check(lib().gat_ctx_create(C.byref(self._h), int(device), C.c_void_p(stream) if stream else None))
+        if stream is None:
+            handle = None
+        else:
+            handle = C.c_void_p(int(stream) if int(stream) != 0 else 1)      # hipStreamLegacy == (hipStream_t)1
+        _check(lib().gat_ctx_create(C.byref(self._h), int(device), handle))
         self.device = device
 
     def close(self):

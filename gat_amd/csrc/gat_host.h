@@ -151,6 +151,7 @@ struct AnnoDev {
   DevBuf<int32_t> m_shift, m_cells, m_slot_off, m_slot_contigs;
   int max_slot_contigs = 0;
   bool has_merged = false;
+  int merged_block = 2;            // index entries k_count_merged fetches per step: 2, or 8 when a scan is expected to pass many
   int64_t merged_entries = 0;
   int64_t max_m = 0;
   int64_t max_cells = 0;
@@ -251,6 +252,6 @@ struct gat_problem {
 
 // gat_prep.hip
 int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
-                int32_t n_groups, bool want_merged, bool checked);
+                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len = 0.0);
 int layout_slab(gat_problem* P);
 int upload_layout(gat_ctx* ctx, gat_problem* P);

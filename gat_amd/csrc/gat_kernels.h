@@ -1833,7 +1833,10 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 #endif
 constexpr int kMergedThreads = GAT_MERGED_THREADS;
 // PATCH (as in k_count_seg): a unit k_tail finished is read as merged list + the record's extras, no k_finalize.
-template <bool PATCH>
+// BLK: index entries fetched per step of a scan: 2 (one 16-byte load) or 8 (a 64-byte block); the host picks by how many
+// entries a scan is expected to pass (AnnoDev::merged_block): config 3 / config 5 pass 3 and take pairs (blocks: 1.27 ->
+// 1.49 ms and 1.76 -> 2.21 ms), the config-4 shape passes 15 and takes blocks (48.7 -> 37.0 ms per 12 500 samples).
+template <bool PATCH, int BLK>
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int T = A.n_tracks;
@@ -1867,8 +1870,62 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
         Rex = reinterpret_cast<const uint2*>(R + kPatchExtra) - nU;
       }
     }
-    constexpr int kR = 4;                                            // segments per lane whose look-ups are in flight together
     uint32_t n_ent = 0;                                              // index entries this lane read (the one that ended a scan too)
+    if constexpr (BLK == 8) {
+    constexpr int kR = 2;                                            // segments per lane whose look-ups are in flight together
+    for (int base = 0; base < n; base += kR * kWave) {
+      uint2 x[kR];
+      uint32_t k[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int i = base + r * kWave + lane;
+        // (an empty segment -- padding, or what a trim emptied -- meets nothing: start < 0 never holds)
+        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }
+      // entries are fetched a 64-byte block (eight of them) at a time: the four 16-byte loads of a block fall into one
+      // 128-byte line and are issued back to back, so the line is asked of the L2 once -- the scan of a segment passes 3
+      // (config 3) to 15 (1 000 tracks) entries, fetched in pairs every pair was a request of its own (too many lanes
+      // are scanning for a line to survive in the 32 KB L1 between two loads), and the rate of those requests is what
+      // bounds the kernel.  A block starts at a multiple of eight: the entries in front of first[cell] in it ended before
+      // the cell began and add nothing (hi > lo fails); a contig's entries start at a multiple of eight and end with
+      // sentinels (start 0xffffffff), and eight more stand behind the last contig.
+      const uint4* __restrict__ Z4 = reinterpret_cast<const uint4*>(Z);
+      uint4 zz[kR][4];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const uint32_t b4 = (k[r] >> 3) << 2;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) zz[r][w] = Z4[b4 + w];
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        uint32_t blk = k[r] >> 3;
+        uint4 q0 = zz[r][0], q1 = zz[r][1], q2 = zz[r][2], q3 = zz[r][3];
+        while (true) {
+          bool more = true;
+#define GAT_MERGED_ENTRY(EX, EY)                                                                     \
+          if (more) {                                                                               \
+            if (!((EX) < x[r].y)) more = false;       /* the contig's sentinel start 0xffffffff ends the scan */ \
+            else {                                                                                  \
+              const uint32_t ze = (EX) + ((EY) & 0xffffu);                                          \
+              const uint32_t lo = (EX) > x[r].x ? (EX) : x[r].x, hi = ze < x[r].y ? ze : x[r].y;      \
+              if (hi > lo) atomicAdd(&acc[(EY) >> 16], hi - lo);                                    \
+            }                                                                                       \
+          }
+          GAT_MERGED_ENTRY(q0.x, q0.y) GAT_MERGED_ENTRY(q0.z, q0.w) GAT_MERGED_ENTRY(q1.x, q1.y) GAT_MERGED_ENTRY(q1.z, q1.w)
+          GAT_MERGED_ENTRY(q2.x, q2.y) GAT_MERGED_ENTRY(q2.z, q2.w) GAT_MERGED_ENTRY(q3.x, q3.y) GAT_MERGED_ENTRY(q3.z, q3.w)
+#undef GAT_MERGED_ENTRY
+          n_ent += 8u;
+          if (!more) break;
+          ++blk;
+          q0 = Z4[blk * 4]; q1 = Z4[blk * 4 + 1]; q2 = Z4[blk * 4 + 2]; q3 = Z4[blk * 4 + 3];
+        }
+      }
+    }
+    } else {
+    constexpr int kR = 4;
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
@@ -1902,6 +1959,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
         }
         n_ent += kk - k[r] + 1u;
       }
+    }
     }
     if (A.mstat != nullptr) {
       const uint32_t tot = wave_total_u32(n_ent);

@@ -138,13 +138,16 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->batch >= want) return GAT_OK;
   PrepTimer tm;
   const char* env = getenv("GAT_SLAB_BYTES");
-  // a batch as large as a tenth of the 288 GB takes: the lane-per-stream kernels have a fixed floor per launch (the serial
-  // chain of the longest unit's tile), so fewer, larger batches are faster (config 3, 10 000 samples: 9.7 ms in two
-  // batches under 12 GB, 9.3 ms in one); capped by what the device has free
-  double budget = env ? atof(env) : 30.0 * 1024 * 1024 * 1024;
+  // a batch as large as a quarter of the 288 GB takes: the lane-per-stream kernels have a fixed floor per launch (the serial
+  // chain of the longest unit's tile) and the wave-per-unit kernels of long-list problems fill the chip only with
+  // thousands of samples in flight, so fewer, larger batches are faster (config 3, 10 000 samples: 9.7 ms in two batches
+  // under 12 GB, 9.3 ms in one; config-4 shape: a rank's shard of 12 500 samples in one batch of 40 GB instead of two);
+  // capped by what the device has free
+  double budget = env ? atof(env) : 72.0 * 1024 * 1024 * 1024;
   if (!env) {
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, 0.6 * (double)(free_b + dev_pool_held()));
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      budget = std::min(std::min(budget, 0.25 * (double)total_b), 0.6 * (double)(free_b + dev_pool_held()));
   }
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
                              (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
@@ -279,11 +282,16 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       const size_t need = (size_t)A.n_contigs * (size_t)A.n_tracks * (size_t)A.n_samples;
       if (part.n < need) HIPCHK(ctx, part.alloc(need));
       A.part = part.p;
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_merged<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
+      const bool patch = A.seg_merged != nullptr, blocks = annos.merged_block == 8;
+      const void* km = patch ? (blocks ? (const void*)gat::k_count_merged<true, 8> : (const void*)gat::k_count_merged<true, 2>)
+                             : (blocks ? (const void*)gat::k_count_merged<false, 8> : (const void*)gat::k_count_merged<false, 2>);
+      HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
-      if (A.seg_merged != nullptr) hipLaunchKernelGGL(gat::k_count_merged<true>, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
-      else hipLaunchKernelGGL(gat::k_count_merged<false>, dim3((unsigned)nblocks), dim3(gat::kMergedThreads), lds_merged, ctx->stream, A);
+      const dim3 gm((unsigned)nblocks), bm(gat::kMergedThreads);
+      if (patch && blocks) hipLaunchKernelGGL((gat::k_count_merged<true, 8>), gm, bm, lds_merged, ctx->stream, A);
+      else if (patch) hipLaunchKernelGGL((gat::k_count_merged<true, 2>), gm, bm, lds_merged, ctx->stream, A);
+      else if (blocks) hipLaunchKernelGGL((gat::k_count_merged<false, 8>), gm, bm, lds_merged, ctx->stream, A);
+      else hipLaunchKernelGGL((gat::k_count_merged<false, 2>), gm, bm, lds_merged, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
       ctx->main_recorded = true;
@@ -876,8 +884,12 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
     HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
     tm.lap("batch enqueued");
-    // ONE synchronisation per batch: the sampler's status word is read behind the count kernels (which ran on whatever
-    // an overflowed unit left -- harmless, the batch is redone with doubled regions)
+    // ONE synchronisation per batch: the sampler's status word is read behind the count kernels, which ran on whatever an
+    // overflowed unit left.  What it left is in bounds: the exits that set a status bit (region full, a contig's lists
+    // beyond the launch's LDS) leave unit_n / contig_n / the hand-over records as an EARLIER batch of this layout wrote them
+    // -- lengths within the regions of this layout -- or as ensure_scratch zeroed them: a new layout (layout_slab +
+    // upload_layout) sets P->batch = 0, so the scratch is sized and zeroed again before the next kernel runs, and no
+    // length written under another layout survives into this one.  The counts of such a batch are thrown away (it is redone)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     tm.lap("batch synchronised");
     if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) {
@@ -894,6 +906,7 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
       local.ms_count_main += ms;
     }
     local.count_kernel = ctx->count_kernel;
+    local.n_batches += 1;
     done += nb;
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));

@@ -150,7 +150,7 @@ static void radix_sort_hi32(std::vector<uint64_t>& v, std::vector<uint64_t>& tmp
 // than `bound` bases; first[g] is the first entry with end > g << shift or start >= g << shift, i.e. where a scan for a
 // segment starting in cell g begins.
 static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend,
-                        int64_t n_tracks, int32_t n_groups) {
+                        int64_t n_tracks, int32_t n_groups, double mean_seg_len) {
   if (n_tracks > 65535) return GAT_OK;                              // (track ids are 16 bits: such problems keep the per-track kernel)
   PrepTimer tm;
   std::vector<int64_t> hz_off((size_t)n_groups + 1, 0), hf_off((size_t)n_groups + 1, 0);
@@ -162,6 +162,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
   std::vector<std::vector<uint64_t>> ck((size_t)n_groups);
   std::vector<std::vector<uint32_t>> cf((size_t)n_groups);
   std::vector<int> c_err((size_t)n_groups, 0);
+  std::vector<double> c_scan((size_t)n_groups, 0.0);                 // entries a scan is expected to pass, x the contig's entries
   const char* env_bf = getenv("GAT_MERGED_BOUND");
   const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
   auto build_one = [&](int c) {
@@ -196,6 +197,8 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     }
     radix_sort_hi32(e, tmp);
     const size_t ne = e.size();
+    // a scan starts up to `bound` bases in front of its segment and ends with it
+    if (span > 0) c_scan[(size_t)c] = (double)ne * ((double)bound * 0.5 + mean_seg_len) * (double)ne / (double)span;
     if (ne >= 0xfffffff0ull) { c_err[(size_t)c] = 1; return; }
     auto st_of = [&](size_t i) { return (uint32_t)(e[i] >> 32); };
     auto en_of = [&](size_t i) { return (uint32_t)(e[i] >> 32) + (uint32_t)(e[i] & 0xffffu); };
@@ -224,8 +227,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     // the device reads an entry as uint2 {start, track << 16 | length}: the two halves of the key the other way round
     for (size_t i = 0; i < ne; ++i) e[i] = (e[i] >> 32) | (e[i] << 32);
     e.push_back(0xffffffffull);                                     // {0xffffffff, 0} ends every scan
-    e.push_back(0xffffffffull);                                     // (entries are read in pairs)
-    if (e.size() & 1) e.push_back(0xffffffffull);                   // ... and the next contig starts at an even index
+    while (e.size() & 7) e.push_back(0xffffffffull);                // (entries are read in blocks of eight: the next contig starts at one)
   };
   parallel_for(n_groups, [&](int64_t c) { build_one((int)c); });
   tm.lap("  merged index: per contig");
@@ -235,7 +237,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     hf_off[(size_t)c + 1] = hf_off[(size_t)c] + (int64_t)cf[(size_t)c].size();
   }
   static_assert(sizeof(uint2) == sizeof(uint64_t), "index entries");
-  std::vector<uint2> hz((size_t)hz_off[(size_t)n_groups]);
+  std::vector<uint2> hz((size_t)hz_off[(size_t)n_groups] + 8, make_uint2(0xffffffffu, 0u));   // (+ a block of sentinels behind the last contig)
   std::vector<uint32_t> hf((size_t)hf_off[(size_t)n_groups]);
   parallel_for(n_groups, [&](int64_t c) {
     if (!ck[(size_t)c].empty()) memcpy(hz.data() + hz_off[(size_t)c], ck[(size_t)c].data(), ck[(size_t)c].size() * 8);
@@ -276,6 +278,13 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
   }
   A.has_merged = true;
   A.merged_entries = (int64_t)hz.size();
+  {
+    // entries per step of a scan (k_count_merged<.., BLK>): blocks of eight where a scan passes six or more on average
+    double num = 0, den = 0;
+    for (int c = 0; c < n_groups; ++c) { num += c_scan[(size_t)c]; den += (double)(hz_off[(size_t)c + 1] - hz_off[(size_t)c]); }
+    const char* env_b = getenv("GAT_MERGED_BLOCK");
+    A.merged_block = env_b ? (atoi(env_b) == 8 ? 8 : 2) : (den > 0 && num / den >= 6.0 ? 8 : 2);
+  }
   tm.lap("  merged index: gather + upload");
   return GAT_OK;
 }
@@ -284,7 +293,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
 // (a CSR array passes off and off + 1); checked: whether the lists have to be verified normalized (the ones the library
 // merged itself are).  want_merged: build the merged index when the problem's shape asks for it (see below).
 int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
-                int32_t n_groups, bool want_merged, bool checked) {
+                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len) {
   PrepTimer tm;
   A.h_off.assign((size_t)n_lists + 1, 0);
   A.max_m = 0;
@@ -395,7 +404,7 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
   const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
   if (want_merged && n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
-    int rc = build_merged(ctx, A, annos, lbeg, lend, n_tracks, n_groups);
+    int rc = build_merged(ctx, A, annos, lbeg, lend, n_tracks, n_groups, mean_seg_len);
     if (rc) return rc;
   }
   return GAT_OK;
@@ -833,6 +842,12 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   int rc = upload_layout(ctx, P.get());
   if (rc) return rc;
   tm.lap("units, layout, their uploads");
+  double mean_seg_len = 0.0;                         // of the segments that are placed (for the merged index's scan estimate)
+  {
+    double bases = 0, segs = 0;
+    for (int32_t u : P->h_order) { bases += (double)(uint32_t)P->h_units[(size_t)u].ltotal; segs += (double)P->h_units[(size_t)u].hist_total; }
+    mean_seg_len = segs > 0 ? bases / segs : 0.0;
+  }
   if (d->anno_group != nullptr) {
     // lists with a group id each: the library forms the contig-level lists itself (fromIsochores)
     std::vector<gat_segment> buf;
@@ -840,9 +855,10 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     if ((rc = group_annotations(ctx, d, buf, gbeg, gend))) return rc;
     tm.lap("annotations grouped by contig");
     rc = build_annos(ctx, P->annos, buf.data(), gbeg.data(), gend.data(), (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true,
-                     d->merge_contigs != 0);
+                     d->merge_contigs != 0, mean_seg_len);
   } else {
-    rc = build_annos(ctx, P->annos, d->annos, d->anno_off, d->anno_off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false);
+    rc = build_annos(ctx, P->annos, d->annos, d->anno_off, d->anno_off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false,
+                     mean_seg_len);
   }
   if (rc) return rc;
   tm.lap("annotation tables (total)");

@@ -113,6 +113,7 @@ typedef struct {
                                    the merged lists and k_tail's records                              */
   int64_t n_index_entries;      /* k_count_merged: entries of the merged index its scans read (8 bytes each), and ...   */
   int64_t n_index_lookups;      /*   ... the sample segments it looked up: what the kernel's byte model is made of       */
+  int64_t n_batches;            /* batches the call was cut into (the scratch budget decides how many samples one holds)   */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0
@@ -121,8 +122,8 @@ typedef struct {
 #define GAT_COUNT_KERNEL_MERGED 3   /* k_count_merged: one look-up per sample segment in a merged index of all tracks */
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* device_id: HIP device ordinal.  stream: a hipStream_t to run on (e.g. torch's current
- * stream) or NULL to create a private one. */
+/* device_id: HIP device ordinal.  stream: a hipStream_t to run on (e.g. a torch stream's handle; the default stream is
+ * named by hipStreamLegacy, (hipStream_t)1 -- its own handle is NULL) or NULL to create a private non-blocking one. */
 int gat_ctx_create(gat_ctx** out, int device_id, void* stream);
 void gat_ctx_destroy(gat_ctx* ctx);
 const char* gat_last_error(const gat_ctx* ctx);      /* ctx may be NULL: last error of the thread */

@@ -143,3 +143,30 @@ def test_config_workloads_full_size_properties(ctx, name):
                 assert full[t, S - 1] == int(sum(vals))
     finally:
         P.close()
+
+
+def test_config4_shard_across_batches(ctx):
+    """the config-4 shape cut into batches by the scratch budget (a rank's 12 500-sample shard takes more than one batch
+    under a small budget; here 96 samples under a budget that holds fewer than 40): the matrix equals the one-batch matrix
+    column for column, and the columns on both sides of the batch seams equal the oracle's."""
+    cfg, flat = _flat("config4")
+    counters = [cfg["counter"]]
+    seed, S = 777, 96
+    P = _lib.Problem(ctx, flat)
+    try:
+        one = P.sample_and_count(counters, seed, 0, S)[0]
+        stride = P.info()["slab_segments_per_sample"]
+    finally:
+        P.close()
+    os.environ["GAT_SLAB_BYTES"] = str(stride * 8 * 40)      # (the slab alone: rows, records and partials make a sample larger)
+    Q = _lib.Problem(ctx, flat)
+    try:
+        cut = Q.sample_and_count(counters, seed, 0, S)[0]
+    finally:
+        os.environ.pop("GAT_SLAB_BYTES")
+        Q.close()
+    assert np.array_equal(cut, one)
+    assert Q.last_stats["n_batches"] >= 3 and P.last_stats["n_batches"] == 1
+    for s in (0, 39, 40, S - 1):                             # (a batch holds fewer than 40: these straddle at least one seam)
+        want, _ = O.run_samples(flat, counters, seed, 1, s, s + 1)
+        assert np.array_equal(cut[:, s], want[0][:, 0]), s

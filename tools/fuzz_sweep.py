@@ -30,7 +30,7 @@ for seed in range(first, first + n):
     os.environ.pop("GAT_TEST_HUGE", None)
     try:
         if merged:
-            for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED"):
+            for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED", "GAT_MERGED_BLOCK"):
                 os.environ.pop(k, None)
             m.test_merged_track_index_vs_oracle(ctx, seed, MP())
         elif long_lists:
