@@ -229,6 +229,7 @@ struct gat_problem {
 #endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
+  DevBuf<uint32_t> d_rng_ckpt;           // k_seed -> k_rng: 16 checkpoints of every stream's seeded state (4 KB per tile)
   DevBuf<uint2> d_fslab;                 // split path: the units' final lists (k_finalize writes out of place)
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit

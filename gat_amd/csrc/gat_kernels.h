@@ -43,6 +43,7 @@ struct SamplerArgs {
   const int64_t* rng_off;     // per active index: word offset of the unit's first tile in rng_out
   const int32_t* rng_rows;    // per active index: rows (raw outputs per stream) generated
   uint32_t* rng_out;          // tile (active a, sample block sb): rng_out[rng_off[a] + (sb*rows + j)*64 + lane]
+  uint32_t* rng_ckpt;         // k_seed -> k_rng: word 39 w of every stream's seeded state, [tile = a * n_blocks + sb][w < 16][lane]
   int4* st;                   // [batch][n_units] hand-off from k_place, one 16-byte record per work unit:
                               //   x = segments placed before the first consolidation, y = `remaining` at that point,
                               //   z = the pending length (>0), -1: run the unit in full, -2: SamplerSegments complete,
@@ -104,6 +105,36 @@ constexpr int kRngChunk = 24;      // 624 = 26 * 24
 
 constexpr int kRngTwistWaves = 8;  // NT twist waves + NT temper waves per workgroup (four waves per SIMD)
 constexpr int kRngThreads = 2 * kRngTwistWaves * kWave;
+constexpr int kRngWaves = kRngThreads / kWave;
+constexpr int kSeedSpan = kMtN / kRngWaves;          // 39: words of a stream's seeded state between two checkpoints
+static_assert(kSeedSpan * kRngWaves == kMtN, "16 waves x 39 words = 624");
+
+__device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) {       // init_genrand: word i from word i - 1
+  return 1812433253u * (x ^ (x >> 30)) + i;
+}
+
+// k_seed: init_genrand of every stream of the batch, one stream per LANE, keeping only every 39th word.  The recurrence
+// is one dependent chain of 624 multiply-adds per stream (28 cycles a step on gfx950: v_mul_lo_u32 is a quarter-rate
+// instruction); inside k_rng -- whose 156 KB of LDS admit one workgroup per CU -- it kept ONE wave per CU busy for
+// 17 500 cycles per tile while fifteen waited (config 3: 0.86 of k_rng's 1.57 ms).  Here it runs with nothing but a few
+// registers per wave, so every SIMD has waves to issue from, and leaves 16 checkpoints per stream (4 KB per tile);
+// k_rng's sixteen waves then regenerate 39 words each, side by side: 39 steps instead of 624 in front of the first twist.
+constexpr int kSeedThreads = 256;
+__global__ __launch_bounds__(kSeedThreads) void k_seed(SamplerArgs A, int n_blocks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)blockIdx.x * (kSeedThreads / kWave) + (threadIdx.x >> 6);
+  if (tile >= (int64_t)A.n_active * n_blocks) return;
+  const int a = (int)(tile / n_blocks), sb = (int)(tile - (int64_t)a * n_blocks);
+  const int u = A.units_o[a].pad;
+  const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
+  uint32_t x = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
+  uint32_t* __restrict__ dst = A.rng_ckpt + tile * (kRngWaves * kWave) + lane;
+  for (int w = 0; w < kRngWaves; ++w) {
+    dst[w * kWave] = x;                                             // word 39 w
+#pragma unroll
+    for (int j = 1; j <= kSeedSpan; ++j) x = mt_seed_step(x, (uint32_t)(w * kSeedSpan + j));
+  }
+}
 
 __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -113,14 +144,15 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
   uint32_t* mt = lds + lane;                        // lane column, stride 64
   const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_active) return;                      // (whole workgroup: no barrier has been reached)
-  const int u = A.units_o[a].pad;
   const int rows = A.rng_rows[a];
-  if (wv == 0) {
-    const uint64_t sample_id = (uint64_t)(A.sample_begin + (int64_t)sb * kWave + lane);
-    uint32_t x = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
-    for (int i = 0; i < kMtN; ++i) {                // init_genrand
+  {
+    // words 39 wv .. 39 wv + 38 of the seeded state from k_seed's checkpoint (init_genrand's recurrence, 39 steps)
+    uint32_t x = A.rng_ckpt[((int64_t)a * gridDim.x + sb) * (kRngWaves * kWave) + wv * kWave + lane];
+#pragma unroll
+    for (int j = 0; j < kSeedSpan; ++j) {
+      const int i = wv * kSeedSpan + j;
       mt[i * kWave] = x;
-      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
+      x = mt_seed_step(x, (uint32_t)(i + 1));
     }
   }
   __syncthreads();

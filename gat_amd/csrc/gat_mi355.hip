@@ -176,6 +176,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     HIPCHK(ctx, staged_h2d(ctx, P->d_rng_off.p, P->h_rng_off.data(), P->h_rng_off.size() * 8));
     tm.lap("  scratch: rng offsets up");
     HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
+    HIPCHK(ctx, P->d_rng_ckpt.alloc((size_t)nsb * std::max<size_t>(1, P->h_order.size()) * gat::kRngWaves * gat::kWave));
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
     HIPCHK(ctx, P->d_st.alloc(ns));
     HIPCHK(ctx, P->d_st2.alloc(ns));
@@ -427,7 +428,15 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         const unsigned nsb = (unsigned)((nb + 63) / 64);
         (void)nsb_alloc;
         A.rng_off = P->d_rng_off.p; A.rng_rows = P->d_rng_rows.p; A.rng_out = P->d_rng_out.p;
+        A.rng_ckpt = P->d_rng_ckpt.p;
         A.st = P->d_st.p;
+        {
+          // the streams' seeding chains at full occupancy, 16 checkpoints each; k_rng's waves regenerate the rest
+          const int64_t n_tiles = (int64_t)nsb * n_act, per_block = gat::kSeedThreads / gat::kWave;
+          hipLaunchKernelGGL(gat::k_seed, dim3((unsigned)((n_tiles + per_block - 1) / per_block)), dim3(gat::kSeedThreads), 0, ctx->stream,
+                             A, (int)nsb);
+          HIPCHK(ctx, hipGetLastError());
+        }
         const size_t lds_rng = (size_t)gat::kMtN * 64 * 4;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rng));
         hipLaunchKernelGGL(gat::k_rng, dim3(nsb, gy, gz), dim3(gat::kRngThreads), lds_rng, ctx->stream, A);

@@ -1,0 +1,10 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+OUT=$R/gpurun_out/exp4; mkdir -p $OUT
+i=0
+for flags in "$@"; do
+  i=$((i+1))
+  make -C gat_amd/csrc -s -j2 EXTRA="$flags" BUILD=$OUT/build_$i OUT=$OUT/lib_$i.so || exit 1
+  GAT_LIB_PATH=$OUT/lib_$i.so python3 bench.py --no-cpu-baseline --no-api --no-strong --sustain-seconds 0 --extra "" --config config4 --samples 12500 --steps 5 --warmup 2 > $OUT/bench_$i.json 2>$OUT/err_$i.log
+  echo "== $flags"; python3 tools/show_bench.py $OUT/bench_$i.json
+done
