@@ -135,7 +135,7 @@ def counters_profile(config, S):
     """what the committed rocprofv3 passes of this command say about the kernels of (config, S): HBM-side bytes
     (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 FETCH correction applied) and VALU issue share.
     Produced by tools/summarize_profiles.py from gpurun_out/; NOT measured in this run -- the source is named."""
-    for fn in ("r02_kernel_counters.json", "r01_count_kernel_traffic.json"):
+    for fn in ("r03_kernel_counters.json", "r02_kernel_counters.json", "r01_count_kernel_traffic.json"):
         path = os.path.join(ROOT, "profiles", fn)
         if not os.path.exists(path):
             continue
@@ -319,7 +319,7 @@ class Workload(object):
         if k and "fetch_kib_per_launch" in k and "write_kib_per_launch" in k:
             # FETCH_SIZE counts half the bytes of wide coalesced streaming reads on gfx950 (MI355X_MICROARCH.md, HBM);
             # a gather-bound kernel's narrow requests are uncalibrated: x2 only for the streaming kernel
-            fx = 1.0 if merged else 2.0
+            fx = k.get("fetch_factor", 1.0 if merged else 2.0)
             roof["fetch_factor"] = fx
             traffic = (fx * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
             roof["traffic"] = traffic

@@ -389,7 +389,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
 // serial_state: the run's ONE MT19937 state on the device (k_serial: the reference's own stream) instead of the per-unit streams
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
                              gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false,
-                             uint32_t* serial_state = nullptr) {
+                             uint32_t* serial_state = nullptr, bool loose_ok = false) {
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -502,9 +502,18 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           for (size_t c = 0; c + 1 < P->h_class_start.size() && (unsigned)P->h_class_start[c] < n_long; ++c) {
             // one launch per size class: LDS for the class's longest list and its histogram
             const int a0 = P->h_class_start[c], a1 = std::min<int>(P->h_class_start[c + 1], (int)n_long);
-            const int ccap = P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap;
-            int cnbk = 1024;
-            while (cnbk < ccap && cnbk < 8192) cnbk <<= 1;
+            // LDS for what the class's longest unit is EXPECTED to have placed at its first consolidation, not for its slab
+            // region (a quarter + 96 above the unit's segments): the count of placements is the unit's segments +- a
+            // renewal count's spread, cv(length) x sqrt(n) -- 90 for 8 000 segments -- so a twelfth + 64 on top is seven of
+            // those; a list beyond it takes k_sampler's own (slow) way.  And as many histogram buckets (a power of two, at
+            // least 1 024: a few elements per bucket sort as fast as one) as leave the number of workgroups a CU can hold
+            // at its maximum: this kernel is a chain of dependent passes, and chr1's 8 000 segments with 8 192 buckets were
+            // 113 KB -- ONE workgroup per CU for the classes that take most of its time (config-4 shape: 22.9 of 27.4 ms)
+            const int n0 = (int)P->h_units[(size_t)P->h_order[(size_t)a0]].hist_total;
+            const int ccap = std::min<int>(P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap, (n0 + n0 / 12 + 64 + 63) / 64 * 64);
+            auto wgs_at = [&](int nbk_) { return (int)(((size_t)ctx->max_lds) / ((size_t)2 * ccap * 4 + (size_t)(nbk_ + 1) * 4 + 1024)); };
+            int cnbk = 8192;
+            while (cnbk > 1024 && (cnbk / 2 >= ccap || wgs_at(cnbk) < wgs_at(1024))) cnbk >>= 1;
             const size_t lds_c = (size_t)2 * ccap * 4 + (size_t)(cnbk + 1) * 4;
             M.a_base = a0; M.a_end = a1; M.lds_cap = ccap; M.big_buckets = cnbk;
             const unsigned cnt = (unsigned)(a1 - a0), gmy = std::min(cnt, 32768u);
@@ -520,6 +529,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             gat::TailArgs TB;
             TB.S = A;
             TB.cum = nullptr; TB.patch = P->d_patch.p; TB.todo = nullptr; TB.todo_count = nullptr;
+            // (counts alone, by k_count_merged -- or through k_contig, which merge(0)s the lists again: what a trim emptied may
+            //  stay in the list as [0, 0))
+            TB.loose_ok = (loose_ok && !need_unit_lists && !getenv("GAT_RESUME_COMPACT")) ? 1 : 0;
             const unsigned gby = std::min(n_long, 32768u);
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
                                ctx->stream, TB);
@@ -548,6 +560,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
         gat::TailArgs T;
         T.S = A;
+        T.loose_ok = 0;
         T.S.st2 = P->d_st2.p;
         T.S.n_long = (int32_t)n_long_big;                           // (whose verdict k_consolidate respects)
         T.S.lds_cap = std::min(P->max_unit_cap, 1280);              // k_consolidate: the lists the wave bucket sorts take
@@ -878,7 +891,9 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     const int route = count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx);
     const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok, d_state))) return rc;   // (enqueued only)
+    // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
+    const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok, d_state, loose_ok))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);

@@ -57,6 +57,8 @@ struct TailArgs {
   TailPatch* patch;       // [batch][n_units] by launch position
   uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
+  int32_t loose_ok;       // k_resume_big: the lists' only readers are the segment-side count kernels (or k_contig, which
+                          // merge(0)s them again): what a trim emptied may stay in the list as [0, 0) -- no compaction pass
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -723,6 +725,9 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   rng.pre_base = rng.pre_j - (uint32_t)kWave;
   rng.pre = A.rng_out + A.rng_off[a] + (int64_t)(sidx >> 6) * rng.pre_rows * kWave + (sidx & 63);
   bool redo = false, trim_assert = false;
+  constexpr int kMaxPartial = 4;
+  int part_idx[kMaxPartial] = {-1, -1, -1, -1};                     // the segments trims left partly standing
+  int n_part = 0;
   while (true_remaining != 0 && nuns < 20) {
     if (true_remaining > 0) { redo = true; break; }                 // (a trim leaves remaining <= 0: cannot be)
     // ---- overshoot: trim (:608-626), as in k_sampler, the list in the slab
@@ -755,6 +760,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     if (rng.exhausted) { redo = true; break; }
     if (!((uint64_t)total > (uint64_t)(uint32_t)s)) { trim_assert = true; break; }
     uint32_t removed = 0;                                           // workspace bases taken away by the trim (lane 0)
+    int partial = -1;                                               // ... and the segment it left partly standing
     if (lane == 0) {
       int idx = k;
       while (s > 0) {
@@ -766,11 +772,18 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
           if (forward) { out[idx] = make_uint2(v.x + (uint32_t)s, v.y); ra = v.x; rb = v.x + (uint32_t)s; }
           else { out[idx] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
           s = 0;
+          partial = idx;
         }
         if (rb > ra) removed += ws_overlap_regs(W, ra, rb);
         if (forward) { idx++; if (idx == nU) idx = 0; }
         else { idx--; if (idx < 0) idx = nU - 1; }
       }
+    }
+    partial = __builtin_amdgcn_readfirstlane(partial);
+    if (partial >= 0) {
+#pragma unroll
+      for (int j = 0; j < kMaxPartial; ++j) if (j == n_part) part_idx[j] = partial;
+      n_part++;
     }
     cov -= (uint32_t)__builtin_amdgcn_readfirstlane((int)removed);
     total -= (uint32_t)(-true_remaining);
@@ -797,7 +810,24 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   // dropped, compacted in place (forward: a round's output never passes its input)
   int nout = 0;
   uint32_t tsum = 0;
-  {
+  if (T.loose_ok && n_part <= kMaxPartial) {
+    // The readers of this list skip [0, 0): no compaction pass (a read and a write of the whole list, a third of this
+    // kernel's traffic -- it is bound by the HBM: 45 GB per 12 500 samples of the config-4 shape at 5.6 TB/s).  What the
+    // filter would drop besides the emptied segments can only be what a trim left of a partly trimmed one (every other
+    // segment is a union of placed segments, each overlapping its workspace segment, :331-343): those are looked at here
+    uint32_t gone = 0;
+    if (lane == 0) {
+#pragma unroll
+      for (int j = 0; j < kMaxPartial; ++j) {
+        if (j < n_part) {
+          const uint2 v = out[part_idx[j]];
+          if (v.x != v.y && ws_overlap_regs(W, v.x, v.y) == 0) { out[part_idx[j]] = make_uint2(0u, 0u); gone += v.y - v.x; }
+        }
+      }
+    }
+    nout = nU;
+    tsum = total - (uint32_t)__builtin_amdgcn_readfirstlane((int)gone);
+  } else {
     constexpr int kB = 8;
     for (int base0 = 0; base0 < nU; base0 += kB * kWave) {
       uint2 v[kB];
@@ -813,8 +843,8 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
         nout += __popcll(b);
       }
     }
+    tsum = wave_total_u32(tsum);
   }
-  tsum = wave_total_u32(tsum);
   if (lane == 0) {
     A.unit_n[so] = tsum > 0 ? nout : 0;
     if (!(tsum > 0)) atomicOr(A.flags, kStatusAssert);

@@ -9,11 +9,11 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 TAG=$1; shift
-SHAPES=${@:-"config2:10000 config3:10000 config5:16384 config4:4096"}
+SHAPES=${@:-"config2:10000 config3:10000 config5:16384 config4:12500"}
 for SH in $SHAPES; do
   CFG=${SH%%:*}; S=${SH##*:}
   OUT=$R/gpurun_out/prof_${TAG}/${CFG}; rm -rf $OUT; mkdir -p $OUT
-  ARGS="--no-cpu-baseline --extra= --config $CFG --samples $S --steps 3 --warmup 1"
+  ARGS="--no-cpu-baseline --no-api --no-strong --sustain-seconds 0 --extra= --config $CFG --samples $S --steps 3 --warmup 1"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.log 2>&1

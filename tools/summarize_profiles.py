@@ -5,9 +5,12 @@ counters per kernel and launch, and <tag>_kernel_counters.json, which bench.py r
 fields of its roofline block (keyed "config:samples per step").
 
 Counters (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are KiB summed over the 8 XCDs,
-collected in separate passes; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced read, so HBM bytes =
-(2 x FETCH_SIZE + WRITE_SIZE) KiB (the factor was re-checked in round 1 on k_place, whose reads are exactly the rows
-k_rng writes).  VALU issue share = SQ_INSTS_VALU x 2 cycles (a wave64 instruction occupies a SIMD-32 for two cycles) /
+collected in separate passes; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced streaming read (re-checked
+in round 1 on k_place, whose reads are exactly the rows k_rng writes), other access shapes are uncalibrated.  So the
+correction is applied per kernel: x 2 for the kernels whose reads are coalesced streams (STREAMING below), x 1 -- the raw
+counter -- for the ones that gather (per-lane binary searches, index look-ups): doubling those gave rates above what a copy
+achieves (6.29 TB/s), i.e. not evidence.  Both figures are written; a x 2 figure beyond 6.29 TB/s falls back to the raw
+one and is flagged.  VALU issue share = SQ_INSTS_VALU x 2 cycles (a wave64 instruction occupies a SIMD-32 for two cycles) /
 (4 SIMDs x 256 CUs x kernel cycles); kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the XCDs).
 usage: tools/summarize_profiles.py gpurun_out/prof_<tag> <tag>"""
 import collections
@@ -17,6 +20,11 @@ import json
 import os
 import shutil
 import sys
+
+# kernels whose global reads are coalesced streams over whole lists / rows (the FETCH_SIZE x 2 correction applies)
+STREAMING = ("k_place", "k_rng", "k_seed", "k_finalize", "k_consolidate", "k_merge_big", "k_count_seg<", "k_count_finish", "k_reduce_stats",
+             "k_sampler", "k_count_swap", "k_null_stats")
+HBM_ACHIEVABLE_GBPS = 6290.0
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,11 +84,20 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
                 if stats.get(n):
                     rec["l2_requests_per_us"] = v["TCC_REQ_sum"] / (stats[n] / 1e3)
                     out.write("   %-28s %16.1f per us, hit rate %.3f\n" % ("l2_requests", rec["l2_requests_per_us"], rec["l2_hit_rate"]))
-            hbm = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
+            raw = (rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
+            x2 = (2.0 * rec["fetch_kib_per_launch"] + rec["write_kib_per_launch"]) * 1024.0
+            factor = 2.0 if any(k in n for k in STREAMING) else 1.0
+            note = "coalesced streaming reads" if factor == 2.0 else "gathers: raw counter"
+            if factor == 2.0 and stats.get(n) and x2 / stats[n] > HBM_ACHIEVABLE_GBPS:
+                factor, note = 1.0, "x 2 would exceed what a copy achieves: raw counter"
+            hbm = x2 if factor == 2.0 else raw
+            rec["fetch_factor"], rec["fetch_factor_why"] = factor, note
+            rec["hbm_bytes_raw_per_launch"], rec["hbm_bytes_x2_per_launch"] = raw, x2
             rec["hbm_bytes_per_launch"] = hbm
             if stats.get(n):
                 rec["hbm_GBps"] = hbm / stats[n]
-                out.write("   %-28s %16.1f GB/s (2 x FETCH + WRITE over the average launch)\n" % ("hbm_rate", rec["hbm_GBps"]))
+                out.write("   %-28s %16.1f GB/s (%g x FETCH + WRITE over the average launch; %s; raw %.1f, x 2 %.1f)\n" %
+                          ("hbm_rate", rec["hbm_GBps"], factor, note, raw / stats[n], x2 / stats[n]))
             per_kernel[n] = rec
     if S is not None:
         count = [n for n in per_kernel if ("k_count_merged" in n and "finish" not in n) or "k_count_seg<" in n or "k_count_swap" in n]
