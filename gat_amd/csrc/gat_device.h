@@ -806,4 +806,28 @@ __device__ __forceinline__ uint32_t ws_overlap_regs(const WsRegs& W, uint32_t s,
   return ov;
 }
 
+// The same by binary search over the lanes (cross-lane reads with a per-lane source: ds_bpermute) instead of a loop over
+// all workspace segments: bases of the workspace below a position = the whole segments in front of it (their cumulated
+// lengths) + the part of the last one that starts below it.  7 x n instructions become ~60 whatever n is: a unit of an
+// isochore-partitioned workspace has dozens of workspace segments (config 3: 31 on chr1), and k_consolidate, which calls
+// this once per unit there, is bound by its instruction count.  EVERY lane of the wave must be active at the call (an
+// inactive lane's registers read as 0 through ds_bpermute).
+__device__ __forceinline__ uint32_t ws_below_search(const WsRegs& W, uint32_t x) {
+  int k = 0;                                          // number of workspace segments with start < x
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute((k + step - 1) << 2, (int)W.start);
+    k = sv < x ? k + step : k;                        // (lanes behind the last segment hold 0xffffffff)
+  }
+  const int j = k > 0 ? k - 1 : 0;
+  const uint32_t ps = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)W.start);
+  const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute(j << 2, (int)W.end);
+  const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((k >= 2 ? k - 2 : 0) << 2, (int)W.cdf);
+  const uint32_t whole = k >= 2 ? before + 1u : 0u;   // cdf[i] = cumulated length - 1
+  return k == 0 ? 0u : whole + (x < pe ? x : pe) - ps;
+}
+__device__ __forceinline__ uint32_t ws_overlap_search(const WsRegs& W, uint32_t s, uint32_t e) {
+  return ws_below_search(W, e) - ws_below_search(W, s);
+}
+
 }  // namespace gat

@@ -123,7 +123,10 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     const int i = base + lane;
     uint2 v = make_uint2(0u, 0u);
     if (i < nU) v = seg[i];
-    if (nws <= kWsLoopMax) cov += ws_overlap_regs(W, v.x, v.y);
+    // (all lanes are here: the search's cross-lane reads see every lane's workspace segment; a short workspace is
+    //  cheaper by the loop)
+    if (nws <= 8) cov += ws_overlap_regs(W, v.x, v.y);
+    else if (nws <= kWsLoopMax) cov += ws_overlap_search(W, v.x, v.y);
     else if constexpr (TREE) { if (i < nU) cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y); }
     const uint32_t incl = run + wave_incl_sum_u32(v.y - v.x, lane);
     if (i < nU) { out[i] = v; cum[i] = incl; }
