@@ -203,6 +203,7 @@ class Workload(object):
                 for k in self.KEYS:
                     acc[k] += st.get(k, 0.0)
                 acc["count_kernel"] = st.get("count_kernel", 1)
+                acc["merged_form"] = st.get("merged_form", 0)
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
@@ -291,27 +292,35 @@ class Workload(object):
             # counted by the kernel itself (gat_stats n_index_lookups / n_index_entries): per sample segment 8 bytes of the
             # segment + 4 of its grid cell + 8 per index entry its scan reads, and the partial sums it leaves per
             # (contig, sample, track), 4 bytes each
-            lookups, entries = acc["n_index_lookups"] / steps, acc["n_index_entries"] / steps
-            moved = 12.0 * lookups + 8.0 * entries + 4.0 * flat["n_contigs"] * A * S
+            lookups, words = acc["n_index_lookups"] / steps, acc["n_index_entries"] / steps
+            moved = 8.0 * lookups + 4.0 * words + 4.0 * flat["n_contigs"] * A * S
             roof["contract_bytes_per_launch"] = bytes_per_sample * S
             roof["contract_GBps"] = achieved
             roof["algorithmic_bytes_per_launch"] = moved
             roof["algorithmic_bytes_per_sample"] = moved / max(1, S)
-            roof["index_entries_per_lookup"] = entries / max(1.0, lookups)
+            roof["index_bytes_per_lookup"] = 4.0 * words / max(1.0, lookups)
             achieved = moved / count_s / 1e9 if count_s > 0 else 0.0
             roof["achieved"], roof["frac"] = achieved, achieved / HBM_PEAK_GBPS
             roof["note"] = ("bound by the rate at which the L2s serve its gathers (l2_request_frac), not by HBM: achieved/frac = the "
-                            "bytes the algorithm moves (segments once + grid cells + index entries read + partials, counted by "
-                            "the kernel) / kernel time against the HBM peak; contract_GBps is SURVEY 8d's figure (every "
-                            "annotation interval charged once per sample), which this algorithm never moves")
+                            "bytes the algorithm moves (segments once + the index words its scans read, counted by the kernel, + "
+                            "partials) / kernel time against the HBM peak; contract_GBps is SURVEY 8d's figure (every annotation "
+                            "interval charged once per sample), which this algorithm never moves")
             roof["lookups_per_s"] = lookups / count_s if count_s > 0 else 0.0
-            # one L2 request per segment load (16 lanes x 8 B = a 128-byte line), per grid cell and per 64-byte BLOCK of
-            # eight entries (n_index_entries counts whole blocks); against the 34.5 TB/s / 128 B = 270 requests per ns the
-            # L2s deliver (MI355X_MICROARCH.md, L2)
-            # (scans that pass few entries fetch them in pairs, one request per pair: entries_per_lookup says which)
-            per_req = 8.0 if entries / max(1.0, lookups) >= 8.0 else 2.0
-            reqs = lookups / 16.0 + lookups + entries / per_req + (0.5 * lookups if per_req == 2.0 else 0.0)
-            # (an upper bound: lanes of one load that fall into the same line are one request -- sorted segments often do)
+            # L2 requests: one per segment load (16 lanes x 8 B = a 128-byte line) and, per look-up, what the scan's form
+            # asks for -- a 32-byte cell record (+ a pair per two entries behind the first two), or a grid cell + a pair per
+            # two entries, or a grid cell + a 64-byte block per eight; against the 34.5 TB/s / 128 B = 270 requests per ns
+            # the L2s deliver (MI355X_MICROARCH.md, L2).  An upper bound: lanes of one load that fall into the same line are
+            # one request -- sorted segments often do
+            wpl = words / max(1.0, lookups)
+            form = int(acc.get("merged_form", 2))
+            roof["index_form"] = {8: "blocks of eight entries", 2: "pairs of entries", 1: "cell records + pairs"}.get(form, str(form))
+            if form == 8:
+                per_lookup = 1.0 + (wpl - 1.0) / 16.0
+            elif form == 1:
+                per_lookup = 1.0 + max(0.0, wpl - 8.0) / 4.0
+            else:
+                per_lookup = 1.0 + (wpl - 1.0) / 4.0 + 0.5
+            reqs = lookups / 16.0 + lookups * per_lookup
             roof["l2_requests_per_launch_model"] = reqs
             roof["l2_request_frac"] = min(1.0, reqs / count_s / (34500.0e9 / 128.0)) if count_s > 0 else 0.0
         prof, src = counters_profile(self.name, S) if self.args.scale == 1.0 else (None, None)

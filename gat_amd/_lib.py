@@ -98,6 +98,7 @@ class Stats(C.Structure):
         ("n_index_entries", C.c_int64),
         ("n_index_lookups", C.c_int64),
         ("n_batches", C.c_int64),
+        ("merged_form", C.c_int64),
     ]
 
     def asdict(self):

@@ -147,11 +147,12 @@ struct AnnoDev {
   // merged multi-track index (k_count_merged), built for problems with several tracks
   DevBuf<uint2> mz;
   DevBuf<uint32_t> mfirst;
+  DevBuf<uint4> mcell;             // merged_block 1: per grid cell {first, 0, entry first, entry first + 1, 0, 0} (32 bytes)
   DevBuf<int64_t> mz_off, mf_off;
   DevBuf<int32_t> m_shift, m_cells, m_slot_off, m_slot_contigs;
   int max_slot_contigs = 0;
   bool has_merged = false;
-  int merged_block = 2;            // index entries k_count_merged fetches per step: 2, or 8 when a scan is expected to pass many
+  int merged_block = 2;            // how k_count_merged's scans fetch the index: 8 blocks of eight, 2 pairs, 1 cell records + pairs
   int64_t merged_entries = 0;
   int64_t max_m = 0;
   int64_t max_cells = 0;

@@ -1610,13 +1610,15 @@ struct CountArgs {
   const uint2* mz;            // entries {start, length:16 | track:16}; long intervals cut into pieces; a sentinel start ends every contig
   const int64_t* mz_off;      // n_contigs+1
   const uint32_t* mfirst;     // per contig and position cell: first entry that reaches into the cell or starts in / after it
+  const uint4* mcell;         // BLK 1: per cell a 32-byte record {first, -, entry first, entry first + 1, -, -} (same offsets, x 2)
   const int64_t* mf_off;      // n_contigs+1
   const int32_t* m_shift;     // n_contigs: log2 of the cell width
   const int32_t* m_cells;     // n_contigs
   const int32_t* m_slot_off;  // kMergedSlots+1: the contigs of an XCD slot are m_slot_contigs[m_slot_off[x] .. m_slot_off[x+1])
   const int32_t* m_slot_contigs;
-  unsigned long long* mstat;  // k_count_merged's own traffic, for the byte model of its roofline: 256 pairs {index entries read,
-                              // sample segments looked up}, a wave adds to pair blockIdx % 256 once per sample (nullptr: not kept)
+  unsigned long long* mstat;  // k_count_merged's own traffic, for the byte model of its roofline: 256 pairs {4-byte words of
+                              // index read (grid cells, cell records, entries), sample segments looked up}, a wave adds to
+                              // pair blockIdx % 256 once per sample (nullptr: not kept)
   // split path without k_finalize (k_count_seg<.., PATCH>; contig == unit): a unit k_tail finished is read as (merged
   // list in seg_merged, k_tail's record), any other from seg as usual
   const uint2* seg_merged;
@@ -1865,9 +1867,10 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 #endif
 constexpr int kMergedThreads = GAT_MERGED_THREADS;
 // PATCH (as in k_count_seg): a unit k_tail finished is read as merged list + the record's extras, no k_finalize.
-// BLK: index entries fetched per step of a scan: 2 (one 16-byte load) or 8 (a 64-byte block); the host picks by how many
-// entries a scan is expected to pass (AnnoDev::merged_block): config 3 / config 5 pass 3 and take pairs (blocks: 1.27 ->
-// 1.49 ms and 1.76 -> 2.21 ms), the config-4 shape passes 15 and takes blocks (48.7 -> 37.0 ms per 12 500 samples).
+// BLK: how a scan fetches the index: 8 = 64-byte blocks of eight entries; 2 = pairs (one 16-byte load); 1 = the first two
+// entries out of the grid cell's own 32-byte record, pairs behind them.  The host picks by how many entries a scan is
+// expected to pass (AnnoDev::merged_block): config 3 / config 5 pass 3 (blocks: 1.27 -> 1.49 ms and 1.76 -> 2.21 ms; cell
+// records: see DESIGN.md), the config-4 shape passes 15 and takes blocks (48.7 -> 37.0 ms per 12 500 samples).
 template <bool PATCH, int BLK>
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -1934,6 +1937,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         uint32_t blk = k[r] >> 3;
+        n_ent += 1u;                                                 // (the grid cell)
         uint4 q0 = zz[r][0], q1 = zz[r][1], q2 = zz[r][2], q3 = zz[r][3];
         while (true) {
           bool more = true;
@@ -1949,10 +1953,70 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           GAT_MERGED_ENTRY(q0.x, q0.y) GAT_MERGED_ENTRY(q0.z, q0.w) GAT_MERGED_ENTRY(q1.x, q1.y) GAT_MERGED_ENTRY(q1.z, q1.w)
           GAT_MERGED_ENTRY(q2.x, q2.y) GAT_MERGED_ENTRY(q2.z, q2.w) GAT_MERGED_ENTRY(q3.x, q3.y) GAT_MERGED_ENTRY(q3.z, q3.w)
 #undef GAT_MERGED_ENTRY
-          n_ent += 8u;
+          n_ent += 16u;                                              // (words: a block is 64 bytes)
           if (!more) break;
           ++blk;
           q0 = Z4[blk * 4]; q1 = Z4[blk * 4 + 1]; q2 = Z4[blk * 4 + 2]; q3 = Z4[blk * 4 + 3];
+        }
+      }
+    }
+    } else if constexpr (BLK == 1) {
+    // short scans (three entries on configs 3 and 5): the grid cell holds, beside the index of its first entry, that entry
+    // and the next -- one 32-byte record, one request to the L2 where the cell and the first pair of entries were two; only
+    // a scan that passes more goes on in the index, in pairs
+    constexpr int kR = 4;
+    const uint4* __restrict__ FC = A.mcell + 2 * A.mf_off[c];
+    const uint4* __restrict__ Z2 = reinterpret_cast<const uint4*>(Z);
+    for (int base = 0; base < n; base += kR * kWave) {
+      uint2 x[kR];
+      uint4 c0[kR], c1[kR];
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const int i = base + r * kWave + lane;
+        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const uint32_t g = x[r].x >> shift, gi = g < last ? g : last;
+        c0[r] = FC[2 * gi];
+        c1[r] = FC[2 * gi + 1];
+      }
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        n_ent += 8u;                                                 // (words: the record)
+        uint32_t kk = c0[r].x + 2u;
+        bool more = true;
+        {
+          const uint2 e = make_uint2(c0[r].z, c0[r].w);
+          if (!(e.x < x[r].y)) more = false;
+          else {
+            const uint32_t ze = e.x + (e.y & 0xffffu);
+            const uint32_t lo = e.x > x[r].x ? e.x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
+            if (hi > lo) atomicAdd(&acc[e.y >> 16], hi - lo);
+          }
+        }
+        if (more) {
+          const uint2 e = make_uint2(c1[r].x, c1[r].y);
+          if (!(e.x < x[r].y)) more = false;
+          else {
+            const uint32_t ze = e.x + (e.y & 0xffffu);
+            const uint32_t lo = e.x > x[r].x ? e.x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
+            if (hi > lo) atomicAdd(&acc[e.y >> 16], hi - lo);
+          }
+        }
+        if (more) {
+          const uint32_t k0 = kk;
+          uint4 q = Z2[kk >> 1];
+          while (true) {
+            const uint2 e = (kk & 1u) ? make_uint2(q.z, q.w) : make_uint2(q.x, q.y);
+            if (!(e.x < x[r].y)) break;                              // the contig's sentinel start 0xffffffff ends the scan
+            const uint32_t ze = e.x + (e.y & 0xffffu);
+            const uint32_t lo = e.x > x[r].x ? e.x : x[r].x, hi = ze < x[r].y ? ze : x[r].y;
+            if (hi > lo) atomicAdd(&acc[e.y >> 16], hi - lo);
+            ++kk;
+            if (!(kk & 1u)) q = Z2[kk >> 1];
+          }
+          n_ent += 2u * (kk - k0 + 1u);
         }
       }
     }
@@ -1989,7 +2053,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           ++kk;
           if (!(kk & 1u)) q = Z2[kk >> 1];
         }
-        n_ent += kk - k[r] + 1u;
+        n_ent += 2u * (kk - k[r] + 1u) + 1u;                         // (words: the entries and the grid cell)
       }
     }
     }

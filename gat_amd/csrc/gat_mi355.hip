@@ -283,15 +283,21 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       const size_t need = (size_t)A.n_contigs * (size_t)A.n_tracks * (size_t)A.n_samples;
       if (part.n < need) HIPCHK(ctx, part.alloc(need));
       A.part = part.p;
-      const bool patch = A.seg_merged != nullptr, blocks = annos.merged_block == 8;
-      const void* km = patch ? (blocks ? (const void*)gat::k_count_merged<true, 8> : (const void*)gat::k_count_merged<true, 2>)
-                             : (blocks ? (const void*)gat::k_count_merged<false, 8> : (const void*)gat::k_count_merged<false, 2>);
+      const bool patch = A.seg_merged != nullptr;
+      const int blk = annos.merged_block;
+      A.mcell = annos.mcell.p;
+      const void* km = patch ? (blk == 8 ? (const void*)gat::k_count_merged<true, 8> : blk == 1 ? (const void*)gat::k_count_merged<true, 1>
+                                                                                                 : (const void*)gat::k_count_merged<true, 2>)
+                             : (blk == 8 ? (const void*)gat::k_count_merged<false, 8> : blk == 1 ? (const void*)gat::k_count_merged<false, 1>
+                                                                                                  : (const void*)gat::k_count_merged<false, 2>);
       HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
       const dim3 gm((unsigned)nblocks), bm(gat::kMergedThreads);
-      if (patch && blocks) hipLaunchKernelGGL((gat::k_count_merged<true, 8>), gm, bm, lds_merged, ctx->stream, A);
+      if (patch && blk == 8) hipLaunchKernelGGL((gat::k_count_merged<true, 8>), gm, bm, lds_merged, ctx->stream, A);
+      else if (patch && blk == 1) hipLaunchKernelGGL((gat::k_count_merged<true, 1>), gm, bm, lds_merged, ctx->stream, A);
       else if (patch) hipLaunchKernelGGL((gat::k_count_merged<true, 2>), gm, bm, lds_merged, ctx->stream, A);
-      else if (blocks) hipLaunchKernelGGL((gat::k_count_merged<false, 8>), gm, bm, lds_merged, ctx->stream, A);
+      else if (blk == 8) hipLaunchKernelGGL((gat::k_count_merged<false, 8>), gm, bm, lds_merged, ctx->stream, A);
+      else if (blk == 1) hipLaunchKernelGGL((gat::k_count_merged<false, 1>), gm, bm, lds_merged, ctx->stream, A);
       else hipLaunchKernelGGL((gat::k_count_merged<false, 2>), gm, bm, lds_merged, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
@@ -930,6 +936,7 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
       local.ms_count_main += ms;
     }
     local.count_kernel = ctx->count_kernel;
+    local.merged_form = ctx->count_kernel == GAT_COUNT_KERNEL_MERGED ? P->annos.merged_block : 0;
     local.n_batches += 1;
     done += nb;
   }

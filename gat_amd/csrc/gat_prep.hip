@@ -283,7 +283,22 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     double num = 0, den = 0;
     for (int c = 0; c < n_groups; ++c) { num += c_scan[(size_t)c]; den += (double)(hz_off[(size_t)c + 1] - hz_off[(size_t)c]); }
     const char* env_b = getenv("GAT_MERGED_BLOCK");
-    A.merged_block = env_b ? (atoi(env_b) == 8 ? 8 : 2) : (den > 0 && num / den >= 6.0 ? 8 : 2);
+    // short scans: the first two entries ride in the grid cell's own record (32 bytes per cell: where the cells are few
+    // enough -- the records of the config-4 shape would be 160 MB, but its scans are long and take the blocks anyway)
+    const int by_length = den > 0 && num / den >= 6.0 ? 8 : (hf.size() <= ((size_t)64 << 20) / 32 ? 1 : 2);
+    A.merged_block = env_b ? (atoi(env_b) == 8 ? 8 : atoi(env_b) == 1 ? 1 : 2) : by_length;
+  }
+  if (A.merged_block == 1) {
+    std::vector<uint4> hc(hf.size() * 2);
+    parallel_for(n_groups, [&](int64_t c) {
+      const uint2* z = hz.data() + hz_off[(size_t)c];
+      for (int64_t g = hf_off[(size_t)c]; g < hf_off[(size_t)c + 1]; ++g) {
+        const uint32_t first = hf[(size_t)g];
+        hc[(size_t)2 * g] = make_uint4(first, 0u, z[first].x, z[first].y);          // (sentinels stand behind the last entry)
+        hc[(size_t)2 * g + 1] = make_uint4(z[first + 1].x, z[first + 1].y, 0u, 0u);
+      }
+    });
+    HIPCHK(ctx, A.mcell.upload(hc, ctx));
   }
   tm.lap("  merged index: gather + upload");
   return GAT_OK;

@@ -111,9 +111,11 @@ typedef struct {
                                    by k_tail_big before k_sampler resumed them                        */
   int64_t lists_from_records;   /* != 0: no final unit lists were written; their consumer (k_contig or k_count_seg) took
                                    the merged lists and k_tail's records                              */
-  int64_t n_index_entries;      /* k_count_merged: entries of the merged index its scans read (8 bytes each), and ...   */
+  int64_t n_index_entries;      /* k_count_merged: 4-byte words of index its scans read (grid cells, entries), and ...  */
   int64_t n_index_lookups;      /*   ... the sample segments it looked up: what the kernel's byte model is made of       */
   int64_t n_batches;            /* batches the call was cut into (the scratch budget decides how many samples one holds)   */
+  int64_t merged_form;          /* k_count_merged: how its scans fetched the index: 8 blocks of eight entries, 2 pairs,    */
+                                /* 1 the grid cell's record (its first two entries) + pairs; 0: the kernel did not run     */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0

@@ -928,9 +928,9 @@ def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
     import collections
     from gat_amd import problem, intervals as iv
     monkeypatch.setenv("GAT_MERGED_MIN_TRACKS", "1")
-    # both forms of the scan: index entries fetched in pairs / in 64-byte blocks of eight (the host picks by the expected
-    # length of a scan; here the seed does)
-    monkeypatch.setenv("GAT_MERGED_BLOCK", "8" if seed % 2 else "2")
+    # the three forms of the scan: index entries fetched in 64-byte blocks of eight / in pairs / the first two out of the
+    # grid cell's record (the host picks by the expected length of a scan; here the seed does)
+    monkeypatch.setenv("GAT_MERGED_BLOCK", ("8", "2", "1")[seed % 3])
     rs = np.random.RandomState(seed)
     contigs = collections.OrderedDict(("m%d" % i, int(rs.randint(100000, 2000000))) for i in range(int(rs.randint(1, 4))))
     segs = synthetic.random_segments(contigs, int(rs.choice([40, 400, 3000])), int(rs.choice([30, 300, 2000])), int(rs.randint(1 << 30)))
