@@ -288,17 +288,16 @@ class Workload(object):
                         "the kernel serves annotations from LDS / L2, so real HBM traffic is lower: see hbm_measured_GBps"}
         if merged:
             # k_count_merged looks every sample segment up ONCE in a merged index of all tracks; the contract's bytes (every
-            # annotation interval once per sample) are never moved.  Its algorithmic bytes are what the algorithm does move,
-            # counted by the kernel itself (gat_stats n_index_lookups / n_index_entries): per sample segment 8 bytes of the
-            # segment + 4 of its grid cell + 8 per index entry its scan reads, and the partial sums it leaves per
-            # (contig, sample, track), 4 bytes each
+            # annotation interval once per sample) are never moved.  Its algorithmic bytes are what the algorithm does look
+            # at, counted by the kernel itself (gat_stats n_index_lookups / n_index_entries, the latter in 4-byte words):
+            # per sample segment 8 bytes of the segment + 4 of its grid cell + 8 per index entry its scan examines (whatever
+            # the granularity of the fetch), and the partial sums it leaves per (contig, sample, track), 4 bytes each
             lookups, words = acc["n_index_lookups"] / steps, acc["n_index_entries"] / steps
             moved = 8.0 * lookups + 4.0 * words + 4.0 * flat["n_contigs"] * A * S
             roof["contract_bytes_per_launch"] = bytes_per_sample * S
             roof["contract_GBps"] = achieved
             roof["algorithmic_bytes_per_launch"] = moved
             roof["algorithmic_bytes_per_sample"] = moved / max(1, S)
-            roof["index_bytes_per_lookup"] = 4.0 * words / max(1.0, lookups)
             achieved = moved / count_s / 1e9 if count_s > 0 else 0.0
             roof["achieved"], roof["frac"] = achieved, achieved / HBM_PEAK_GBPS
             roof["note"] = ("bound by the rate at which the L2s serve its gathers (l2_request_frac), not by HBM: achieved/frac = the "
@@ -312,14 +311,16 @@ class Workload(object):
             # the L2s deliver (MI355X_MICROARCH.md, L2).  An upper bound: lanes of one load that fall into the same line are
             # one request -- sorted segments often do
             wpl = words / max(1.0, lookups)
+            ent = max(0.0, (wpl - 1.0) / 2.0)                         # entries a scan looks at (the one that ends it too)
             form = int(acc.get("merged_form", 2))
             roof["index_form"] = {8: "blocks of eight entries", 2: "pairs of entries", 1: "cell records + pairs"}.get(form, str(form))
+            roof["index_entries_per_lookup"] = ent
             if form == 8:
-                per_lookup = 1.0 + (wpl - 1.0) / 16.0
+                per_lookup = 1.0 + (ent + 3.5) / 8.0                  # the cell + the blocks the scan runs through
             elif form == 1:
-                per_lookup = 1.0 + max(0.0, wpl - 8.0) / 4.0
+                per_lookup = 1.0 + max(0.0, ent - 2.0) / 2.0          # the record + pairs behind its two entries
             else:
-                per_lookup = 1.0 + (wpl - 1.0) / 4.0 + 0.5
+                per_lookup = 1.0 + ent / 2.0 + 0.5                    # the cell + pairs
             reqs = lookups / 16.0 + lookups * per_lookup
             roof["l2_requests_per_launch_model"] = reqs
             roof["l2_request_frac"] = min(1.0, reqs / count_s / (34500.0e9 / 128.0)) if count_s > 0 else 0.0

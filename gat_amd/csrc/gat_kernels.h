@@ -1865,6 +1865,9 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 #ifndef GAT_MERGED_THREADS
 #define GAT_MERGED_THREADS 256
 #endif
+#ifndef GAT_MERGED_KR
+#define GAT_MERGED_KR 8            // look-ups a lane has in flight in the pair / cell-record forms (config 3: 2 -> 1.32 ms, 4 -> 1.27, 8 -> 1.16)
+#endif
 constexpr int kMergedThreads = GAT_MERGED_THREADS;
 // PATCH (as in k_count_seg): a unit k_tail finished is read as merged list + the record's extras, no k_finalize.
 // BLK: how a scan fetches the index: 8 = 64-byte blocks of eight entries; 2 = pairs (one 16-byte load); 1 = the first two
@@ -1905,7 +1908,8 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
         Rex = reinterpret_cast<const uint2*>(R + kPatchExtra) - nU;
       }
     }
-    uint32_t n_ent = 0;                                              // index entries this lane read (the one that ended a scan too)
+    uint32_t n_ent = 0;                                              // 4-byte words of index this lane's scans looked at: per segment the
+                                                                     // grid cell + two per entry (the one that ended the scan too)
     if constexpr (BLK == 8) {
     constexpr int kR = 2;                                            // segments per lane whose look-ups are in flight together
     for (int base = 0; base < n; base += kR * kWave) {
@@ -1943,6 +1947,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           bool more = true;
 #define GAT_MERGED_ENTRY(EX, EY)                                                                     \
           if (more) {                                                                               \
+            n_ent += 2u;                                                                            \
             if (!((EX) < x[r].y)) more = false;       /* the contig's sentinel start 0xffffffff ends the scan */ \
             else {                                                                                  \
               const uint32_t ze = (EX) + ((EY) & 0xffffu);                                          \
@@ -1953,7 +1958,6 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           GAT_MERGED_ENTRY(q0.x, q0.y) GAT_MERGED_ENTRY(q0.z, q0.w) GAT_MERGED_ENTRY(q1.x, q1.y) GAT_MERGED_ENTRY(q1.z, q1.w)
           GAT_MERGED_ENTRY(q2.x, q2.y) GAT_MERGED_ENTRY(q2.z, q2.w) GAT_MERGED_ENTRY(q3.x, q3.y) GAT_MERGED_ENTRY(q3.z, q3.w)
 #undef GAT_MERGED_ENTRY
-          n_ent += 16u;                                              // (words: a block is 64 bytes)
           if (!more) break;
           ++blk;
           q0 = Z4[blk * 4]; q1 = Z4[blk * 4 + 1]; q2 = Z4[blk * 4 + 2]; q3 = Z4[blk * 4 + 3];
@@ -1964,7 +1968,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     // short scans (three entries on configs 3 and 5): the grid cell holds, beside the index of its first entry, that entry
     // and the next -- one 32-byte record, one request to the L2 where the cell and the first pair of entries were two; only
     // a scan that passes more goes on in the index, in pairs
-    constexpr int kR = 4;
+    constexpr int kR = GAT_MERGED_KR;
     const uint4* __restrict__ FC = A.mcell + 2 * A.mf_off[c];
     const uint4* __restrict__ Z2 = reinterpret_cast<const uint4*>(Z);
     for (int base = 0; base < n; base += kR * kWave) {
@@ -1983,7 +1987,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
-        n_ent += 8u;                                                 // (words: the record)
+        n_ent += 3u;                                                 // (words: the cell and the first entry)
         uint32_t kk = c0[r].x + 2u;
         bool more = true;
         {
@@ -1996,6 +2000,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
           }
         }
         if (more) {
+          n_ent += 2u;
           const uint2 e = make_uint2(c1[r].x, c1[r].y);
           if (!(e.x < x[r].y)) more = false;
           else {
@@ -2021,7 +2026,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       }
     }
     } else {
-    constexpr int kR = 4;
+    constexpr int kR = GAT_MERGED_KR;
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
