@@ -1865,6 +1865,9 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
 #ifndef GAT_MERGED_THREADS
 #define GAT_MERGED_THREADS 256
 #endif
+#ifndef GAT_MERGED_KR_BLOCKS
+#define GAT_MERGED_KR_BLOCKS 4     // ... in the block form (config-4 shape: 1 -> 36.5 ms, 2 -> 36.9, 4 -> 34.4 per 12 500 samples)
+#endif
 #ifndef GAT_MERGED_KR
 #define GAT_MERGED_KR 8            // look-ups a lane has in flight in the pair / cell-record forms (config 3: 2 -> 1.32 ms, 4 -> 1.27, 8 -> 1.16)
 #endif
@@ -1911,7 +1914,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     uint32_t n_ent = 0;                                              // 4-byte words of index this lane's scans looked at: per segment the
                                                                      // grid cell + two per entry (the one that ended the scan too)
     if constexpr (BLK == 8) {
-    constexpr int kR = 2;                                            // segments per lane whose look-ups are in flight together
+    constexpr int kR = GAT_MERGED_KR_BLOCKS;                         // segments per lane whose look-ups are in flight together
     for (int base = 0; base < n; base += kR * kWave) {
       uint2 x[kR];
       uint32_t k[kR];
