@@ -237,6 +237,8 @@ struct gat_problem {
   DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
   DevBuf<uint32_t> d_serial;             // gat_sample_and_count_serial: the MT19937 state (and its copy at the batch's start)
   DevBuf<int32_t> d_unit_pos;            // unit id -> launch position (k_contig reads k_tail's records by it)
+  std::vector<int32_t> h_unit_pos;
+  DevBuf<int4> d_cu_rec;                 // k_contig: per entry of contig_units {unit, slab offset, launch position, 0} (follows the layout)
   bool patched_contigs = false;          // the last batch skipped k_finalize: k_contig took (merged list, record)
   bool patched_counts = false;           // ... k_count_seg takes (merged list, record)
   std::vector<int32_t> h_class_start;    // launch positions where a size class begins (+ the end): one launch per class

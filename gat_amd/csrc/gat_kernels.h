@@ -1458,6 +1458,8 @@ __global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict
 struct ContigArgs {
   const int32_t* contig_unit_off;  // n_contigs+1: range into contig_units
   const int32_t* contig_units;     // unit ids grouped by contig, reference order
+  const int4* cu_rec;              // the same order: {unit id, its place in a sample's slab, its launch position (-1: inactive), 0} --
+                                   // what a lane needs of unit k in ONE load instead of three dependent ones
   const UnitDev* units;
   const int32_t* contig_slab_off;  // n_contigs: output region of the contig inside a sample slab
   int32_t n_units, n_contigs;
@@ -1502,16 +1504,32 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     int my_cnt = 0, my_off = 0, my_copy = 0;
     bool my_patched = false;
     const int32_t* my_patch = nullptr;
+    int my_u = 0;
+    uint4 pw[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
     if (lane < nu) {
-      const int u = A.contig_units[ub + lane];
-      my_off = A.units[u].slab_off;
-      if (A.slab_merged != nullptr && A.unit_pos[u] >= 0) {
-        const int64_t sa = (int64_t)sidx * A.n_units + A.unit_pos[u];
+      // the unit's record, then everything that depends on it at once: k_tail's hand-over record (state, extras), the merged
+      // list's length, the final list's length -- one round trip where state -> length -> extras were three
+      const int4 rec = A.cu_rec[ub + lane];
+      my_u = rec.x;
+      my_off = rec.y;
+      const bool have_patch = A.slab_merged != nullptr && rec.z >= 0;
+      const int64_t sa = (int64_t)sidx * A.n_units + (have_patch ? rec.z : 0);
+      int4 c2 = make_int4(0, 0, 0, 0);
+      if (have_patch) {
         my_patch = A.patch + sa * A.patch_stride;
-        my_patched = my_patch[kPatchState] == 1;
-        if (my_patched) { my_copy = A.st2[sa].x; my_cnt = my_copy + my_patch[kPatchNExtra]; }
+        const uint2* __restrict__ p2 = reinterpret_cast<const uint2*>(my_patch);       // (72-byte records: 8-byte aligned)
+        // words 0..13: state, n_extra, placed, ndraws, nuns, pad, four extras
+        const uint2 w0 = p2[0], w1 = p2[1], w2 = p2[2], w3 = p2[3], w4 = p2[4], w5 = p2[5], w6 = p2[6];
+        pw[0] = make_uint4(w0.x, w0.y, w1.x, w1.y);
+        pw[1] = make_uint4(w2.x, w2.y, w3.x, w3.y);
+        pw[2] = make_uint4(w4.x, w4.y, w5.x, w5.y);
+        pw[3] = make_uint4(w6.x, w6.y, 0u, 0u);
+        c2 = A.st2[sa];
       }
-      if (!my_patched) my_cnt = my_copy = A.unit_n[(int64_t)sidx * A.n_units + u];
+      const int final_n = A.unit_n[(int64_t)sidx * A.n_units + my_u];
+      my_patched = have_patch && (int32_t)pw[0].x == 1;
+      if (my_patched) { my_copy = c2.x; my_cnt = my_copy + (int32_t)pw[0].y; }
+      else my_cnt = my_copy = final_n;
     }
     const int my_dst = n + (int)(wave_incl_sum_u32((uint32_t)my_cnt, lane) - (uint32_t)my_cnt);
     if (!HUGE && n + (int)wave_total_u32((uint32_t)my_cnt) > A.lds_cap) {      // (wave-uniform; nothing of this batch is kept)
@@ -1547,13 +1565,13 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
       // inside the contig's list does not matter: it is sorted below, and merge(0) drops the emptied segments)
       wave_sync<HUGE>();
       if (my_patched) {
-        const int nU = my_copy, nE = my_patch[kPatchNExtra];
+        // (record words: 0 state, 1 n_extra, 2 placed, 3 ndraws, 4 nuns, 5 pad, 6.. extras)
+        const int nU = my_copy, nE = (int32_t)pw[0].y;
+        const uint2 ex[4] = {make_uint2(pw[1].z, pw[1].w), make_uint2(pw[2].x, pw[2].y), make_uint2(pw[2].z, pw[2].w), make_uint2(pw[3].x, pw[3].y)};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (j < nE) seg[my_dst + nU + j] = make_uint2((uint32_t)my_patch[kPatchExtra + 2 * j], (uint32_t)my_patch[kPatchExtra + 2 * j + 1]);
-        const int u = A.contig_units[ub + lane];
-        *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + u) * 4) =
-            make_uint4((uint32_t)my_patch[kPatchPlaced], (uint32_t)my_patch[kPatchNdraws], (uint32_t)my_patch[kPatchNuns], 0u);
+          if (j < nE) seg[my_dst + nU + j] = ex[j];
+        *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + my_u) * 4) = make_uint4(pw[0].z, pw[0].w, pw[1].x, 0u);
       }
       wave_sync<HUGE>();
     }

@@ -686,6 +686,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (P->merge_contigs && P->n_contigs > 0) {
       gat::ContigArgs B;
       B.contig_unit_off = P->d_contig_unit_off.p; B.contig_units = P->d_contig_units.p; B.units = P->d_units.p;
+      B.cu_rec = P->d_cu_rec.p;
       B.contig_slab_off = P->d_contig_slab_off.p; B.n_units = P->n_units; B.n_contigs = P->n_contigs;
       B.slab_in = P->final_slab(); B.slab_out = P->d_cslab.p; B.slab_stride = P->slab_stride;
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;

@@ -612,6 +612,15 @@ int upload_layout(gat_ctx* ctx, gat_problem* P) {
   }
   HIPCHK(ctx, P->d_contig_slab_off.upload(P->h_contig_slab_off, ctx));
   {
+    // k_contig's per-unit record: the unit, where its list stands in a sample's slab under THIS layout, its launch position
+    std::vector<int4> rec;
+    rec.reserve(P->h_contig_units.size() + 1);
+    for (int32_t u : P->h_contig_units)
+      rec.push_back(make_int4(u, P->h_units[(size_t)u].slab_off, (size_t)u < P->h_unit_pos.size() ? P->h_unit_pos[(size_t)u] : -1, 0));
+    if (rec.empty()) rec.push_back(make_int4(0, 0, -1, 0));
+    HIPCHK(ctx, P->d_cu_rec.upload(rec, ctx));
+  }
+  {
     std::vector<int32_t> o = P->h_contig_order;
     if (o.empty()) o.push_back(0);
     HIPCHK(ctx, P->d_contig_order.upload(o, ctx));
@@ -844,6 +853,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     std::vector<int32_t> pos((size_t)std::max(1, d->n_units), -1);
     for (size_t a = 0; a < P->h_order.size(); ++a) pos[(size_t)P->h_order[a]] = (int32_t)a;
     HIPCHK(ctx, P->d_unit_pos.upload(pos, ctx));
+    P->h_unit_pos = pos;
   }
   HIPCHK(ctx, P->d_rng_rows.upload(P->h_rng_rows, ctx));
   HIPCHK(ctx, P->d_contig_unit_off.upload(P->h_contig_unit_off, ctx));
