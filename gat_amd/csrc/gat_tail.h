@@ -139,6 +139,43 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
 // ------------------------------------------------------------------------------------------------------------------
 // k_tail: the loop of gat/Engine.pyx:572-635 from behind the first consolidation to its end, one stream per lane.
 // Workgroup = one tile of 64 samples x one unit (the tiles of k_place); everything about the unit is wave-uniform.
+// The first index i of [0, n) with val(i) > key, val non-decreasing (an upper bound), for a lane by itself.  A binary
+// search is log2(n) DEPENDENT probes, each a round trip to the L2 or the HBM; the values searched here -- starts of
+// segments placed uniformly over a workspace, running lengths of such a list -- grow nearly linearly with the index, so the
+// place of a key between two known values is nearly proportional: two probes at the ends (in flight together), up to four
+// interpolated ones, and the bisection of what is left (usually a handful of elements): 9 dependent probes become ~5 for a
+// list of 400, 6 become ~3 for one of 50.  The guess only decides where to look, never what is returned.
+template <typename Val>
+__device__ __forceinline__ int interp_upper_bound(int n, uint32_t key, Val val) {
+  if (n <= 0) return 0;
+  if (n <= 96) {                                    // (short lists: the bisection's six probes; measured no gain below ~100)
+    int lo = 0, hi = n;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (val(mid) > key) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  }
+  int L = 0, H = n - 1;                             // val(L) <= key < val(H) once past the two tests below
+  uint32_t vL = val(0), vH = val(n - 1);
+  if (vL > key) return 0;
+  if (!(vH > key)) return n;
+#pragma unroll 1
+  for (int it = 0; it < 4 && H - L > 4; ++it) {
+    const float t = (float)(key - vL) / (float)(vH - vL);
+    int mid = L + 1 + (int)(t * (float)(H - L - 1));
+    mid = mid < L + 1 ? L + 1 : (mid > H - 1 ? H - 1 : mid);
+    const uint32_t v = val(mid);
+    if (v > key) { H = mid; vH = v; } else { L = mid; vL = v; }
+  }
+  int lo = L + 1, hi = H;                           // the answer is in [L + 1, H]
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (val(mid) > key) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
 struct TailRng {
   const uint32_t* rp;     // the lane's column of the tile's rows
   uint32_t used, rows;    // raw outputs consumed / generated
@@ -264,14 +301,13 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       if (trim) { bail = true; break; }                              // a second trim: k_sampler's
       const uint32_t p = tail_range(rng, total - 1u);
       // leftmost element whose inclusive running length exceeds p (searchsorted over cdf = incl - 1)
-      int lo = 0, hi = nU;
-      while (lo < hi) {
-        const int mid = lo + ((hi - lo) >> 1);
-        uint32_t c = cum[mid];
+      // ((int32_t)(c - 1 - p) >= 0 is c > p: running lengths stay below 2^31)
+      const int lo = interp_upper_bound(nU, p, [&](int i) -> uint32_t {
+        uint32_t c = cum[i];
 #pragma unroll
-        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= mid) c += ex[j].y - ex[j].x;
-        if ((int32_t)(c - 1u - p) >= 0) hi = mid; else lo = mid + 1;
-      }
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= i) c += ex[j].y - ex[j].x;
+        return c;
+      });
       // extras standing right in front of merged-list element lo come first
       uint32_t before = lo > 0 ? cum[lo - 1] : 0u;
       int nbefore = 0;
@@ -370,8 +406,8 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 #pragma unroll
         for (int j = 0; j < kTailMaxExtra; ++j) if (j == q) x = pend[j];
         if (x.x == x.y) { bail = true; break; }
-        int lo = 0, hi = nU;                                         // merged-list elements with start <= x.start
-        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (U[mid].x <= x.x) lo = mid + 1; else hi = mid; }
+        // merged-list elements with start <= x.start
+        const int lo = interp_upper_bound(nU, x.x, [&](int i) -> uint32_t { return U[i].x; });
         if (lo > 0 && (int32_t)x.x <= (int32_t)U[lo - 1].y) { bail = true; break; }
         if (lo < nU && (int32_t)U[lo].x <= (int32_t)x.y) { bail = true; break; }
 #pragma unroll
@@ -545,8 +581,8 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
     // only the bookkeeping is left): where it stands in the merged list, what it touches there and in the log
     bool applied = false;
     if (!broken && x.x != x.y) {
-      int lo = 0, hi = nU;                                           // merged-list elements with start <= x.start
-      while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (U[mid].x <= x.x) lo = mid + 1; else hi = mid; }
+      // merged-list elements with start <= x.start
+      const int lo = interp_upper_bound(nU, x.x, [&](int i) -> uint32_t { return U[i].x; });
       const uint2 pv = lo > 0 ? U[lo - 1] : make_uint2(0u, 0u), nv = lo < nU ? U[lo] : make_uint2(0u, 0u);
       const uint2 nn = lo + 1 < nU ? U[lo + 1] : make_uint2(0xffffffffu, 0xffffffffu);
       const bool tl = lo > 0 && (int32_t)x.x <= (int32_t)pv.y;
