@@ -835,8 +835,12 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       const double var_n = P->sampler == GAT_SAMPLER_SEGMENTS ? 0.0 : len_cv2[(size_t)u] * e * e;
       // (the multiple follows what running out costs: ONE wave redoing the unit placement by placement -- 0.5 ms for 800
       //  segments, a few dozen us for 50, where five sigma are plenty and the rows saved are a sixth of k_rng's work)
-      const double sigmas = std::min(7.5, std::max(5.0, 4.5 + nplace / 130.0));
-      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + 96.0;
+      const char* env_s0 = getenv("GAT_RNG_SIGMA_MIN");
+      const char* env_s1 = getenv("GAT_RNG_SIGMA_MAX");
+      const char* env_tr = getenv("GAT_RNG_TAIL_ROWS");
+      const double s_min = env_s0 ? atof(env_s0) : 5.0, s_max = env_s1 ? atof(env_s1) : 7.5;
+      const double sigmas = std::min(s_max, std::max(s_min, s_min - 0.5 + nplace / 130.0));
+      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + (env_tr ? atof(env_tr) : 96.0);
       int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
