@@ -504,6 +504,8 @@ def main():
                                       str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", dev_index))))
         out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                               "devices": [list(d) for d in devs], "one_gpu_per_rank": len(set(devs)) == world}
+        if not share and not out["distributed"]["one_gpu_per_rank"]:
+            raise SystemExit("bench.py: %d ranks landed on %d devices: %r" % (world, len(set(devs)), devs))
     if args.dump_counts and rank == 0:
         import numpy as np
         torch.cuda.synchronize()
