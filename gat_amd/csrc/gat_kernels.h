@@ -305,6 +305,33 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   } else if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
+  // The workspace segment of a position draw straight from a grid over the cumulated lengths instead of a halving search
+  // (five dependent LDS reads per raw output for an isochore unit's 31 blocks, looked up for EVERY output of a chunk since
+  // the look-up depends on the value alone): up to 128 cells, cell c = the first segment whose cumulated length reaches
+  // c << gshift; when no cell spans more than two segments (equal blocks, assembly pieces: the usual workspaces) the
+  // segment is grid[p >> gshift] or the one behind it, which the look-up's last step decides anyway.  The grid (one byte
+  // per cell) lives in the unused end of the workspace table.
+  bool use_grid = false;
+  int gshift = 0;
+  uint8_t* l_grid = reinterpret_cast<uint8_t*>(l_ws + (kWsTab - 9));
+  if (!ALL_SIMPLE && ws_lds && !simple_shape && nws > 2 && nws <= kWsTab - 9) {          // (wave-uniform)
+    const uint32_t top = ws_total - 1u;
+    gshift = top >= 128u ? (32 - __builtin_clz(top)) - 7 : 0;
+    const int cells = (int)(top >> gshift) + 1;
+    for (int c = lane; c <= cells; c += kWave) {
+      const uint32_t t = (uint32_t)c << gshift;
+      int lo_ = 0, hi_ = nws;                          // leftmost i with (int)(cdf[i] - t) >= 0
+      while (lo_ < hi_) {
+        const int mid = lo_ + ((hi_ - lo_) >> 1);
+        if ((int32_t)(l_ws[mid].x - t) < 0) lo_ = mid + 1; else hi_ = mid;
+      }
+      l_grid[c] = (uint8_t)(lo_ < nws ? lo_ : nws - 1);
+    }
+    __syncthreads();
+    bool wide = false;
+    for (int c = lane; c < cells; c += kWave) wide = wide || (int)l_grid[c + 1] - (int)l_grid[c] > 1;
+    use_grid = __ballot(wide) == 0;
+  }
   const uint32_t* __restrict__ rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
 
@@ -477,6 +504,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     uint32_t pv[kPlaceChunk]; int lo[kPlaceChunk];                                                             \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
       const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; lo[c] = 0; }                        \
+    if (use_grid) {                                                                                            \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lo[c] = (int)l_grid[pv[c] >> gshift];             \
+    } else                                                                                                     \
     for (int n = nws; n > 1;) {                                                                                \
       const int half = n >> 1;                                                                                 \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                  \

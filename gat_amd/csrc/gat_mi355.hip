@@ -155,13 +155,11 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
-  tm.lap("  scratch: budget");
   HIPCHK(ctx, P->d_slab.alloc((size_t)(b * P->slab_stride)));
   if (P->merge_contigs) HIPCHK(ctx, P->d_cslab.alloc((size_t)(b * P->slab_stride)));
   HIPCHK(ctx, P->d_unit_n.alloc((size_t)(b * std::max(1, P->n_units))));
   HIPCHK(ctx, P->d_contig_n.alloc((size_t)(b * std::max(1, P->n_contigs))));
   HIPCHK(ctx, P->d_ws_stat.alloc((size_t)(b * std::max(1, P->n_units)) * 4));
-  tm.lap("  scratch: slab, counts");
   HIPCHK(ctx, hipMemsetAsync(P->d_unit_n.p, 0, (size_t)(b * std::max(1, P->n_units)) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(P->d_contig_n.p, 0, (size_t)(b * std::max(1, P->n_contigs)) * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(P->d_ws_stat.p, 0, (size_t)(b * std::max(1, P->n_units)) * 16, ctx->stream));
@@ -169,12 +167,8 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     const int64_t nsb = (b + 63) / 64;
     P->h_rng_off.assign(P->h_order.size() + 1, 0);
     for (size_t a = 0; a < P->h_order.size(); ++a) P->h_rng_off[a + 1] = P->h_rng_off[a] + nsb * (int64_t)P->h_rng_rows[a] * 64;
-    tm.lap("  scratch: memsets enqueued");
-    if (tm.on) { (void)hipStreamSynchronize(ctx->stream); tm.lap("  scratch: (timing only) memsets done"); }
     HIPCHK(ctx, P->d_rng_off.alloc(P->h_rng_off.size()));
-    tm.lap("  scratch: rng offsets alloc");
     HIPCHK(ctx, staged_h2d(ctx, P->d_rng_off.p, P->h_rng_off.data(), P->h_rng_off.size() * 8));
-    tm.lap("  scratch: rng offsets up");
     HIPCHK(ctx, P->d_rng_out.alloc((size_t)P->h_rng_off.back()));
     HIPCHK(ctx, P->d_rng_ckpt.alloc((size_t)nsb * std::max<size_t>(1, P->h_order.size()) * gat::kRngWaves * gat::kWave));
     const size_t ns = (size_t)(b * std::max(1, P->n_units));
