@@ -305,14 +305,15 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   } else if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
   __syncthreads();
-  // The workspace segment of a position draw straight from a grid over the cumulated lengths instead of a halving search
-  // (five dependent LDS reads per raw output for an isochore unit's 31 blocks, looked up for EVERY output of a chunk since
-  // the look-up depends on the value alone): up to 128 cells, cell c = the first segment whose cumulated length reaches
-  // c << gshift; when no cell spans more than two segments (equal blocks, assembly pieces: the usual workspaces) the
-  // segment is grid[p >> gshift] or the one behind it, which the look-up's last step decides anyway.  The grid (one byte
-  // per cell) lives in the unused end of the workspace table.
+  // The workspace segment of a position draw from a grid over the cumulated lengths instead of a halving search over the
+  // whole table (five dependent LDS reads per raw output for an isochore unit's 31 blocks, looked up for EVERY output of a
+  // chunk since the look-up depends on the value alone): up to 128 cells, cell c = the first segment whose cumulated length
+  // reaches c << gshift.  The segment of p lies between grid[cell] and grid[cell + 1]: the halving search runs over the
+  // widest such span of the unit only -- not at all when no cell spans more than two segments (equal blocks, assembly
+  // pieces), where the look-up's last step decides between the two.  The grid (one byte per cell) lives in the unused end
+  // of the workspace table.
   bool use_grid = false;
-  int gshift = 0;
+  int gshift = 0, gspan = 0;
   uint8_t* l_grid = reinterpret_cast<uint8_t*>(l_ws + (kWsTab - 9));
   if (!ALL_SIMPLE && ws_lds && !simple_shape && nws > 2 && nws <= kWsTab - 9) {          // (wave-uniform)
     const uint32_t top = ws_total - 1u;
@@ -328,16 +329,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       l_grid[c] = (uint8_t)(lo_ < nws ? lo_ : nws - 1);
     }
     __syncthreads();
-    bool wide = false;
-    for (int c = lane; c < cells; c += kWave) wide = wide || (int)l_grid[c + 1] - (int)l_grid[c] > 1;
-    use_grid = __ballot(wide) == 0;
+    uint32_t span = 0;
+    for (int c = lane; c < cells; c += kWave) span = max(span, (uint32_t)l_grid[c + 1] - (uint32_t)l_grid[c]);
+    gspan = (int)wave_max_u32(span);
+    use_grid = true;
   }
   const uint32_t* __restrict__ rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + lane;
   uint2* __restrict__ out = A.slab + (int64_t)(live ? sidx : 0) * A.slab_stride + Up->slab_off;
 
-  enum { S_L = 0, S_B = 1, S_P = 2, S_O = 3, S_HALT = 4 };
-  int st = live ? S_L : S_HALT;
-  uint32_t curmask = maskL, currange = rangeL;
   int32_t rem = Up->ltotal;
   int nS = 0;
   uint32_t len = 0, cs = 0, ce = 0;
@@ -347,46 +346,11 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   int flag = 0;
 
 
-  // Straight-line form: a lane's state only selects which of the three small results it keeps, so the wave runs
-  // one instruction stream instead of three divergent ones.  `lr` is the length of rank 1 + (y & maskL), read
-  // from LDS for the whole chunk up front (one exposed LDS latency per chunk instead of one per output).
-#define GAT_STEP_SIMPLE(Y, LR, JJ)                                                                            \
-  {                                                                                                            \
-    const uint32_t v = (Y) & curmask;                                                                          \
-    const bool acc = st != S_HALT && v <= currange;                                                            \
-    const bool isL = acc && st == S_L, isP = acc && st == S_P, isO = acc && st == S_O;                         \
-    const bool trig = isL && !kind1 && rem <= (int32_t)(LR);           /* :582 -> consolidate */               \
-    len = isL ? (LR) : len;                                                                                    \
-    const int32_t sstartP = (int32_t)ws0.x - (int32_t)len + 1;                                                 \
-    const uint32_t range3 = ws0.y - 1u - (uint32_t)sstartP;                                                    \
-    const uint32_t mask3 = 0xffffffffu >> __builtin_clz(range3 | 1u);                                          \
-    int nst = isL ? S_P : (isP ? S_O : (isO ? S_L : st));                                                      \
-    if (trig) { pend = (int32_t)len; used = (JJ) + 1u; nst = S_HALT; }                                         \
-    if (isO) {                                                                                                 \
-      const int32_t q = sstart + (int32_t)v;                                                                   \
-      const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                        \
-      const uint32_t end = (uint32_t)(q + (int32_t)len);                                                       \
-      const int32_t omin = (int32_t)ws0.y < (int32_t)end ? (int32_t)ws0.y : (int32_t)end;                      \
-      const int32_t omax = (int32_t)ws0.x > (int32_t)start ? (int32_t)ws0.x : (int32_t)start;                  \
-      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
-      if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
-      else {                                                                                                   \
-        l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
-        nS++;                                                                                                  \
-        rem -= overlap;                                                                                        \
-        if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
-      }                                                                                                        \
-    }                                                                                                          \
-    sstart = isP ? sstartP : sstart;                                                                           \
-    curmask = isL ? maskP : (isP ? mask3 : (isO ? maskL : curmask));                                           \
-    currange = isL ? rangeP : (isP ? range3 : (isO ? rangeL : currange));                                      \
-    st = nst;                                                                                                  \
-  }
-
-  // The same step with the lane's state held as three booleans (in L / in P / in O; none: halted) instead of a number:
-  // the compiler keeps them as lane masks in scalar registers and the transitions become scalar logic beside the vector
-  // work (51 -> 3x vector instructions per output).  LR1 is read from the rank table shifted by one (entry v = length of
-  // rank 1 + v), filled that way when this loop is the one that runs.
+  // Straight-line form: a lane's state only selects which of the small results it keeps, so the wave runs one
+  // instruction stream instead of divergent ones.  The state is held as booleans (in L / in P / in O; none: halted), not
+  // as a number: the compiler keeps them as lane masks in scalar registers and the transitions become scalar logic beside
+  // the vector work (51 -> 3x vector instructions per output).  LR1 = the length of rank 1 + (y & maskL), read for the
+  // whole chunk up front (one exposed latency per chunk instead of one per output).
   bool sL = live, sP = false, sO = false;
   const int32_t c_ss = (int32_t)ws0.x + 1;               // sampling_start = ws.start - length + 1 (:318)
   const uint32_t c_r3 = ws0.y - ws0.x - 2u;              // its range: ws.end - 1 - sampling_start = c_r3 + length
@@ -443,47 +407,52 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       nF += 8;
     }
   };
-  // The general shape in the same straight-line form: several workspace segments (table in LDS), optional bucket
-  // draw.  The workspace lookup of an output depends only on its value, not on the lane's state, so the lookups of
-  // a whole chunk (PCS/PCE/PPE: chosen segment's start, end, previous end) are done up front, interleaved; a lane
-  // keeps the one it needs when it is in state P at that output.
-#define GAT_STEP_TABLE(Y, LR, PCS, PCE, PPE, JJ)                                                               \
+  // The general shape in the same straight-line form: several workspace segments (table in LDS or search tree),
+  // optional bucket draw.  The workspace lookup of an output depends only on its value, not on the lane's state, so the
+  // lookups of a whole chunk (PCS/PCE/PPE: chosen segment's start, end, previous end) are done up front, interleaved; a
+  // lane keeps the one it needs when it is in state P at that output.  State as booleans (in L / B / P / O; none: halted):
+  // whether an output would be accepted is worked out for every kind of draw, the lane's state picks; the offset draw's
+  // mask and range (they follow from the chosen workspace segment and the length) are kept from the position draw on.
+  bool sB = false;
+  uint32_t omask = 0u, orange = 0u;
+#define GAT_STEP_TABLE_B(Y, LR, PCS, PCE, PPE, JJ)                                                             \
   {                                                                                                            \
-    const uint32_t v = (Y) & curmask;                                                                          \
-    const bool acc = st != S_HALT && v <= currange;                                                            \
-    const bool isL = acc && st == S_L, isB = acc && st == S_B, isP = acc && st == S_P, isO = acc && st == S_O; \
-    len = isL ? (LR) * bucket : (isB ? len + v : len);                 /* :419-433 */                          \
-    const bool have_len = (isL && !drawB) || isB;                                                              \
+    const uint32_t y_ = (Y);                                                                                   \
+    const uint32_t vB = y_ & maskB, vO = y_ & omask;                                                           \
+    const bool isL = sL && (y_ & maskL) <= rangeL, isB = sB && vB <= rangeB;                                   \
+    const bool isP = sP && (y_ & maskP) <= rangeP, isO = sO && vO <= orange;                                   \
+    len = isL ? (LR) * bucket : (isB ? len + vB : len);                /* :419-433 */                          \
+    const bool have_len = drawB ? isB : isL;                                                                   \
     const bool trig = have_len && !kind1 && rem <= (int32_t)len;       /* :582 -> consolidate */               \
     cs = isP ? (PCS) : cs;                                                                                     \
     ce = isP ? (PCE) : ce;                                                                                     \
     int32_t sstartP = (int32_t)(PCS) - (int32_t)len + 1;               /* :318-325 */                          \
     sstartP = (int32_t)(PPE) > sstartP ? (int32_t)(PPE) : sstartP;                                             \
     const uint32_t range3 = (PCE) - 1u - (uint32_t)sstartP;                                                    \
-    const uint32_t mask3 = 0xffffffffu >> __builtin_clz(range3 | 1u);                                          \
     const bool placeP = isP && range3 == 0;                            /* range 0: randint consumes nothing */ \
     const bool place = isO || placeP;                                                                          \
-    const int32_t q = isO ? sstart + (int32_t)v : sstartP;                                                     \
-    int nst = (isL && drawB) ? S_B : (have_len ? S_P : ((isP && !placeP) ? S_O : (place ? S_L : st)));         \
-    if (trig) { pend = (int32_t)len; used = (JJ) + 1u; nst = S_HALT; }                                         \
-    if (place) {                                                       /* :331-343, :630-635 */                \
-      const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                        \
-      const uint32_t end = (uint32_t)(q + (int32_t)len);                                                       \
-      const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;                            \
-      const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;                        \
-      const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                               \
-      if (nS >= cap) { flag |= kStatusOverflow; nst = S_HALT; }                                                \
-      else {                                                                                                   \
-        l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
-        nS++;                                                                                                  \
-        rem -= overlap;                                                                                        \
-        if (kind1 && nS == target) { pend = -2; used = (JJ) + 1u; nst = S_HALT; }                              \
-      }                                                                                                        \
-    }                                                                                                          \
+    const int32_t q = isO ? sstart + (int32_t)vO : sstartP;                                                    \
+    const uint32_t start = (uint32_t)(q > 0 ? q : 0);                  /* :331-343, :630-635 */                \
+    const uint32_t end = (uint32_t)(q + (int32_t)len);                                                         \
+    const int32_t omin = (int32_t)ce < (int32_t)end ? (int32_t)ce : (int32_t)end;                              \
+    const int32_t omax = (int32_t)cs > (int32_t)start ? (int32_t)cs : (int32_t)start;                          \
+    const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                                 \
+    const bool full = place && nS >= cap;                                                                      \
+    const bool put = place && !full;                                                                           \
+    if (put) l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
+    nS += put ? 1 : 0;                                                                                         \
+    rem -= put ? overlap : 0;                                                                                  \
+    flag |= full ? kStatusOverflow : 0;                                                                        \
+    const bool fin = kind1 && put && nS == target;                                                             \
+    pend = trig ? (int32_t)len : (fin ? -2 : pend);                                                            \
+    used = (trig || fin) ? (JJ) + 1u : used;                                                                   \
     sstart = isP ? sstartP : sstart;                                                                           \
-    curmask = nst == S_L ? maskL : (nst == S_B ? maskB : (nst == S_P ? maskP : (nst == S_O ? (isP ? mask3 : curmask) : curmask))); \
-    currange = nst == S_L ? rangeL : (nst == S_B ? rangeB : (nst == S_P ? rangeP : (nst == S_O ? (isP ? range3 : currange) : currange))); \
-    st = nst;                                                                                                  \
+    omask = isP ? 0xffffffffu >> __builtin_clz(range3 | 1u) : omask;                                           \
+    orange = isP ? range3 : orange;                                                                            \
+    sL = (sL && !isL) || (put && !fin);                                                                        \
+    sB = (sB && !isB) || (isL && drawB);                                                                       \
+    sP = (sP && !isP) || (have_len && !trig);                                                                  \
+    sO = (sO && !isO) || (isP && !placeP);                                                                     \
   }
 
   uint32_t ya[kPlaceChunk], yb[kPlaceChunk], lr[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -506,11 +475,13 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       const uint32_t v = (Y)[c] & maskP; pv[c] = v <= rangeP ? v : rangeP; lo[c] = 0; }                        \
     if (use_grid) {                                                                                            \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lo[c] = (int)l_grid[pv[c] >> gshift];             \
-    } else                                                                                                     \
-    for (int n = nws; n > 1;) {                                                                                \
+    }                                                                                                          \
+    for (int n = use_grid ? gspan : nws; n > 1;) {      /* (the last step below covers a span of two) */        \
       const int half = n >> 1;                                                                                 \
-      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c)                                                  \
-        lo[c] = (int32_t)(l_ws[lo[c] + half - 1].x - pv[c]) < 0 ? lo[c] + half : lo[c];                        \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        const int pr = lo[c] + half - 1;                /* (a span may reach beyond the table: its last entry holds) */ \
+        lo[c] = (int32_t)(l_ws[pr < nws ? pr : nws - 1].x - pv[c]) < 0 ? lo[c] + half : lo[c];                 \
+      }                                                                                                        \
       n -= half;                                                                                               \
     }                                                                                                          \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
@@ -542,11 +513,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_PRE_TABLE_GL(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS(Y)
 #define GAT_PRE_TABLE_LG(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS2(Y)
 #define GAT_PRE_TABLE_GG(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS2(Y)
-#define GAT_ONE_SIMPLE(Y, C, JJ) GAT_STEP_SIMPLE((Y)[C], lr[C], JJ)
 #define GAT_ONE_SIMPLE_B(Y, C, JJ) GAT_STEP_SIMPLE_B((Y)[C], lr[C], JJ)
-#define GAT_ALIVE_ST (st != S_HALT)
 #define GAT_ALIVE_B (sL || sP || sO)
-#define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
+#define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE_B((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
+#define GAT_ALIVE_TB (sL || sB || sP || sO)
   // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
   // Two loops.  GAT_PLACE_LOOP: two chunk buffers, loads left to the compiler -- which, for a register loaded in one
   // trip and used in the next, waits for EVERYTHING in flight (loads and stores share one in-order counter, vmcnt, and the
@@ -584,6 +554,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_PLACE_LOOP_PIPE(PRE, ONE, ALIVE)                                                                 \
   {                                                                                                          \
     static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
+    asm volatile("; GAT_PINNED_BEGIN" ::: "memory");     /* (markers for tools/check_pinned_regs.py) */      \
     GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, 0)                                                      \
     GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, kPlaceChunk)                                        \
     GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, 2 * kPlaceChunk)                                    \
@@ -605,7 +576,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
       GAT_PLACE_CHUNK(PRE, ONE, 3)                                                                           \
     }                                                                                                        \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* nothing on its way into a register at the end */\
+    asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");   /* nothing on its way into a register at the end */\
   }
 #define GAT_PLACE_LOOP(PRE, ONE, ALIVE)                                                                        \
   {                                                                                                            \
@@ -633,13 +604,15 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   if (simple_lds) {
     if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
     else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
-    st = (sL || sP || sO) ? S_L : S_HALT;
   } else if constexpr (!ALL_SIMPLE) {
-    if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE, GAT_ALIVE_ST)
-    else if (ws_lds) {
-      if (rank_lds) { if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_ST) else GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_ST) } else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_ST)
-    } else if constexpr (TREES) {
-      if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_ST) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_ST)
+    if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    else {
+      if (ws_lds) {
+        // (not through the pinned registers: a chunk of this loop has more values in flight than the 96 registers below them hold)
+        if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_TB)
+      } else if constexpr (TREES) {
+        if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_TB)
+      }
     }
   }
 #undef GAT_PLACE_LOOP
@@ -648,9 +621,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PIN_TAKE
 #undef GAT_PIN_LOAD
 #undef GAT_ONE_TABLE
-#undef GAT_ONE_SIMPLE
 #undef GAT_ONE_SIMPLE_B
-#undef GAT_ALIVE_ST
 #undef GAT_ALIVE_B
 #undef GAT_STEP_SIMPLE_B
 #undef GAT_PRE_TABLE_GG
@@ -663,11 +634,12 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PRE_WS
 #undef GAT_PRE_RANK_G
 #undef GAT_PRE_RANK_L
-#undef GAT_STEP_TABLE
-#undef GAT_STEP_SIMPLE
+#undef GAT_STEP_TABLE_B
+#undef GAT_ALIVE_TB
   if (live) {
+    const bool halted = !(sL || sB || sP || sO);
     for (int i = nF; i < nS; ++i) out[i] = l_out[i & 15][lane];   // what the last flush left
-    A.st[so] = make_int4(nS, rem, (st == S_HALT && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
+    A.st[so] = make_int4(nS, rem, (halted && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
                          (int)used);
     if (flag) atomicOr(A.flags, flag);
   }

@@ -449,8 +449,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<1, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
-          // (k_place_pipe: every look-up of every unit in LDS -- the rows prefetched by hand, see GAT_PLACE_LOOP_PIPE)
-          const bool pipe = !getenv("GAT_PLACE_NO_PIPE");
+          // (k_place_pipe: the rows of the single-workspace-segment units prefetched by hand, see GAT_PLACE_LOOP_PIPE)
+          const bool pipe = P->pipe_pays && !getenv("GAT_PLACE_NO_PIPE");
           const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
           if (mode == 1 && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);

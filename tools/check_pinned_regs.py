@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Build-time guard for k_place_pipe's hand-pipelined rows (gat_kernels.h, GAT_PLACE_LOOP_PIPE): the loop keeps loads in
+flight into v96..v127 and nothing tells the register allocator so -- it stays below v96 only because the loop's own values fit
+there (the amdgpu_num_vgpr attribute does not bind on gfx950).  This script reads the device assembly the compile leaves
+behind (-save-temps=obj) and fails the build if, between the markers GAT_PINNED_BEGIN / GAT_PINNED_END the loop emits, any
+instruction other than the loop's own loads (global_load_dword v9x, ..., off) and takes (v_mov_b32 vN, v9x) names one of
+those registers; a silent corruption of the random rows becomes a build error.
+usage: tools/check_pinned_regs.py <device .s>"""
+import re
+import sys
+
+PINNED = re.compile(r"\bv(9[6-9]|1[01][0-9]|12[0-7])\b|\bv\[(\d+):(\d+)\]")
+LOAD = re.compile(r"^\s*global_load_dword v(9[6-9]|1[01][0-9]|12[0-7]), v\[\d+:\d+\], off( offset:\d+)?\s*$")
+TAKE = re.compile(r"^\s*v_mov_b32(_e32)? v(\d+), v(9[6-9]|1[01][0-9]|12[0-7])\s*$")
+
+
+def touches(line):
+    for m in PINNED.finditer(line):
+        if m.group(1):
+            return True
+        lo, hi = int(m.group(2)), int(m.group(3))
+        if lo <= 127 and hi >= 96:
+            return True
+    return False
+
+
+def main(path):
+    kernel, inside, regions, bad = None, False, 0, []
+    for no, line in enumerate(open(path, errors="replace"), 1):
+        code = line.split("//")[0]
+        m = re.match(r"^(_ZN3gat\w+):", line)
+        if m:
+            kernel, inside = m.group(1), False
+        if "GAT_PINNED_BEGIN" in line:
+            inside, regions = True, regions + 1
+            continue
+        if "GAT_PINNED_END" in line:
+            inside = False
+            continue
+        if not inside or not code.strip() or code.lstrip().startswith((";", ".")):
+            continue
+        if touches(code):
+            t = TAKE.match(code)
+            if LOAD.match(code) or (t and int(t.group(2)) < 96):
+                continue
+            bad.append((kernel, no, code.strip()))
+    if regions == 0:
+        sys.exit("check_pinned_regs: no GAT_PINNED_BEGIN marker in %s (wrong file?)" % path)
+    if bad:
+        for k, no, code in bad[:20]:
+            sys.stderr.write("%s:%d: %s  [%s]\n" % (path, no, code, k))
+        sys.exit("check_pinned_regs: %d instruction(s) inside a pinned-register loop use v96..v127: the loop's values no "
+                 "longer fit below v96 -- lower the pressure or take the loop off the pipe" % len(bad))
+    print("check_pinned_regs: %d pinned-register loops clean" % regions)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
