@@ -251,6 +251,8 @@ struct gat_problem {
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
+  bool all_one_ws = false;               // every active unit: one workspace segment, bucket 1, and most of the working segments in units
+                                         // whose rank table is beyond k_place's LDS table but within k_place_wide's (k_place MODE 3)
   bool pipe_pays = false;                // the single-workspace-segment units hold at least half of the working segments: only their
                                          // loop of k_place_pipe runs through the hand-pipelined rows, and the kernel costs registers
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS

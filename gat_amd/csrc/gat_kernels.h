@@ -233,7 +233,11 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
 constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 
 // MODE (chosen by the host from the units' shapes, so that the common problems run a lean kernel): 1 every unit is of
-// the single-workspace-segment shape, only that loop is compiled in; 0 no workspace beyond the LDS table; 2 everything.
+// the single-workspace-segment shape with its rank table within the LDS table, only that loop is compiled in; 3 the
+// same shape with units of thousands of segments (k_place_wide): a workgroup is kPlaceWide tiles of ONE unit that
+// share the unit's whole rank table in (dynamic) LDS -- read from global memory, the eight gathers of a chunk are 512
+// separate lines for the CU's vector cache to look up, which bounded the kernel on the config-4 shape; no lean kernel
+// per tile can afford 32 KB of table; 0 no workspace beyond the LDS table; 2 everything.
 // SMALL: every unit has at most 64 workspace segments and fewer than 256 working segments: quarter-size LDS tables,
 // so that more tiles are resident per CU (the kernel has few waves and hides latency by their number).
 // SMALL 2: at most 64 workspace segments, rank table at full size (a quarter of the workspace table's LDS back).
@@ -241,14 +245,21 @@ constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 // GAT_PLACE_LOOP_PIPE below; only k_place_pipe, which is compiled for 96 registers of its own, may set it.
 template <int KIND, int MODE, int SMALL, bool PIPE>
 __device__ __forceinline__ void place_body(const SamplerArgs& A) {
-  constexpr bool ALL_SIMPLE = MODE == 1;
+  constexpr bool ALL_SIMPLE = MODE == 1 || MODE == 3;
   constexpr bool TREES = MODE == 2;
-  constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = SMALL == 1 ? 256 : kPlaceRankLds;
+  constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = MODE == 3 ? 1 : (SMALL == 1 ? 256 : kPlaceRankLds);
+  constexpr int WIDE = MODE == 3 ? kPlaceWide : 1;                         // tiles (waves) of a workgroup
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
-  __shared__ uint32_t l_rank[kRankTab];
-  __shared__ uint2 l_out[16][kWave];      // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
-  const int lane = threadIdx.x;
-  const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  __shared__ uint32_t l_rank_tab[kRankTab];
+  __shared__ uint2 l_out_all[WIDE][16][kWave];   // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
+  extern __shared__ __attribute__((aligned(16))) uint32_t l_rank_wide[];   // MODE 3: the unit's rank table, entry v = length of rank 1 + v
+  uint32_t* const l_rank = MODE == 3 ? l_rank_wide : l_rank_tab;
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  uint2 (*const l_out)[kWave] = l_out_all[wv];
+  const int n_tiles = (A.batch + kWave - 1) / kWave;
+  const int sb_own = (int)blockIdx.x * WIDE + wv;          // (a wide workgroup's last waves may be beyond the batch: they idle
+  const int sb = sb_own < n_tiles ? sb_own : n_tiles - 1;  //  through the loop on the last tile's rows and write nothing)
+  const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
@@ -259,7 +270,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
   const int rows = A.rng_rows[a];
   const int sidx = sb * kWave + lane;
-  const bool live = sidx < A.batch;
+  const bool live = sb_own < n_tiles && sidx < A.batch;
   const int64_t so = (int64_t)sidx * A.n_units + a;      // hand-off record, indexed by launch position
 
   // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
@@ -285,7 +296,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     else if (q == 2) __builtin_amdgcn_s_setprio(1);
   }
   const bool ws_lds = nws <= kWsTab;
-  const bool rank_lds = hist_total < (uint32_t)kRankTab;
+  const bool rank_lds = MODE == 3 || hist_total < (uint32_t)kRankTab;
   // longer workspaces are looked up through their 16-ary tree in global memory (WsTree, gat_device.h)
   const uint32_t* __restrict__ tree_cdf = A.ws_tree + (Up->tree_cdf_off >= 0 ? Up->tree_cdf_off : 0);
   const WsTreeGeom G = ws_tree_geom(nws);
@@ -298,8 +309,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // the common shape -- one workspace segment (longer than one base), bucket size 1, rank table in
   // LDS -- needs no workspace search, no bucket draw and never an immediate placement
   const bool simple_shape = nws == 1 && !drawB && ws0.y - ws0.x > 1u;
-  const bool simple_lds = ALL_SIMPLE || (simple_shape && rank_lds);      // GAT_STEP_SIMPLE_B's loop runs
-  if (simple_lds) {
+  const bool simple_lds = ALL_SIMPLE || (simple_shape && rank_lds);      // GAT_STEP_SIMPLE_B's loop with the rank table in LDS runs
+  if constexpr (MODE == 3) {
+    for (int i = (int)threadIdx.x; i <= (int)rangeL; i += WIDE * kWave) l_rank[i] = rank_len[i + 1];
+  } else if (simple_lds) {
     // entry v = length of rank 1 + v for v <= rangeL (the others are never accepted)
     for (int i = lane; i <= (int)maskL && i < kRankTab; i += kWave) l_rank[i] = (uint32_t)i <= rangeL ? rank_len[i + 1] : 0u;
   } else if (rank_lds)
@@ -508,6 +521,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   }
 #define GAT_PRE_SIMPLE_L(Y)                                                                                    \
   _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lr[c] = l_rank[(Y)[c] & maskL];
+#define GAT_PRE_SIMPLE_W(Y)                    /* (k_place_wide's table ends at rangeL) */                    \
+  _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                    \
+    const uint32_t v = (Y)[c] & maskL; lr[c] = l_rank[v <= rangeL ? v : 0u]; }
 #define GAT_PRE_SIMPLE_G(Y) GAT_PRE_RANK_G(Y)
 #define GAT_PRE_TABLE_LL(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS(Y)
 #define GAT_PRE_TABLE_GL(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS(Y)
@@ -601,7 +617,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       flush();                                                                                                 \
     }                                                                                                          \
   }
-  if (simple_lds) {
+  if constexpr (MODE == 3) {
+    static_assert(PIPE, "k_place_wide runs the hand-pipelined loop");
+    GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_W, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+  } else if (simple_lds) {
     if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
     else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
   } else if constexpr (!ALL_SIMPLE) {
@@ -629,6 +648,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PRE_TABLE_GL
 #undef GAT_PRE_TABLE_LL
 #undef GAT_PRE_SIMPLE_G
+#undef GAT_PRE_SIMPLE_W
 #undef GAT_PRE_SIMPLE_L
 #undef GAT_PRE_WS2
 #undef GAT_PRE_WS
@@ -653,6 +673,12 @@ __global__ __launch_bounds__(64) void k_place(SamplerArgs A) { place_body<KIND, 
 template <int KIND, int MODE, int SMALL = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) void k_place_pipe(SamplerArgs A) {
   place_body<KIND, MODE, SMALL, true>(A);
+}
+
+// MODE 3: kPlaceWide tiles of one unit per workgroup around the unit's rank table in LDS (dynamic: 4 bytes per working segment)
+template <int KIND>
+__global__ __launch_bounds__(kPlaceWide * 64) void k_place_wide(SamplerArgs A) {
+  place_body<KIND, 3, 0, true>(A);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -443,16 +443,25 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[0], ctx->stream));
         const dim3 gp(nsb, gy, gz);
-        const int mode = P->all_simple ? 1 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0);
+        const int mode = P->all_simple ? 1 : (P->all_one_ws && !getenv("GAT_PLACE_NO_MODE3") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
+        // (k_place_wide: kPlaceWide tiles per workgroup, the largest unit's rank table beside their rings)
+        const dim3 gw((nsb + gat::kPlaceWide - 1) / gat::kPlaceWide, gy, gz);
+        const size_t lds_wide = (size_t)P->max_hist * 4;
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
-          if (mode == 1) hipLaunchKernelGGL((gat::k_place<1, 1>), gp, dim3(64), 0, ctx->stream, A);
+          if (mode == 3) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
+            hipLaunchKernelGGL((gat::k_place_wide<1>), gw, dim3(gat::kPlaceWide * 64), lds_wide, ctx->stream, A);
+          } else if (mode == 1) hipLaunchKernelGGL((gat::k_place<1, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0) hipLaunchKernelGGL((gat::k_place<1, 0>), gp, dim3(64), 0, ctx->stream, A);
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
           // (k_place_pipe: the rows of the single-workspace-segment units prefetched by hand, see GAT_PLACE_LOOP_PIPE)
           const bool pipe = P->pipe_pays && !getenv("GAT_PLACE_NO_PIPE");
           const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
-          if (mode == 1 && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 1>), gp, dim3(64), 0, ctx->stream, A);
+          if (mode == 3) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_wide<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
+            hipLaunchKernelGGL((gat::k_place_wide<0>), gw, dim3(gat::kPlaceWide * 64), lds_wide, ctx->stream, A);
+          } else if (mode == 1 && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 1) hipLaunchKernelGGL((gat::k_place<0, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0 && P->small_tables && pipe) hipLaunchKernelGGL((gat::k_place_pipe<0, 0, 1>), gp, dim3(64), 0, ctx->stream, A);
           else if (mode == 0 && P->small_tables) hipLaunchKernelGGL((gat::k_place<0, 0, 1>), gp, dim3(64), 0, ctx->stream, A);

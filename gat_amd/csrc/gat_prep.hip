@@ -774,18 +774,22 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   for (auto& w : work) P->h_order.push_back(w.second);
   P->all_simple = !P->h_order.empty();
   uint32_t max_hist = 0;
-  uint64_t work_simple = 0, work_all = 0;
+  uint64_t work_simple = 0, work_all = 0, work_big_rank = 0;
+  P->all_one_ws = !P->h_order.empty();
   for (int32_t u : P->h_order) {
     const UnitDev& U = P->h_units[(size_t)u];
     const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
     const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
     if (!degenerate && !simple) P->all_simple = false;
     if (!degenerate) { work_all += U.hist_total; if (simple) work_simple += U.hist_total; }
+    if (!degenerate && !(U.n_ws == 1 && U.bucket <= 1)) P->all_one_ws = false;
+    if (!degenerate && U.hist_total >= (uint32_t)gat::kPlaceRankLds) work_big_rank += U.hist_total;
     P->max_nws = std::max(P->max_nws, U.n_ws);
     max_hist = std::max(max_hist, U.hist_total);
   }
   P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
   P->pipe_pays = 2 * work_simple >= work_all;
+  P->all_one_ws = P->all_one_ws && !P->all_simple && 2 * work_big_rank >= work_all && max_hist <= (uint32_t)gat::kPlaceWideMaxRank;
   P->long_lists = max_hist + max_hist / 8 > 1024;
   P->max_hist = max_hist;
   {

@@ -365,6 +365,31 @@ def _long_list_case(ctx, seed):
     return handed
 
 
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_wide_placement_tiles_vs_oracle(ctx, sampler):
+    """k_place_wide (units of thousands of segments on one workspace segment: eight tiles of a unit per workgroup around
+    the unit's rank table in LDS) over more than one workgroup, the last one with idle waves and a ragged tile: 600 samples
+    = 10 tiles; both sampler kinds; counts and sampled lists against the oracle."""
+    import collections
+    from gat_amd import problem
+    contigs = collections.OrderedDict([("W0", 3000000), ("W1", 1700000)])
+    segs = synthetic.random_segments(contigs, 4200, 60, 77)
+    annos = [("t0", synthetic.random_segments(contigs, 300, 2000, 78))]
+    ws = synthetic.workspace_ungapped(contigs, pieces=1, gap=500)
+    flat = problem.flatten_arrays(segs, annos, ws, None, bucket_size=1, nbuckets=100000)
+    flat["sampler"] = sampler
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S = 600
+    want, wsamples = O.run_samples(flat, counters, 5, 1, 0, S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    got = P.sample_and_count(counters, 5, 0, S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    seg, off = P.sample(5, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
 @pytest.mark.parametrize("seed", list(range(900, 912)))
 def test_long_lists_vs_oracle(ctx, seed):
     _long_list_case(ctx, seed)
