@@ -443,7 +443,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[0], ctx->stream));
         const dim3 gp(nsb, gy, gz);
-        const int mode = P->all_simple ? 1 : (P->all_one_ws && !getenv("GAT_PLACE_NO_MODE3") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
+        const int mode = P->all_simple ? (getenv("GAT_PLACE_WIDE") ? 3 : 1)
+                                       : (P->all_one_ws && !getenv("GAT_PLACE_NO_WIDE") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
         // (k_place_wide: kPlaceWide tiles per workgroup, the largest unit's rank table beside their rings)
         const dim3 gw((nsb + gat::kPlaceWide - 1) / gat::kPlaceWide, gy, gz);
         const size_t lds_wide = (size_t)P->max_hist * 4;
