@@ -587,7 +587,11 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
           // one launch per size class, its LDS sized for the class's longest list
           const int a0 = P->h_class_start[c], a1 = P->h_class_start[c + 1];
-          const int ccap = std::min(P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap, T.S.lds_cap);
+          // (as for k_merge_big: LDS for what the class's longest unit is expected to have placed -- its segments +- a renewal
+          //  count's spread -- not for its slab region; the rare list beyond it is k_sampler's.  GAT_CONSOLIDATE_SLAB_LDS: the old size)
+          const int n0 = (int)P->h_units[(size_t)P->h_order[(size_t)a0]].hist_total;
+          const int tight = getenv("GAT_CONSOLIDATE_SLAB_LDS") ? INT32_MAX : (n0 + n0 / 12 + 64 + 31) / 32 * 32;
+          const int ccap = std::min(std::min(P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap, T.S.lds_cap), tight);
           gat::TailArgs C = T;
           C.S.a_base = a0; C.S.a_end = a1; C.S.lds_cap = ccap;
           const size_t lds_c = (size_t)(gat::kSortScratchWords + 2 * (size_t)ccap) * 4;
