@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -85,12 +86,13 @@ inline hipError_t ctx_stage(gat_ctx* ctx, size_t bytes) {
   if (e == hipSuccess) ctx->h_stage_bytes = want;
   return e;
 }
+void parallel_copy(void* dst, const void* src, size_t bytes);      // memcpy, on the host threads from a few megabytes up (gat_prep.hip)
 inline hipError_t staged_h2d(gat_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   for (size_t o = 0; o < bytes; o += kStagePiece) {
     const size_t n = std::min(kStagePiece, bytes - o);
     hipError_t e = ctx_stage(ctx, n);
     if (e != hipSuccess) return e;
-    memcpy(ctx->h_stage, (const char*)src_host + o, n);
+    parallel_copy(ctx->h_stage, (const char*)src_host + o, n);
     if ((e = hipMemcpyAsync((char*)dst_dev + o, ctx->h_stage, n, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
   }
@@ -135,6 +137,23 @@ struct DevBuf {
     if (e != hipSuccess) return e;
     if (!h.empty()) e = staged_h2d(ctx, p, h.data(), h.size() * sizeof(T));
     return e;
+  }
+  // count elements written by build(T*) straight into the pinned staging buffer (no host vector that is zero-filled first
+  // and copied a second time); beyond one staging piece: a plain array and the copy in pieces
+  template <typename Build>
+  hipError_t upload_built(size_t count, gat_ctx* ctx, Build build) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    const size_t nbytes = count * sizeof(T);
+    if (nbytes <= kStagePiece) {
+      if ((e = ctx_stage(ctx, nbytes)) != hipSuccess) return e;
+      build(reinterpret_cast<T*>(ctx->h_stage));
+      if ((e = hipMemcpyAsync(p, ctx->h_stage, nbytes, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return e;
+      return hipStreamSynchronize(ctx->stream);
+    }
+    std::unique_ptr<T[]> h(new T[count]);
+    build(h.get());
+    return staged_h2d(ctx, p, h.get(), nbytes);
   }
 };
 

@@ -119,6 +119,16 @@ int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, 
   return GAT_OK;
 }
 
+// staged copies: one thread's memcpy into pinned memory is 5-8 GB/s, a third of what the DMA behind it moves
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+  constexpr size_t kChunk = (size_t)2 << 20;
+  if (bytes < 4 * kChunk) { memcpy(dst, src, bytes); return; }
+  parallel_for((int64_t)((bytes + kChunk - 1) / kChunk), [&](int64_t i) {
+    const size_t o = (size_t)i * kChunk;
+    memcpy((char*)dst + o, (const char*)src + o, std::min(kChunk, bytes - o));
+  });
+}
+
 // stable LSD radix sort of 64-bit keys by their upper 32 bits (three passes of 11 / 11 / 10 bits); tmp is scratch
 static void radix_sort_hi32(std::vector<uint64_t>& v, std::vector<uint64_t>& tmp) {
   const size_t n = v.size();
@@ -237,16 +247,18 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     hf_off[(size_t)c + 1] = hf_off[(size_t)c] + (int64_t)cf[(size_t)c].size();
   }
   static_assert(sizeof(uint2) == sizeof(uint64_t), "index entries");
-  std::vector<uint2> hz((size_t)hz_off[(size_t)n_groups] + 8, make_uint2(0xffffffffu, 0u));   // (+ a block of sentinels behind the last contig)
-  std::vector<uint32_t> hf((size_t)hf_off[(size_t)n_groups]);
-  parallel_for(n_groups, [&](int64_t c) {
-    if (!ck[(size_t)c].empty()) memcpy(hz.data() + hz_off[(size_t)c], ck[(size_t)c].data(), ck[(size_t)c].size() * 8);
-    if (!cf[(size_t)c].empty()) memcpy(hf.data() + hf_off[(size_t)c], cf[(size_t)c].data(), cf[(size_t)c].size() * 4);
-    std::vector<uint64_t>().swap(ck[(size_t)c]);
-    std::vector<uint32_t>().swap(cf[(size_t)c]);
-  });
-  HIPCHK(ctx, A.mz.upload(hz, ctx));
-  HIPCHK(ctx, A.mfirst.upload(hf, ctx));
+  const size_t n_hz = (size_t)hz_off[(size_t)n_groups] + 8, n_hf = (size_t)hf_off[(size_t)n_groups];   // (+ a block of sentinels behind the last contig)
+  HIPCHK(ctx, A.mz.upload_built(n_hz, ctx, [&](uint2* hz) {
+    parallel_for(n_groups, [&](int64_t c) {
+      if (!ck[(size_t)c].empty()) memcpy(hz + hz_off[(size_t)c], ck[(size_t)c].data(), ck[(size_t)c].size() * 8);
+    });
+    for (size_t i = n_hz - 8; i < n_hz; ++i) hz[i] = make_uint2(0xffffffffu, 0u);
+  }));
+  HIPCHK(ctx, A.mfirst.upload_built(n_hf, ctx, [&](uint32_t* hf) {
+    parallel_for(n_groups, [&](int64_t c) {
+      if (!cf[(size_t)c].empty()) memcpy(hf + hf_off[(size_t)c], cf[(size_t)c].data(), cf[(size_t)c].size() * 4);
+    });
+  }));
   HIPCHK(ctx, A.mz_off.upload(hz_off, ctx));
   HIPCHK(ctx, A.mf_off.upload(hf_off, ctx));
   HIPCHK(ctx, A.m_shift.upload(h_shift, ctx));
@@ -277,7 +289,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     HIPCHK(ctx, A.m_slot_contigs.upload(sc, ctx));
   }
   A.has_merged = true;
-  A.merged_entries = (int64_t)hz.size();
+  A.merged_entries = (int64_t)n_hz;
   {
     // entries per step of a scan (k_count_merged<.., BLK>): blocks of eight where a scan passes six or more on average
     double num = 0, den = 0;
@@ -285,20 +297,25 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     const char* env_b = getenv("GAT_MERGED_BLOCK");
     // short scans: the first two entries ride in the grid cell's own record (32 bytes per cell: where the cells are few
     // enough -- the records of the config-4 shape would be 160 MB, but its scans are long and take the blocks anyway)
-    const int by_length = den > 0 && num / den >= 6.0 ? 8 : (hf.size() <= ((size_t)64 << 20) / 32 ? 1 : 2);
+    const int by_length = den > 0 && num / den >= 6.0 ? 8 : (n_hf <= ((size_t)64 << 20) / 32 ? 1 : 2);
     A.merged_block = env_b ? (atoi(env_b) == 8 ? 8 : atoi(env_b) == 1 ? 1 : 2) : by_length;
   }
   if (A.merged_block == 1) {
-    std::vector<uint4> hc(hf.size() * 2);
-    parallel_for(n_groups, [&](int64_t c) {
-      const uint2* z = hz.data() + hz_off[(size_t)c];
-      for (int64_t g = hf_off[(size_t)c]; g < hf_off[(size_t)c + 1]; ++g) {
-        const uint32_t first = hf[(size_t)g];
-        hc[(size_t)2 * g] = make_uint4(first, 0u, z[first].x, z[first].y);          // (sentinels stand behind the last entry)
-        hc[(size_t)2 * g + 1] = make_uint4(z[first + 1].x, z[first + 1].y, 0u, 0u);
-      }
-    });
-    HIPCHK(ctx, A.mcell.upload(hc, ctx));
+    HIPCHK(ctx, A.mcell.upload_built(n_hf * 2, ctx, [&](uint4* hc) {
+      parallel_for(n_groups, [&](int64_t c) {
+        const uint2* z = reinterpret_cast<const uint2*>(ck[(size_t)c].data());
+        const size_t nz = ck[(size_t)c].size();                               // (entries + the sentinels behind them)
+        const uint32_t* f = cf[(size_t)c].data();
+        uint4* out = hc + 2 * hf_off[(size_t)c];
+        for (size_t g = 0; g < cf[(size_t)c].size(); ++g) {
+          const uint32_t first = f[g];
+          const uint2 e0 = first < nz ? z[first] : make_uint2(0xffffffffu, 0u);
+          const uint2 e1 = (size_t)first + 1 < nz ? z[first + 1] : make_uint2(0xffffffffu, 0u);
+          out[2 * g] = make_uint4(first, 0u, e0.x, e0.y);
+          out[2 * g + 1] = make_uint4(e1.x, e1.y, 0u, 0u);
+        }
+      });
+    }));
   }
   tm.lap("  merged index: gather + upload");
   return GAT_OK;
