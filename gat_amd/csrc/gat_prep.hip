@@ -357,8 +357,17 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
         return check_list(ctx, annos + lbeg[l], lend[l] - lbeg[l], "annotation", l);
       }
   }
-  std::vector<uint32_t> hs((size_t)total), he((size_t)total), hc((size_t)total);
   {
+    // starts / ends / running lengths: one pass over the lists, written straight into the pinned staging buffer (three
+    // arrays side by side) when they fit one piece of it, and sent from there
+    const size_t tn = (size_t)std::max<int64_t>(total, 1);
+    const bool in_stage = 3 * tn * 4 <= kStagePiece;
+    std::unique_ptr<uint32_t[]> heap;
+    uint32_t* hs;
+    if (in_stage) { HIPCHK(ctx, ctx_stage(ctx, 3 * tn * 4)); hs = reinterpret_cast<uint32_t*>(ctx->h_stage); }
+    else { heap.reset(new uint32_t[3 * tn]); hs = heap.get(); }
+    uint32_t* he = hs + tn;
+    uint32_t* hc = he + tn;
     constexpr int64_t kBlock = 256;                                 // lists per task
     parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
       for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
@@ -373,6 +382,21 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
         }
       }
     });
+    HIPCHK(ctx, A.start.alloc((size_t)total));
+    HIPCHK(ctx, A.end.alloc((size_t)total));
+    HIPCHK(ctx, A.cumx.alloc((size_t)total));
+    if (total > 0) {
+      if (in_stage) {
+        HIPCHK(ctx, hipMemcpyAsync(A.start.p, hs, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(A.end.p, he, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(A.cumx.p, hc, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        HIPCHK(ctx, staged_h2d(ctx, A.start.p, hs, (size_t)total * 4));
+        HIPCHK(ctx, staged_h2d(ctx, A.end.p, he, (size_t)total * 4));
+        HIPCHK(ctx, staged_h2d(ctx, A.cumx.p, hc, (size_t)total * 4));
+      }
+    }
   }
   // per group (contig) a uniform grid over the start coordinates, about one start per cell:
   // grid[g] = #starts < (g << shift); the count kernels look a position up instead of bisecting
@@ -400,8 +424,7 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
     A.max_cells = std::max<int64_t>(A.max_cells, h_cells[(size_t)c]);
   }
   for (int64_t l = 0; l < n_lists; ++l) h_goff[(size_t)l + 1] = h_goff[(size_t)l] + h_cells[(size_t)(l % n_groups)] + 1;
-  std::vector<uint32_t> hg((size_t)h_goff[(size_t)n_lists]);
-  {
+  HIPCHK(ctx, A.grid.upload_built((size_t)h_goff[(size_t)n_lists], ctx, [&](uint32_t* hg) {
     constexpr int64_t kBlock = 256;
     parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
       for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
@@ -409,7 +432,7 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
         const gat_segment* s = annos + lbeg[l];
         const int64_t m = lend[l] - lbeg[l];
         const int sh = h_shift[(size_t)c], cells = h_cells[(size_t)c];
-        uint32_t* g = hg.data() + h_goff[(size_t)l];
+        uint32_t* g = hg + h_goff[(size_t)l];
         int64_t k = 0;
         for (int cell = 0; cell <= cells; ++cell) {
           const uint64_t bound = (uint64_t)cell << sh;
@@ -418,17 +441,13 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
         }
       }
     });
-  }
-  tm.lap("  annotation tables: SoA + grids");
-  HIPCHK(ctx, A.grid.upload(hg, ctx));
+  }));
+  tm.lap("  annotation tables: SoA + grids, sent");
   HIPCHK(ctx, A.goff.upload(h_goff, ctx));
   HIPCHK(ctx, A.shift.upload(h_shift, ctx));
   HIPCHK(ctx, A.cells.upload(h_cells, ctx));
-  HIPCHK(ctx, A.start.upload(hs, ctx));
-  HIPCHK(ctx, A.end.upload(he, ctx));
-  HIPCHK(ctx, A.cumx.upload(hc, ctx));
   HIPCHK(ctx, A.off.upload(A.h_off, ctx));
-  tm.lap("  annotation tables: upload");
+  tm.lap("  annotation tables: offsets sent");
   // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
   // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
   // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
