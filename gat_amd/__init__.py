@@ -34,12 +34,12 @@ class _CountsPerTrack(list):
 
 def _dist_state():
     """(rank, world size, backend) of an initialised torch.distributed, else (0, 1, None)."""
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size(), dist.get_backend()
-    except ImportError:
-        pass
+    # (a process group can only have been initialised by a caller that imported torch.distributed: importing it here
+    #  would cost every plain run -- gat-run.py included -- torch's import, seconds to minutes on a cold machine)
+    import sys
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist.get_backend()
     return 0, 1, None
 
 

@@ -34,12 +34,10 @@ def default_device():
     if _DEFAULT_DEVICE is not None:
         return _DEFAULT_DEVICE
     import os
-    try:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and "LOCAL_RANK" in os.environ:
-            return int(os.environ["LOCAL_RANK"])
-    except ImportError:
-        pass
+    import sys
+    dist = sys.modules.get("torch.distributed")           # (never imported here: see gat_amd._dist_state)
+    if dist is not None and dist.is_available() and dist.is_initialized() and "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"])
     return 0
 
 

@@ -584,3 +584,16 @@ def test_intersection_sizes_equal_the_intersections():
     y = iv.make([10, 30], [15, 40])
     p, s = _lib.intersection_sizes(x, [0, 3], y, [0], [2], 1)
     assert (int(p[0]), int(s[0])) == (2, 15)
+
+
+def test_plain_runs_do_not_import_torch():
+    """torch is plumbing for the multi-GPU path only: importing the package, asking for the process-group state and for the
+    default device must not import it (its import costs a plain gat-run.py seconds, minutes on a cold machine)"""
+    import subprocess
+    import sys
+    code = ("import sys, gat_amd; from gat_amd import engine; "
+            "assert gat_amd._dist_state() == (0, 1, None); assert engine.default_device() == 0; "
+            "assert not any(m == 'torch' or m.startswith('torch.') for m in sys.modules), 'torch was imported'")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
