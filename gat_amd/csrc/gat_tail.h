@@ -89,6 +89,40 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
   constexpr int kWsRegMax = 64, kWsLoopMax = 32;
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
+  if (n <= kWave) {
+    // A list within one round (the units of an isochore problem: ~50 segments) never touches LDS: one load, the sorting
+    // network on registers, merge(0) as one scan -- heads by the running maximum of the ends, a head's merged end = the
+    // running maximum in front of the next head --, coverage and running lengths on the head lanes, one store.
+    const uint2 x = lane < n ? out[lane] : make_uint2(0xffffffffu, 0xffffffffu);
+    uint32_t ks[1] = {x.x}, ke[1] = {x.y};
+    for (int lk = 1; lk <= 6; ++lk) {
+      sort_stage_lanes<1>(ks, ke, (1 << lk) - 1, lk - 1, lane);   // flip
+      sort_disperse_below64<1>(ks, ke, lk - 2, lane);
+    }
+    const bool valid = ks[0] != ke[0];                            // (empty segments are dropped; the padding is empty)
+    const int32_t m = wave_incl_max_i32(valid ? (int32_t)ke[0] : INT32_MIN, lane);
+    const int32_t excl = __builtin_amdgcn_update_dpp(INT32_MIN, m, 0x138, 0xf, 0xf, false);   // wave_shr:1
+    const uint64_t vb = __ballot(valid);
+    const bool head = valid && ((vb & lanemask_lt(lane)) == 0 || (int32_t)ks[0] > excl);
+    const uint64_t hb = __ballot(head);
+    const int pos = __popcll(hb & lanemask_lt(lane));
+    const int nU1 = __popcll(hb);
+    const uint64_t later = lane < kWave - 1 ? hb >> (lane + 1) : 0ull;
+    const int last = later ? lane + __builtin_ctzll(later) : kWave - 1;                        // the lane in front of the next head
+    const uint32_t mend = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, m);
+    const uint32_t s1 = head ? ks[0] : 0u, e1 = head ? mend : 0u;
+    uint32_t cov1 = 0;
+    const uint32_t* __restrict__ tree_start1 = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
+    if (nws <= 8) cov1 = ws_overlap_regs(W, s1, e1);
+    else if (nws <= kWsLoopMax) cov1 = ws_overlap_search(W, s1, e1);
+    else if constexpr (TREE) { if (head) cov1 = seg_overlap_tree1(ws, ws_cdf, tree_start1, ws_tree_geom(nws), s1, e1); }
+    const uint32_t incl1 = wave_incl_sum_u32(e1 - s1, lane);
+    if (head) { out[pos] = make_uint2(s1, e1); cum[pos] = incl1; }
+    cov1 = wave_total_u32(cov1);
+    const uint32_t run1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, kWave - 1);
+    if (lane == 0) A.st2[sa] = make_int4(nU1, (int)cov1, (int)run1, 1);
+    return;
+  }
   if (n > 1024) {
     if (!wave_sort_bucket_global(seg, out, n, scratch, 512, lane)) {
       for (int i = lane; i < n; i += kWave) seg[i] = out[i];
