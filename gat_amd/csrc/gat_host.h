@@ -30,6 +30,7 @@ struct gat_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool kernel_times = false;       // gat_ctx_set_kernel_times: events behind the sampler's kernels, their times in gat_stats
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_main[2] = {nullptr, nullptr};   // around the dominant count kernel alone (k_count_seg / k_count_swap)
   bool main_recorded = false;

@@ -94,6 +94,12 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   delete ctx;
 }
 
+extern "C" int gat_ctx_set_kernel_times(gat_ctx* ctx, int on) {
+  if (!ctx) return set_err(nullptr, GAT_ERR_ARG, "ctx is NULL");
+  ctx->kernel_times = on != 0;
+  return GAT_OK;
+}
+
 extern "C" int gat_ctx_synchronize(gat_ctx* ctx) {
   if (!ctx) return set_err(nullptr, GAT_ERR_ARG, "ctx is NULL");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -908,7 +914,9 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, false, true, records_ok, d_state, loose_ok))) return rc;   // (enqueued only)
+    // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
+    const bool timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, timed, false, true, records_ok, d_state, loose_ok))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
@@ -916,12 +924,19 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     A.out_stride = S;
     A.out_begin = done;
     A.mstat = P->d_mstat.p;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     ctx->main_recorded = false;
     ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
     if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+    const bool last_batch = done + nb == S;
+    if (last_batch) {
+      // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
+      //  that has to be repeated enqueues it again)
+      HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
     tm.lap("batch enqueued");
     // ONE synchronisation per batch: the sampler's status word is read behind the count kernels, which ran on whatever an
     // overflowed unit left.  What it left is in bounds: the exits that set a status bit (region full, a contig's lists
@@ -931,15 +946,17 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     // length written under another layout survives into this one.  The counts of such a batch are thrown away (it is redone)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     tm.lap("batch synchronised");
-    if ((rc = finish_sampler_batch(ctx, P, nb, &local, true)) == kRelayout) {
+    if ((rc = finish_sampler_batch(ctx, P, nb, &local, timed)) == kRelayout) {
       if (d_state != nullptr)        // (the repeated batch draws from where this one began)
         HIPCHK(ctx, hipMemcpyAsync(d_state, d_state + GAT_MT_STATE_WORDS, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
       continue;
     }
     if (rc) return rc;
     float ms = 0;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]));
-    local.ms_count += ms;
+    if (timed) {
+      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]));
+      local.ms_count += ms;
+    }
     if (ctx->main_recorded) {
       HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_main[0], ctx->ev_main[1]));
       local.ms_count_main += ms;
@@ -949,9 +966,11 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     local.n_batches += 1;
     done += nb;
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (S == 0) {                                                   // (no batch ran: nothing rode on one)
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if (d_state != nullptr) HIPCHK(ctx, staged_d2h(ctx, state_host, d_state, GAT_MT_STATE_WORDS * 4));
   for (int i = 0; i < 256; ++i) { local.n_index_entries += (int64_t)ctx->h_mstat[2 * i]; local.n_index_lookups += (int64_t)ctx->h_mstat[2 * i + 1]; }
   float ms = 0;

@@ -87,7 +87,9 @@ typedef struct {
 } gat_problem_desc;
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
- * ctx stream; counts summed over all (sample, unit) work units of the call) */
+ * ctx stream; counts summed over all (sample, unit) work units of the call).  ms_total and ms_count_main are always
+ * measured; the other ms_* fields -- an event behind every kernel of the sampler, 2 % of a 10 000-sample call and 6 % of
+ * a 1 250-sample one -- only after gat_ctx_set_kernel_times(ctx, 1), else 0 */
 typedef struct {
   float ms_sampler;             /* placement + consolidation kernel                             */
   float ms_contig;              /* fromIsochores kernel (0 when keys carry no isochore)         */
@@ -131,6 +133,9 @@ void gat_ctx_destroy(gat_ctx* ctx);
 const char* gat_last_error(const gat_ctx* ctx);      /* ctx may be NULL: last error of the thread */
 const char* gat_version(void);
 int gat_ctx_synchronize(gat_ctx* ctx);
+/* per-kernel device times in gat_stats (see there) on / off; off by default.  GAT_KERNEL_TIMES=1 in the environment
+ * switches them on for every context. */
+int gat_ctx_set_kernel_times(gat_ctx* ctx, int on);
 
 /* device memory helpers so a ctypes host needs no other HIP binding */
 int gat_dev_alloc(gat_ctx* ctx, void** out, size_t bytes);

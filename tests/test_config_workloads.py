@@ -23,7 +23,7 @@ CONFIGS = {
     "config2": (16, 10000, 6),      # 1 x MI355X: 10k segments x 1 track, 10 000 samples
     "config3": (16, 10000, 4),      # 1 x MI355X: 10k segments x 100 tracks, 192 isochore units, 10 000 samples
     "config4": (3, 12500, 2),       # 8 x MI355X: 100k segments x 1000 tracks; a rank's whole 12 500-sample shard, one call
-    "config5": (16, 16384, 4),      # 8 x MI355X: density, 1M-interval annotation; one call of a rank's 125 000 samples
+    "config5": (16, 125000, 4),     # 8 x MI355X: density, 1M-interval annotation; a rank's whole 125 000-sample shard, one call
 }
 _CACHE = {}
 

@@ -1,5 +1,6 @@
 """samples/s on the reference's own test dataset (tests/golden/refdata), per segment track."""
 import os, sys, time
+os.environ.setdefault("GAT_KERNEL_TIMES", "1")      # the per-kernel times of gat_stats (off by default)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import gat_amd

@@ -1,6 +1,7 @@
 """k_place (and the other sampler kernels) against the number of samples in a call: a kernel bound by throughput scales
 with it, one bound by its longest serial chain does not.  usage: tools/place_scaling.py [config] [S ...]"""
 import os, sys
+os.environ.setdefault("GAT_KERNEL_TIMES", "1")      # the per-kernel times of gat_stats (off by default)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from gat_amd import _lib, problem, synthetic
 
