@@ -45,7 +45,7 @@ struct gat_ctx {
   void* h_stage = nullptr;                      // pinned staging buffer of gat_memcpy_d2h (grows; pageable targets are filled from it)
   size_t h_stage_bytes = 0;
   int32_t* h_flags = nullptr;                   // pinned
-  unsigned long long* h_stat = nullptr;         // pinned, 8 words
+  unsigned long long* h_stat = nullptr;         // pinned, 16 words: the statistics, the status word in word 8
   unsigned long long* h_mstat = nullptr;        // pinned, 512 words: k_count_merged's traffic counters of a call
   std::string err;
   int max_lds = 65536;
@@ -235,7 +235,10 @@ struct gat_problem {
   // per-batch scratch
   int64_t batch = 0;
   DevBuf<uint2> d_slab, d_cslab;
-  DevBuf<int32_t> d_unit_n, d_contig_n, d_flags;
+  DevBuf<int32_t> d_unit_n, d_contig_n;
+  // the status word of a batch lives behind its statistics (word 8 of d_stat): one memset, one read-back for both
+  int32_t* flags_dev() const { return reinterpret_cast<int32_t*>(d_stat.p + 8); }
+  uint32_t* todo_count_dev() const { return reinterpret_cast<uint32_t*>(d_stat.p + 9); }   // (k_tail's queue length: word 9)
   DevBuf<unsigned long long> d_stat;
   DevBuf<unsigned long long> d_mstat;    // k_count_merged: 256 pairs {index entries read, segments looked up} (CountArgs::mstat)
   // lane-parallel front end (k_rng + k_place)
@@ -254,7 +257,7 @@ struct gat_problem {
   DevBuf<uint2> d_fslab;                 // split path: the units' final lists (k_finalize writes out of place)
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
-  DevBuf<uint32_t> d_todo, d_todo_count; // ... and the units it leaves to k_sampler
+  DevBuf<uint32_t> d_todo;               // ... and the units it leaves to k_sampler (their number: todo_count_dev())
   DevBuf<uint32_t> d_serial;             // gat_sample_and_count_serial: the MT19937 state (and its copy at the batch's start)
   DevBuf<int32_t> d_unit_pos;            // unit id -> launch position (k_contig reads k_tail's records by it)
   std::vector<int32_t> h_unit_pos;

@@ -72,7 +72,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev_t) HIPCHK(ctx, hipEventCreate(&ev));
   for (auto& ev : ctx->ev_cnt) HIPCHK(ctx, hipEventCreate(&ev));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 64, hipHostMallocDefault));
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 128, hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_mstat, 512 * 8, hipHostMallocDefault));
   *out = ctx;
   return GAT_OK;
@@ -189,7 +189,6 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
       HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_patch.alloc(ns));
       HIPCHK(ctx, P->d_todo.alloc(ns));
-      HIPCHK(ctx, P->d_todo_count.alloc(1));
     }
   }
   P->batch = b;
@@ -402,8 +401,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (P->batch < nb) return set_err(ctx, GAT_ERR_MEMORY, "internal: batch %lld > scratch %lld", (long long)nb, (long long)P->batch);
     // (unit_n, contig_n and ws_stat are zeroed once when allocated: the kernels rewrite every entry of the active units
     //  in every batch and never touch the others)
-    HIPCHK(ctx, hipMemsetAsync(P->d_flags.p, 0, 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 8 * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 10 * 8, ctx->stream));         // (statistics, status word, k_tail's queue length)
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const int32_t* skip_ptr = nullptr;
     int skip_stride = 0;
@@ -415,7 +413,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
-      A.unit_n = P->d_unit_n.p; A.flags = P->d_flags.p; A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
+      A.unit_n = P->d_unit_n.p; A.flags = P->flags_dev(); A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
 #ifdef GAT_DIAG
       {
         const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
@@ -584,8 +582,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         T.cum = P->d_cum.p;
         T.patch = P->d_patch.p;
         T.todo = P->d_todo.p;
-        T.todo_count = P->d_todo_count.p;
-        HIPCHK(ctx, hipMemsetAsync(P->d_todo_count.p, 0, 4, ctx->stream));
+        T.todo_count = P->todo_count_dev();                         // (zeroed with the statistics at the batch's start)
         const size_t lds_max = (size_t)(gat::kSortScratchWords + 2 * (size_t)T.S.lds_cap) * 4;
         const dim3 gu((unsigned)nb, gy, gz), gt((unsigned)((nb + 63) / 64), gy, gz);
         if (tree) HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -624,7 +621,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         A.skip = &P->d_patch.p->state;
         A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
         A.todo = P->d_todo.p;
-        A.todo_count = P->d_todo_count.p;
+        A.todo_count = P->todo_count_dev();
       } else if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
       // variant: sampler kind x (long lists: counting-sort scratch) x (workspaces beyond the register loop: search trees)
       int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
@@ -719,7 +716,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
       HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       B.order = P->d_contig_order.p;
-      B.flags = P->d_flags.p;
+      B.flags = P->flags_dev();
       // one launch per size class: LDS for the class's longest expected list (more waves per CU for the short contigs)
       for (size_t k = 0; k + 1 < P->h_contig_class_start.size(); ++k) {
         const int c0 = P->h_contig_class_start[k], c1 = P->h_contig_class_start[k + 1];
@@ -741,8 +738,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                          (int64_t)nb * P->n_units, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_flags, P->d_flags.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stat, P->d_stat.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stat, P->d_stat.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (defer) return GAT_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return finish_sampler_batch(ctx, P, nb, st, timed);
@@ -753,7 +749,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
 static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed) {
   {
     int rc;
-    const int32_t flags = *ctx->h_flags;
+    const int32_t flags = *reinterpret_cast<const int32_t*>(ctx->h_stat + 8);
     const unsigned long long* stat = ctx->h_stat;
     if (flags & (gat::kStatusAssert | gat::kStatusTrimAssert))
       return set_err(ctx, GAT_ERR_ASSERT, "sampler assertion failed on device (flags=%d): %s", flags,
@@ -895,8 +891,12 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     d_state = P->d_serial.p;
     HIPCHK(ctx, staged_h2d(ctx, d_state, state_host, GAT_MT_STATE_WORDS * 4));
   }
-  if (P->d_mstat.n < 512) HIPCHK(ctx, P->d_mstat.alloc(512));
-  HIPCHK(ctx, hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream));
+  // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel)
+  const bool mstat_on = P->annos.has_merged;
+  if (mstat_on) {
+    if (P->d_mstat.n < 512) HIPCHK(ctx, P->d_mstat.alloc(512));
+    HIPCHK(ctx, hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream));
+  }
   int64_t done = 0;
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
@@ -923,7 +923,7 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
     A.out = (int64_t*)counts_dev;
     A.out_stride = S;
     A.out_begin = done;
-    A.mstat = P->d_mstat.p;
+    A.mstat = mstat_on ? P->d_mstat.p : nullptr;
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     ctx->main_recorded = false;
     ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
@@ -935,7 +935,7 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
       // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
       //  that has to be repeated enqueues it again)
       HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      if (mstat_on) HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     tm.lap("batch enqueued");
     // ONE synchronisation per batch: the sampler's status word is read behind the count kernels, which ran on whatever an
@@ -968,10 +968,10 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
   }
   if (S == 0) {                                                   // (no batch ran: nothing rode on one)
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (d_state != nullptr) HIPCHK(ctx, staged_d2h(ctx, state_host, d_state, GAT_MT_STATE_WORDS * 4));
+  if (mstat_on && S > 0)
   for (int i = 0; i < 256; ++i) { local.n_index_entries += (int64_t)ctx->h_mstat[2 * i]; local.n_index_lookups += (int64_t)ctx->h_mstat[2 * i + 1]; }
   float ms = 0;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));

@@ -943,8 +943,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     (void)lds_need; (void)capx;
     if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
   }
-  HIPCHK(ctx, P->d_flags.alloc(1));
-  HIPCHK(ctx, P->d_stat.alloc(8));
+  HIPCHK(ctx, P->d_stat.alloc(16));                 // (8 statistics words, the status word in word 8)
   *out = P.release();
   return GAT_OK;
 }
