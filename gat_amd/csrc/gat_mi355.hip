@@ -81,6 +81,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
 extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  (void)stage_flush(ctx);
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);

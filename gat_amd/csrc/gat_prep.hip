@@ -675,6 +675,9 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: negative size / nbuckets <= 0");
   PrepTimer tm;
   std::unique_ptr<gat_problem> P(new gat_problem());
+  // (declared behind P, so it runs first on every return: the small tables' copies in flight -- stage_push_h2d -- have
+  //  landed before a half-built problem's buffers go back to the pool)
+  struct FlushOnExit { gat_ctx* c; ~FlushOnExit() { (void)stage_flush(c); } } flush_on_exit{ctx};
   P->ctx = ctx;
   P->n_units = d->n_units;
   P->n_contigs = d->n_contigs;
@@ -944,6 +947,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
   }
   HIPCHK(ctx, P->d_stat.alloc(16));                 // (8 statistics words, the status word in word 8)
+  HIPCHK(ctx, stage_flush(ctx));                    // the small tables' copies (one wait for all of them)
   *out = P.release();
   return GAT_OK;
 }
@@ -953,6 +957,7 @@ extern "C" void gat_problem_destroy(gat_problem* p) {
   if (p->ctx) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);      // its blocks go back to the pool: nothing may still be running on them
+    p->ctx->stage_used = 0;
   }
   delete p;
 }
