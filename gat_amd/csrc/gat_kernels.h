@@ -241,8 +241,9 @@ constexpr int kPlaceChunk = 8;        // rows fetched per step (624 = 8 * 78)
 // SMALL: every unit has at most 64 workspace segments and fewer than 256 working segments: quarter-size LDS tables,
 // so that more tiles are resident per CU (the kernel has few waves and hides latency by their number).
 // SMALL 2: at most 64 workspace segments, rank table at full size (a quarter of the workspace table's LDS back).
-// PIPE: the rows are prefetched into pinned registers (v96..v127) by hand-written loads and waits, see
-// GAT_PLACE_LOOP_PIPE below; only k_place_pipe, which is compiled for 96 registers of its own, may set it.
+// PIPE: the rows of the single-workspace-segment loop are prefetched into pinned registers (v96..v127) by hand-written
+// loads and waits, see GAT_PLACE_LOOP_PIPE below (k_place_pipe, k_place_wide).  Nothing reserves those registers: the
+// loop's own values fit below v96 and tools/check_pinned_regs.py, run by the Makefile, fails the build when they do not.
 template <int KIND, int MODE, int SMALL, bool PIPE>
 __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   constexpr bool ALL_SIMPLE = MODE == 1 || MODE == 3;
@@ -540,8 +541,8 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // memory.  The kernel has few waves (every tile of the batch is resident at once, 3-4 per SIMD) and cannot end before
   // the serial chain of the longest unit's tile has: tools/place_scaling.py, config 2: 0.70 ms for 5 000 samples and
   // 0.91 ms for 10 000 with this loop, 0.58 / 0.89 ms with the one below (the floor, 1 250 samples: 0.54 ms).
-  // GAT_PLACE_LOOP_PIPE, for the loops whose look-ups are all in LDS (k_place_pipe): four chunk buffers in registers the
-  // compiler does not manage (v96..v127: the kernel is compiled for 96), loads and waits written out by hand.  A chunk's
+  // GAT_PLACE_LOOP_PIPE, for the single-workspace-segment loop with its rank table in LDS: four chunk buffers in registers
+  // the compiler does not use there (v96..v127: see PIPE above), loads and waits written out by hand.  A chunk's
   // loads are issued three chunks (24 rows) before it is worked on and waited for with vmcnt(24): the 24 loads issued
   // after it may stay in flight (returns are in order; stores issued in between only make the wait stricter).  Every
   // load is always issued (rows beyond the tile's end re-read its last chunk and are not used), so the count holds.
@@ -668,8 +669,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 template <int KIND, int MODE, int SMALL = 0>
 __global__ __launch_bounds__(64) void k_place(SamplerArgs A) { place_body<KIND, MODE, SMALL, false>(A); }
 
-// every unit's look-up tables in LDS (MODE 1, or MODE 0 with all rank and workspace tables within the LDS tables' sizes):
-// the rows pipelined through v96..v127 by hand
+// the single-workspace-segment units' rows pipelined through v96..v127 by hand (MODE 1, or MODE 0 where such units hold
+// most of the working segments: gat_problem::pipe_pays).  (amdgpu_num_vgpr does NOT keep the compiler below v96 on
+// gfx950 -- the unified register file doubles the number -- it is kept because the allocation it was tuned with is.)
 template <int KIND, int MODE, int SMALL = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) void k_place_pipe(SamplerArgs A) {
   place_body<KIND, MODE, SMALL, true>(A);
