@@ -597,3 +597,28 @@ def test_plain_runs_do_not_import_torch():
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_pinned_register_check_catches_a_stray_use(tmp_path):
+    """tools/check_pinned_regs.py (run by the library's Makefile on the device assembly): inside a hand-pipelined loop only the
+    loop's own loads into v96..v127 and its moves out of them may name those registers; a temporary there, alone or inside
+    a register range, fails the build; outside the markers anything goes."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    tool = os.path.join(root, "tools", "check_pinned_regs.py")
+    head = "_ZN3gat12k_place_pipeILi0ELi1ELi0EEEvNS_11SamplerArgsE:\n\tv_add_u32_e32 v97, s3, v82\n\t; GAT_PINNED_BEGIN\n"
+    body = ("\tglobal_load_dword v96, v[2:3], off\n\tglobal_load_dword v127, v[2:3], off offset:1792\n"
+            "\ts_waitcnt vmcnt(24)\n\tv_mov_b32 v5, v96\n\tv_add_u32_e32 v6, v5, v7\n")
+    tail = "\t; GAT_PINNED_END\n\tds_read_b32 v100, v3\n\ts_endpgm\n"
+
+    def run(text):
+        f = tmp_path / "k.s"
+        f.write_text(text)
+        return subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+
+    assert run(head + body + tail).returncode == 0
+    for stray in ("\tv_add_u32_e32 v97, s3, v82\n", "\tds_read_b128 v[94:97], v3\n", "\tv_mov_b32 v100, v96\n"):
+        r = run(head + body + stray + tail)
+        assert r.returncode != 0 and "pinned-register loop" in (r.stderr + r.stdout), stray
+    assert run("\tv_mov_b32 v1, v2\n").returncode != 0            # no markers: the wrong file
