@@ -159,11 +159,13 @@ class Workload(object):
         # ONE stream for the library's kernels, the collective and the read-back: a torch stream of its own (the default
         # stream's handle is 0, which the library reads as "make a private stream")
         self.stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.stream)               # ... and torch's current stream from here on (one workload at a time)
         self.ctx = _lib.Context(dev_index, stream=self.stream.cuda_stream)
         self.P = _lib.Problem(self.ctx, self.flat)
         self.info = self.P.info()
         K, A = len(self.counters), self.flat["n_tracks"]
         self.counts = torch.zeros((K, A, S), dtype=torch.int64, device=self.dev)
+        self.counts_ptr = self.counts.data_ptr()
         self.gathered = torch.zeros((world * K, A, S), dtype=torch.int64, device=self.dev) if world > 1 else None
         # the matrix a host consumer gets: pinned, filled inside the timed region (rank 0 holds all ranks' columns)
         self.host = torch.empty((world * K, A, S), dtype=torch.int64, pin_memory=True) if rank == 0 else None
@@ -174,14 +176,15 @@ class Workload(object):
         # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
         if begin is None:
             begin = (i * self.world + self.rank) * self.S
-        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts.data_ptr())
-        with torch.cuda.stream(self.stream):
-            src = self.counts
-            if self.world > 1:
-                dist.all_gather_into_tensor(self.gathered, self.counts)
-                src = self.gathered
-            if self.host is not None:
-                self.host.copy_(src, non_blocking=True)
+        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts_ptr)
+        # (the workload's stream is torch's current stream -- set once in __init__, not entered per step: the context
+        #  manager costs a step ~10 us)
+        src = self.counts
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.counts)
+            src = self.gathered
+        if self.host is not None:
+            self.host.copy_(src, non_blocking=True)
         return st
 
     KEYS = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
