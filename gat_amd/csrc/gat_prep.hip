@@ -733,21 +733,19 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     // getLengthDistribution (gat/SegmentList.pyx:1148-1184)
     int64_t bucket = d->bucket_size;
     if (bucket == 0) bucket = (int64_t)std::ceil((double)(int32_t)maxlen / (double)d->nbuckets);
-    std::map<uint32_t, uint32_t> hist;
+    // the histogram over the buckets, cumulated, read as "rank r -> bucket": the bucket indices in ascending order (a sort
+    // of the unit's lengths; a std::map insertion per segment was most of this stage: 0.8 of config 2's 1.2 ms)
+    U.rank_off = (int32_t)h_rank_len.size();
+    h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
     for (uint32_t l : lens) {
       const int64_t i = ((int64_t)l + bucket - 1) / bucket;
       if (i >= d->nbuckets)
         return set_err(ctx, GAT_ERR_VALUE, "unit %d: segment of length %u too large: increase nbuckets (%d) or bucket_size (%lld)",
                        u, l, d->nbuckets, (long long)bucket);
-      hist[(uint32_t)i] += 1;
+      h_rank_len.push_back((uint32_t)i);
     }
-    uint32_t cum = 0;
-    U.rank_off = (int32_t)h_rank_len.size();
-    h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
-    for (auto& kv : hist) {
-      cum += kv.second;
-      for (uint32_t q = 0; q < kv.second; ++q) h_rank_len.push_back(kv.first);   // ranks (cum-count, cum]
-    }
+    std::sort(h_rank_len.begin() + U.rank_off + 1, h_rank_len.end());           // ranks (cum-count, cum] of a bucket hold it
+    const uint32_t cum = (uint32_t)lens.size();
     U.hist_total = cum;
     U.bucket = (uint32_t)bucket;
     {
