@@ -781,7 +781,11 @@ class IntervalCollection(object):
                 p.fromSegmentList(vv[contig], method=method)
                 vv[contig] = p
 
+    _points_memo = None        # set for the duration of a gat_amd.run() call (the collection is not changed inside it)
+
     def hasPositions(self):
+        if self._points_memo is not None:
+            return self._points_memo
         return any(vv._has_points() for vv in self.intervals.values())
 
     def merge(self, delete=False):
