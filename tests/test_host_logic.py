@@ -622,3 +622,69 @@ def test_pinned_register_check_catches_a_stray_use(tmp_path):
         r = run(head + body + stray + tail)
         assert r.returncode != 0 and "pinned-register loop" in (r.stderr + r.stdout), stray
     assert run("\tv_mov_b32 v1, v2\n").returncode != 0            # no markers: the wrong file
+
+
+_BED_CASES = {
+    "three_columns": "chr2\t10\t20\nchr1\t5\t9\nchr2\t30\t40\n",
+    "names_and_order": "chr2\t10\t20\tB\nchr1\t5\t9\tA\nchr2\t30\t40\tA\nchr1\t50\t60\tB\nchr3\t1\t2\tA\nchr2\t41\t45\tB\n",
+    "empty_names_beside_the_files_own": "chr1\t1\t2\t\nchr1\t3\t4\tx\nchr2\t5\t6\t\nchr1\t7\t8\tf.bed\n",
+    "comments_and_blank_lines": "# header\nchr1\t1\t2\tA\n\n#chr1\t9\t9\tZ\nchr1\t3\t4\tA\n",
+    "six_columns": "chr1\t1\t2\tA\t0\t+\nchr1\t3\t4\tB\t0\t-\n",
+    "na_like_names": "chr1\t1\t2\tNA\nchr1\t3\t4\tnull\nchr1\t5\t6\tnan\nchr1\t7\t8\tN/A\n",
+    "hash_in_a_name": "chr1\t1\t2\ta#b\nchr1\t3\t4\ta#b\n",
+    "quotes": 'chr1\t1\t2\t"q\nchr1\t3\t4\tq"\n',
+    "track_lines": 'track name="T1"\nchr1\t1\t2\ntrack name=T2\nchr1\t3\t4\tignored\n',
+    "contig_called_track": "track7\t1\t2\n",
+    "short_line": "chr1\t1\t2\tA\nchr1\t3\n",
+    "short_name": "chr1\t1\t2\tA\nchr1\t3\t4\n",
+    "more_fields_later": "chr1\t1\t2\nchr1\t3\t4\tA\n",
+    "carriage_returns": "chr1\t1\t2\tA\r\nchr1\t3\t4\tA\r\n",
+    "start_behind_end": "chr1\t1\t2\nchr1\t9\t4\n",
+    "not_a_number": "chr1\t1\tx\n",
+    "spaces_and_signs": "chr1\t 1\t+2\nchr1\t3\t4 \n",
+    "negative": "chr1\t-5\t4\n",
+    "float": "chr1\t1.0\t4\n",
+    "no_final_newline": "chr1\t1\t2\tA\nchr1\t3\t4\tB",
+    "empty": "",
+    "only_comments": "# nothing\n",
+}
+
+
+def _read_bed_either_way(monkeypatch, paths, lines, **kw):
+    from gat_amd import io as IO
+    monkeypatch.setattr(IO, "_BED_TABLE_MIN_BYTES", 0)
+    if lines:
+        monkeypatch.setenv("GAT_BED_LINE_READER", "1")
+    else:
+        monkeypatch.delenv("GAT_BED_LINE_READER", raising=False)
+    try:
+        r = IO.readFromBed(paths, **kw)
+    except Exception as e:                       # noqa: BLE001 -- the kind of the error is what is compared
+        return type(e).__name__
+    return [(t, [(c, r[t][c]._a.tolist()) for c in r[t].keys()]) for t in r.keys()]
+
+
+@pytest.mark.parametrize("case", sorted(_BED_CASES))
+@pytest.mark.parametrize("ignore_tracks", [False, True])
+def test_bed_table_reader_equals_the_line_reader(tmp_path, monkeypatch, case, ignore_tracks):
+    """readFromBed's table parser (files from 8 MB on) against the line-by-line reader it falls back to: the same tracks in
+    the same order, the same contigs in the same order, the same intervals -- or the same kind of error"""
+    f = tmp_path / "f.bed"
+    f.write_text(_BED_CASES[case], newline="")
+    want = _read_bed_either_way(monkeypatch, str(f), True, ignore_tracks=ignore_tracks)
+    got = _read_bed_either_way(monkeypatch, str(f), False, ignore_tracks=ignore_tracks)
+    assert got == want, case
+
+
+def test_bed_table_reader_over_several_files(tmp_path, monkeypatch):
+    """a track's lists grow over files in file order; a track in two files is an error unless split tracks are allowed"""
+    import gzip
+    a, b = tmp_path / "a.bed", tmp_path / "b.bed.gz"
+    a.write_text("chr2\t1\t2\tT\nchr1\t3\t4\tU\n")
+    with gzip.open(str(b), "wt") as f:
+        f.write("chr1\t5\t6\tT\nchr2\t7\t8\tT\nchr9\t1\t3\n")
+    for kw in (dict(allow_multiple=True), dict(allow_multiple=False), dict(ignore_tracks=True)):
+        want = _read_bed_either_way(monkeypatch, [str(a), str(b)], True, **kw)
+        got = _read_bed_either_way(monkeypatch, [str(a), str(b)], False, **kw)
+        assert got == want, kw
+    assert _read_bed_either_way(monkeypatch, [str(a), str(b)], False, allow_multiple=False) == "ValueError"
