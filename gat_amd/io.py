@@ -200,9 +200,12 @@ def readFromBed(filenames, allow_multiple=False, ignore_tracks=False):
                 se[1].append(e_sorted[cut[g]:cut[g + 1]])
             continue
         local = collections.OrderedDict()
+        last_name = last_contig = se = None
         for name, contig, start, end in _bed_lines(filename, default_name, ignore_tracks):
-            seen(name, filename)
-            se = local.setdefault(name, collections.OrderedDict()).setdefault(contig, ([], []))
+            if name != last_name or contig != last_contig:       # (sorted files: runs of lines of one list)
+                seen(name, filename)
+                se = local.setdefault(name, collections.OrderedDict()).setdefault(contig, ([], []))
+                last_name, last_contig = name, contig
             assert start <= end, "attempting to add invalid segment %i-%i" % (start, end)
             se[0].append(start)
             se[1].append(end)
