@@ -388,7 +388,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     const int32_t overlap = omin - omax > 0 ? omin - omax : 0;                                                 \
     const bool full = isO && nS >= cap;                                                                        \
     const bool put = isO && !full;                                                                             \
-    if (put) l_out[nS & 15][lane] = make_uint2(start, end);                                                    \
+    /* (k_place_wide stores always -- a slot that is not kept is written again: 11.2 -> 10.75 ms on the config-4 shape; \
+        the lean kernels lose by it, 0.95 -> 0.96 ms on config 2) */                                          \
+    if (MODE == 3 || put) l_out[nS & 15][lane] = make_uint2(start, end);                                       \
     nS += put ? 1 : 0;                                                                                         \
     rem -= put ? overlap : 0;                                                                                  \
     flag |= full ? kStatusOverflow : 0;                                                                        \
