@@ -30,7 +30,7 @@ SYMBOLS = [
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
-    "gat_sample_and_count_serial", "gat_mt19937_seed",
+    "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -144,6 +144,10 @@ def lib():
     L.gat_problem_destroy.argtypes = [vp]
     L.gat_sample_and_count.restype = C.c_int
     L.gat_sample_and_count.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp, C.POINTER(Stats)]
+    L.gat_sample_and_count_enqueue.restype = C.c_int
+    L.gat_sample_and_count_enqueue.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp]
+    L.gat_wait.restype = C.c_int
+    L.gat_wait.argtypes = [vp, vp, C.POINTER(Stats)]
     L.gat_sample_and_count_serial.restype = C.c_int
     L.gat_sample_and_count_serial.argtypes = [vp, vp, vp, C.c_int, vp, i64, vp, C.POINTER(Stats)]
     L.gat_mt19937_seed.restype = None
@@ -383,6 +387,20 @@ class Problem(object):
         _check(lib().gat_sample_and_count(self.ctx._h, self._h, _p(ids), len(ids), int(seed) & 0xFFFFFFFF,
                                           int(sample_begin), int(sample_end), C.c_void_p(counts_dev_ptr), C.byref(st)),
                self.ctx._h)
+        self.last_stats = st.asdict()
+        return self.last_stats
+
+    def enqueue(self, counters, seed, sample_begin, sample_end, counts_dev_ptr):
+        """first half of the batch seam (gat_sample_and_count_enqueue): the call's batches are put on the context's stream
+        and the host goes on; counts_dev_ptr must stay valid until wait()."""
+        ids = np.array([COUNTER_IDS[c] for c in counters], dtype=np.int32)
+        _check(lib().gat_sample_and_count_enqueue(self.ctx._h, self._h, _p(ids), len(ids), int(seed) & 0xFFFFFFFF,
+                                                  int(sample_begin), int(sample_end), C.c_void_p(counts_dev_ptr)), self.ctx._h)
+
+    def wait(self):
+        """second half (gat_wait): blocks until the call has completed, raises what sample_and_count_device would have"""
+        st = Stats()
+        _check(lib().gat_wait(self.ctx._h, self._h, C.byref(st)), self.ctx._h)
         self.last_stats = st.asdict()
         return self.last_stats
 

@@ -26,16 +26,46 @@ using gat::UnitDev;
 
 extern thread_local std::string g_last_error;
 
+// What a call of the batch seam keeps while its batches are in flight (gat_sample_and_count_enqueue ... gat_wait): pinned
+// words for the batches' status / statistics and the events that time the call.  Pinned allocations change the device's
+// page tables (see staged_h2d), so the blocks belong to the context and are lent to a problem for the length of a call.
+constexpr int kMaxInflight = 8;               // batches of one call enqueued before the first status word is read
+struct CallBlock {
+  unsigned long long* h_stat = nullptr;       // pinned, kMaxInflight x 16 words: per batch the statistics, the status word in word 8
+  unsigned long long* h_mstat = nullptr;      // pinned, 512 words: k_count_merged's traffic counters of the call
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_main[kMaxInflight][2] = {};   // around the dominant count kernel of every batch in flight
+};
+struct CallState {
+  bool active = false;
+  CallBlock* blk = nullptr;
+  int32_t ids[GAT_NUM_COUNTERS] = {0, 0, 0, 0, 0, 0};
+  int n_counters = 0;
+  uint32_t seed = 0;
+  int64_t begin = 0, S = 0;                   // samples [begin, begin + S)
+  void* counts_dev = nullptr;
+  uint32_t* state_host = nullptr;             // gat_sample_and_count_serial: the caller's MT19937 state
+  int64_t done = 0;                           // samples whose batches have completed and passed their checks
+  int64_t enq = 0;                            // samples enqueued (>= done)
+  int n_flight = 0;                           // batches enqueued and not yet checked
+  int64_t nb[kMaxInflight] = {};
+  int count_kernel[kMaxInflight] = {};
+  bool main_rec[kMaxInflight] = {};
+  bool timed = false, mstat_on = false;
+  gat_stats local;
+};
+
 struct gat_ctx {
+  int refs = 1;                    // the handle + one per live problem: gat_ctx_destroy frees when the last one is gone
+  bool closed = false;             // gat_ctx_destroy was called (problems still alive)
+  std::vector<CallBlock*> call_blocks;          // idle blocks (see CallBlock)
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   size_t stage_used = 0;           // bytes at the start of h_stage that copies in flight read from (stage_push_h2d)
   bool kernel_times = false;       // gat_ctx_set_kernel_times: events behind the sampler's kernels, their times in gat_stats
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t ev_main[2] = {nullptr, nullptr};   // around the dominant count kernel alone (k_count_seg / k_count_swap)
-  bool main_recorded = false;
-  int count_kernel = 0;                         // GAT_COUNT_KERNEL_* of the last launch_count
+  hipEvent_t ev_main[2] = {nullptr, nullptr};   // around the dominant count kernel alone (gat_count_lists; the batch seam has its own: CallBlock)
   hipEvent_t ev_k[4] = {nullptr, nullptr, nullptr, nullptr};   // behind k_rng, k_place, k_merge_big, k_sampler
   bool k_recorded = false;
   hipEvent_t ev_t[2] = {nullptr, nullptr};      // split path: behind k_tail, k_finalize
@@ -46,11 +76,12 @@ struct gat_ctx {
   void* h_stage = nullptr;                      // pinned staging buffer of gat_memcpy_d2h (grows; pageable targets are filled from it)
   size_t h_stage_bytes = 0;
   int32_t* h_flags = nullptr;                   // pinned
-  unsigned long long* h_stat = nullptr;         // pinned, 16 words: the statistics, the status word in word 8
-  unsigned long long* h_mstat = nullptr;        // pinned, 512 words: k_count_merged's traffic counters of a call
+  unsigned long long* h_stat = nullptr;         // pinned, 16 words: statistics and status word of a gat_sample batch
   std::string err;
   int max_lds = 65536;
 };
+
+void ctx_release(gat_ctx* ctx);     // gat_mi355.hip: drops one reference, frees the context with the last
 
 inline int set_err(gat_ctx* ctx, int code, const char* fmt, ...) {
   char buf[1024];
@@ -221,22 +252,21 @@ struct PrepTimer {
 
 int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx);
 
-// host threads for the per-list / per-contig preparation of gat_problem_create (GAT_HOST_THREADS, default min(16, cores))
+// host threads for the per-list / per-contig preparation of gat_problem_create, the observed counts' tables and the input
+// statistics (GAT_HOST_THREADS, default min(16, cores)): ONE pool per process, created at the first use and kept -- a
+// problem's creation is a dozen of these loops of 0.1-2 ms each, and fifteen threads created and joined per loop were
+// 0.3-0.5 ms of every one (gat_prep.hip: host_pool_run; GAT_HOST_POOL=0: threads per loop as before)
+void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg);
 template <typename F>
 inline void parallel_for(int64_t n, F body) {
-  const char* env_t = getenv("GAT_HOST_THREADS");
-  unsigned nthreads = env_t ? (unsigned)std::max(1, atoi(env_t)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-  nthreads = (unsigned)std::min<int64_t>(nthreads, std::max<int64_t>(1, n));
-  std::atomic<int64_t> next(0);
-  auto worker = [&]() { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i); };
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& th : pool) th.join();
+  if (n <= 0) return;
+  if (n == 1) { body(0); return; }
+  host_pool_run(n, [](void* a, int64_t i) { (*static_cast<F*>(a))(i); }, &body);
 }
 
 struct gat_problem {
   gat_ctx* ctx = nullptr;
+  CallState call;                        // the call in flight, if any (one per problem)
   int32_t n_units = 0, n_contigs = 0, n_tracks = 0, merge_contigs = 0, sampler = 0;
   std::vector<UnitDev> h_units;
   std::vector<int32_t> h_order;          // active units, largest first

@@ -73,15 +73,45 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev_cnt) HIPCHK(ctx, hipEventCreate(&ev));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 128, hipHostMallocDefault));
-  HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_mstat, 512 * 8, hipHostMallocDefault));
   *out = ctx;
   return GAT_OK;
 }
 
+// pinned words + events of a call in flight: taken from the context's idle blocks, made when there is none
+static int call_block_get(gat_ctx* ctx, CallBlock** out) {
+  if (!ctx->call_blocks.empty()) { *out = ctx->call_blocks.back(); ctx->call_blocks.pop_back(); return GAT_OK; }
+  std::unique_ptr<CallBlock> b(new CallBlock());
+  HIPCHK(ctx, hipHostMalloc((void**)&b->h_stat, (size_t)kMaxInflight * 16 * 8 + 512 * 8, hipHostMallocDefault));
+  b->h_mstat = b->h_stat + (size_t)kMaxInflight * 16;
+  HIPCHK(ctx, hipEventCreate(&b->ev_begin));
+  HIPCHK(ctx, hipEventCreate(&b->ev_end));
+  for (auto& pair : b->ev_main) for (auto& ev : pair) HIPCHK(ctx, hipEventCreate(&ev));
+  *out = b.release();
+  return GAT_OK;
+}
+static void call_block_free(CallBlock* b) {
+  if (!b) return;
+  if (b->h_stat) (void)hipHostFree(b->h_stat);
+  if (b->ev_begin) (void)hipEventDestroy(b->ev_begin);
+  if (b->ev_end) (void)hipEventDestroy(b->ev_end);
+  for (auto& pair : b->ev_main) for (auto& ev : pair) if (ev) (void)hipEventDestroy(ev);
+  delete b;
+}
+
+// the context lives as long as its handle or a problem made on it does (a host may close them in either order)
+void ctx_release(gat_ctx* ctx);
 extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
-  if (!ctx) return;
+  if (!ctx || ctx->closed) return;
+  ctx->closed = true;
+  ctx_release(ctx);
+}
+void ctx_release(gat_ctx* ctx) {
+  if (--ctx->refs > 0) return;
   (void)hipSetDevice(ctx->device);
-  (void)stage_flush(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->stage_used = 0;
+  for (CallBlock* b : ctx->call_blocks) call_block_free(b);
+  ctx->call_blocks.clear();
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
@@ -90,7 +120,6 @@ extern "C" void gat_ctx_destroy(gat_ctx* ctx) {
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
   if (ctx->h_stat) (void)hipHostFree(ctx->h_stat);
-  if (ctx->h_mstat) (void)hipHostFree(ctx->h_mstat);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -225,8 +254,16 @@ static int count_route(const gat_ctx* ctx, const AnnoDev& annos, const Counters&
 }
 
 // launch the count kernels over n_lists sample lists
+// ev_main: the pair of events recorded around the dominant kernel; main_recorded / count_kernel: what was launched
+struct CountLaunch {
+  hipEvent_t* ev_main = nullptr;
+  bool main_recorded = false;
+  int count_kernel = GAT_COUNT_KERNEL_NONE;
+};
 static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part,
-                        int swap_capx = 0, int list_cap = 0) {
+                        int swap_capx, int list_cap, CountLaunch& L) {
+  L.main_recorded = false;
+  L.count_kernel = GAT_COUNT_KERNEL_NONE;
   for (int i = 0; i < GAT_NUM_COUNTERS; ++i) A.counter_slot[i] = C.slot[i];
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
   A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
@@ -291,7 +328,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
                              : (blk == 8 ? (const void*)gat::k_count_merged<false, 8> : blk == 1 ? (const void*)gat::k_count_merged<false, 1>
                                                                                                   : (const void*)gat::k_count_merged<false, 2>);
       HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged));
-      HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
+      HIPCHK(ctx, hipEventRecord(L.ev_main[0], ctx->stream));
       const dim3 gm((unsigned)nblocks), bm(gat::kMergedThreads);
       if (patch && blk == 8) hipLaunchKernelGGL((gat::k_count_merged<true, 8>), gm, bm, lds_merged, ctx->stream, A);
       else if (patch && blk == 1) hipLaunchKernelGGL((gat::k_count_merged<true, 1>), gm, bm, lds_merged, ctx->stream, A);
@@ -300,9 +337,9 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       else if (blk == 1) hipLaunchKernelGGL((gat::k_count_merged<false, 1>), gm, bm, lds_merged, ctx->stream, A);
       else hipLaunchKernelGGL((gat::k_count_merged<false, 2>), gm, bm, lds_merged, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
-      ctx->main_recorded = true;
-      ctx->count_kernel = GAT_COUNT_KERNEL_MERGED;
+      HIPCHK(ctx, hipEventRecord(L.ev_main[1], ctx->stream));
+      L.main_recorded = true;
+      L.count_kernel = GAT_COUNT_KERNEL_MERGED;
       const int64_t tiles = (int64_t)((A.n_tracks + 15) / 16) * ((A.n_samples + 15) / 16);
       hipLaunchKernelGGL(gat::k_count_merged_finish, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
@@ -317,16 +354,16 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       B.lds_grid = lcells;
       const size_t lds_swap = (size_t)3 * swap_capx * 4 + ((size_t)(1 << lcells) + 1) * 4;
       HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_count_swap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_swap));
-      HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
+      HIPCHK(ctx, hipEventRecord(L.ev_main[0], ctx->stream));
       hipLaunchKernelGGL(gat::k_count_swap, dim3((unsigned)A.n_samples, gcy, gcz), dim3(gat::kSwapThreads), lds_swap, ctx->stream, B);
       HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
-      ctx->main_recorded = true;
-      ctx->count_kernel = GAT_COUNT_KERNEL_SWAP;
+      HIPCHK(ctx, hipEventRecord(L.ev_main[1], ctx->stream));
+      L.main_recorded = true;
+      L.count_kernel = GAT_COUNT_KERNEL_SWAP;
     } else
     if (A.n_contigs > 0) {
     const bool hits = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] >= 0 || C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] >= 0;
-    HIPCHK(ctx, hipEventRecord(ctx->ev_main[0], ctx->stream));
+    HIPCHK(ctx, hipEventRecord(L.ev_main[0], ctx->stream));
     const int kv = (staged ? 4 : 0) + (hits ? 2 : 0) + (A.seg_merged != nullptr ? 1 : 0);
     const void* fn = kv == 7 ? (const void*)gat::k_count_seg<true, true, true> : kv == 6 ? (const void*)gat::k_count_seg<true, true, false>
                    : kv == 5 ? (const void*)gat::k_count_seg<true, false, true> : kv == 4 ? (const void*)gat::k_count_seg<true, false, false>
@@ -344,9 +381,9 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       default: hipLaunchKernelGGL((gat::k_count_seg<false, false, false>), grid, dim3(256), lds, ctx->stream, A); break;
     }
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipEventRecord(ctx->ev_main[1], ctx->stream));
-    ctx->main_recorded = true;
-    ctx->count_kernel = GAT_COUNT_KERNEL_SEG;
+    HIPCHK(ctx, hipEventRecord(L.ev_main[1], ctx->stream));
+    L.main_recorded = true;
+    L.count_kernel = GAT_COUNT_KERNEL_SEG;
     }
     {
       const int64_t nfin = (int64_t)A.n_tracks * A.n_samples;
@@ -389,13 +426,14 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
 // capacities (scratch released: the batch that fits the budget may now be smaller) and nothing of this batch is valid;
 // the caller sizes the batch again and repeats it (results do not depend on the batching: streams are per unit).
 constexpr int kRelayout = 1;
-static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed);
+static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed, const unsigned long long* h_stat);
 // defer: only enqueue (the caller adds the count kernels behind, synchronises once and calls finish_sampler_batch)
 // records_ok: the consumer is k_count_seg alone, which reads (merged list, k_tail's record): no k_finalize
 // serial_state: the run's ONE MT19937 state on the device (k_serial: the reference's own stream) instead of the per-unit streams
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
                              gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false,
-                             uint32_t* serial_state = nullptr, bool loose_ok = false) {
+                             uint32_t* serial_state = nullptr, bool loose_ok = false, unsigned long long* h_stat = nullptr) {
+  if (h_stat == nullptr) h_stat = ctx->h_stat;
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -739,19 +777,19 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                          (int64_t)nb * P->n_units, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_stat, P->d_stat.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_stat, P->d_stat.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (defer) return GAT_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return finish_sampler_batch(ctx, P, nb, st, timed);
+    return finish_sampler_batch(ctx, P, nb, st, timed, h_stat);
   }
 }
 
 // the checks and statistics of a sampler batch whose kernels have completed (the stream has been synchronised)
-static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed) {
+static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_stats* st, bool timed, const unsigned long long* h_stat) {
   {
     int rc;
-    const int32_t flags = *reinterpret_cast<const int32_t*>(ctx->h_stat + 8);
-    const unsigned long long* stat = ctx->h_stat;
+    const int32_t flags = *reinterpret_cast<const int32_t*>(h_stat + 8);
+    const unsigned long long* stat = h_stat;
     if (flags & (gat::kStatusAssert | gat::kStatusTrimAssert))
       return set_err(ctx, GAT_ERR_ASSERT, "sampler assertion failed on device (flags=%d): %s", flags,
                      (flags & gat::kStatusAssert) ? "sampled list has no overlap with the workspace (gat/Engine.pyx:645)"
@@ -844,64 +882,28 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
   }
 }
 
-static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
-                                 uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
-                                 gat_stats* stats, uint32_t* state_host);
-
-extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
-                                    uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
-                                    gat_stats* stats) {
-  return sample_and_count_impl(ctx, P, counter_ids, n_counters, seed, sample_begin, sample_end, counts_dev, stats, nullptr);
-}
-
-extern "C" int gat_sample_and_count_serial(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
-                                           uint32_t* mt_state, int64_t n_samples, void* counts_dev, gat_stats* stats) {
-  if (!mt_state) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: NULL state");
-  if (mt_state[GAT_MT_STATE_WORDS - 1] > 624u) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: position %u > 624", mt_state[GAT_MT_STATE_WORDS - 1]);
-  return sample_and_count_impl(ctx, P, counter_ids, n_counters, 0u, 0, n_samples, counts_dev, stats, mt_state);
-}
-
-extern "C" void gat_mt19937_seed(uint32_t seed, uint32_t* mt_state) {
-  // numpy.random.seed(int): init_genrand (numpy/random/src/mt19937/mt19937.c: mt19937_seed), position = 624
-  uint32_t x = seed;
-  for (int i = 0; i < 624; ++i) { mt_state[i] = x; x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1); }
-  mt_state[624] = 624u;
-}
-
-static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
-                                 uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
-                                 gat_stats* stats, uint32_t* state_host) {
-  if (!ctx || !P || !counts_dev || (n_counters > 0 && !counter_ids)) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count: NULL argument");
-  if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+// ---- the batch seam: enqueue / wait ---------------------------------------------------------------------------
+// A call is cut into batches that fit the scratch budget.  call_begin enqueues them one behind the other on the context's
+// stream -- sampler kernels, count kernels, the copy of the batch's status word and statistics into a pinned slot of its own
+// -- up to kMaxInflight of them, and returns; the host does what else it has to do.  call_wait synchronises once, reads the
+// slots in order, and where a batch has to be repeated (a unit's region overflowed, a contig's lists beyond the launch's
+// LDS) lays the slab out again and enqueues that batch and everything behind it once more: results do not depend on the
+// batching (streams are per unit) and every batch writes its own columns of the count matrix.
+static int call_enqueue_more(gat_ctx* ctx, gat_problem* P) {
+  CallState& K = P->call;
   Counters C;
-  int rc = parse_counters(ctx, counter_ids, n_counters, C);
+  int rc = parse_counters(ctx, K.ids, K.n_counters, C);
   if (rc) return rc;
-  if (P->sampler == GAT_SAMPLER_SEGMENTS && !P->merge_contigs && n_counters > 0)
-    return set_err(ctx, GAT_ERR_ASSERT, "SamplerSegments output is not normalized unless fromIsochores merges it "
-                   "(keys without isochores): the counters assert (gat/SegmentList.pyx:1031)");
-  gat_stats local;
-  memset(&local, 0, sizeof(local));
-  const int64_t S = sample_end - sample_begin;
+  const bool serial = K.state_host != nullptr;
+  uint32_t* d_state = serial ? P->d_serial.p : nullptr;
+  // (the events behind every kernel and the serial stream's saved state exist once: such calls keep one batch in flight)
+  const int max_flight = (K.timed || serial) ? 1 : kMaxInflight;
   PrepTimer tm;
-  HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-  uint32_t* d_state = nullptr;
-  if (state_host != nullptr) {
-    // the run's one stream: its state lives on the device over the batches (a copy restores it when a batch is repeated)
-    if (P->d_serial.n < 2 * (size_t)GAT_MT_STATE_WORDS) HIPCHK(ctx, P->d_serial.alloc(2 * (size_t)GAT_MT_STATE_WORDS));
-    d_state = P->d_serial.p;
-    HIPCHK(ctx, staged_h2d(ctx, d_state, state_host, GAT_MT_STATE_WORDS * 4));
-  }
-  // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel)
-  const bool mstat_on = P->annos.has_merged;
-  if (mstat_on) {
-    if (P->d_mstat.n < 512) HIPCHK(ctx, P->d_mstat.alloc(512));
-    HIPCHK(ctx, hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream));
-  }
-  int64_t done = 0;
-  while (done < S) {
-    if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
-    const int64_t nb = std::min<int64_t>(P->batch, S - done);
+  while (K.enq < K.S && K.n_flight < max_flight) {
+    // the scratch is sized while nothing of this problem is in flight; batches behind the first fit by construction
+    if (K.n_flight == 0 && (rc = ensure_scratch(ctx, P, K.S - K.enq))) return rc;
+    const int64_t nb = std::min<int64_t>(P->batch, K.S - K.enq);
+    const int slot = K.n_flight;
     if (d_state != nullptr)
       HIPCHK(ctx, hipMemcpyAsync(d_state + GAT_MT_STATE_WORDS, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
     int swap_capx = 0;
@@ -915,70 +917,172 @@ static int sample_and_count_impl(gat_ctx* ctx, gat_problem* P, const int32_t* co
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
-    // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
-    const bool timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, timed, false, true, records_ok, d_state, loose_ok))) return rc;   // (enqueued only)
+    if ((rc = run_sampler_batch(ctx, P, K.seed, K.begin + K.enq, nb, &K.local, K.timed, false, true, records_ok, d_state, loose_ok,
+                                K.blk->h_stat + (size_t)slot * 16))) return rc;   // (enqueued only)
     gat::CountArgs A;
     memset(&A, 0, sizeof(A));
     fill_count_args(P, A, nb);
-    A.out = (int64_t*)counts_dev;
-    A.out_stride = S;
-    A.out_begin = done;
-    A.mstat = mstat_on ? P->d_mstat.p : nullptr;
-    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
-    ctx->main_recorded = false;
-    ctx->count_kernel = GAT_COUNT_KERNEL_NONE;
+    A.out = (int64_t*)K.counts_dev;
+    A.out_stride = K.S;
+    A.out_begin = K.enq;
+    A.mstat = K.mstat_on ? P->d_mstat.p : nullptr;
+    if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
+    CountLaunch L;
+    L.ev_main = K.blk->ev_main[slot];
     if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
-                           P->merge_contigs ? P->max_contig_cap : P->max_unit_cap))) return rc;
-    if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
-    const bool last_batch = done + nb == S;
-    if (last_batch) {
+                           P->merge_contigs ? P->max_contig_cap : P->max_unit_cap, L))) return rc;
+    if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+    K.nb[slot] = nb;
+    K.main_rec[slot] = L.main_recorded;
+    K.count_kernel[slot] = L.count_kernel;
+    K.n_flight = slot + 1;
+    K.enq += nb;
+    if (K.enq == K.S) {
       // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
       //  that has to be repeated enqueues it again)
-      HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-      if (mstat_on) HIPCHK(ctx, hipMemcpyAsync(ctx->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipEventRecord(K.blk->ev_end, ctx->stream));
+      if (K.mstat_on) HIPCHK(ctx, hipMemcpyAsync(K.blk->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    tm.lap("batch enqueued");
-    // ONE synchronisation per batch: the sampler's status word is read behind the count kernels, which ran on whatever an
-    // overflowed unit left.  What it left is in bounds: the exits that set a status bit (region full, a contig's lists
-    // beyond the launch's LDS) leave unit_n / contig_n / the hand-over records as an EARLIER batch of this layout wrote them
-    // -- lengths within the regions of this layout -- or as ensure_scratch zeroed them: a new layout (layout_slab +
-    // upload_layout) sets P->batch = 0, so the scratch is sized and zeroed again before the next kernel runs, and no
-    // length written under another layout survives into this one.  The counts of such a batch are thrown away (it is redone)
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    tm.lap("batch synchronised");
-    if ((rc = finish_sampler_batch(ctx, P, nb, &local, timed)) == kRelayout) {
-      if (d_state != nullptr)        // (the repeated batch draws from where this one began)
-        HIPCHK(ctx, hipMemcpyAsync(d_state, d_state + GAT_MT_STATE_WORDS, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      continue;
-    }
-    if (rc) return rc;
-    float ms = 0;
-    if (timed) {
-      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]));
-      local.ms_count += ms;
-    }
-    if (ctx->main_recorded) {
-      HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_main[0], ctx->ev_main[1]));
-      local.ms_count_main += ms;
-    }
-    local.count_kernel = ctx->count_kernel;
-    local.merged_form = ctx->count_kernel == GAT_COUNT_KERNEL_MERGED ? P->annos.merged_block : 0;
-    local.n_batches += 1;
-    done += nb;
   }
-  if (S == 0) {                                                   // (no batch ran: nothing rode on one)
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  if (d_state != nullptr) HIPCHK(ctx, staged_d2h(ctx, state_host, d_state, GAT_MT_STATE_WORDS * 4));
-  if (mstat_on && S > 0)
-  for (int i = 0; i < 256; ++i) { local.n_index_entries += (int64_t)ctx->h_mstat[2 * i]; local.n_index_lookups += (int64_t)ctx->h_mstat[2 * i + 1]; }
-  float ms = 0;
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]));
-  local.ms_total = ms;
-  if (stats) *stats = local;
+  tm.lap("batches enqueued");
   return GAT_OK;
+}
+
+static void call_end(gat_ctx* ctx, gat_problem* P) {
+  CallState& K = P->call;
+  if (K.blk) ctx->call_blocks.push_back(K.blk);
+  K.blk = nullptr;
+  K.active = false;
+}
+
+static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters, uint32_t seed,
+                      int64_t sample_begin, int64_t sample_end, void* counts_dev, uint32_t* state_host) {
+  if (!ctx || !P || !counts_dev || (n_counters > 0 && !counter_ids)) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count: NULL argument");
+  if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
+  if (n_counters < 0 || n_counters > GAT_NUM_COUNTERS) return set_err(ctx, GAT_ERR_ARG, "%d counters (0..%d)", n_counters, GAT_NUM_COUNTERS);
+  if (P->ctx != ctx) return set_err(ctx, GAT_ERR_ARG, "the problem was created on another context");
+  CallState& K = P->call;
+  if (K.active) return set_err(ctx, GAT_ERR_ARG, "a call is in flight on this problem: gat_wait first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Counters C;
+  int rc = parse_counters(ctx, counter_ids, n_counters, C);
+  if (rc) return rc;
+  if (P->sampler == GAT_SAMPLER_SEGMENTS && !P->merge_contigs && n_counters > 0)
+    return set_err(ctx, GAT_ERR_ASSERT, "SamplerSegments output is not normalized unless fromIsochores merges it "
+                   "(keys without isochores): the counters assert (gat/SegmentList.pyx:1031)");
+  if ((rc = call_block_get(ctx, &K.blk))) return rc;
+  K.active = true;
+  for (int i = 0; i < n_counters; ++i) K.ids[i] = counter_ids[i];
+  K.n_counters = n_counters;
+  K.seed = seed; K.begin = sample_begin; K.S = sample_end - sample_begin;
+  K.counts_dev = counts_dev; K.state_host = state_host;
+  K.done = K.enq = 0; K.n_flight = 0;
+  memset(&K.local, 0, sizeof(K.local));
+  // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
+  K.timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
+  // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel)
+  K.mstat_on = P->annos.has_merged;
+  auto fail = [&](int code) { call_end(ctx, P); return code; };
+  if (hipEventRecord(K.blk->ev_begin, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
+  if (state_host != nullptr) {
+    // the run's one stream: its state lives on the device over the batches (a copy restores it when a batch is repeated)
+    if (P->d_serial.n < 2 * (size_t)GAT_MT_STATE_WORDS && P->d_serial.alloc(2 * (size_t)GAT_MT_STATE_WORDS) != hipSuccess)
+      return fail(set_err(ctx, GAT_ERR_MEMORY, "device memory for the stream's state"));
+    if (staged_h2d(ctx, P->d_serial.p, state_host, GAT_MT_STATE_WORDS * 4) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "upload of the stream's state failed"));
+  }
+  if (K.mstat_on) {
+    if (P->d_mstat.n < 512 && P->d_mstat.alloc(512) != hipSuccess) return fail(set_err(ctx, GAT_ERR_MEMORY, "device memory for the traffic counters"));
+    if (hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipMemsetAsync failed"));
+  }
+  if (K.S == 0) {                                                  // (no batch will run: nothing to ride on)
+    if (hipEventRecord(K.blk->ev_end, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
+    return GAT_OK;
+  }
+  if ((rc = call_enqueue_more(ctx, P))) return fail(rc);
+  return GAT_OK;
+}
+
+static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
+  if (!ctx || !P) return set_err(ctx, GAT_ERR_ARG, "gat_wait: NULL argument");
+  CallState& K = P->call;
+  if (!K.active) return set_err(ctx, GAT_ERR_ARG, "gat_wait: no call in flight on this problem");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); call_end(ctx, P); return code; };
+  PrepTimer tm;
+  int rc;
+  for (;;) {
+    // ONE synchronisation per flight of batches: a sampler's status word is read behind the count kernels, which ran on
+    // whatever an overflowed unit left.  What it left is in bounds: the exits that set a status bit (region full, a contig's
+    // lists beyond the launch's LDS) leave unit_n / contig_n / the hand-over records as an EARLIER batch of this layout wrote
+    // them -- lengths within the regions of this layout -- or as ensure_scratch zeroed them: a new layout (layout_slab +
+    // upload_layout) sets P->batch = 0, so the scratch is sized and zeroed again before the next kernel runs, and no length
+    // written under another layout survives into this one.  The counts of such a batch, and of the batches enqueued behind
+    // it, are thrown away (they are redone)
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError())));
+    tm.lap("batches synchronised");
+    for (int slot = 0; slot < K.n_flight; ++slot) {
+      rc = finish_sampler_batch(ctx, P, K.nb[slot], &K.local, K.timed, K.blk->h_stat + (size_t)slot * 16);
+      if (rc == kRelayout) {
+        if (K.state_host != nullptr)        // (the repeated batch draws from where this one began)
+          if (hipMemcpyAsync(P->d_serial.p, P->d_serial.p + GAT_MT_STATE_WORDS, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            return fail(set_err(ctx, GAT_ERR_DEVICE, "restoring the stream's state failed"));
+        break;
+      }
+      if (rc) return fail(rc);
+      float ms = 0;
+      if (K.timed) {
+        if (hipEventElapsedTime(&ms, ctx->ev_cnt[0], ctx->ev_cnt[1]) == hipSuccess) K.local.ms_count += ms;
+      }
+      if (K.main_rec[slot] && hipEventElapsedTime(&ms, K.blk->ev_main[slot][0], K.blk->ev_main[slot][1]) == hipSuccess)
+        K.local.ms_count_main += ms;
+      K.local.count_kernel = K.count_kernel[slot];
+      K.local.merged_form = K.count_kernel[slot] == GAT_COUNT_KERNEL_MERGED ? P->annos.merged_block : 0;
+      K.local.n_batches += 1;
+      K.done += K.nb[slot];
+    }
+    K.n_flight = 0;
+    K.enq = K.done;                                              // (what a repeated batch had behind it is enqueued again)
+    if (K.done == K.S) break;
+    if ((rc = call_enqueue_more(ctx, P))) return fail(rc);
+  }
+  if (K.state_host != nullptr && staged_d2h(ctx, K.state_host, P->d_serial.p, GAT_MT_STATE_WORDS * 4) != hipSuccess)
+    return fail(set_err(ctx, GAT_ERR_DEVICE, "read-back of the stream's state failed"));
+  if (K.mstat_on && K.S > 0)
+    for (int i = 0; i < 256; ++i) { K.local.n_index_entries += (int64_t)K.blk->h_mstat[2 * i]; K.local.n_index_lookups += (int64_t)K.blk->h_mstat[2 * i + 1]; }
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, K.blk->ev_begin, K.blk->ev_end) == hipSuccess) K.local.ms_total = ms; else (void)hipGetLastError();
+  if (stats) *stats = K.local;
+  call_end(ctx, P);
+  return GAT_OK;
+}
+
+extern "C" int gat_sample_and_count_enqueue(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                            uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev) {
+  return call_begin(ctx, P, counter_ids, n_counters, seed, sample_begin, sample_end, counts_dev, nullptr);
+}
+
+extern "C" int gat_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) { return call_wait(ctx, P, stats); }
+
+extern "C" int gat_sample_and_count(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                    uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev,
+                                    gat_stats* stats) {
+  const int rc = call_begin(ctx, P, counter_ids, n_counters, seed, sample_begin, sample_end, counts_dev, nullptr);
+  return rc ? rc : call_wait(ctx, P, stats);
+}
+
+extern "C" int gat_sample_and_count_serial(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters,
+                                           uint32_t* mt_state, int64_t n_samples, void* counts_dev, gat_stats* stats) {
+  if (!mt_state) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: NULL state");
+  if (mt_state[GAT_MT_STATE_WORDS - 1] > 624u) return set_err(ctx, GAT_ERR_ARG, "gat_sample_and_count_serial: position %u > 624", mt_state[GAT_MT_STATE_WORDS - 1]);
+  const int rc = call_begin(ctx, P, counter_ids, n_counters, 0u, 0, n_samples, counts_dev, mt_state);
+  return rc ? rc : call_wait(ctx, P, stats);
+}
+
+extern "C" void gat_mt19937_seed(uint32_t seed, uint32_t* mt_state) {
+  // numpy.random.seed(int): init_genrand (numpy/random/src/mt19937/mt19937.c: mt19937_seed), position = 624
+  uint32_t x = seed;
+  for (int i = 0; i < 624; ++i) { mt_state[i] = x; x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1); }
+  mt_state[624] = 624u;
 }
 
 // gat_sample / gat_sample_units: the lists of every (sample, contig) after fromIsochores, or of every (sample, unit)
@@ -1000,6 +1104,7 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
                         gat_segment* out_host, int64_t cap, int64_t* off_host, gat_stats* stats, bool unit_level) {
   if (!ctx || !P || !off_host) return set_err(ctx, GAT_ERR_ARG, "gat_sample: NULL argument");
   if (sample_end < sample_begin) return set_err(ctx, GAT_ERR_ARG, "sample_end < sample_begin");
+  if (P->call.active) return set_err(ctx, GAT_ERR_ARG, "a call is in flight on this problem (its scratch is in use): gat_wait first");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   gat_stats local;
   memset(&local, 0, sizeof(local));
@@ -1098,7 +1203,9 @@ static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_coun
     K.out = d_out.p; K.out_stride = n_lists; K.out_begin = l;
     int32_t longest = 0;
     for (int g = 0; g < n_groups; ++g) longest = std::max(longest, h_n[(size_t)(l * n_groups + g)]);
-    if ((rc = launch_count(ctx, A, C, K, d_part, 0, longest))) return rc;
+    CountLaunch L;
+    L.ev_main = ctx->ev_main;
+    if ((rc = launch_count(ctx, A, C, K, d_part, 0, longest, L))) return rc;
   }
   HIPCHK(ctx, staged_d2h(ctx, counts_host, d_out.p, nslots * 8));
   return GAT_OK;

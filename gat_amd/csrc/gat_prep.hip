@@ -8,7 +8,9 @@
 #include <map>
 #include <memory>
 
+#include <condition_variable>
 #include <mutex>
+#include <unistd.h>
 
 #include "gat_host.h"
 
@@ -103,6 +105,101 @@ size_t dev_pool_held() {
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   return g_pools[dev].held;
+}
+
+// ------------------------------------------------------------------------------------------
+// the host threads behind parallel_for (gat_host.h): one pool per process, kept between calls.  A job is (fn, arg, n):
+// the caller and the invited workers take indices from one atomic counter; every worker acknowledges every job (invited or
+// not), the caller returns when all have.  Workers spin for a few dozen microseconds behind a job -- the loops of a problem's
+// creation follow each other at that distance -- and then sleep on a condition variable.
+namespace {
+struct HostPool {
+  std::mutex m;
+  std::condition_variable cv;
+  std::mutex run_mutex;                       // one job at a time; a second caller falls back to threads of its own
+  std::vector<std::thread> threads;
+  void (*fn)(void*, int64_t) = nullptr;
+  void* arg = nullptr;
+  int64_t n = 0;
+  int invited = 0;                            // workers 0 .. invited-1 take part in the current job
+  std::atomic<int64_t> next{0};
+  std::atomic<int> pending{0};                // workers that have not acknowledged the current job
+  std::atomic<uint64_t> gen{0};
+  pid_t pid = 0;
+};
+HostPool* g_host_pool = nullptr;
+std::mutex g_host_pool_mutex;
+thread_local bool t_in_pool_job = false;
+
+inline void cpu_relax() { __builtin_ia32_pause(); }
+
+void host_pool_worker(HostPool* P, int index) {
+  uint64_t seen = 0;
+  t_in_pool_job = true;                       // (a parallel_for inside a job's body runs on the calling worker)
+  for (;;) {
+    uint64_t g;
+    int spins = 0;
+    while ((g = P->gen.load(std::memory_order_acquire)) == seen) {
+      if (++spins < 4000) { cpu_relax(); continue; }
+      std::unique_lock<std::mutex> lk(P->m);
+      P->cv.wait(lk, [&] { return P->gen.load(std::memory_order_acquire) != seen; });
+    }
+    seen = g;
+    if (index < P->invited) {
+      const int64_t n = P->n;
+      for (int64_t i = P->next.fetch_add(1, std::memory_order_relaxed); i < n; i = P->next.fetch_add(1, std::memory_order_relaxed))
+        P->fn(P->arg, i);
+    }
+    P->pending.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+void run_with_own_threads(int64_t n, void (*fn)(void*, int64_t), void* arg, unsigned nthreads) {
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() { for (int64_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(arg, i); };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+}
+}  // namespace
+
+void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg) {
+  const char* env_t = getenv("GAT_HOST_THREADS");
+  unsigned nthreads = env_t ? (unsigned)std::max(1, atoi(env_t)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  nthreads = (unsigned)std::min<int64_t>(nthreads, std::max<int64_t>(1, n));
+  if (nthreads <= 1 || t_in_pool_job) { for (int64_t i = 0; i < n; ++i) fn(arg, i); return; }
+  const char* env_p = getenv("GAT_HOST_POOL");
+  if (env_p && atoi(env_p) == 0) { run_with_own_threads(n, fn, arg, nthreads); return; }
+  HostPool* P;
+  {
+    std::lock_guard<std::mutex> lock(g_host_pool_mutex);
+    // (a forked child has the parent's pool object but none of its threads: it starts one of its own)
+    if (g_host_pool == nullptr || g_host_pool->pid != getpid()) { g_host_pool = new HostPool(); g_host_pool->pid = getpid(); }
+    P = g_host_pool;
+  }
+  if (!P->run_mutex.try_lock()) { run_with_own_threads(n, fn, arg, nthreads); return; }
+  while (P->threads.size() + 1 < nthreads) {                       // (grows to the largest team asked for; no job is out)
+    const int index = (int)P->threads.size();
+    P->threads.emplace_back(host_pool_worker, P, index);
+    P->threads.back().detach();
+  }
+  P->fn = fn; P->arg = arg; P->n = n;
+  P->invited = (int)nthreads - 1;
+  P->next.store(0, std::memory_order_relaxed);
+  P->pending.store((int)P->threads.size(), std::memory_order_relaxed);
+  {
+    std::lock_guard<std::mutex> lk(P->m);
+    P->gen.fetch_add(1, std::memory_order_release);
+  }
+  P->cv.notify_all();
+  t_in_pool_job = true;
+  for (int64_t i = P->next.fetch_add(1, std::memory_order_relaxed); i < n; i = P->next.fetch_add(1, std::memory_order_relaxed)) fn(arg, i);
+  t_in_pool_job = false;
+  for (int spins = 0; P->pending.load(std::memory_order_acquire) != 0; ++spins) {
+    if (spins < 20000) cpu_relax(); else std::this_thread::yield();
+  }
+  P->run_mutex.unlock();
 }
 
 int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, int64_t idx) {
@@ -946,18 +1043,23 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   }
   HIPCHK(ctx, P->d_stat.alloc(16));                 // (8 statistics words, the status word in word 8)
   HIPCHK(ctx, stage_flush(ctx));                    // the small tables' copies (one wait for all of them)
+  ctx->refs += 1;                                   // (the context outlives its handle while a problem made on it is alive)
   *out = P.release();
   return GAT_OK;
 }
 
 extern "C" void gat_problem_destroy(gat_problem* p) {
   if (!p) return;
-  if (p->ctx) {
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);      // its blocks go back to the pool: nothing may still be running on them
-    p->ctx->stage_used = 0;
+  gat_ctx* ctx = p->ctx;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);         // its blocks go back to the pool: nothing may still be running on them
+    ctx->stage_used = 0;
+    if (p->call.blk) ctx->call_blocks.push_back(p->call.blk);     // (destroyed with a call in flight: the call is dropped)
+    p->call.blk = nullptr;
   }
   delete p;
+  if (ctx) ctx_release(ctx);
 }
 
 extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,

@@ -168,11 +168,27 @@ void gat_problem_destroy(gat_problem* p);
  * counts_dev: DEVICE pointer to n_counters*n_tracks*(sample_end-sample_begin) 8-byte slots laid
  * out [counter][track][sample]; int64 for the integer counters, IEEE double for
  * nucleotide-density.  Work is enqueued on the ctx stream; the call returns after the
- * kernels have completed and per-unit status words have been checked. */
+ * kernels have completed and per-unit status words have been checked.  A context may be destroyed before the problems
+ * made on it: it lives until the last of them is gone. */
 int gat_sample_and_count(gat_ctx* ctx, gat_problem* p,
                          const int32_t* counter_ids, int n_counters,
                          uint32_t seed, int64_t sample_begin, int64_t sample_end,
                          void* counts_dev, gat_stats* stats /* nullable */);
+
+/* The same call in two halves, for a host that has work of its own to do while the device samples (gat.run computes the
+ * observed counts, gat/__init__.py:933-940, and the sizes of its result rows, :1000-1068, around the sampling; the
+ * reference's process pool -- map_async, gat/__init__.py:681-700 -- is asynchronous in the same way).
+ * gat_sample_and_count_enqueue validates the arguments, enqueues the call's batches on the ctx stream (up to 8 ahead) and
+ * returns; counts_dev must stay valid and untouched until gat_wait.  gat_wait(ctx, p, stats) blocks until the batches have
+ * completed, checks their status words -- a batch that has to be repeated (a unit's region of the slab overflowed) is
+ * repeated in here, with everything that was enqueued behind it -- and reports what gat_sample_and_count would have
+ * (GAT_ERR_ASSERT where the reference's sampler asserts, :645).  One call in flight per problem; several problems of one
+ * context may each have one (they run one behind the other on the context's stream).  gat_problem_destroy drops a call in
+ * flight.  gat_sample_and_count(...) == enqueue + wait. */
+int gat_sample_and_count_enqueue(gat_ctx* ctx, gat_problem* p,
+                                 const int32_t* counter_ids, int n_counters,
+                                 uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev);
+int gat_wait(gat_ctx* ctx, gat_problem* p, gat_stats* stats /* nullable */);
 
 /* Sampler only: replaces sampler.sample() + sample.fromIsochores() (gat/__init__.py:541, :563)
  * for a range of samples and returns the contig-level lists to the HOST:

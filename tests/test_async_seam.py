@@ -1,0 +1,151 @@
+"""GPU: the batch seam in two halves (gat_sample_and_count_enqueue / gat_wait, include/gat_mi355.h) -- what the reference does
+with map_async over its process pool (gat/__init__.py:681-700): the host goes on while the samples are computed.  Same
+columns as the blocking call and as the oracle, whatever is enqueued ahead, repeated or interleaved."""
+import numpy as np
+import pytest
+
+from gat_amd import _lib
+from oracle import oracle as O
+from test_hip_parity import _big_problem, _random_problem
+
+pytestmark = pytest.mark.gpu
+COUNTERS = ["nucleotide-overlap", "nucleotide-density", "segment-overlap", "annotation-overlap"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _enqueue_wait(ctx, P, counters, seed, lo, hi, between=None):
+    n = max(1, len(counters) * P.n_tracks * (hi - lo))
+    dev = ctx.alloc(n * 8)
+    try:
+        P.enqueue(counters, seed, lo, hi, dev)
+        if between is not None:
+            between()
+        st = P.wait()
+        host = np.empty((len(counters), P.n_tracks, hi - lo), dtype=np.int64)
+        if host.size:
+            ctx.d2h(host, dev)
+    finally:
+        ctx.free(dev)
+    return [host[k].view(np.float64) if c == "nucleotide-density" else host[k] for k, c in enumerate(counters)], st
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_enqueue_wait_equals_the_blocking_call_and_the_oracle(ctx, seed):
+    rs = np.random.RandomState(seed)
+    flat = _random_problem(rs, n_contigs=int(rs.randint(1, 6)), n_segs=int(rs.randint(20, 600)),
+                           n_tracks=int(rs.randint(1, 6)), isochores=bool(seed % 2))
+    S = 48
+    want, _ = O.run_samples(flat, COUNTERS, 500 + seed, 1, 7, 7 + S)
+    P = _lib.Problem(ctx, flat)
+    # the host does device work of its own on the same context between the two halves (run() computes observed counts there)
+    other = _lib.Problem(ctx, flat)
+    between = lambda: other.sample_and_count(["nucleotide-overlap"], 1, 0, 5)      # noqa: E731
+    got, st = _enqueue_wait(ctx, P, COUNTERS, 500 + seed, 7, 7 + S, between)
+    blocking = P.sample_and_count(COUNTERS, 500 + seed, 7, 7 + S)
+    for k, c in enumerate(COUNTERS):
+        assert np.array_equal(got[k], want[k]), c
+        assert np.array_equal(blocking[k], want[k]), c
+    assert st["n_batches"] == 1 and st["ms_total"] > 0
+    other.close()
+    P.close()
+
+
+def test_more_batches_than_one_flight_holds(ctx, monkeypatch):
+    """a scratch budget of a few samples: the call is dozens of batches, enqueued eight at a time"""
+    rs = np.random.RandomState(77)
+    flat = _big_problem(rs, 700, 5)
+    counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    S = 150
+    want, _ = O.run_samples(flat, counters, 31, 1, 2, 2 + S)
+    monkeypatch.setenv("GAT_SLAB_BYTES", "400000")
+    P = _lib.Problem(ctx, flat)
+    got, st = _enqueue_wait(ctx, P, counters, 31, 2, 2 + S)
+    assert st["n_batches"] > 8, st
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    P.close()
+
+
+def test_overflow_in_flight_repeats_the_batch_and_what_was_behind_it(ctx, monkeypatch):
+    """tiny slab regions: a batch in the middle of a flight overflows, the slab is laid out again (the batch that fits the
+    budget shrinks) and everything from that batch on is redone inside gat_wait"""
+    rs = np.random.RandomState(78)
+    flat = _big_problem(rs, 700, 5)
+    counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
+    S = 90
+    want, wsamples = O.run_samples(flat, counters, 32, 1, 0, S, want_samples=True)
+    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+    monkeypatch.setenv("GAT_SLAB_BYTES", "300000")
+    P = _lib.Problem(ctx, flat)
+    got, st = _enqueue_wait(ctx, P, counters, 32, 0, S)
+    assert st["n_retried"] > 0 and st["n_batches"] > 2, st
+    for k, c in enumerate(counters):
+        assert np.array_equal(got[k], want[k]), c
+    seg, off = P.sample(32, 0, S)
+    assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    P.close()
+
+
+def test_two_problems_in_flight_on_one_context(ctx):
+    """run() keeps the next segment track's call enqueued behind the current one's"""
+    rs = np.random.RandomState(5)
+    flats = [_random_problem(rs, 3, 200, 3, True), _random_problem(rs, 2, 300, 2, False)]
+    S = 40
+    wants = [O.run_samples(f, COUNTERS, 9 + i, 1, 0, S)[0] for i, f in enumerate(flats)]
+    Ps = [_lib.Problem(ctx, f) for f in flats]
+    devs = [ctx.alloc(len(COUNTERS) * P.n_tracks * S * 8) for P in Ps]
+    for i, (P, d) in enumerate(zip(Ps, devs)):
+        P.enqueue(COUNTERS, 9 + i, 0, S, d)
+    for i in (1, 0):                                       # (waited for in the other order)
+        Ps[i].wait()
+        host = np.empty((len(COUNTERS), Ps[i].n_tracks, S), dtype=np.int64)
+        ctx.d2h(host, devs[i])
+        for k, c in enumerate(COUNTERS):
+            got = host[k].view(np.float64) if c == "nucleotide-density" else host[k]
+            assert np.array_equal(got, wants[i][k]), (i, c)
+    for P, d in zip(Ps, devs):
+        ctx.free(d)
+        P.close()
+
+
+def test_seam_errors(ctx):
+    rs = np.random.RandomState(6)
+    flat = _random_problem(rs, 2, 100, 2, False)
+    P = _lib.Problem(ctx, flat)
+    with pytest.raises(ValueError):
+        P.wait()                                           # nothing in flight
+    dev = ctx.alloc(2 * P.n_tracks * 16 * 8)
+    P.enqueue(["nucleotide-overlap"], 1, 0, 16, dev)
+    with pytest.raises(ValueError):
+        P.enqueue(["nucleotide-overlap"], 1, 0, 16, dev)   # one call per problem
+    with pytest.raises(ValueError):
+        P.sample(1, 0, 4)                                  # the scratch is in use
+    P.wait()
+    with pytest.raises(ValueError):
+        P.enqueue(["nucleotide-overlap", "nucleotide-overlap"], 1, 0, 16, dev)   # (arguments are checked at enqueue)
+    with pytest.raises(ValueError):
+        P.wait()
+    P.enqueue(["nucleotide-overlap"], 1, 0, 0, dev)        # an empty range is a call like any other
+    assert P.wait()["n_batches"] == 0
+    P.enqueue(["nucleotide-overlap"], 1, 0, 16, dev)
+    P.close()                                              # destroyed with a call in flight: dropped, nothing leaks
+    ctx.free(dev)
+
+
+def test_context_closed_before_its_problem():
+    """a host may close the handles in either order (the context lives until the last problem made on it is gone)"""
+    rs = np.random.RandomState(7)
+    flat = _random_problem(rs, 2, 100, 2, False)
+    want, _ = O.run_samples(flat, ["nucleotide-overlap"], 3, 1, 0, 8)
+    c = _lib.Context(0)
+    P = _lib.Problem(c, flat)
+    got = P.sample_and_count(["nucleotide-overlap"], 3, 0, 8)
+    assert np.array_equal(got[0], want[0])
+    c.close()
+    P.close()
