@@ -112,25 +112,43 @@ def _device_stats_wanted(n_values):
     return n_values > 0 and _numpy_summation_model_holds()
 
 
-def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
-                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None, mt_state=None, _aflat=None):
-    """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
+class _TrackJob(object):
+    """the sampling of one segment track between its two halves (_sample_start / _sample_finish): the problem on the device,
+    the count matrix there, and -- when the call could be enqueued -- the call in flight"""
+    __slots__ = ("ctx", "P", "flat", "names", "tracks", "num_samples", "seed", "dev", "enqueued", "samples_outfile", "mt_state",
+                 "result")
 
-    segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
-    workspace_generator (gat/__init__.py:727): segments and workspace the sampler sees are
-    generator(segs, None, workspace); the counters keep the contig form of `workspace`.
-    only_tracks: count these annotation tracks only (the conditional sampler's per-annotation pass).
-    stat_vals: {counter name: {annotation: value}} -- the values whose p-value will be asked for (observed, or
-    observed / reference fold); given them, large matrices get their statistics on the device (gat_null_stats) and the
-    result carries `.stats[counter index][annotation]` for AnnotatorResult.
-    mt_state: the reference's own stream (run(reference_stream=True)): the samples are drawn from this ONE MT19937
-    state (_lib.mt19937_seed), which is advanced in place; one GPU, no sharding.
-    Returns ([ {annotation: array of num_samples} per counter ] like the reference, number of work
-    units), or (None, 0) for an empty workspace.  If torch.distributed is initialised, samples are
-    sharded over the ranks and the count matrix is all-gathered (RCCL)."""
-    from . import _lib, distributed
+    def __init__(self, **kw):
+        self.dev, self.enqueued, self.result, self.P = None, False, None, None
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def abandon(self):
+        """let go of the device side (an error elsewhere in the run)"""
+        try:
+            if self.P is not None:
+                self.P.close()                      # (drops a call in flight)
+                self.P = None
+            if self.dev is not None:
+                self.ctx.free(self.dev)
+                self.dev = None
+        except Exception:
+            pass
+
+
+def _sample_start(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None, samples_outfile=None,
+                  workspace_generator=None, only_tracks=None, mt_state=None, _aflat=None, _shared=None):
+    """First half of the batch seam (UnconditionalSampler.sample, gat/__init__.py:704-778): the inputs go to the device --
+    the annotation tables only if no earlier track of this run() left them there (_shared) -- and, on the plain
+    single-process path, the samples are ENQUEUED (gat_sample_and_count_enqueue): the caller computes observed counts and
+    the sizes of its rows while the device samples, then calls _sample_finish.  Returns a _TrackJob; job.result is set
+    already where there is nothing to sample."""
+    from . import _lib
+    job = _TrackJob(ctx=None, flat=None, names=[c.name for c in counters], tracks=None, num_samples=num_samples, seed=seed,
+                    samples_outfile=samples_outfile, mt_state=mt_state)
     if workspace.sum() == 0:
-        return None, 0
+        job.result = (None, 0)
+        return job
     if annotations.hasPositions():
         # point annotations: the reference gets as far as the two counters that call into PositionList without isochores
         # (probed on the scratch build); anything else dies with this TypeError (gat/Engine.pyx:2866, :1417-1457)
@@ -139,29 +157,64 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
             raise _points_type_error()
         if any(c.name not in POINT_COUNTERS for c in counters):
             raise _points_type_error("annotations")
-    ctx = ctx or get_context()
-    tracks = list(annotations.tracks) if only_tracks is None else list(only_tracks)
+    ctx = job.ctx = ctx or get_context()
+    tracks = job.tracks = list(annotations.tracks) if only_tracks is None else list(only_tracks)
     count_workspace = None
     if workspace_generator is not None and type(workspace_generator) is not UnconditionalWorkspace:
         count_workspace = workspace
         annos = annotations[tracks[0]] if only_tracks is not None else None
         segs, _, workspace = workspace_generator(segs, annos, workspace)
     bucket_size, nbuckets = getattr(sampler, "bucket_size", 0), getattr(sampler, "nbuckets", 100000)
+    share = _shared if (only_tracks is None and count_workspace is None) else None
     flat = problem.flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size, nbuckets, count_workspace=count_workspace,
-                                        _aflat=_aflat if only_tracks is None else None)
+                                        _aflat=_aflat if only_tracks is None else None, _shared=share)
     if flat is None:
         flat = problem.flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) for t in tracks],
                                      bucket_size, nbuckets,
                                      count_workspace=None if count_workspace is None else count_workspace.asArrays())
     flat["sampler"] = getattr(sampler, "kind", 0)
-    names = [c.name for c in counters]
+    job.flat = flat
+    names = job.names
     if flat["n_contigs"] == 0:
         # nothing to place (the generated workspace holds no segments): computeSample skips every unit
         # (gat/__init__.py:536-538) and each counter sums over no contigs
         zero = [np.zeros(num_samples, dtype=np.float64 if n == "nucleotide-density" else np.int64) for n in names]
-        return [collections.OrderedDict((t, zero[k].copy()) for t in tracks) for k in range(len(names))], flat["n_units"]
+        job.result = ([collections.OrderedDict((t, zero[k].copy()) for t in tracks) for k in range(len(names))], flat["n_units"])
+        return job
+    # the annotation tables: one device object per (contigs in order, merge) of this run(), shared by its segment tracks
+    shared_annos = None
+    akey = flat.get("annotations_key")
+    if share is not None and akey is not None:
+        shared_annos = share.get(akey)
+        if shared_annos is None and flat.get("annos") is not None:
+            total = float(len(flat["segs"]))
+            mean = float((flat["segs"]["end"].astype(np.int64) - flat["segs"]["start"]).sum()) / total if total else 0.0
+            shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean)
+    job.P = _lib.Problem(ctx, flat, annotations=shared_annos)
+    rank, world, _ = _dist_state()
+    if world == 1 and mt_state is None and num_samples > 0:
+        try:
+            job.dev = ctx.alloc(len(names) * len(tracks) * num_samples * 8)
+            job.P.enqueue(names, seed, 0, num_samples, job.dev)
+            job.enqueued = True
+        except Exception:
+            job.abandon()
+            raise
+    return job
+
+
+def _sample_finish(job, stat_vals=None):
+    """Second half: waits for the samples (gat_wait), takes the null distributions' statistics where the matrix is
+    (stat_vals: {counter name: {annotation: value}} -- the values whose p-value will be asked for, observed or observed /
+    reference fold; large matrices then get their statistics on the device, gat_null_stats, and the result carries
+    `.stats[counter index][annotation]` for AnnotatorResult), reads the matrix back, gathers it over the ranks of an
+    initialised torch.distributed.  Returns ([ {annotation: array of num_samples} per counter ], number of work units)."""
+    from . import distributed
+    if job.result is not None:
+        return job.result
+    ctx, P, flat, names, tracks, num_samples, seed = job.ctx, job.P, job.flat, job.names, job.tracks, job.num_samples, job.seed
+    mt_state, samples_outfile = job.mt_state, job.samples_outfile
     rank, world, backend = _dist_state()
-    P = _lib.Problem(ctx, flat)
     stats = None
     want_stats = stat_vals is not None and _device_stats_wanted(len(names) * len(tracks) * num_samples)
 
@@ -173,7 +226,17 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
 
     try:
         begin, end = distributed.shard_range(num_samples, rank, world)
-        if mt_state is not None:
+        if job.enqueued:
+            # the call was enqueued by _sample_start; the matrix stays on the device until its statistics are taken
+            P.wait()
+            if want_stats:
+                stats = device_stats(job.dev)
+            host = np.empty((len(names), len(tracks), num_samples), dtype=np.int64)
+            ctx.d2h(host, job.dev)
+            ctx.free(job.dev)
+            job.dev = None
+            local = [host[k].view(np.float64) if n == "nucleotide-density" else host[k] for k, n in enumerate(names)]
+        elif mt_state is not None:
             if world > 1:
                 raise NotImplementedError("reference_stream: one stream is one GPU (the samples depend on each other)")
             if samples_outfile is not None:
@@ -181,35 +244,8 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
             local = P.sample_and_count_serial(names, mt_state, num_samples)
             begin, end = 0, num_samples
         elif world > 1 and backend == "nccl":
-            # the shard's matrix stays on the device: one RCCL all-gather of device memory, one read-back
-            import torch
-            per = distributed.padded_shard(num_samples, world)
-            dev = torch.device("cuda", ctx.device)
-            # (the context runs on a stream of its own: what torch enqueues -- the fills, the collective, the re-ordering of the
-            #  gathered blocks -- is ordered against it by hand, both ways)
-            shard = torch.zeros((len(names), len(tracks), end - begin), dtype=torch.int64, device=dev)
-            torch.cuda.current_stream(dev).synchronize()              # the fill has landed before the kernels write
-            P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())   # (returns after its stream has drained)
-            stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
-            stack_t[:, :, :end - begin] = shard
-            full_t = distributed.allgather_counts(stack_t, num_samples)
-            if want_stats:
-                torch.cuda.current_stream(dev).synchronize()          # gathered and re-ordered before k_null_stats reads
-                stats = device_stats(full_t.data_ptr())
-            full = full_t.cpu().numpy()
-            local = [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))]
-        elif world == 1 and want_stats and num_samples > 0:
-            # the matrix stays on the device until its statistics are taken
-            nslots = len(names) * len(tracks) * num_samples
-            dev = ctx.alloc(nslots * 8)
-            try:
-                P.sample_and_count_device(names, seed, 0, num_samples, dev)
-                stats = device_stats(dev)
-                host = np.empty((len(names), len(tracks), num_samples), dtype=np.int64)
-                ctx.d2h(host, dev)
-            finally:
-                ctx.free(dev)
-            local = [host[k].view(np.float64) if n == "nucleotide-density" else host[k] for k, n in enumerate(names)]
+            local, stats = _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples, world,
+                                                  device_stats if want_stats else None)
         else:
             local = P.sample_and_count(names, seed, begin, end)
             if world > 1:
@@ -232,12 +268,62 @@ def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, 
                     for s, e in seg[off[i * U + u]:off[i * U + u + 1]].tolist():
                         samples_outfile.write("%s\t%i\t%i\n" % (flat["unit_names"][u], s, e))
     finally:
-        P.close()
+        job.abandon()
     out = _CountsPerTrack()
     for k in range(len(names)):
         out.append(collections.OrderedDict((t, local[k][a]) for a, t in enumerate(tracks)))
     out.stats = stats
-    return out, flat["n_units"]
+    job.result = (out, flat["n_units"])
+    return job.result
+
+
+def _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples, world, device_stats):
+    """torch.distributed with the nccl backend (= RCCL): the shard's matrix stays on the device, ONE all-gather of device
+    memory (the collation of the reference's pool, gat/__init__.py:694-700, :770-774), one read-back."""
+    import torch
+    from . import distributed
+    per = distributed.padded_shard(num_samples, world)
+    dev = torch.device("cuda", ctx.device)
+    # (the context runs on a stream of its own: what torch enqueues -- the fills, the collective, the re-ordering of the
+    #  gathered blocks -- is ordered against it by hand, both ways)
+    shard = torch.zeros((len(names), len(tracks), max(1, end - begin)), dtype=torch.int64, device=dev)
+    torch.cuda.current_stream(dev).synchronize()              # the fill has landed before the kernels write
+    if end > begin:                                           # (a rank whose shard is empty still takes part in the gather)
+        P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())   # (returns after its stream has drained)
+    stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
+    if end > begin:
+        stack_t[:, :, :end - begin] = shard[:, :, :end - begin]
+    full_t = distributed.allgather_counts(stack_t, num_samples)
+    stats = None
+    if device_stats is not None:
+        torch.cuda.current_stream(dev).synchronize()          # gathered and re-ordered before k_null_stats reads
+        stats = device_stats(full_t.data_ptr())
+    full = full_t.cpu().numpy()
+    return [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))], stats
+
+
+def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,
+                  samples_outfile=None, workspace_generator=None, only_tracks=None, stat_vals=None, mt_state=None, _aflat=None,
+                  _shared=None):
+    """The batch seam: replaces UnconditionalSampler.sample (gat/__init__.py:704-778).
+
+    segs / workspace: IntervalDictionary (isochore level); annotations: IntervalCollection.
+    workspace_generator (gat/__init__.py:727): segments and workspace the sampler sees are
+    generator(segs, None, workspace); the counters keep the contig form of `workspace`.
+    only_tracks: count these annotation tracks only (the conditional sampler's per-annotation pass).
+    stat_vals: {counter name: {annotation: value}} -- the values whose p-value will be asked for (observed, or
+    observed / reference fold); given them, large matrices get their statistics on the device (gat_null_stats) and the
+    result carries `.stats[counter index][annotation]` for AnnotatorResult.
+    mt_state: the reference's own stream (run(reference_stream=True)): the samples are drawn from this ONE MT19937
+    state (_lib.mt19937_seed), which is advanced in place; one GPU, no sharding.
+    Returns ([ {annotation: array of num_samples} per counter ] like the reference, number of work
+    units), or (None, 0) for an empty workspace.  If torch.distributed is initialised, samples are
+    sharded over the ranks and the count matrix is all-gathered (RCCL).
+    (The two halves -- _sample_start enqueues, _sample_finish waits -- are what run() calls with its own work in between.)"""
+    job = _sample_start(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=ctx, samples_outfile=samples_outfile,
+                        workspace_generator=workspace_generator, only_tracks=only_tracks, mt_state=mt_state, _aflat=_aflat,
+                        _shared=_shared)
+    return _sample_finish(job, stat_vals)
 
 
 def run(segments, annotations, workspace, sampler, counters, workspace_generator, **kwargs):
@@ -288,32 +374,42 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
         from . import _lib
         mt_state = _lib.mt19937_seed(seed)
 
-    observed_counts = computeCountsAll(counters, sum, segments, annotations, workspace, workspace_generator)
-    # the annotations as one array (IntervalCollection._flat), looked over once for the whole run
-    aflat = annotations._flat(list(annotations.tracks)) if len(annotations) else None
+    # The reference's order is observed counts (gat/__init__.py:933-940), then per segment track the sampling (:971-1010),
+    # then the rows (:1000-1068).  Here a track's sampling is ENQUEUED on the device first, and what the host has to do
+    # itself -- the observed counts (a device call of its own, queued behind the samples), the sizes of the rows'
+    # dictionaries and intersections -- happens while the device samples; the next track is enqueued before the current
+    # one is waited for, and the annotation tables are made once for all tracks (_shared).
+    from .engine import _lookup_every_key
+    if len(segments.tracks) and len(annotations.tracks) and counters:
+        _lookup_every_key(segments, annotations, workspace)      # (what computeCounts does to the dictionaries comes first, as there)
+    aflat = annotations._flat(list(annotations.tracks)) if len(annotations) else None   # the annotations as one array, looked over once
     sampled_counts = {}
-    for track in segments.tracks:
-        outf = None
-        if output_samples_pattern:
-            # (under torch.distributed every rank writes the samples of its own shard: <file>.rank<r>)
-            outf = open(re.sub("%s", track, output_samples_pattern) + (".rank%d" % rank if world > 1 else ""), "w")
-        if conditional:
-            # ConditionalSampler.sample (gat/__init__.py:780-850): one sampling pass per annotation, each in the
-            # workspace conditioned on (segments, that annotation); only that annotation is counted
-            r = None
-            if workspace.sum() > 0:
-                r = [collections.OrderedDict() for _ in counters]
-                for annotation in annotations.tracks:
-                    ra, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples,
-                                                seed, samples_outfile=outf, workspace_generator=workspace_generator,
-                                                only_tracks=[annotation], mt_state=mt_state)
-                    for k in range(len(counters)):
-                        r[k][annotation] = ra[k][annotation]
-                    seed = (seed + num_samples * n_units) & 0xFFFFFFFF
-        else:
+    state = {"observed": None}
+    shared = {}                      # (contigs, merge) -> the annotation tables on the device
+    sizes = {}                       # (counts, sum) per dictionary object: the same track / workspace recur in every row
+    overlaps = {}                    # the intersections' sizes, every annotation of a segment track in one call
+    unconditional = type(workspace_generator) is UnconditionalWorkspace
+
+    def observed():
+        if state["observed"] is None:
+            state["observed"] = computeCountsAll(counters, sum, segments, annotations, workspace, workspace_generator)
+            if unconditional and aflat is not None and len(aflat[2]) >= 16 and not annotations.hasPositions():
+                # (counts, sum) of every annotation dictionary in one pass over the collection's array: list sums as
+                # SegmentList.sum() forms them (a uint32 accumulator each), added up per dictionary
+                data, bases, flats = aflat
+                run_ = np.zeros(len(data) + 1, dtype=np.int64)
+                np.cumsum(data["end"].astype(np.int64) - data["start"], out=run_[1:])
+                for t, f, base in zip(annotations.tracks, flats, bases.tolist()):
+                    per = (run_[f.off[1:] + base] - run_[f.off[:-1] + base]) & 0xFFFFFFFF
+                    sizes[id(annotations[t])] = (int(f.off[-1]), int(per.sum()))
+        return state["observed"]
+
+    def finish(track, outf, job):
+        stat_vals = None
+        if not conditional:
             # the values whose p-values the rows will ask for: large matrices get their statistics on the device
             stat_vals = {}
-            for c, oc in zip(counters, observed_counts):
+            for c, oc in zip(counters, observed()):
                 stat_vals[c.name] = {}
                 for annotation in annotations.tracks:
                     v = float(oc[track][annotation]) if track in oc and annotation in oc[track] else 0.0
@@ -321,32 +417,71 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
                         f = reference[track][annotation].fold
                         v = v / f if f > 0 else v
                     stat_vals[c.name][annotation] = v
-            r, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
-                                       samples_outfile=outf, workspace_generator=workspace_generator, stat_vals=stat_vals,
-                                       mt_state=mt_state, _aflat=aflat)
+        try:
+            r, _ = _sample_finish(job, stat_vals)
+        finally:
+            if outf:
+                outf.close()
+        if r is not None:
+            sampled_counts[track] = r
+
+    inflight = collections.deque()
+    try:
+        for track in segments.tracks:
+            outf = None
+            if output_samples_pattern:
+                # (under torch.distributed every rank writes the samples of its own shard: <file>.rank<r>)
+                outf = open(re.sub("%s", track, output_samples_pattern) + (".rank%d" % rank if world > 1 else ""), "w")
+            if conditional:
+                observed()
+                # ConditionalSampler.sample (gat/__init__.py:780-850): one sampling pass per annotation, each in the
+                # workspace conditioned on (segments, that annotation); only that annotation is counted
+                r = None
+                if workspace.sum() > 0:
+                    r = [collections.OrderedDict() for _ in counters]
+                    for annotation in annotations.tracks:
+                        ra, n_units = sample_counts(segments[track], annotations, workspace, sampler, counters, num_samples,
+                                                    seed, samples_outfile=outf, workspace_generator=workspace_generator,
+                                                    only_tracks=[annotation], mt_state=mt_state)
+                        for k in range(len(counters)):
+                            r[k][annotation] = ra[k][annotation]
+                        seed = (seed + num_samples * n_units) & 0xFFFFFFFF
+                if outf:
+                    outf.close()
+                if r is not None:
+                    sampled_counts[track] = r
+                continue
+            try:
+                job = _sample_start(segments[track], annotations, workspace, sampler, counters, num_samples, seed,
+                                    samples_outfile=outf, workspace_generator=workspace_generator, mt_state=mt_state,
+                                    _aflat=aflat, _shared=shared)
+            except Exception:
+                observed()           # (the reference has counted before it samples: an error there comes first)
+                raise
+            n_units = job.result[1] if job.result is not None else job.flat["n_units"]
             seed = (seed + num_samples * n_units) & 0xFFFFFFFF    # next track: disjoint unit streams
-        if outf:
-            outf.close()
-        if r is None:
-            continue
-        sampled_counts[track] = r
+            inflight.append((track, outf, job))
+            # ... while the device samples: first what needs no device (the observed counts' own device call is queued
+            # behind the samples)
+            if unconditional and job.result is None:              # (the rows see the dictionaries themselves)
+                overlaps[track] = overlap_sizes(segments[track], annotations, _aflat=aflat)
+            observed()
+            while len(inflight) > 1:
+                finish(*inflight.popleft())
+        observed()
+        while inflight:
+            finish(*inflight.popleft())
+    finally:
+        for _, outf, job in inflight:
+            job.abandon()
+            if outf:
+                outf.close()
+        for a in shared.values():
+            a.close()
+    observed_counts = observed()
 
     annotator_results = []
-    sizes = {}                       # (counts, sum) per dictionary object: the same track / workspace recur in every row
-    keep = []                        # ... and the objects stay alive so that their ids stay theirs
-    overlaps = {}                    # the intersections' sizes, every annotation of a segment track in one call
-    if type(workspace_generator) is UnconditionalWorkspace:      # (the rows see the dictionaries themselves)
-        for track in sampled_counts:
-            overlaps[track] = overlap_sizes(segments[track], annotations, _aflat=aflat)
-        if aflat is not None and len(aflat[2]) >= 16 and not annotations.hasPositions():
-            # (counts, sum) of every annotation dictionary in one pass over the collection's array: list sums as
-            # SegmentList.sum() forms them (a uint32 accumulator each), added up per dictionary
-            data, bases, flats = aflat
-            run_ = np.zeros(len(data) + 1, dtype=np.int64)
-            np.cumsum(data["end"].astype(np.int64) - data["start"], out=run_[1:])
-            for t, f, base in zip(annotations.tracks, flats, bases.tolist()):
-                per = (run_[f.off[1:] + base] - run_[f.off[:-1] + base]) & 0xFFFFFFFF
-                sizes[id(annotations[t])] = (int(f.off[-1]), int(per.sum()))
+    keep = []                        # the generated dictionaries stay alive so that their ids stay theirs
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
         for track, r in observed_count.items():
             if track not in sampled_counts:

@@ -31,6 +31,7 @@ SYMBOLS = [
     "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
+    "gat_annotations_create", "gat_annotations_destroy",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -70,6 +71,21 @@ class ProblemDesc(C.Structure):
         ("n_anno_lists", C.c_int64),
         ("anno_end", C.c_void_p),
         ("anno_group", C.c_void_p),
+        ("annotations", C.c_void_p),
+    ]
+
+
+class AnnotationsDesc(C.Structure):
+    _fields_ = [
+        ("n_tracks", C.c_int32),
+        ("n_contigs", C.c_int32),
+        ("merge_contigs", C.c_int32),
+        ("annos", C.c_void_p),
+        ("anno_off", C.c_void_p),
+        ("n_anno_lists", C.c_int64),
+        ("anno_end", C.c_void_p),
+        ("anno_group", C.c_void_p),
+        ("mean_segment_length", C.c_double),
     ]
 
 
@@ -142,6 +158,10 @@ def lib():
     L.gat_problem_create.argtypes = [vp, C.POINTER(ProblemDesc), C.POINTER(vp)]
     L.gat_problem_destroy.restype = None
     L.gat_problem_destroy.argtypes = [vp]
+    L.gat_annotations_create.restype = C.c_int
+    L.gat_annotations_create.argtypes = [vp, C.POINTER(AnnotationsDesc), C.POINTER(vp)]
+    L.gat_annotations_destroy.restype = None
+    L.gat_annotations_destroy.argtypes = [vp]
     L.gat_sample_and_count.restype = C.c_int
     L.gat_sample_and_count.argtypes = [vp, vp, vp, C.c_int, u32, i64, i64, vp, C.POINTER(Stats)]
     L.gat_sample_and_count_enqueue.restype = C.c_int
@@ -319,12 +339,53 @@ class Comm(object):
             self._h = C.c_void_p()
 
 
+class Annotations(object):
+    """the annotation side of a problem as a device-resident object of its own (gat_annotations): made once per run(),
+    shared by the problems of every segment track whose contigs are `flat`'s (same names, same order)."""
+
+    def __init__(self, ctx, flat, mean_segment_length=0.0):
+        self.ctx = ctx
+        keep = {}
+
+        def arr(name, dtype):
+            keep[name] = np.ascontiguousarray(flat[name], dtype=dtype)
+            return _p(keep[name])
+
+        d = AnnotationsDesc()
+        d.n_tracks, d.n_contigs, d.merge_contigs = int(flat["n_tracks"]), int(flat["n_contigs"]), int(flat["merge_contigs"])
+        d.annos = arr("annos", SEG)
+        d.anno_off = arr("anno_off", np.int64)
+        if flat.get("anno_group") is not None:
+            d.n_anno_lists = len(flat["anno_group"])
+            d.anno_group = arr("anno_group", np.int32)
+            d.anno_end = arr("anno_end", np.int64)
+            assert len(keep["anno_off"]) == len(keep["anno_end"]) == d.n_anno_lists
+        else:
+            assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1
+        d.mean_segment_length = float(mean_segment_length)
+        self.n_tracks, self.n_contigs, self.merge_contigs = d.n_tracks, d.n_contigs, d.merge_contigs
+        self._h = C.c_void_p()
+        _check(lib().gat_annotations_create(ctx._h, C.byref(d), C.byref(self._h)), ctx._h)
+
+    def close(self):
+        if self._h:
+            lib().gat_annotations_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Problem(object):
     """device-resident inputs of one segment track (gat_problem).
 
-    `flat` is a mapping with the fields of gat_problem_desc (numpy arrays / ints)."""
+    `flat` is a mapping with the fields of gat_problem_desc (numpy arrays / ints); annotations: an Annotations object made
+    for the same tracks and contigs (flat's annotation lists are then not looked at and may be missing)."""
 
-    def __init__(self, ctx, flat):
+    def __init__(self, ctx, flat, annotations=None):
         self.ctx = ctx
         keep = {}
 
@@ -342,15 +403,20 @@ class Problem(object):
         d.n_contigs = int(flat["n_contigs"])
         d.merge_contigs = int(flat["merge_contigs"])
         d.n_tracks = int(flat["n_tracks"])
-        d.annos = arr("annos", SEG)
-        d.anno_off = arr("anno_off", np.int64)
+        if annotations is None:
+            d.annos = arr("annos", SEG)
+            d.anno_off = arr("anno_off", np.int64)
+        else:
+            d.annotations = annotations._h
         d.cws_nseg = arr("cws_nseg", np.int64)
         d.bucket_size = int(flat.get("bucket_size", 0))
         d.nbuckets = int(flat.get("nbuckets", 100000))
         d.sampler = int(flat.get("sampler", 0))
         assert len(keep["seg_off"]) == d.n_units + 1 and len(keep["ws_off"]) == d.n_units + 1
         assert len(keep["cws_nseg"]) == d.n_contigs
-        if flat.get("anno_group") is not None:
+        if annotations is not None:
+            pass
+        elif flat.get("anno_group") is not None:
             # the annotation lists as the host holds them (one per track and key), grouped into contigs by the library
             d.n_anno_lists = len(flat["anno_group"])
             d.anno_group = arr("anno_group", np.int32)

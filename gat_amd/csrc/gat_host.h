@@ -237,6 +237,18 @@ struct AnnoDev {
   int64_t total = 0;
 };
 
+// The annotation side of a problem as an object of its own (gat_annotations_create): the contig-level lists of every track
+// and the count kernels' look-up structures, built once per run() and shared by the problems of all segment tracks whose
+// contigs are the same (the reference hands the same `annotations` to every track's sampling, gat/__init__.py:971-1010).
+struct gat_annotations {
+  gat_ctx* ctx = nullptr;
+  int refs = 1;                    // the handle + one per problem that counts against it
+  bool closed = false;
+  int32_t n_tracks = 0, n_groups = 0, merge_groups = 0;
+  AnnoDev dev;
+};
+void annotations_release(gat_annotations* a);     // gat_prep.hip
+
 // wall-clock stamps of problem creation (GAT_TIME_CREATE=1; tools/time_create.py)
 struct PrepTimer {
   bool on;
@@ -265,6 +277,7 @@ inline void parallel_for(int64_t n, F body) {
 }
 
 struct gat_problem {
+  ~gat_problem() { if (anno) annotations_release(anno); }
   gat_ctx* ctx = nullptr;
   CallState call;                        // the call in flight, if any (one per problem)
   int32_t n_units = 0, n_contigs = 0, n_tracks = 0, merge_contigs = 0, sampler = 0;
@@ -288,7 +301,7 @@ struct gat_problem {
   DevBuf<uint32_t> d_ws_cdf, d_rank_len;
   DevBuf<uint32_t> d_ws_tree;            // 16-ary search trees over the starts and the cumulated lengths of long workspaces
   DevBuf<int64_t> d_cws_nseg;
-  AnnoDev annos;
+  gat_annotations* anno = nullptr;       // the annotation tables: its own (made from the lists of its desc) or a shared object
   // per-batch scratch
   int64_t batch = 0;
   DevBuf<uint2> d_slab, d_cslab;

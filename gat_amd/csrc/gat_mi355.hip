@@ -912,7 +912,7 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P) {
       if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
     }
     // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
-    const int route = count_route(ctx, P->annos, C, P->n_contigs, P->n_tracks, swap_capx);
+    const int route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, swap_capx);
     const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
@@ -929,7 +929,7 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P) {
     if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
     CountLaunch L;
     L.ev_main = K.blk->ev_main[slot];
-    if ((rc = launch_count(ctx, P->annos, C, A, P->d_part, swap_capx,
+    if ((rc = launch_count(ctx, P->anno->dev, C, A, P->d_part, swap_capx,
                            P->merge_contigs ? P->max_contig_cap : P->max_unit_cap, L))) return rc;
     if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
     K.nb[slot] = nb;
@@ -981,7 +981,7 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
   K.timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
   // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel)
-  K.mstat_on = P->annos.has_merged;
+  K.mstat_on = P->anno->dev.has_merged;
   auto fail = [&](int code) { call_end(ctx, P); return code; };
   if (hipEventRecord(K.blk->ev_begin, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
   if (state_host != nullptr) {
@@ -1036,7 +1036,7 @@ static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
       if (K.main_rec[slot] && hipEventElapsedTime(&ms, K.blk->ev_main[slot][0], K.blk->ev_main[slot][1]) == hipSuccess)
         K.local.ms_count_main += ms;
       K.local.count_kernel = K.count_kernel[slot];
-      K.local.merged_form = K.count_kernel[slot] == GAT_COUNT_KERNEL_MERGED ? P->annos.merged_block : 0;
+      K.local.merged_form = K.count_kernel[slot] == GAT_COUNT_KERNEL_MERGED ? P->anno->dev.merged_block : 0;
       K.local.n_batches += 1;
       K.done += K.nb[slot];
     }

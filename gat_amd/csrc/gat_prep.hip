@@ -764,6 +764,66 @@ int upload_layout(gat_ctx* ctx, gat_problem* P) {
   return GAT_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// the annotation object
+extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* d, gat_annotations** out) {
+  if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (d->n_tracks < 0 || d->n_contigs < 0) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: negative size");
+  PrepTimer tm;
+  std::unique_ptr<gat_annotations> A(new gat_annotations());
+  struct FlushOnExit { gat_ctx* c; ~FlushOnExit() { (void)stage_flush(c); } } flush_on_exit{ctx};
+  A->ctx = ctx;
+  A->n_tracks = d->n_tracks;
+  A->n_groups = d->n_contigs;
+  A->merge_groups = d->merge_contigs ? 1 : 0;
+  int rc;
+  if (d->anno_group != nullptr) {
+    // lists with a group id each: the library forms the contig-level lists itself (fromIsochores)
+    gat_problem_desc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.n_tracks = d->n_tracks; pd.n_contigs = d->n_contigs; pd.merge_contigs = d->merge_contigs;
+    pd.annos = d->annos; pd.anno_off = d->anno_off; pd.n_anno_lists = d->n_anno_lists; pd.anno_end = d->anno_end; pd.anno_group = d->anno_group;
+    std::vector<gat_segment> buf;
+    std::vector<int64_t> gbeg, gend;
+    if ((rc = group_annotations(ctx, &pd, buf, gbeg, gend))) return rc;
+    tm.lap("annotations grouped by contig");
+    rc = build_annos(ctx, A->dev, buf.data(), gbeg.data(), gend.data(), (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true,
+                     d->merge_contigs != 0, d->mean_segment_length);
+  } else {
+    if ((int64_t)d->n_tracks * d->n_contigs > 0 && (!d->anno_off || (!d->annos && d->anno_off[(int64_t)d->n_tracks * d->n_contigs] > 0)))
+      return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: NULL lists");
+    static const int64_t kZero[2] = {0, 0};
+    const int64_t* off = d->anno_off ? d->anno_off : kZero;
+    rc = build_annos(ctx, A->dev, d->annos, off, off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false,
+                     d->mean_segment_length);
+  }
+  if (rc) return rc;
+  HIPCHK(ctx, stage_flush(ctx));
+  ctx->refs += 1;
+  *out = A.release();
+  return GAT_OK;
+}
+
+void annotations_release(gat_annotations* a) {
+  if (--a->refs > 0) return;
+  gat_ctx* ctx = a->ctx;
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);         // its blocks go back to the pool: nothing may still be reading them
+    ctx->stage_used = 0;
+  }
+  delete a;
+  if (ctx) ctx_release(ctx);
+}
+
+extern "C" void gat_annotations_destroy(gat_annotations* a) {
+  if (!a || a->closed) return;
+  a->closed = true;
+  annotations_release(a);
+}
+
 extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_problem** out) {
   if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: NULL argument");
   *out = nullptr;
@@ -1018,24 +1078,31 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     for (int32_t u : P->h_order) { bases += (double)(uint32_t)P->h_units[(size_t)u].ltotal; segs += (double)P->h_units[(size_t)u].hist_total; }
     mean_seg_len = segs > 0 ? bases / segs : 0.0;
   }
-  if (d->anno_group != nullptr) {
-    // lists with a group id each: the library forms the contig-level lists itself (fromIsochores)
-    std::vector<gat_segment> buf;
-    std::vector<int64_t> gbeg, gend;
-    if ((rc = group_annotations(ctx, d, buf, gbeg, gend))) return rc;
-    tm.lap("annotations grouped by contig");
-    rc = build_annos(ctx, P->annos, buf.data(), gbeg.data(), gend.data(), (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true,
-                     d->merge_contigs != 0, mean_seg_len);
+  if (d->annotations != nullptr) {
+    // the tables exist: made once for the run's annotations, shared by every segment track with these contigs
+    gat_annotations* A = const_cast<gat_annotations*>(d->annotations);
+    if (A->ctx != ctx) return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: the annotations were made on another context");
+    if (A->n_tracks != d->n_tracks || A->n_groups != d->n_contigs || (A->merge_groups != 0) != (d->merge_contigs != 0))
+      return set_err(ctx, GAT_ERR_ARG, "gat_problem_create: annotations of %d tracks x %d contigs (merge %d) for a problem of %d x %d (merge %d)",
+                     A->n_tracks, A->n_groups, A->merge_groups, d->n_tracks, d->n_contigs, d->merge_contigs);
+    A->refs += 1;
+    P->anno = A;
   } else {
-    rc = build_annos(ctx, P->annos, d->annos, d->anno_off, d->anno_off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false,
-                     mean_seg_len);
+    gat_annotations_desc ad;
+    memset(&ad, 0, sizeof(ad));
+    ad.n_tracks = d->n_tracks; ad.n_contigs = d->n_contigs; ad.merge_contigs = d->merge_contigs;
+    ad.annos = d->annos; ad.anno_off = d->anno_off; ad.n_anno_lists = d->n_anno_lists; ad.anno_end = d->anno_end;
+    ad.anno_group = d->anno_group; ad.mean_segment_length = mean_seg_len;
+    gat_annotations* A = nullptr;
+    if ((rc = gat_annotations_create(ctx, &ad, &A))) return rc;
+    A->closed = true;                                // (no handle of its own: it goes with the problem)
+    P->anno = A;
   }
-  if (rc) return rc;
   tm.lap("annotation tables (total)");
   {
     // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
     const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
-    const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->annos.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
+    const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->anno->dev.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
     const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
     const size_t lds_need = (size_t)3 * capx * 4 + (8192 + 1) * 4;
     (void)lds_need; (void)capx;
@@ -1058,7 +1125,7 @@ extern "C" void gat_problem_destroy(gat_problem* p) {
     if (p->call.blk) ctx->call_blocks.push_back(p->call.blk);     // (destroyed with a call in flight: the call is dropped)
     p->call.blk = nullptr;
   }
-  delete p;
+  delete p;                                          // (lets go of its annotation tables)
   if (ctx) ctx_release(ctx);
 }
 
@@ -1070,7 +1137,7 @@ extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t*
   if (n_tracks) *n_tracks = p->n_tracks;
   if (slab) *slab = p->slab_stride;
   // B_sample = 8*sum n' + 8*sum_a sum_c m + 8*A, with n' ~ n input segments
-  if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->annos.total + 8 * (int64_t)p->n_tracks;
+  if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->anno->dev.total + 8 * (int64_t)p->n_tracks;
   return GAT_OK;
 }
 

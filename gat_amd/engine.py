@@ -1057,6 +1057,20 @@ def computeCounts(counter, aggregator, segments, annotations, workspace, workspa
     return computeCountsAll([counter], aggregator, segments, annotations, workspace, workspace_generator)[0]
 
 
+def _lookup_every_key(segments, annotations, workspace):
+    """the reference's computeCounts looks every (track, isochore) up (segments[track][isochore], gat/Engine.pyx:2196-2200):
+    a dictionary that lacks the key GAINS an empty list -- and with it a work unit (and a place in the numbering of the
+    unit streams) in the sampling that follows.  run() does this before it flattens anything, whenever the counts
+    themselves are taken."""
+    isochores = list(workspace.keys())
+    for coll in (segments, annotations):
+        for t in list(coll.tracks):
+            d = coll[t]
+            if list(d.keys()) != isochores:
+                for i in isochores:
+                    d[i]
+
+
 def computeCountsAll(counters, aggregator, segments, annotations, workspace, workspace_generator=None):
     """computeCounts for several counters at once: the lists cross to the device once, every counter is evaluated by
     the same launch (gat_count_list_ranges).  Returns one {track: {annotation: count}} per counter."""
@@ -1071,14 +1085,7 @@ def computeCountsAll(counters, aggregator, segments, annotations, workspace, wor
         return all_counts
     if annotations.hasPositions() and any(c.name not in POINT_COUNTERS for c in counters):
         raise _points_type_error("annotations")              # gat/Engine.pyx:2200: counter(SegmentList, PositionList, ..)
-    # the reference looks every (track, isochore) up (segments[track][isochore], :2196-2200): a dictionary that lacks the
-    # key gains an empty list
-    for coll, names in ((segments, seg_tracks), (annotations, tracks)):
-        for t in names:
-            d = coll[t]
-            if list(d.keys()) != isochores:
-                for i in isochores:
-                    d[i]
+    _lookup_every_key(segments, annotations, workspace)
     sdata, sbases, sflats = segments._flat(seg_tracks)
     lb, le = zip(*[f.ranges(isochores, base) for f, base in zip(sflats, sbases)])
     lb, le = np.concatenate(lb), np.concatenate(le)

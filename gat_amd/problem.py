@@ -105,13 +105,16 @@ def flatten_units(segs, workspace, annotations, bucket_size=0, nbuckets=100000, 
                 bucket_size=int(bucket_size), nbuckets=int(nbuckets))
 
 
-def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nbuckets=100000, count_workspace=None, _aflat=None):
+def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nbuckets=100000, count_workspace=None, _aflat=None,
+                         _shared=None):
     """flatten_units from the host classes themselves (IntervalDictionary / IntervalCollection, gat_amd/engine.py) without a
     numpy call per list: segments and workspace per unit from the dictionaries' flat forms, and the annotation lists
     handed over as they are -- one per (track, key), each with the contig it belongs to -- for the library to form the
     contig-level lists (gat_problem_desc::anno_group; IntervalDictionary.fromIsochores on its host threads).  Same result as
     flatten_units(segs.asArrays(), workspace.asArrays(), [(t, annotations[t].asArrays()) ...]); None when the shortcut
-    does not apply (a track mixing keys with and without isochores)."""
+    does not apply (a track mixing keys with and without isochores).
+    _shared: {annotations_key: device annotation object} of the run -- when the key of this problem (its contigs in order,
+    whether fromIsochores merges) is in there the annotation lists are not walked again (flat["annos"] is None)."""
     fs, fw = segs._flat(), workspace._flat()
     units = fs.keys
     seg_len = np.diff(fs.off)
@@ -137,8 +140,17 @@ def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nb
         ws_cat, ws_off = fw.data, fw.off
     else:
         ws_cat, ws_off = _cat([fw.data[b:e] for b, e in zip(wb.tolist(), we.tolist())])
-    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
     n_contigs = len(contigs)
+    akey = (tuple(contigs), merge)
+    if _shared is not None and akey in _shared:
+        contig_workspace = from_isochores((workspace if count_workspace is None else count_workspace).asArrays())
+        return dict(n_units=len(units), unit_names=list(units), segs=fs.data, seg_off=fs.off, ws=ws_cat, ws_off=ws_off,
+                    unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=n_contigs, contig_names=list(contigs),
+                    merge_contigs=merge, n_tracks=len(tracks), track_names=list(tracks),
+                    annos=None, anno_off=None, anno_end=None, anno_group=None, annotations_key=akey,
+                    cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
+                    bucket_size=int(bucket_size), nbuckets=int(nbuckets))
+    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
     groups, begins, ends = [], [], []
     last_keys, last_group = None, None
     for t, (f, base) in enumerate(zip(aflats, abases.tolist())):
@@ -160,6 +172,7 @@ def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nb
                 unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=n_contigs, contig_names=list(contigs),
                 merge_contigs=merge, n_tracks=len(tracks), track_names=list(tracks),
                 annos=adata, anno_off=cat(begins, np.int64), anno_end=cat(ends, np.int64), anno_group=cat(groups, np.int32),
+                annotations_key=akey,
                 cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
                 bucket_size=int(bucket_size), nbuckets=int(nbuckets))
 

@@ -27,6 +27,7 @@ typedef struct { uint32_t start, end; } gat_segment;
 
 typedef struct gat_ctx gat_ctx;
 typedef struct gat_problem gat_problem;
+typedef struct gat_annotations gat_annotations;
 
 #define GAT_OK 0
 #define GAT_ERR_VALUE (-1)      /* reference raises ValueError (gat/SegmentList.pyx:1170-1182)      */
@@ -84,7 +85,27 @@ typedef struct {
   const int64_t* anno_end;      /* n_anno_lists, or NULL: anno_off has n_anno_lists + 1 entries (CSR)                 */
   const int32_t* anno_group;    /* n_anno_lists: track * n_contigs + contig of the list's key, or -1 (its contig has   */
                                 /* no unit that computeSample samples: the counters never see it)                      */
+  /* Optional: the annotation side as an object made before (gat_annotations_create) -- the reference passes the SAME
+   * annotations to the sampling of every segment track (gat/__init__.py:971-1010); a host that loops over tracks builds
+   * their tables once.  n_tracks / n_contigs / merge_contigs must be the object's; annos / anno_* above are ignored. */
+  const gat_annotations* annotations;
 } gat_problem_desc;
+
+/* The annotation side of gat_problem_desc by itself: the tracks' lists per contig -- [track][contig] CSR, or with
+ * anno_group one list per (track, isochore key) that the library groups as IntervalDictionary.fromIsochores does
+ * (gat/Engine.pyx:2857-2876) -- for the contigs, IN THE ORDER, of the problems that will count against it. */
+typedef struct {
+  int32_t n_tracks;
+  int32_t n_contigs;
+  int32_t merge_contigs;
+  const gat_segment* annos;
+  const int64_t* anno_off;      /* n_tracks*n_contigs+1, or per list (see anno_end)                                   */
+  int64_t n_anno_lists;         /* with anno_group: number of lists                                                    */
+  const int64_t* anno_end;
+  const int32_t* anno_group;
+  double mean_segment_length;   /* of the segments that will be counted against them, 0 if unknown: picks the form of  */
+                                /* the merged index (speed only, never a result)                                       */
+} gat_annotations_desc;
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
  * ctx stream; counts summed over all (sample, unit) work units of the call).  ms_total and ms_count_main are always
@@ -152,6 +173,12 @@ int gat_memcpy_h2d(gat_ctx* ctx, void* dst_dev, const void* src_host, size_t byt
  * on-chip memory are worked on in device memory. */
 int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* desc, gat_problem** out);
 void gat_problem_destroy(gat_problem* p);
+
+/* Uploads the annotation tracks and builds what the counters look them up in (SoA lists + position grids, the merged
+ * index of all tracks): the part of gat_problem_create that does not depend on the segment track.  Problems created with
+ * desc->annotations = this object share it; it may be destroyed before them (it lives until the last one is gone). */
+int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* desc, gat_annotations** out);
+void gat_annotations_destroy(gat_annotations* a);
 
 /* ---- the batch seam ---------------------------------------------------------------------
  * Replaces UnconditionalSampler.sample / computeSamples / computeSample
