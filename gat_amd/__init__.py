@@ -189,7 +189,8 @@ def _sample_start(segs, annotations, workspace, sampler, counters, num_samples, 
         if shared_annos is None and flat.get("annos") is not None:
             total = float(len(flat["segs"]))
             mean = float((flat["segs"]["end"].astype(np.int64) - flat["segs"]["start"]).sum()) / total if total else 0.0
-            shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean)
+            # (built by a thread of the library while this one goes on: the sampler's kernels do not wait for the tables)
+            shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean, asynchronous=True)
     job.P = _lib.Problem(ctx, flat, annotations=shared_annos)
     rank, world, _ = _dist_state()
     if world == 1 and mt_state is None and num_samples > 0:
@@ -330,12 +331,14 @@ def run(segments, annotations, workspace, sampler, counters, workspace_generator
     """run an enrichment analysis: same signature and result type as the reference's gat.run
     (gat/__init__.py:855-1088); see _run.  (Whether the annotations hold point lists is asked of every list once for the
     whole call instead of at each of its three uses: 19 200 lists on an isochore problem.)"""
-    annotations._points_memo = None
+    annotations._points_memo = annotations._plain_memo = None
+    annotations._ranges_memo = {}
     annotations._points_memo = annotations.hasPositions()
+    annotations._plain_memo = (not annotations._points_memo) and all(d._all_normalized() for d in annotations.intervals.values())
     try:
         return _run(segments, annotations, workspace, sampler, counters, workspace_generator, **kwargs)
     finally:
-        annotations._points_memo = None
+        annotations._points_memo = annotations._plain_memo = annotations._ranges_memo = None
 
 
 def _run(segments, annotations, workspace, sampler, counters, workspace_generator, **kwargs):
@@ -392,16 +395,23 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
 
     def observed():
         if state["observed"] is None:
-            state["observed"] = computeCountsAll(counters, sum, segments, annotations, workspace, workspace_generator)
+            state["observed"] = computeCountsAll(counters, sum, segments, annotations, workspace, workspace_generator, _aflat=aflat)
             if unconditional and aflat is not None and len(aflat[2]) >= 16 and not annotations.hasPositions():
-                # (counts, sum) of every annotation dictionary in one pass over the collection's array: list sums as
-                # SegmentList.sum() forms them (a uint32 accumulator each), added up per dictionary
+                # (counts, sum) of every annotation dictionary from one native pass over the collection's array: list sums
+                # as SegmentList.sum() forms them (a uint32 accumulator each), added up per dictionary
+                from . import _lib
                 data, bases, flats = aflat
-                run_ = np.zeros(len(data) + 1, dtype=np.int64)
-                np.cumsum(data["end"].astype(np.int64) - data["start"], out=run_[1:])
-                for t, f, base in zip(annotations.tracks, flats, bases.tolist()):
-                    per = (run_[f.off[1:] + base] - run_[f.off[:-1] + base]) & 0xFFFFFFFF
-                    sizes[id(annotations[t])] = (int(f.off[-1]), int(per.sum()))
+                nl = np.fromiter((len(f.keys) for f in flats), dtype=np.int64, count=len(flats))
+                lb = np.concatenate([f.off[:-1] for f in flats]) + np.repeat(bases[:-1], nl)
+                le = np.concatenate([f.off[1:] for f in flats]) + np.repeat(bases[:-1], nl)
+                per = _lib.list_sums(data, lb, le)
+                first = np.zeros(len(flats) + 1, dtype=np.int64)
+                np.cumsum(nl, out=first[1:])
+                run_ = np.zeros(len(per) + 1, dtype=np.int64)
+                np.cumsum(per, out=run_[1:])
+                tot = (run_[first[1:]] - run_[first[:-1]]).tolist()
+                for t, f, x in zip(annotations.tracks, flats, tot):
+                    sizes[id(annotations[t])] = (int(f.off[-1]), int(x))
         return state["observed"]
 
     def finish(track, outf, job):

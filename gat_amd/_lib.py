@@ -31,7 +31,7 @@ SYMBOLS = [
     "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
-    "gat_annotations_create", "gat_annotations_destroy",
+    "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -86,6 +86,7 @@ class AnnotationsDesc(C.Structure):
         ("anno_end", C.c_void_p),
         ("anno_group", C.c_void_p),
         ("mean_segment_length", C.c_double),
+        ("flags", C.c_int32),
     ]
 
 
@@ -160,6 +161,8 @@ def lib():
     L.gat_problem_destroy.argtypes = [vp]
     L.gat_annotations_create.restype = C.c_int
     L.gat_annotations_create.argtypes = [vp, C.POINTER(AnnotationsDesc), C.POINTER(vp)]
+    L.gat_annotations_wait.restype = C.c_int
+    L.gat_annotations_wait.argtypes = [vp, vp]
     L.gat_annotations_destroy.restype = None
     L.gat_annotations_destroy.argtypes = [vp]
     L.gat_sample_and_count.restype = C.c_int
@@ -182,6 +185,8 @@ def lib():
     L.gat_count_list_ranges.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, vp, i32, vp, i32, vp]
     L.gat_intersection_sizes.restype = C.c_int
     L.gat_intersection_sizes.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
+    L.gat_list_sums.restype = C.c_int
+    L.gat_list_sums.argtypes = [vp, vp, vp, i64, vp]
     L.gat_problem_info.restype = C.c_int
     L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.gat_null_stats.restype = C.c_int
@@ -310,6 +315,17 @@ def intersection_sizes(a, a_off, b, b_begin, b_end, n_tracks):
     return pairs, bases
 
 
+def list_sums(a, begin, end):
+    """SegmentList.sum() (a uint32 accumulator, gat/SegmentList.pyx:1607) of every list a[begin[l]:end[l]] (gat_list_sums)"""
+    a = np.ascontiguousarray(a, dtype=SEG)
+    begin = np.ascontiguousarray(begin, dtype=np.int64)
+    end = np.ascontiguousarray(end, dtype=np.int64)
+    assert len(begin) == len(end)
+    out = np.zeros(len(begin), dtype=np.int64)
+    _check(lib().gat_list_sums(_p(a), _p(begin), _p(end), len(begin), _p(out)))
+    return out
+
+
 COMM_ID_BYTES = 128
 
 
@@ -343,9 +359,11 @@ class Annotations(object):
     """the annotation side of a problem as a device-resident object of its own (gat_annotations): made once per run(),
     shared by the problems of every segment track whose contigs are `flat`'s (same names, same order)."""
 
-    def __init__(self, ctx, flat, mean_segment_length=0.0):
+    def __init__(self, ctx, flat, mean_segment_length=0.0, asynchronous=False):
+        """asynchronous: the tables are built by a thread of the library while the caller goes on (GAT_ANNOTATIONS_ASYNC);
+        the arrays handed over stay referenced by this object."""
         self.ctx = ctx
-        keep = {}
+        keep = self._keep = {}
 
         def arr(name, dtype):
             keep[name] = np.ascontiguousarray(flat[name], dtype=dtype)
@@ -363,14 +381,22 @@ class Annotations(object):
         else:
             assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1
         d.mean_segment_length = float(mean_segment_length)
+        d.flags = 1 if asynchronous else 0
         self.n_tracks, self.n_contigs, self.merge_contigs = d.n_tracks, d.n_contigs, d.merge_contigs
         self._h = C.c_void_p()
         _check(lib().gat_annotations_create(ctx._h, C.byref(d), C.byref(self._h)), ctx._h)
 
+    def wait(self):
+        """an asynchronous build has finished (raises its error, if any)"""
+        _check(lib().gat_annotations_wait(self.ctx._h, self._h), self.ctx._h)
+
     def close(self):
         if self._h:
+            if getattr(self.ctx, "_h", None):
+                lib().gat_annotations_wait(self.ctx._h, self._h)     # (a build still running has the arrays below in use)
             lib().gat_annotations_destroy(self._h)
             self._h = C.c_void_p()
+        self._keep = {}
 
     def __del__(self):
         try:

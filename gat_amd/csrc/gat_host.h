@@ -52,6 +52,8 @@ struct CallState {
   int count_kernel[kMaxInflight] = {};
   bool main_rec[kMaxInflight] = {};
   bool timed = false, mstat_on = false;
+  bool count_pending = false;                 // the newest batch's sampler kernels are enqueued, its count kernels wait for the
+                                              // annotation tables (an asynchronous build)
   gat_stats local;
 };
 
@@ -59,6 +61,9 @@ struct gat_ctx {
   int refs = 1;                    // the handle + one per live problem: gat_ctx_destroy frees when the last one is gone
   bool closed = false;             // gat_ctx_destroy was called (problems still alive)
   std::vector<CallBlock*> call_blocks;          // idle blocks (see CallBlock)
+  gat_ctx* aux_ctx = nullptr;                   // stream + staging buffer of gat_count_lists: observed counts do not queue behind samples in flight
+  gat_ctx* build_ctx = nullptr;                 // stream + staging buffer of asynchronous annotation builds (made at the first one)
+  struct gat_annotations* building = nullptr;   // ... and the object whose build has them (one at a time)
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -246,8 +251,17 @@ struct gat_annotations {
   bool closed = false;
   int32_t n_tracks = 0, n_groups = 0, merge_groups = 0;
   AnnoDev dev;
+  // GAT_ANNOTATIONS_ASYNC: the tables are built by a thread of the library (its own stream and staging buffer: ctx->build_ctx)
+  // while the caller goes on -- a problem made against the object samples at once and counts when the tables are there
+  std::thread worker;
+  std::atomic<int> ready{1};       // 0 while the worker runs
+  int build_rc = 0;
+  std::string build_err;
+  bool will_merge = false;         // known before the build: the merged index will exist (decides the count kernel's route)
 };
 void annotations_release(gat_annotations* a);     // gat_prep.hip
+inline bool annotations_ready(const gat_annotations* a) { return a->ready.load(std::memory_order_acquire) != 0; }
+int annotations_wait(gat_ctx* ctx, gat_annotations* a);   // joins the build; returns its error, if any, as the caller's
 
 // wall-clock stamps of problem creation (GAT_TIME_CREATE=1; tools/time_create.py)
 struct PrepTimer {
@@ -269,6 +283,7 @@ int check_list(gat_ctx* ctx, const gat_segment* s, int64_t n, const char* what, 
 // problem's creation is a dozen of these loops of 0.1-2 ms each, and fifteen threads created and joined per loop were
 // 0.3-0.5 ms of every one (gat_prep.hip: host_pool_run; GAT_HOST_POOL=0: threads per loop as before)
 void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg);
+void host_pool_select(int pool);              // the calling thread's pool from now on: 0 callers (default), 1 the library's builder
 template <typename F>
 inline void parallel_for(int64_t n, F body) {
   if (n <= 0) return;
@@ -349,6 +364,7 @@ struct gat_problem {
   bool pipe_pays = false;                // the single-workspace-segment units hold at least half of the working segments: only their
                                          // loop of k_place_pipe runs through the hand-pipelined rows, and the kernel costs registers
   int swap_capx = 0;                     // > 0: count with k_count_swap, sample lists of up to this many segments in LDS
+  bool swap_decided = false;             // (decided at the first call: it takes the size of the annotation tables)
 };
 
 // gat_prep.hip

@@ -112,6 +112,8 @@ void ctx_release(gat_ctx* ctx) {
   ctx->stage_used = 0;
   for (CallBlock* b : ctx->call_blocks) call_block_free(b);
   ctx->call_blocks.clear();
+  if (ctx->build_ctx) { gat_ctx_destroy(ctx->build_ctx); ctx->build_ctx = nullptr; }
+  if (ctx->aux_ctx) { gat_ctx_destroy(ctx->aux_ctx); ctx->aux_ctx = nullptr; }
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_main) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->ev_k) if (ev) (void)hipEventDestroy(ev);
@@ -889,7 +891,24 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
 // slots in order, and where a batch has to be repeated (a unit's region overflowed, a contig's lists beyond the launch's
 // LDS) lays the slab out again and enqueues that batch and everything behind it once more: results do not depend on the
 // batching (streams are per unit) and every batch writes its own columns of the count matrix.
-static int call_enqueue_more(gat_ctx* ctx, gat_problem* P) {
+// sample lists much longer than the annotation lists they meet: swap the roles in the count kernel (needs the tables' size)
+static void decide_swap(gat_problem* P) {
+  if (P->swap_decided) return;
+  P->swap_decided = true;
+  const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
+  const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->anno->dev.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
+  if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
+}
+
+static int call_swap_capx(const gat_ctx* ctx, const gat_problem* P) {
+  if (!P->swap_capx) return 0;
+  const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
+  return ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) ? capx : 0;
+}
+
+// block: wait for annotation tables that are still being built (gat_wait); else return with the newest batch's count
+// kernels still to come (gat_sample_and_count_enqueue: the host goes on, the device samples)
+static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
   CallState& K = P->call;
   Counters C;
   int rc = parse_counters(ctx, K.ids, K.n_counters, C);
@@ -899,50 +918,85 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P) {
   // (the events behind every kernel and the serial stream's saved state exist once: such calls keep one batch in flight)
   const int max_flight = (K.timed || serial) ? 1 : kMaxInflight;
   PrepTimer tm;
-  while (K.enq < K.S && K.n_flight < max_flight) {
+  for (;;) {
+    if (K.count_pending) {
+      // ---- the count kernels of the newest batch
+      if (!annotations_ready(P->anno) && !block) break;
+      if ((rc = annotations_wait(ctx, P->anno))) return rc;
+      decide_swap(P);
+      const int slot = K.n_flight - 1;
+      const int64_t nb = K.nb[slot];
+      const int swap_capx = call_swap_capx(ctx, P);
+      K.mstat_on = P->anno->dev.has_merged;
+      if (K.mstat_on && K.enq == nb) {
+        // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel; zeroed in front of
+        //  the call's first count kernel)
+        if (P->d_mstat.n < 512) HIPCHK(ctx, P->d_mstat.alloc(512));
+        HIPCHK(ctx, hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream));
+      }
+      gat::CountArgs A;
+      memset(&A, 0, sizeof(A));
+      fill_count_args(P, A, nb);
+      A.out = (int64_t*)K.counts_dev;
+      A.out_stride = K.S;
+      A.out_begin = K.enq - nb;
+      A.mstat = K.mstat_on ? P->d_mstat.p : nullptr;
+      if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
+      CountLaunch L;
+      L.ev_main = K.blk->ev_main[slot];
+      if ((rc = launch_count(ctx, P->anno->dev, C, A, P->d_part, swap_capx,
+                             P->merge_contigs ? P->max_contig_cap : P->max_unit_cap, L))) return rc;
+      if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
+      K.main_rec[slot] = L.main_recorded;
+      K.count_kernel[slot] = L.count_kernel;
+      K.count_pending = false;
+      if (K.enq == K.S) {
+        // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
+        //  that has to be repeated enqueues it again)
+        HIPCHK(ctx, hipEventRecord(K.blk->ev_end, ctx->stream));
+        if (K.mstat_on) HIPCHK(ctx, hipMemcpyAsync(K.blk->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+      }
+    }
+    if (!(K.enq < K.S && K.n_flight < max_flight)) break;
+    // ---- the sampler kernels of the next batch
+    // which count kernel will follow decides the sampler's last steps (final lists or not); with the tables still being built
+    // it is known only where the shape alone says so -- many tracks, nucleotide counters: the merged index -- else wait
+    int route;
+    if (annotations_ready(P->anno)) {
+      if ((rc = annotations_wait(ctx, P->anno))) return rc;
+      decide_swap(P);
+      route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+    } else {
+      const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
+      const size_t lds_merged = (size_t)P->n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
+      if (C.any_seg && P->n_contigs > 0 && only_overlap && P->anno->will_merge && (int64_t)lds_merged + 1024 <= ctx->max_lds &&
+          !getenv("GAT_COUNT_NO_MERGED")) {
+        route = GAT_COUNT_KERNEL_MERGED;
+      } else {
+        if ((rc = annotations_wait(ctx, P->anno))) return rc;
+        decide_swap(P);
+        route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+      }
+    }
     // the scratch is sized while nothing of this problem is in flight; batches behind the first fit by construction
     if (K.n_flight == 0 && (rc = ensure_scratch(ctx, P, K.S - K.enq))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, K.S - K.enq);
     const int slot = K.n_flight;
     if (d_state != nullptr)
       HIPCHK(ctx, hipMemcpyAsync(d_state + GAT_MT_STATE_WORDS, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    int swap_capx = 0;
-    if (P->swap_capx) {
-      const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
-      if ((int64_t)3 * capx * 4 + (8192 + 1) * 4 <= (int64_t)ctx->max_lds - 1024) swap_capx = capx;
-    }
     // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
-    const int route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, swap_capx);
     const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
     if ((rc = run_sampler_batch(ctx, P, K.seed, K.begin + K.enq, nb, &K.local, K.timed, false, true, records_ok, d_state, loose_ok,
                                 K.blk->h_stat + (size_t)slot * 16))) return rc;   // (enqueued only)
-    gat::CountArgs A;
-    memset(&A, 0, sizeof(A));
-    fill_count_args(P, A, nb);
-    A.out = (int64_t*)K.counts_dev;
-    A.out_stride = K.S;
-    A.out_begin = K.enq;
-    A.mstat = K.mstat_on ? P->d_mstat.p : nullptr;
-    if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
-    CountLaunch L;
-    L.ev_main = K.blk->ev_main[slot];
-    if ((rc = launch_count(ctx, P->anno->dev, C, A, P->d_part, swap_capx,
-                           P->merge_contigs ? P->max_contig_cap : P->max_unit_cap, L))) return rc;
-    if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
     K.nb[slot] = nb;
-    K.main_rec[slot] = L.main_recorded;
-    K.count_kernel[slot] = L.count_kernel;
+    K.main_rec[slot] = false;
+    K.count_kernel[slot] = GAT_COUNT_KERNEL_NONE;
     K.n_flight = slot + 1;
     K.enq += nb;
-    if (K.enq == K.S) {
-      // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
-      //  that has to be repeated enqueues it again)
-      HIPCHK(ctx, hipEventRecord(K.blk->ev_end, ctx->stream));
-      if (K.mstat_on) HIPCHK(ctx, hipMemcpyAsync(K.blk->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    K.count_pending = true;
   }
   tm.lap("batches enqueued");
   return GAT_OK;
@@ -980,8 +1034,8 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   memset(&K.local, 0, sizeof(K.local));
   // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
   K.timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
-  // (k_count_merged's own traffic counters: only a problem with a merged index can take that kernel)
-  K.mstat_on = P->anno->dev.has_merged;
+  K.mstat_on = false;                              // (set with the first count kernels: it takes the tables)
+  K.count_pending = false;
   auto fail = [&](int code) { call_end(ctx, P); return code; };
   if (hipEventRecord(K.blk->ev_begin, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
   if (state_host != nullptr) {
@@ -990,15 +1044,11 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
       return fail(set_err(ctx, GAT_ERR_MEMORY, "device memory for the stream's state"));
     if (staged_h2d(ctx, P->d_serial.p, state_host, GAT_MT_STATE_WORDS * 4) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "upload of the stream's state failed"));
   }
-  if (K.mstat_on) {
-    if (P->d_mstat.n < 512 && P->d_mstat.alloc(512) != hipSuccess) return fail(set_err(ctx, GAT_ERR_MEMORY, "device memory for the traffic counters"));
-    if (hipMemsetAsync(P->d_mstat.p, 0, 512 * 8, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipMemsetAsync failed"));
-  }
   if (K.S == 0) {                                                  // (no batch will run: nothing to ride on)
     if (hipEventRecord(K.blk->ev_end, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
     return GAT_OK;
   }
-  if ((rc = call_enqueue_more(ctx, P))) return fail(rc);
+  if ((rc = call_enqueue_more(ctx, P, false))) return fail(rc);
   return GAT_OK;
 }
 
@@ -1010,6 +1060,7 @@ static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
   auto fail = [&](int code) { (void)hipStreamSynchronize(ctx->stream); call_end(ctx, P); return code; };
   PrepTimer tm;
   int rc;
+  if (K.count_pending && (rc = call_enqueue_more(ctx, P, true))) return fail(rc);   // (the tables were still being built)
   for (;;) {
     // ONE synchronisation per flight of batches: a sampler's status word is read behind the count kernels, which ran on
     // whatever an overflowed unit left.  What it left is in bounds: the exits that set a status bit (region full, a contig's
@@ -1043,7 +1094,7 @@ static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
     K.n_flight = 0;
     K.enq = K.done;                                              // (what a repeated batch had behind it is enqueued again)
     if (K.done == K.S) break;
-    if ((rc = call_enqueue_more(ctx, P))) return fail(rc);
+    if ((rc = call_enqueue_more(ctx, P, true))) return fail(rc);
   }
   if (K.state_host != nullptr && staged_d2h(ctx, K.state_host, P->d_serial.p, GAT_MT_STATE_WORDS * 4) != hipSuccess)
     return fail(set_err(ctx, GAT_ERR_DEVICE, "read-back of the stream's state failed"));
@@ -1149,6 +1200,14 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
   return GAT_OK;
 }
 
+static int count_lists_on(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                          const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                          const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                          const int64_t* ws_nseg, int32_t n_groups, void* counts_host);
+
+// Observed counts are independent of whatever samples are in flight on the caller's context: they run on a stream (and
+// through a staging buffer) of their own -- every staged upload waits for its stream, and on the caller's stream that would
+// be the end of the sampling (run() computes them while the device samples, gat/__init__.py:933-940)
 static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                             const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
                             const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
@@ -1156,6 +1215,23 @@ static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_coun
   if (!ctx || !list_off || !anno_begin || !anno_end || !counts_host || (n_groups > 0 && !ws_nseg))
     return set_err(ctx, GAT_ERR_ARG, "gat_count_lists: NULL argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->aux_ctx == nullptr) {
+    int rc = gat_ctx_create(&ctx->aux_ctx, ctx->device, nullptr);
+    if (rc) return rc;
+  }
+  gat_ctx* x = ctx->aux_ctx;
+  const int rc = count_lists_on(x, counter_ids, n_counters, lists, list_off, n_lists, annos, anno_begin, anno_end, n_tracks, ws_nseg,
+                                n_groups, counts_host);
+  (void)hipStreamSynchronize(x->stream);            // (its buffers have gone back to the pool: nothing may still be using them)
+  x->stage_used = 0;
+  if (rc) return set_err(ctx, rc, "%s", x->err.c_str());
+  return GAT_OK;
+}
+
+static int count_lists_on(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                          const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                          const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                          const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
   Counters C;
   int rc = parse_counters(ctx, counter_ids, n_counters, C);
   if (rc) return rc;

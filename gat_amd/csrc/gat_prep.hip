@@ -127,9 +127,10 @@ struct HostPool {
   std::atomic<uint64_t> gen{0};
   pid_t pid = 0;
 };
-HostPool* g_host_pool = nullptr;
+HostPool* g_host_pool[2] = {nullptr, nullptr};   // 0: the callers' threads, 1: the asynchronous annotation build's
 std::mutex g_host_pool_mutex;
 thread_local bool t_in_pool_job = false;
+thread_local int t_pool = 0;
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
 
@@ -164,6 +165,8 @@ void run_with_own_threads(int64_t n, void (*fn)(void*, int64_t), void* arg, unsi
 }
 }  // namespace
 
+void host_pool_select(int pool) { t_pool = pool == 1 ? 1 : 0; }
+
 void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg) {
   const char* env_t = getenv("GAT_HOST_THREADS");
   unsigned nthreads = env_t ? (unsigned)std::max(1, atoi(env_t)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -175,8 +178,9 @@ void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg) {
   {
     std::lock_guard<std::mutex> lock(g_host_pool_mutex);
     // (a forked child has the parent's pool object but none of its threads: it starts one of its own)
-    if (g_host_pool == nullptr || g_host_pool->pid != getpid()) { g_host_pool = new HostPool(); g_host_pool->pid = getpid(); }
-    P = g_host_pool;
+    HostPool*& slot = g_host_pool[t_pool];
+    if (slot == nullptr || slot->pid != getpid()) { slot = new HostPool(); slot->pid = getpid(); }
+    P = slot;
   }
   if (!P->run_mutex.try_lock()) { run_with_own_threads(n, fn, arg, nthreads); return; }
   while (P->threads.size() + 1 < nthreads) {                       // (grows to the largest team asked for; no job is out)
@@ -766,18 +770,10 @@ int upload_layout(gat_ctx* ctx, gat_problem* P) {
 
 // ------------------------------------------------------------------------------------------
 // the annotation object
-extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* d, gat_annotations** out) {
-  if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: NULL argument");
-  *out = nullptr;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (d->n_tracks < 0 || d->n_contigs < 0) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: negative size");
+// the build itself: the contig-level lists, then the tables (on `ctx`'s stream and through its staging buffer)
+static int annotations_build(gat_ctx* ctx, gat_annotations* A, const gat_annotations_desc* d) {
   PrepTimer tm;
-  std::unique_ptr<gat_annotations> A(new gat_annotations());
   struct FlushOnExit { gat_ctx* c; ~FlushOnExit() { (void)stage_flush(c); } } flush_on_exit{ctx};
-  A->ctx = ctx;
-  A->n_tracks = d->n_tracks;
-  A->n_groups = d->n_contigs;
-  A->merge_groups = d->merge_contigs ? 1 : 0;
   int rc;
   if (d->anno_group != nullptr) {
     // lists with a group id each: the library forms the contig-level lists itself (fromIsochores)
@@ -801,6 +797,65 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
   }
   if (rc) return rc;
   HIPCHK(ctx, stage_flush(ctx));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // (the tables are resident when the build is reported done)
+  return GAT_OK;
+}
+
+static void annotations_build_worker(gat_annotations* A, gat_annotations_desc d) {
+  host_pool_select(1);                               // (the callers' pool stays theirs: they prepare observed counts meanwhile)
+  gat_ctx* b = A->ctx->build_ctx;
+  int rc = GAT_OK;
+  if (hipSetDevice(b->device) != hipSuccess) rc = set_err(b, GAT_ERR_DEVICE, "hipSetDevice failed in the annotation build");
+  if (rc == GAT_OK) rc = annotations_build(b, A, &d);
+  A->build_rc = rc;
+  if (rc) A->build_err = b->err;
+  A->ready.store(1, std::memory_order_release);
+}
+
+int annotations_wait(gat_ctx* ctx, gat_annotations* a) {
+  if (a->worker.joinable()) {
+    a->worker.join();
+    if (a->ctx && a->ctx->building == a) a->ctx->building = nullptr;
+  }
+  if (a->build_rc) return set_err(ctx, a->build_rc, "%s", a->build_err.c_str());
+  return GAT_OK;
+}
+
+extern "C" int gat_annotations_wait(gat_ctx* ctx, gat_annotations* a) {
+  if (!a) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_wait: NULL argument");
+  return annotations_wait(ctx, a);
+}
+
+extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* d, gat_annotations** out) {
+  if (!ctx || !d || !out) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: NULL argument");
+  *out = nullptr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (d->n_tracks < 0 || d->n_contigs < 0) return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: negative size");
+  std::unique_ptr<gat_annotations> A(new gat_annotations());
+  A->ctx = ctx;
+  A->n_tracks = d->n_tracks;
+  A->n_groups = d->n_contigs;
+  A->merge_groups = d->merge_contigs ? 1 : 0;
+  // whether the merged index will exist is known from the shape alone when there are enough tracks (build_annos): only then
+  // may a problem sample before the tables are there (the sampler's last steps depend on the count kernel that follows)
+  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  A->will_merge = d->n_contigs > 0 && d->n_tracks >= (env_mm ? atoi(env_mm) : 4) && d->n_tracks <= 65535;
+  const char* env_a = getenv("GAT_ANNOTATIONS_SYNC");
+  const bool async = (d->flags & GAT_ANNOTATIONS_ASYNC) != 0 && A->will_merge && !(env_a && atoi(env_a) != 0);
+  if (!async) {
+    int rc = annotations_build(ctx, A.get(), d);
+    if (rc) return rc;
+  } else {
+    if (ctx->building != nullptr) (void)annotations_wait(ctx, ctx->building);     // (one build at a time has the build context)
+    if (ctx->build_ctx == nullptr) {
+      int rc = gat_ctx_create(&ctx->build_ctx, ctx->device, nullptr);
+      if (rc) return rc;
+    }
+    ctx->build_ctx->err.clear();
+    A->ready.store(0, std::memory_order_release);
+    ctx->building = A.get();
+    A->worker = std::thread(annotations_build_worker, A.get(), *d);
+  }
   ctx->refs += 1;
   *out = A.release();
   return GAT_OK;
@@ -809,6 +864,7 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
 void annotations_release(gat_annotations* a) {
   if (--a->refs > 0) return;
   gat_ctx* ctx = a->ctx;
+  (void)annotations_wait(nullptr, a);                // (a build still running has its arrays in use)
   if (ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);         // its blocks go back to the pool: nothing may still be reading them
@@ -1099,15 +1155,6 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     P->anno = A;
   }
   tm.lap("annotation tables (total)");
-  {
-    // sample lists much longer than the annotation lists they meet: swap the roles in the count kernel
-    const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
-    const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->anno->dev.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
-    const int capx = P->merge_contigs ? P->max_contig_cap : P->max_unit_cap;
-    const size_t lds_need = (size_t)3 * capx * 4 + (8192 + 1) * 4;
-    (void)lds_need; (void)capx;
-    if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
-  }
   HIPCHK(ctx, P->d_stat.alloc(16));                 // (8 statistics words, the status word in word 8)
   HIPCHK(ctx, stage_flush(ctx));                    // the small tables' copies (one wait for all of them)
   ctx->refs += 1;                                   // (the context outlives its handle while a problem made on it is alive)
@@ -1137,7 +1184,11 @@ extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t*
   if (n_tracks) *n_tracks = p->n_tracks;
   if (slab) *slab = p->slab_stride;
   // B_sample = 8*sum n' + 8*sum_a sum_c m + 8*A, with n' ~ n input segments
-  if (bytes) *bytes = 8 * p->n_seg_total + 8 * p->anno->dev.total + 8 * (int64_t)p->n_tracks;
+  if (bytes) {
+    int rc = annotations_wait(p->ctx, p->anno);
+    if (rc) return rc;
+    *bytes = 8 * p->n_seg_total + 8 * p->anno->dev.total + 8 * (int64_t)p->n_tracks;
+  }
   return GAT_OK;
 }
 
@@ -1169,6 +1220,20 @@ extern "C" int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off
     }
     pairs_out[t] = pairs;
     bases_out[t] = bases;
+  });
+  return GAT_OK;
+}
+
+// SegmentList.sum() of many lists at once (gat/SegmentList.pyx:1607: a Position accumulator per list)
+extern "C" int gat_list_sums(const gat_segment* a, const int64_t* begin, const int64_t* end, int64_t n_lists, int64_t* sums_out) {
+  if ((n_lists > 0 && (!begin || !end || !sums_out)) || n_lists < 0) return set_err(nullptr, GAT_ERR_ARG, "gat_list_sums: bad argument");
+  constexpr int64_t kBlock = 512;
+  parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t b) {
+    for (int64_t l = b * kBlock; l < std::min(n_lists, (b + 1) * kBlock); ++l) {
+      uint32_t sum = 0;
+      for (int64_t i = begin[l]; i < end[l]; ++i) sum += a[i].end - a[i].start;
+      sums_out[l] = (int64_t)sum;
+    }
   });
   return GAT_OK;
 }

@@ -782,6 +782,31 @@ class IntervalCollection(object):
                 vv[contig] = p
 
     _points_memo = None        # set for the duration of a gat_amd.run() call (the collection is not changed inside it)
+    _plain_memo = None         # likewise: every list a normalized SegmentList (no points)
+    _ranges_memo = None        # likewise: {keys: (begin, end)} of _ranges
+
+    def _ranges(self, aflat, target_keys):
+        """(begin, end): where the lists of `target_keys` lie in aflat's one array, dictionary after dictionary (a key a
+        dictionary lacks gives (0, 0)): what the device calls and the input statistics take instead of the lists.  The
+        observed counts, the intersections' sizes and the problem ask for the same arrays: kept for the length of a run()."""
+        memo = self._ranges_memo
+        key = tuple(target_keys)
+        if memo is not None and key in memo and memo[key][0] is aflat:
+            return memo[key][1], memo[key][2]
+        _, bases, flats = aflat
+        target_keys = list(target_keys)
+        if flats and all(f.keys is flats[0].keys or f.keys == target_keys for f in flats) and flats[0].keys == target_keys:
+            n = len(target_keys)
+            off = np.concatenate([f.off for f in flats]).reshape(len(flats), n + 1) + bases[:-1, None]
+            b, e = np.ascontiguousarray(off[:, :-1]).ravel(), np.ascontiguousarray(off[:, 1:]).ravel()
+        elif flats:
+            bb, ee = zip(*[f.ranges(target_keys, base) for f, base in zip(flats, bases)])
+            b, e = np.concatenate(bb), np.concatenate(ee)
+        else:
+            b = e = np.zeros(0, dtype=np.int64)
+        if memo is not None:
+            memo[key] = (aflat, b, e)
+        return b, e
 
     def hasPositions(self):
         if self._points_memo is not None:
@@ -1071,9 +1096,10 @@ def _lookup_every_key(segments, annotations, workspace):
                     d[i]
 
 
-def computeCountsAll(counters, aggregator, segments, annotations, workspace, workspace_generator=None):
+def computeCountsAll(counters, aggregator, segments, annotations, workspace, workspace_generator=None, _aflat=None):
     """computeCounts for several counters at once: the lists cross to the device once, every counter is evaluated by
-    the same launch (gat_count_list_ranges).  Returns one {track: {annotation: count}} per counter."""
+    the same launch (gat_count_list_ranges).  Returns one {track: {annotation: count}} per counter.
+    _aflat: annotations._flat(tracks) from a caller that has it and has not touched the collection since."""
     if aggregator is not sum:
         raise NotImplementedError("only aggregator=sum is supported")
     all_counts = [collections.defaultdict(lambda: collections.defaultdict(float)) for _ in counters]
@@ -1093,12 +1119,11 @@ def computeCountsAll(counters, aggregator, segments, annotations, workspace, wor
         lcat, loff = sdata, np.append(lb, le[-1])
     else:
         lcat, loff = _problem._cat([sdata[b:e] for b, e in zip(lb.tolist(), le.tolist())])
-    adata, abases, aflats = annotations._flat(tracks)
-    ab, ae = zip(*[f.ranges(isochores, base) for f, base in zip(aflats, abases)])
+    af = annotations._flat(tracks, _have=_aflat)
+    ab, ae = annotations._ranges(af, isochores)
     ws_nseg = [len(workspace[i]) for i in isochores]
     names = [c.name for c in counters]
-    r = ctx.count_lists(names, lcat, loff, len(seg_tracks), adata, np.concatenate(ab), len(tracks), ws_nseg, len(isochores),
-                        anno_end=np.concatenate(ae))
+    r = ctx.count_lists(names, lcat, loff, len(seg_tracks), af[0], ab, len(tracks), ws_nseg, len(isochores), anno_end=ae)
     for k, name in enumerate(names):
         vals = r[k].tolist()                                 # [annotation][segment track]: Python floats / ints
         counts = all_counts[k]
@@ -1116,14 +1141,15 @@ def overlap_sizes(track_segments, annotations, tracks=None, _aflat=None):
     tracks = list(annotations.tracks) if tracks is None else list(tracks)
     if not tracks or track_segments._has_points() or not track_segments._all_normalized():
         return None
-    for t in tracks:
-        d = annotations[t]
-        if d is track_segments or d._has_points() or not d._all_normalized():
-            return None
+    plain = annotations._plain_memo                    # (run(): every list of the collection looked at once per call)
+    if plain is None:
+        plain = all(not annotations[t]._has_points() and annotations[t]._all_normalized() for t in tracks)
+    if not plain or any(annotations[t] is track_segments for t in tracks):
+        return None
     fs = track_segments._flat()
-    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
-    bb, be = zip(*[f.ranges(fs.keys, base) for f, base in zip(aflats, abases)])
-    pairs, bases = _lib.intersection_sizes(fs.data, fs.off, adata, np.concatenate(bb), np.concatenate(be), len(tracks))
+    af = annotations._flat(tracks, _have=_aflat)
+    bb, be = annotations._ranges(af, fs.keys)
+    pairs, bases = _lib.intersection_sizes(fs.data, fs.off, af[0], bb, be, len(tracks))
     return dict((t, (int(p), int(b))) for t, p, b in zip(tracks, pairs.tolist(), bases.tolist()))
 
 
@@ -1165,8 +1191,10 @@ class AnnotatorResult(object):
         # the reference builds a Python list of floats and sorts it; the same numbers come out of array operations
         # without the sort (two order statistics by selection, the p-value from two counts), which is what keeps
         # 1000 tracks x 100 000 samples from spending longer here than on the GPU
-        self._samples = np.array(samples, dtype=np.float64)
-        l = len(self._samples)  # noqa: E741
+        # (with the statistics given the row is only kept; the float copy the reference holds is made when somebody asks)
+        self._raw = samples if (_stats is not None and isinstance(samples, np.ndarray)) else None
+        self._samples_cache = None if self._raw is not None else np.array(samples, dtype=np.float64)
+        l = len(samples)  # noqa: E741
         if l < 1:
             raise ValueError("no samples")
         self.observed = float(observed)
@@ -1222,6 +1250,13 @@ class AnnotatorResult(object):
         else:
             idx += n_eq
         return max(1.0 / l, float(idx) / l)
+
+    @property
+    def _samples(self):
+        if self._samples_cache is None:
+            self._samples_cache = np.array(self._raw, dtype=np.float64)
+            self._raw = None
+        return self._samples_cache
 
     @property
     def _sorted(self):

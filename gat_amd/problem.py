@@ -49,6 +49,42 @@ def from_isochores(d):
     return new
 
 
+def contig_list_lengths(dictionary):
+    """{contig: len(dictionary.fromIsochores()[contig])} (IntervalDictionary.fromIsochores, gat/Engine.pyx:2857-2876: the
+    lists of a contig's isochore keys concatenated, sorted and merge(0)d -- empty segments dropped, a segment starting at or
+    before the running end joins it, gat/SegmentList.pyx:756-816) from the dictionary's flat form, all contigs in one pass:
+    only the LENGTHS are wanted (len(workspace[contig]): the density counter's divisor, gat/Engine.pyx:1437)."""
+    f = dictionary._flat()
+    contigs, index, cid, dotted_any = [], {}, [], False
+    for k in f.keys:
+        contig, dotted = split_key(k)
+        dotted_any |= dotted
+        if contig not in index:
+            index[contig] = len(contigs)
+            contigs.append(contig)
+        cid.append(index[contig])
+    if not dotted_any:
+        # a key IS its contig (a later list of the same contig replaces an earlier one: dictionary assignment)
+        out = collections.OrderedDict()
+        for k, c, n in zip(f.keys, cid, np.diff(f.off).tolist()):
+            out[contigs[c]] = n
+        return out
+    counts = np.zeros(len(contigs), dtype=np.int64)
+    if len(f.data):
+        hi = np.repeat(np.asarray(cid, dtype=np.int64) << 32, np.diff(f.off))
+        start, end = f.data["start"].astype(np.int64), f.data["end"].astype(np.int64)
+        keep = end > start                               # merge() drops empty segments
+        ks, ke = (hi + start)[keep], (hi + end)[keep]
+        order = np.argsort(ks, kind="stable")
+        ks, ke = ks[order], ke[order]
+        if len(ks):
+            run = np.maximum.accumulate(ke)
+            head = np.ones(len(ks), dtype=bool)
+            head[1:] = ks[1:] > run[:-1]                 # (another contig's keys lie above every end of this one)
+            counts = np.bincount((ks[head] >> 32), minlength=len(contigs)).astype(np.int64)
+    return collections.OrderedDict((c, int(n)) for c, n in zip(contigs, counts.tolist()))
+
+
 def to_isochores(d, isochores, truncate):
     """IntervalDictionary.toIsochores (gat/Engine.pyx:2837-2855)."""
     out = collections.OrderedDict()
@@ -143,16 +179,32 @@ def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nb
     n_contigs = len(contigs)
     akey = (tuple(contigs), merge)
     if _shared is not None and akey in _shared:
-        contig_workspace = from_isochores((workspace if count_workspace is None else count_workspace).asArrays())
+        cws = contig_list_lengths(workspace if count_workspace is None else count_workspace)
         return dict(n_units=len(units), unit_names=list(units), segs=fs.data, seg_off=fs.off, ws=ws_cat, ws_off=ws_off,
                     unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=n_contigs, contig_names=list(contigs),
                     merge_contigs=merge, n_tracks=len(tracks), track_names=list(tracks),
                     annos=None, anno_off=None, anno_end=None, anno_group=None, annotations_key=akey,
-                    cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
+                    cws_nseg=np.array([cws.get(c, 0) for c in contigs], dtype=np.int64),
                     bucket_size=int(bucket_size), nbuckets=int(nbuckets))
-    adata, abases, aflats = annotations._flat(tracks, _have=_aflat)
+    aflat3 = annotations._flat(tracks, _have=_aflat)
+    adata, abases, aflats = aflat3
     groups, begins, ends = [], [], []
     last_keys, last_group = None, None
+    same_keys = bool(aflats) and all(f.keys is aflats[0].keys or f.keys == aflats[0].keys for f in aflats)
+    if same_keys and hasattr(annotations, "_ranges"):
+        # every track holds the same keys: one group table, the ranges from the collection (kept over a run())
+        f = aflats[0]
+        g, dotted_t = [], False
+        for k in f.keys:
+            contig, dotted = split_key(k)
+            dotted_t |= dotted
+            g.append(contig_index.get(contig, -1))
+        if f.keys and dotted_t != bool(merge) and len(adata):
+            return None
+        g = np.array(g, dtype=np.int64)
+        gt = np.where(g >= 0, g[None, :] + (np.arange(len(aflats), dtype=np.int64) * n_contigs)[:, None], -1).ravel()
+        rb, re_ = annotations._ranges(aflat3, f.keys)
+        groups, begins, ends, aflats = [gt], [rb], [re_], []
     for t, (f, base) in enumerate(zip(aflats, abases.tolist())):
         if f.keys is not last_keys and f.keys != last_keys:
             g, dotted_t = [], False
@@ -166,14 +218,14 @@ def flatten_dictionaries(segs, workspace, annotations, tracks, bucket_size=0, nb
         groups.append(np.where(last_group >= 0, last_group + t * n_contigs, -1))
         begins.append(f.off[:-1] + base)
         ends.append(f.off[1:] + base)
-    contig_workspace = from_isochores((workspace if count_workspace is None else count_workspace).asArrays())
+    cws = contig_list_lengths(workspace if count_workspace is None else count_workspace)
     cat = (lambda xs, dt: np.concatenate(xs).astype(dt, copy=False) if xs else np.zeros(0, dtype=dt))
     return dict(n_units=len(units), unit_names=list(units), segs=fs.data, seg_off=fs.off, ws=ws_cat, ws_off=ws_off,
                 unit_contig=np.array(unit_contig, dtype=np.int32), n_contigs=n_contigs, contig_names=list(contigs),
                 merge_contigs=merge, n_tracks=len(tracks), track_names=list(tracks),
                 annos=adata, anno_off=cat(begins, np.int64), anno_end=cat(ends, np.int64), anno_group=cat(groups, np.int32),
                 annotations_key=akey,
-                cws_nseg=np.array([len(contig_workspace.get(c, iv.EMPTY)) for c in contigs], dtype=np.int64),
+                cws_nseg=np.array([cws.get(c, 0) for c in contigs], dtype=np.int64),
                 bucket_size=int(bucket_size), nbuckets=int(nbuckets))
 
 

@@ -105,7 +105,16 @@ typedef struct {
   const int32_t* anno_group;
   double mean_segment_length;   /* of the segments that will be counted against them, 0 if unknown: picks the form of  */
                                 /* the merged index (speed only, never a result)                                       */
+  int32_t flags;                /* GAT_ANNOTATIONS_ASYNC or 0                                                           */
 } gat_annotations_desc;
+
+/* gat_annotations_create returns at once and a thread of the library builds the tables (its own stream and staging
+ * buffer): the arrays of the desc must stay valid until gat_annotations_wait -- or a gat_wait of a call counted against the
+ * object -- has returned.  A problem made against such an object can be sampled straight away: gat_sample_and_count_enqueue
+ * puts the sampler's kernels on the stream and the count kernels follow when the tables are there (at the latest in
+ * gat_wait).  Errors of the build are reported by the call that first needs the tables.  Honoured where the shape alone
+ * tells which count kernel will run (four tracks or more); otherwise the build is synchronous. */
+#define GAT_ANNOTATIONS_ASYNC 1
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
  * ctx stream; counts summed over all (sample, unit) work units of the call).  ms_total and ms_count_main are always
@@ -178,6 +187,7 @@ void gat_problem_destroy(gat_problem* p);
  * index of all tracks): the part of gat_problem_create that does not depend on the segment track.  Problems created with
  * desc->annotations = this object share it; it may be destroyed before them (it lives until the last one is gone). */
 int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* desc, gat_annotations** out);
+int gat_annotations_wait(gat_ctx* ctx, gat_annotations* a);      /* an asynchronous build has finished; its error, if any */
 void gat_annotations_destroy(gat_annotations* a);
 
 /* ---- the batch seam ---------------------------------------------------------------------
@@ -261,6 +271,11 @@ int gat_count_list_ranges(gat_ctx* ctx, const int32_t* counter_ids, int n_counte
 int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off, int32_t n_groups,
                            const gat_segment* b, const int64_t* b_begin, const int64_t* b_end, int32_t n_tracks,
                            int64_t* pairs_out, int64_t* bases_out);
+
+/* Sum of the segment lengths of every list a[begin[l] .. end[l]): SegmentList.sum() (gat/SegmentList.pyx:1607-1614, a
+ * Position -- uint32 -- accumulator per list), for the *_size columns of the result rows (AnnotatorResultExtended,
+ * gat/Engine.pyx:1911-1928) of a run over 10^4 lists.  Host arithmetic on the inputs, like gat_intersection_sizes. */
+int gat_list_sums(const gat_segment* a, const int64_t* begin, const int64_t* end, int64_t n_lists, int64_t* sums_out);
 
 /* ---- the reference's own random stream ---------------------------------------------------
  * scripts/gat-run.py:267-271 seeds numpy's global generator ONCE and every (sample, unit) of the run -- in the order of

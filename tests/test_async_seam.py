@@ -149,3 +149,51 @@ def test_context_closed_before_its_problem():
     assert np.array_equal(got[0], want[0])
     c.close()
     P.close()
+
+
+@pytest.mark.parametrize("n_tracks,isochores", [(6, True), (5, False), (2, True)])
+def test_annotation_tables_built_while_the_device_samples(ctx, n_tracks, isochores):
+    """gat_annotations_create with GAT_ANNOTATIONS_ASYNC: the problem is sampled at once, the count kernels follow when the
+    tables are there; fewer than four tracks: the build is synchronous (the count kernel's route is not known beforehand).
+    Two segment tracks share the object."""
+    rs = np.random.RandomState(100 + n_tracks)
+    flat = _random_problem(rs, 4, 400, n_tracks, isochores)
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    S = 64
+    want, _ = O.run_samples(flat, counters, 17, 1, 0, S)
+    A = _lib.Annotations(ctx, flat, mean_segment_length=60.0, asynchronous=True)
+    units = dict(flat)
+    for k in ("annos", "anno_off", "anno_end", "anno_group"):
+        units[k] = None
+    P1, P2 = _lib.Problem(ctx, units, annotations=A), _lib.Problem(ctx, units, annotations=A)
+    got1, st = _enqueue_wait(ctx, P1, counters, 17, 0, S)
+    A.close()                                               # (the problems keep it alive)
+    got2 = P2.sample_and_count(counters + ["segment-overlap"], 17, 0, S)
+    for k, c in enumerate(counters):
+        assert np.array_equal(got1[k], want[k]), c
+        assert np.array_equal(got2[k], want[k]), c
+    assert P1.info()["algorithmic_bytes_per_sample"] == _lib.Problem(ctx, flat).info()["algorithmic_bytes_per_sample"]
+    P1.close()
+    P2.close()
+
+
+def test_an_error_of_the_asynchronous_build_is_reported_by_the_call_that_needs_the_tables(ctx):
+    rs = np.random.RandomState(3)
+    flat = dict(_random_problem(rs, 3, 200, 5, False))
+    annos = np.array(flat["annos"], copy=True)
+    lo = int(flat["anno_off"][2])
+    assert flat["anno_off"][3] - lo >= 2
+    annos[lo + 1]["start"] = annos[lo]["start"]            # list 2 is no longer normalized
+    flat["annos"] = annos
+    A = _lib.Annotations(ctx, flat, asynchronous=True)
+    units = dict(flat, annos=None, anno_off=None)
+    P = _lib.Problem(ctx, units, annotations=A)
+    dev = ctx.alloc(P.n_tracks * 8 * 8)
+    with pytest.raises(AssertionError):                     # (by the enqueue already if the build has finished by then)
+        P.enqueue(["nucleotide-overlap"], 1, 0, 8, dev)     # the sampler's kernels are on their way
+        P.wait()
+    with pytest.raises(AssertionError):
+        A.wait()
+    ctx.free(dev)
+    P.close()
+    A.close()
