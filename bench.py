@@ -164,11 +164,19 @@ class Workload(object):
         self.P = _lib.Problem(self.ctx, self.flat)
         self.info = self.P.info()
         K, A = len(self.counters), self.flat["n_tracks"]
-        self.counts = torch.zeros((K, A, S), dtype=torch.int64, device=self.dev)
-        self.counts_ptr = self.counts.data_ptr()
-        self.gathered = torch.zeros((world * K, A, S), dtype=torch.int64, device=self.dev) if world > 1 else None
+        # The step's tail -- the ONE all-gather of the count matrix (N > 1) and its read-back -- runs on a second stream while
+        # the next step's kernels run on the first: the count matrix, the gathered matrix and the host's copy exist twice, a
+        # step's kernels wait (an event) for the tail that read their buffer two steps earlier.  Every step's matrix still
+        # reaches the host inside the timed region (the region ends with a device-wide synchronisation).
+        self.counts = [torch.zeros((K, A, S), dtype=torch.int64, device=self.dev) for _ in range(2)]
+        self.counts_ptr = [c.data_ptr() for c in self.counts]
+        self.gathered = [torch.zeros((world * K, A, S), dtype=torch.int64, device=self.dev) for _ in range(2)] if world > 1 else None
         # the matrix a host consumer gets: pinned, filled inside the timed region (rank 0 holds all ranks' columns)
-        self.host = torch.empty((world * K, A, S), dtype=torch.int64, pin_memory=True) if rank == 0 else None
+        self.host = [torch.empty((world * K, A, S), dtype=torch.int64, pin_memory=True) for _ in range(2)] if rank == 0 else None
+        self.tail_stream = torch.cuda.Stream(device=self.dev)
+        self.tail_done = [None, None]
+        self.n_step = 0
+        self.last = 0
 
     def step(self, i, begin=None):
         import torch
@@ -176,15 +184,25 @@ class Workload(object):
         # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
         if begin is None:
             begin = (i * self.world + self.rank) * self.S
-        st = self.P.sample_and_count_device(self.counters, self.args.seed, begin, begin + self.S, self.counts_ptr)
-        # (the workload's stream is torch's current stream -- set once in __init__, not entered per step: the context
-        #  manager costs a step ~10 us)
-        src = self.counts
-        if self.world > 1:
-            dist.all_gather_into_tensor(self.gathered, self.counts)
-            src = self.gathered
-        if self.host is not None:
-            self.host.copy_(src, non_blocking=True)
+        b = self.n_step & 1
+        self.n_step += 1
+        if self.tail_done[b] is not None:
+            self.stream.wait_event(self.tail_done[b])           # (the tail of two steps ago has read this buffer)
+        # the batch seam in its two halves: the host is free between them (here it has nothing else to do)
+        self.P.enqueue(self.counters, self.args.seed, begin, begin + self.S, self.counts_ptr[b])
+        st = self.P.wait()
+        # (wait() returns when the step's kernels have completed: the tail needs no event of theirs)
+        with torch.cuda.stream(self.tail_stream):
+            src = self.counts[b]
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.gathered[b], self.counts[b])
+                src = self.gathered[b]
+            if self.host is not None:
+                self.host[b].copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.tail_stream)
+            self.tail_done[b] = ev
+        self.last = b
         return st
 
     KEYS = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
@@ -266,9 +284,9 @@ class Workload(object):
             t1 = time.perf_counter()
             with torch.cuda.stream(self.stream):
                 for _ in range(5):
-                    dist.all_gather_into_tensor(self.gathered, self.counts)
+                    dist.all_gather_into_tensor(self.gathered[0], self.counts[0])
             torch.cuda.synchronize()
-            allgather = {"avg_ms": (time.perf_counter() - t1) / 5 * 1e3, "bytes_per_rank": int(self.counts.numel() * 8),
+            allgather = {"avg_ms": (time.perf_counter() - t1) / 5 * 1e3, "bytes_per_rank": int(self.counts[0].numel() * 8),
                          "collective": "RCCL all_gather_into_tensor", "backend": dist.get_backend(),
                          "world_size": dist.get_world_size()}
         out = self.report(steps, warmup, dt, acc, allgather, acck, ksteps)
@@ -372,8 +390,9 @@ class Workload(object):
                                     flat["n_contigs"], S, self.counters[0]),
                        "samples_per_step_per_gpu": S,
                        "sharding": "samples, contiguous ranges per rank; one RCCL all-gather",
-                       "timed_region": "sampling + counting + all-gather (N > 1) + D2H of the count matrix (%d bytes)"
-                                       % (self.host.numel() * 8 if self.host is not None else 0)},
+                       "timed_region": "sampling + counting + all-gather (N > 1) + D2H of the count matrix (%d bytes); a step's "
+                                       "all-gather and D2H run on a second stream beside the next step's kernels"
+                                       % (self.host[0].numel() * 8 if self.host is not None else 0)},
             "roofline": roof,
             "kernels": {"k_rng_ms": acck["ms_rng"] / ksteps, "k_place_ms": acck["ms_place"] / ksteps,
                         "k_merge_ms": acck["ms_merge"] / ksteps, "k_tail_ms": acck["ms_ktail"] / ksteps,
@@ -526,7 +545,7 @@ def main():
         import numpy as np
         torch.cuda.synchronize()
         last = args.warmup + args.steps - 1 + (main_out.get("sustained") or {}).get("steps", 0)
-        np.savez(args.dump_counts, counts=W.host.numpy(), samples_per_rank=W.S, world=world, seed=args.seed,
+        np.savez(args.dump_counts, counts=W.host[W.last].numpy(), samples_per_rank=W.S, world=world, seed=args.seed,
                  first_sample=last * world * W.S)
     if rank == 0 and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(W.flat, W.counters, args.seed, args.cpu_seconds)

@@ -43,6 +43,13 @@ def _dist_state():
     return 0, 1, None
 
 
+def _force_collective_path():
+    """GAT_FORCE_COLLECTIVE_PATH=1 (tests): a process group of ONE rank takes the multi-rank path -- sharding, the all-gather,
+    the read-back on demand -- so that a one-GPU box runs that code over RCCL"""
+    import os
+    return os.environ.get("GAT_FORCE_COLLECTIVE_PATH") == "1"
+
+
 _NUMPY_MODEL_OK = None
 
 
@@ -193,7 +200,7 @@ def _sample_start(segs, annotations, workspace, sampler, counters, num_samples, 
             shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean, asynchronous=True)
     job.P = _lib.Problem(ctx, flat, annotations=shared_annos)
     rank, world, _ = _dist_state()
-    if world == 1 and mt_state is None and num_samples > 0:
+    if world == 1 and mt_state is None and num_samples > 0 and not _force_collective_path():
         try:
             job.dev = ctx.alloc(len(names) * len(tracks) * num_samples * 8)
             job.P.enqueue(names, seed, 0, num_samples, job.dev)
@@ -244,7 +251,7 @@ def _sample_finish(job, stat_vals=None):
                 raise NotImplementedError("reference_stream: the sampled lists are not kept (counts only)")
             local = P.sample_and_count_serial(names, mt_state, num_samples)
             begin, end = 0, num_samples
-        elif world > 1 and backend == "nccl":
+        elif backend == "nccl" and (world > 1 or _force_collective_path()):
             local, stats = _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples, world,
                                                   device_stats if want_stats else None)
         else:
@@ -278,29 +285,83 @@ def _sample_finish(job, stat_vals=None):
     return job.result
 
 
+class _DeviceCounts(object):
+    """the gathered count matrix [counter][track][sample] where the collective left it -- on the device.  Rank 0 reads it
+    back at once (it writes the count files); the other ranks hold rows that fetch it when somebody asks for their samples
+    (the statistics of the rows come from the device: gat_null_stats)."""
+
+    def __init__(self, tensor, names):
+        self.tensor, self.names, self.host = tensor, names, None
+
+    def fetch(self):
+        if self.host is None:
+            full = self.tensor.cpu().numpy()
+            self.host = [full[k].view(np.float64) if n == "nucleotide-density" else full[k] for k, n in enumerate(self.names)]
+            self.tensor = None
+        return self.host
+
+    def rows(self, k, n_rows, lazy):
+        if not lazy:
+            return self.fetch()[k]
+        return [_DeviceRow(self, k, a) for a in range(n_rows)]
+
+
+class _DeviceRow(object):
+    """one row of a _DeviceCounts matrix: numpy.array(row) reads the matrix back (once for all rows)"""
+    __slots__ = ("owner", "k", "a")
+
+    def __init__(self, owner, k, a):
+        self.owner, self.k, self.a = owner, k, a
+
+    def __len__(self):
+        t = self.owner.tensor
+        return int(t.shape[-1]) if t is not None else len(self.owner.host[self.k][self.a])
+
+    def __array__(self, dtype=None, copy=None):
+        r = self.owner.fetch()[self.k][self.a]
+        return r.astype(dtype) if dtype is not None else r
+
+    def __iter__(self):
+        return iter(self.__array__())
+
+    def __getitem__(self, i):
+        return self.__array__()[i]
+
+
 def _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples, world, device_stats):
     """torch.distributed with the nccl backend (= RCCL): the shard's matrix stays on the device, ONE all-gather of device
-    memory (the collation of the reference's pool, gat/__init__.py:694-700, :770-774), one read-back."""
+    memory (the collation of the reference's pool, gat/__init__.py:694-700, :770-774), the statistics taken where the
+    gathered matrix is, ONE read-back -- on rank 0; the other ranks read theirs when their rows' samples are asked for.
+
+    Every rank computes the same number of samples, ceil(num_samples / world) from rank * that on: the last ranks' surplus
+    samples (ids at or beyond num_samples: streams like any other) fall off the end of the gathered matrix, no rank has an
+    empty shard, and the blocks need no padding.  The library's stream is ordered against torch's with events (no
+    device-wide synchronisation): torch.cuda.ExternalStream around the context's stream."""
     import torch
+    import torch.distributed as dist
     from . import distributed
+    rank = dist.get_rank() if dist.is_initialized() else 0
     per = distributed.padded_shard(num_samples, world)
     dev = torch.device("cuda", ctx.device)
-    # (the context runs on a stream of its own: what torch enqueues -- the fills, the collective, the re-ordering of the
-    #  gathered blocks -- is ordered against it by hand, both ways)
-    shard = torch.zeros((len(names), len(tracks), max(1, end - begin)), dtype=torch.int64, device=dev)
-    torch.cuda.current_stream(dev).synchronize()              # the fill has landed before the kernels write
-    if end > begin:                                           # (a rank whose shard is empty still takes part in the gather)
-        P.sample_and_count_device(names, seed, begin, end, shard.data_ptr())   # (returns after its stream has drained)
-    stack_t = torch.zeros((len(names), len(tracks), per), dtype=torch.int64, device=dev)
-    if end > begin:
-        stack_t[:, :, :end - begin] = shard[:, :, :end - begin]
-    full_t = distributed.allgather_counts(stack_t, num_samples)
+    K, A = len(names), len(tracks)
+    lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+    cur = torch.cuda.current_stream(dev)
+    shard = torch.empty((K, A, per), dtype=torch.int64, device=dev)
+    gathered = torch.empty((world * K, A, per), dtype=torch.int64, device=dev)
+    lib_stream.wait_stream(cur)                               # (whatever torch still runs on memory it hands out here)
+    P.sample_and_count_device(names, seed, rank * per, (rank + 1) * per, shard.data_ptr())
+    cur.wait_stream(lib_stream)
+    dist.all_gather_into_tensor(gathered, shard)
+    # [G, K, A, per] -> [K, A, G * per], the surplus of the last ranks cut off: the one device copy of the path
+    full_t = gathered.view(world, K, A, per).permute(1, 2, 0, 3).reshape(K, A, world * per)[..., :num_samples].contiguous()
     stats = None
     if device_stats is not None:
-        torch.cuda.current_stream(dev).synchronize()          # gathered and re-ordered before k_null_stats reads
+        lib_stream.wait_stream(cur)                           # gathered and re-ordered before k_null_stats reads
         stats = device_stats(full_t.data_ptr())
-    full = full_t.cpu().numpy()
-    return [full[k].view(np.float64) if names[k] == "nucleotide-density" else full[k] for k in range(len(names))], stats
+        full_t.record_stream(lib_stream)
+    counts = _DeviceCounts(full_t, names)
+    lazy = device_stats is not None and rank != 0
+    return [counts.rows(k, A, lazy) for k in range(K)], stats
 
 
 def sample_counts(segs, annotations, workspace, sampler, counters, num_samples, seed, ctx=None,

@@ -25,7 +25,7 @@ COUNTER_IDS = {
 
 # every symbol include/gat_mi355.h declares
 SYMBOLS = [
-    "gat_ctx_create", "gat_ctx_destroy", "gat_last_error", "gat_version", "gat_ctx_synchronize", "gat_ctx_set_kernel_times",
+    "gat_ctx_create", "gat_ctx_destroy", "gat_last_error", "gat_version", "gat_ctx_synchronize", "gat_ctx_stream", "gat_ctx_set_kernel_times",
     "gat_dev_alloc", "gat_dev_free", "gat_memcpy_d2h", "gat_memcpy_h2d",
     "gat_problem_create", "gat_problem_destroy", "gat_sample_and_count", "gat_sample", "gat_sample_units",
     "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
@@ -145,6 +145,8 @@ def lib():
     L.gat_version.argtypes = []
     L.gat_ctx_synchronize.restype = C.c_int
     L.gat_ctx_synchronize.argtypes = [vp]
+    L.gat_ctx_stream.restype = vp
+    L.gat_ctx_stream.argtypes = [vp]
     L.gat_ctx_set_kernel_times.restype = C.c_int
     L.gat_ctx_set_kernel_times.argtypes = [vp, C.c_int]
     L.gat_dev_alloc.restype = C.c_int
@@ -245,6 +247,11 @@ class Context(object):
 
     def synchronize(self):
         _check(lib().gat_ctx_synchronize(self._h), self._h)
+
+    def stream_handle(self):
+        """the hipStream_t the context enqueues on, as an integer (torch.cuda.ExternalStream(handle) orders torch's work
+        against the library's with events, no device-wide synchronisation)"""
+        return int(lib().gat_ctx_stream(self._h) or 0)
 
     def set_kernel_times(self, on):
         """per-kernel device times in the statistics of a call (ms_rng, ms_place, ...): off by default, an event behind

@@ -132,6 +132,8 @@ extern "C" int gat_ctx_set_kernel_times(gat_ctx* ctx, int on) {
   return GAT_OK;
 }
 
+extern "C" void* gat_ctx_stream(const gat_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 extern "C" int gat_ctx_synchronize(gat_ctx* ctx) {
   if (!ctx) return set_err(nullptr, GAT_ERR_ARG, "ctx is NULL");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -48,11 +48,23 @@ def gather_numpy(local_np, n_total, group=None):
     import torch.distributed as dist
     t = torch.from_numpy(np.ascontiguousarray(local_np))
     if dist.is_initialized() and dist.get_backend(group) == "nccl":
-        global _HOST_GROUP
-        if _HOST_GROUP is None:
-            _HOST_GROUP = dist.new_group(backend="gloo")         # (collective: every rank gets here together)
-        return allgather_counts(t, n_total, _HOST_GROUP).numpy()
+        return allgather_counts(t, n_total, _host_group(group)).numpy()
     return allgather_counts(t, n_total, group).numpy()
 
 
-_HOST_GROUP = None
+_HOST_GROUPS = {}
+
+
+def _host_group(group):
+    """a gloo group of the ranks of `group` (None: the world), made once per group and process-group generation: new_group
+    is a collective over the WORLD, so a sub-group's members alone cannot make it -- a host matrix under an nccl sub-group is
+    refused instead of hanging"""
+    import torch.distributed as dist
+    world_pg = dist.group.WORLD
+    if not (group is None or group is world_pg):
+        raise NotImplementedError("gather_numpy under an nccl SUB-group: create a gloo group of its ranks on every rank of "
+                                  "the world (torch.distributed.new_group is a world collective) and pass that")
+    entry = _HOST_GROUPS.get("world")
+    if entry is None or entry[0] is not world_pg:                        # (none yet, or one of a destroyed process group)
+        entry = _HOST_GROUPS["world"] = (world_pg, dist.new_group(backend="gloo"))   # (collective: every rank gets here together)
+    return entry[1]

@@ -1192,7 +1192,7 @@ class AnnotatorResult(object):
         # without the sort (two order statistics by selection, the p-value from two counts), which is what keeps
         # 1000 tracks x 100 000 samples from spending longer here than on the GPU
         # (with the statistics given the row is only kept; the float copy the reference holds is made when somebody asks)
-        self._raw = samples if (_stats is not None and isinstance(samples, np.ndarray)) else None
+        self._raw = samples if (_stats is not None and (isinstance(samples, np.ndarray) or hasattr(samples, "__array__"))) else None
         self._samples_cache = None if self._raw is not None else np.array(samples, dtype=np.float64)
         l = len(samples)  # noqa: E741
         if l < 1:

@@ -163,6 +163,10 @@ void gat_ctx_destroy(gat_ctx* ctx);
 const char* gat_last_error(const gat_ctx* ctx);      /* ctx may be NULL: last error of the thread */
 const char* gat_version(void);
 int gat_ctx_synchronize(gat_ctx* ctx);
+/* the hipStream_t the context's work is enqueued on (the one given to gat_ctx_create, or its private stream): a host that
+ * runs other work on the device -- a collective over the count matrix, a copy -- orders it against the library's with
+ * events on this stream instead of synchronising the device */
+void* gat_ctx_stream(const gat_ctx* ctx);
 /* per-kernel device times in gat_stats (see there) on / off; off by default.  GAT_KERNEL_TIMES=1 in the environment
  * switches them on for every context. */
 int gat_ctx_set_kernel_times(gat_ctx* ctx, int on);

@@ -108,6 +108,46 @@ def test_c_abi_allgather_counts_single_rank():
         ctx.close()
 
 
+def _worker_nccl_one_rank(rank, world, port, path, device_stats):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    os.environ["GAT_DEVICE_STATS"] = "1" if device_stats else "0"
+    os.environ["GAT_FORCE_COLLECTIVE_PATH"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import gat_amd
+    segments, annotations, workspace = _collections()
+    counters = [gat_amd.CounterNucleotideOverlap(), gat_amd.CounterNucleotideDensity(), gat_amd.CounterSegmentOverlap()]
+    res = gat_amd.run(segments, annotations, workspace, gat_amd.SamplerAnnotator(bucket_size=0), counters,
+                      gat_amd.UnconditionalWorkspace(), num_samples=37, random_seed=5,
+                      output_counts_pattern=os.path.join(path, "fcounts_%s.tsv"))
+    with open(os.path.join(path, "forced_rows.txt"), "w") as f:
+        f.write("\n".join(str(r) for r in res))
+    np.save(os.path.join(path, "forced_samples.npy"), np.array([r.samples for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_stats", [True, False])
+def test_the_collective_path_over_rccl_with_one_rank(tmp_path, device_stats):
+    """the code run() takes under the nccl backend -- the library's stream ordered against torch's by events, equal shards,
+    the all-gather of device memory over RCCL, statistics from the gathered matrix, rows that read it back on demand -- with a
+    process group of ONE rank (RCCL refuses two ranks on this box's one GPU): same rows, same samples, same count files."""
+    mp.spawn(_worker_nccl_one_rank, args=(1, _free_port(), str(tmp_path), device_stats), nprocs=1, join=True)
+    rows = open(str(tmp_path / "forced_rows.txt")).read().split("\n")
+    os.environ["GAT_DEVICE_STATS"] = "0"
+    try:
+        assert rows == _run(37, 5, os.path.join(str(tmp_path), "pcounts_%s.tsv"))
+    finally:
+        del os.environ["GAT_DEVICE_STATS"]
+    assert np.load(str(tmp_path / "forced_samples.npy")).shape == (9, 37)
+    for name in ("nucleotide-overlap", "nucleotide-density", "segment-overlap"):
+        assert open(str(tmp_path / ("fcounts_%s.tsv" % name))).read() == open(str(tmp_path / ("pcounts_%s.tsv" % name))).read()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # RCCL with more than one rank: these run the moment a box shows two GPUs (the boxes this suite usually sees have one,
 # where RCCL refuses two ranks on a device and the tests above stand in with gloo).
@@ -152,7 +192,7 @@ def test_c_abi_allgather_counts_two_ranks(tmp_path):
         assert np.array_equal(np.load(str(tmp_path / ("abi%d.npy" % r))), want), r
 
 
-def _worker_nccl(rank, world, port, path, seed, device_stats):
+def _worker_nccl(rank, world, port, path, seed, device_stats, num_samples=37):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -161,7 +201,7 @@ def _worker_nccl(rank, world, port, path, seed, device_stats):
     os.environ["GAT_DEVICE_STATS"] = "1" if device_stats else "0"
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
-    rows = _run(37, seed)
+    rows = _run(num_samples, seed)
     with open(os.path.join(path, "nccl_rows%d.txt" % rank), "w") as f:
         f.write("\n".join(rows))
     dist.barrier()
@@ -169,17 +209,18 @@ def _worker_nccl(rank, world, port, path, seed, device_stats):
 
 
 @needs_two_gpus
-@pytest.mark.parametrize("device_stats", [True, False])
-def test_run_under_nccl_equals_single_process(tmp_path, device_stats):
+@pytest.mark.parametrize("device_stats,num_samples", [(True, 37), (False, 37), (True, 1)])
+def test_run_under_nccl_equals_single_process(tmp_path, device_stats, num_samples):
     """gat_amd.run() under the nccl backend (= RCCL): two ranks, one GPU each, shard the samples, all-gather the device
-    matrix, take the statistics from it (on the device, or with numpy) and print the rows one process prints."""
-    mp.spawn(_worker_nccl, args=(2, _free_port(), str(tmp_path), 5, device_stats), nprocs=2, join=True)
+    matrix, take the statistics from it (on the device, or with numpy) and print the rows one process prints.  One sample
+    over two ranks: the second rank's shard lies beyond the job (every rank computes a full shard; the surplus is cut off)."""
+    mp.spawn(_worker_nccl, args=(2, _free_port(), str(tmp_path), 5, device_stats, num_samples), nprocs=2, join=True)
     r0 = open(str(tmp_path / "nccl_rows0.txt")).read().split("\n")
     r1 = open(str(tmp_path / "nccl_rows1.txt")).read().split("\n")
     assert r0 == r1 and len(r0) == 9
     os.environ["GAT_DEVICE_STATS"] = "0"
     try:
-        assert r0 == _run(37, 5)
+        assert r0 == _run(num_samples, 5)
     finally:
         del os.environ["GAT_DEVICE_STATS"]
 
