@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 METRIC = "Monte Carlo samples/sec + bit-exact p-values, 10k sims, hg19-sized workspace"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6290.0    # ... 6.29 TB/s measured with a float4 copy
+L2_PEAK_GBPS = 34500.0          # ... 34.5 TB/s aggregate L2 bandwidth (128-byte lines)
 # samples per GPU per step of the extra shapes: config3 = its own 10 000; config4 is an 8-GPU job of 12 500 samples per
 # GPU, config5 one of 125 000 per GPU: a rank's whole shard per step (the library cuts it into batches that fit its
 # scratch budget)
@@ -135,13 +136,21 @@ def counters_profile(config, S):
     """what the committed rocprofv3 passes of this command say about the kernels of (config, S): HBM-side bytes
     (FETCH_SIZE / WRITE_SIZE, separate --pmc passes, gfx950 FETCH correction applied) and VALU issue share.
     Produced by tools/summarize_profiles.py from gpurun_out/; NOT measured in this run -- the source is named."""
-    for fn in ("r03_kernel_counters.json", "r02_kernel_counters.json", "r01_count_kernel_traffic.json"):
-        path = os.path.join(ROOT, "profiles", fn)
-        if not os.path.exists(path):
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("gat_kernels.h", "gat_tail.h", "gat_device.h", "gat_stats.h", "gat_types.h"):
+        h.update(open(os.path.join(ROOT, "gat_amd", "csrc", fn), "rb").read())
+    sha = h.hexdigest()[:16]
+    # only counters collected from THESE kernels are quoted (the summary carries the hash of the kernel sources it was
+    # collected from, tools/summarize_profiles.py): the newest such file, none if the kernels have changed since
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_counters.json")), reverse=True):
+        data = json.load(open(path))
+        if (data.get("_meta") or {}).get("kernel_sources_sha") != sha:
             continue
-        rec = json.load(open(path)).get("%s:%d" % (config, S))
+        rec = data.get("%s:%d" % (config, S))
         if rec:
-            return rec, "profiles/" + fn
+            return rec, "profiles/" + os.path.basename(path)
     return None, None
 
 
@@ -184,6 +193,7 @@ class Workload(object):
         # rank r owns sample ids [ (i*world + r)*S, +S ): disjoint ranges, no data-path collective but the gather
         if begin is None:
             begin = (i * self.world + self.rank) * self.S
+            self.last_first = i * self.world * self.S            # (first sample id of the step over all ranks: --dump-counts)
         b = self.n_step & 1
         self.n_step += 1
         if self.tail_done[b] is not None:
@@ -206,7 +216,7 @@ class Workload(object):
         return st
 
     KEYS = ("ms_sampler", "ms_contig", "ms_count", "ms_count_main", "ms_rng", "ms_place", "ms_merge", "ms_tail",
-            "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_tail_units",
+            "ms_ktail", "ms_finalize", "n_placed", "n_draws", "n_retried", "n_full_units", "n_resumed_units", "n_tail_units",
             "n_index_entries", "n_index_lookups", "n_batches", "ms_total")
 
     def timed(self, steps, first_step, acc=None):
@@ -331,10 +341,10 @@ class Workload(object):
             roof["algorithmic_bytes_per_sample"] = moved / max(1, S)
             achieved = moved / count_s / 1e9 if count_s > 0 else 0.0
             roof["achieved"], roof["frac"] = achieved, achieved / HBM_PEAK_GBPS
-            roof["note"] = ("bound by the rate at which the L2s serve its gathers (l2_request_frac), not by HBM: achieved/frac = the "
-                            "bytes the algorithm moves (segments once + the index words its scans read, counted by the kernel, + "
-                            "partials) / kernel time against the HBM peak; contract_GBps is SURVEY 8d's figure (every annotation "
-                            "interval charged once per sample), which this algorithm never moves")
+            roof["note"] = ("bound by the rate at which the L2s serve its gathers, not by HBM: achieved / peak / frac are L2 requests x "
+                            "128 B over the kernel's time against the L2s' 34.5 TB/s; own_model_GBps = the bytes the algorithm moves "
+                            "(segments once + the index words its scans read, counted by the kernel, + partials); contract_GBps is "
+                            "SURVEY 8d's figure (every annotation interval charged once per sample), which this algorithm never moves")
             roof["lookups_per_s"] = lookups / count_s if count_s > 0 else 0.0
             # L2 requests: one per segment load (16 lanes x 8 B = a 128-byte line) and, per look-up, what the scan's form
             # asks for -- a 32-byte cell record (+ a pair per two entries behind the first two), or a grid cell + a pair per
@@ -354,7 +364,16 @@ class Workload(object):
                 per_lookup = 1.0 + ent / 2.0 + 0.5                    # the cell + pairs
             reqs = lookups / 16.0 + lookups * per_lookup
             roof["l2_requests_per_launch_model"] = reqs
-            roof["l2_request_frac"] = min(1.0, reqs / count_s / (34500.0e9 / 128.0)) if count_s > 0 else 0.0
+            # bound "l2": achieved / peak / frac are L2 figures -- requests x 128-byte lines over the kernel's time against the
+            # 34.5 TB/s the L2s deliver.  Live: the request MODEL above from the kernel's own counters (an upper bound);
+            # the committed TCC_REQ counters of this command, when they belong to these kernels, replace it below.  What
+            # the algorithm moves against the HBM peak stays beside it as own_model_* (never a roofline fraction: those
+            # bytes are served by the L2s)
+            roof["own_model_GBps"], roof["own_model_frac_of_hbm_peak"] = achieved, achieved / HBM_PEAK_GBPS
+            l2_gbps = reqs * 128.0 / count_s / 1e9 if count_s > 0 else 0.0
+            roof["achieved"], roof["peak"], roof["frac"] = l2_gbps, L2_PEAK_GBPS, l2_gbps / L2_PEAK_GBPS
+            roof["achieved_source"] = "model: L2 requests derived from the kernel's own look-up / index-word counters of this run"
+            roof["l2_request_frac"] = min(1.0, l2_gbps / L2_PEAK_GBPS)
         prof, src = counters_profile(self.name, S) if self.args.scale == 1.0 else (None, None)
         k = (prof or {}).get("count_kernel")
         if k and "fetch_kib_per_launch" in k and "write_kib_per_launch" in k:
@@ -377,7 +396,18 @@ class Workload(object):
                 # requests x 128-byte lines against the 34.5 TB/s the L2s deliver (MI355X_MICROARCH.md, L2)
                 roof["l2_GBps"] = k["l2_requests_per_launch"] * 128.0 / count_s / 1e9
                 roof["l2_hit_rate"] = k.get("l2_hit_rate")
-                roof["l2_frac_of_peak"] = roof["l2_GBps"] / 34500.0
+                roof["l2_frac_of_peak"] = roof["l2_GBps"] / L2_PEAK_GBPS
+                if merged:
+                    roof["model_GBps"] = roof["achieved"]
+                    roof["achieved"], roof["frac"] = roof["l2_GBps"], roof["l2_frac_of_peak"]
+                    roof["achieved_source"] = "TCC_REQ_sum x 128 B of %s over this run's kernel time" % src
+        step = (prof or {}).get("step")
+        step_block = None
+        if step and step.get("hbm_bytes"):
+            # the whole step against the HBM: every kernel's counter bytes (FETCH corrected per kernel, see
+            # tools/summarize_profiles.py) over this run's time per step
+            step_block = {"hbm_bytes": step["hbm_bytes"], "hbm_GBps": step["hbm_bytes"] / (dt / steps) / 1e9,
+                          "hbm_frac": step["hbm_bytes"] / (dt / steps) / 1e9 / HBM_PEAK_GBPS, "source": src}
         out = {
             "value": S * steps * world / dt,
             "unit": "samples/s",
@@ -410,6 +440,8 @@ class Workload(object):
                         "kernel_samples_per_s": S * ksteps / samp_s if samp_s else 0.0,
                         "contig_kernel_avg_ms": acck["ms_contig"] / ksteps,
                         "units_retried": acc["n_retried"], "units_run_in_full": acc["n_full_units"],
+                        "units_resumed_out_of_rows": acc["n_resumed_units"],
+                        "rows_generated_per_draw_consumed": (self.P.rows_per_sample() * float(self.S) * steps / acc["n_draws"]) if acc["n_draws"] else None,
                         "units_finished_by_k_tail": acc["n_tail_units"],
                         "batches_per_step": acc["n_batches"] / steps,
                         # wall time of a step against what its kernels took on the stream (HIP events around the call)
@@ -417,6 +449,8 @@ class Workload(object):
                         "work_units": S * steps * flat["n_units"]},
             "allgather": allgather,
         }
+        if step_block is not None:
+            out["step"] = step_block
         return out
 
     def close(self):
@@ -528,7 +562,7 @@ def main():
     out = {"metric": METRIC, "value": main_out["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
-    for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained"):
+    for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained", "step"):
         if k in main_out:
             out[k] = main_out[k]
     if "sustained" in main_out:
@@ -544,9 +578,8 @@ def main():
     if args.dump_counts and rank == 0:
         import numpy as np
         torch.cuda.synchronize()
-        last = args.warmup + args.steps - 1 + (main_out.get("sustained") or {}).get("steps", 0)
         np.savez(args.dump_counts, counts=W.host[W.last].numpy(), samples_per_rank=W.S, world=world, seed=args.seed,
-                 first_sample=last * world * W.S)
+                 first_sample=W.last_first)
     if rank == 0 and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(W.flat, W.counters, args.seed, args.cpu_seconds)
         if args.config in REFERENCE_CYTHON:

@@ -31,7 +31,7 @@ SYMBOLS = [
     "gat_count_lists", "gat_count_list_ranges", "gat_intersection_sizes", "gat_problem_info",
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
-    "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums",
+    "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums", "gat_problem_rng_rows",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -116,6 +116,7 @@ class Stats(C.Structure):
         ("n_index_lookups", C.c_int64),
         ("n_batches", C.c_int64),
         ("merged_form", C.c_int64),
+        ("n_resumed_units", C.c_int64),
     ]
 
     def asdict(self):
@@ -187,6 +188,8 @@ def lib():
     L.gat_count_list_ranges.argtypes = [vp, vp, C.c_int, vp, vp, i64, vp, vp, vp, i32, vp, i32, vp]
     L.gat_intersection_sizes.restype = C.c_int
     L.gat_intersection_sizes.argtypes = [vp, vp, i32, vp, vp, vp, i32, vp, vp]
+    L.gat_problem_rng_rows.restype = i64
+    L.gat_problem_rng_rows.argtypes = [vp]
     L.gat_list_sums.restype = C.c_int
     L.gat_list_sums.argtypes = [vp, vp, vp, i64, vp]
     L.gat_problem_info.restype = C.c_int
@@ -478,6 +481,10 @@ class Problem(object):
         _check(lib().gat_problem_info(self._h, *[C.byref(x) for x in v]))
         return dict(n_units=v[0].value, n_contigs=v[1].value, n_tracks=v[2].value,
                     slab_segments_per_sample=v[3].value, algorithmic_bytes_per_sample=v[4].value)
+
+    def rows_per_sample(self):
+        """raw MT19937 outputs generated ahead per sample, over all units (the rows of k_rng)"""
+        return int(lib().gat_problem_rng_rows(self._h))
 
     def sample_and_count_device(self, counters, seed, sample_begin, sample_end, counts_dev_ptr):
         """the batch seam, results left on the device ([counter][track][sample] 8-byte slots)."""

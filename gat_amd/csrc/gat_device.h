@@ -55,6 +55,11 @@ struct WaveRng {
   uint32_t pre_j, pre_rows;
   uint32_t pre_base;   // rbuf holds outputs [pre_base, pre_base+64) of the stream (one vector load per 64 draws)
   bool use_pre, exhausted;
+  // where the rows run out the stream goes on from the in-LDS generator, seeded and moved up to the outputs consumed so far
+  // (rng_switch: the seeding chain + one twist per 624 outputs -- microseconds, against replaying every placement of the unit
+  // from its seed): can_switch says the caller has the LDS words (mt) and the stream's seed for it
+  bool can_switch;
+  uint32_t seed;
 };
 
 // init_genrand(seed): mt[0]=seed; mt[i] = 1812433253*(mt[i-1]^(mt[i-1]>>30)) + i.
@@ -85,7 +90,34 @@ __device__ __forceinline__ void rng_seed(WaveRng& r, uint32_t seed, int lane) {
   r.ndraws = 0;
   r.use_pre = false;
   r.exhausted = false;
+  r.can_switch = false;
   wave_sync();
+}
+
+__device__ __forceinline__ void rng_twist(WaveRng& r, int lane);
+
+// The stream's pre-generated rows are used up: seed the in-LDS generator and move it to output number r.ndraws -- what
+// numpy's generator would hand out next.  (The LDS words may have served as scratch while the rows lasted.)
+__device__ __forceinline__ void rng_switch(WaveRng& r, int lane) {
+  const uint32_t n = r.ndraws, seed = r.seed;
+  const uint32_t* pre = r.pre;
+  rng_seed(r, seed, lane);
+  const uint32_t blocks = n / (uint32_t)kMtN, rem = n - blocks * (uint32_t)kMtN;
+  for (uint32_t b = 0; b <= blocks; ++b) rng_twist(r, lane);         // the state behind outputs [blocks * 624, + 624)
+  r.pos = (int)rem;
+  r.ndraws = n;
+  r.pre = pre;
+  r.seed = seed;
+  r.can_switch = false;
+  if (rem & (uint32_t)(kWave - 1)) {                                 // (rng_next tempers a block of 64 when it enters one)
+    const int i = (int)(rem & ~(uint32_t)(kWave - 1)) + lane;
+    uint32_t y = r.mt[i < kMtN ? i : kMtN - 1];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    r.rbuf = y;
+  }
 }
 
 // genrand twist, in place, 64 lanes per step.  Word i needs old[i], old[i+1] and
@@ -110,8 +142,11 @@ __device__ __forceinline__ void rng_twist(WaveRng& r, int lane) {
 }
 
 __device__ __forceinline__ uint32_t rng_next(WaveRng& r, int lane) {
+  if (r.use_pre && r.pre_j >= r.pre_rows) {
+    if (!r.can_switch) { r.exhausted = true; return 0u; }
+    rng_switch(r, lane);
+  }
   if (r.use_pre) {
-    if (r.pre_j >= r.pre_rows) { r.exhausted = true; return 0u; }
     if (r.pre_j - r.pre_base >= (uint32_t)kWave) {
       r.pre_base = r.pre_j;
       const uint32_t row = r.pre_base + (uint32_t)lane;

@@ -22,11 +22,12 @@ struct SamplerArgs {
   const UnitDev* units_o;     // units[order[a]] with the unit id in `pad`: one load instead of two dependent ones
   int32_t n_units;
   int32_t batch;              // samples in this batch
+  int32_t rec_stride;         // samples the scratch was sized for: stride of the [unit][sample] hand-over records (GAT_REC)
   const uint2* ws;
   const uint32_t* ws_cdf;
   const uint32_t* rank_len;
   const uint32_t* ws_tree;    // 16-ary search trees of the long workspaces (UnitDev::tree_*_off)
-  int4* st2;                  // [batch][n_units] by launch position: first consolidation done by k_merge_big
+  int4* st2;                  // [launch position][rec_stride]: first consolidation done by k_merge_big
                               // {merged segments, workspace bases covered, sum of lengths, 1}, .w == 0 otherwise
   int32_t n_long;             // launch positions [0, n_long) were given to k_merge_big
   int32_t n_active;           // active units; their launch position is blockIdx.y + blockIdx.z * gridDim.y (grid y, z <= 65535)
@@ -37,14 +38,14 @@ struct SamplerArgs {
   int32_t* unit_n;            // [batch][n_units]
   int32_t* flags;             // OR of kStatus*
   unsigned long long* stat;   // [0]=placed [1]=draws [2]=unsuccessful rounds [3]=output segments [4]=full-mode units
-  uint32_t* ws_stat;          // [batch][n_units][4]: the same per work unit (summed by k_reduce_stats; one
+  uint32_t* ws_stat;          // [unit][rec_stride][4]: the same per work unit (summed by k_reduce_stats; one
                               // atomic per work unit on a single line costs more than the sampling itself)
   // lane-parallel front end (k_rng + k_place); all null/0 when the sampler runs stand-alone
   const int64_t* rng_off;     // per active index: word offset of the unit's first tile in rng_out
   const int32_t* rng_rows;    // per active index: rows (raw outputs per stream) generated
   uint32_t* rng_out;          // tile (active a, sample block sb): rng_out[rng_off[a] + (sb*rows + j)*64 + lane]
   uint32_t* rng_ckpt;         // k_seed -> k_rng: word 39 w of every stream's seeded state, [tile = a * n_blocks + sb][w < 16][lane]
-  int4* st;                   // [batch][n_units] hand-off from k_place, one 16-byte record per work unit:
+  int4* st;                   // [launch position][rec_stride] hand-off from k_place, one 16-byte record per work unit:
                               //   x = segments placed before the first consolidation, y = `remaining` at that point,
                               //   z = the pending length (>0), -1: run the unit in full, -2: SamplerSegments complete,
                               //   w = raw outputs consumed so far
@@ -55,7 +56,7 @@ struct SamplerArgs {
                               // launch per size class, so that the dynamic LDS of a launch fits ITS longest list (a_end 0: all)
   uint32_t* cum;              // split path: inclusive running lengths of the merged lists, parallel to the slab (k_merge_big fills it too)
   uint2* slab_final;          // split path: where the units' FINAL lists go (a second slab: k_finalize writes out of place)
-  const int32_t* skip;        // split path: skip[(sidx * n_units + a) * skip_stride] != 0: the unit was finished by k_tail / k_finalize
+  const int32_t* skip;        // split path: skip[GAT_REC(a, sidx) * skip_stride] != 0: the unit was finished by k_tail / k_finalize
   int32_t skip_stride;
   const uint32_t* todo_count; // split path: k_sampler works off the queue of units k_tail left alone (k_finalize fills it)
   const uint32_t* todo;       //   entries sidx * n_active + launch position
@@ -65,6 +66,13 @@ struct SamplerArgs {
   const int32_t* unit_pos;    // unit id -> launch position, -1: inactive (k_serial walks the units in the reference's order)
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
 };
+
+// The hand-over records between the sampler's kernels -- st, st2, TailPatch by launch position, ws_stat by unit id -- are laid
+// out [unit][sample]: the 64 lanes of a tile of the lane-per-stream kernels (k_place, k_tail, k_tail_big: one unit, 64
+// consecutive samples) touch consecutive records -- eight lines for a wave's 16-byte records where [sample][unit] made every
+// lane's access a line of its own (k_tail on config 3: 2.4 GB fetched per 10 000 samples, ten lines per lane of which four
+// were records).  The stride is the number of samples the scratch was sized for, the same in every batch of a call.
+#define GAT_REC(A_, sidx_, a_) ((int64_t)(a_) * (int64_t)(A_).rec_stride + (int64_t)(sidx_))
 
 // layout of a TailPatch record in 32-bit words (gat_tail.h static_asserts it)
 constexpr int kPatchState = 0, kPatchNExtra = 1, kPatchPlaced = 2, kPatchNdraws = 3, kPatchNuns = 4, kPatchPad = 5, kPatchExtra = 6,
@@ -272,7 +280,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   const int rows = A.rng_rows[a];
   const int sidx = sb * kWave + lane;
   const bool live = sb_own < n_tiles && sidx < A.batch;
-  const int64_t so = (int64_t)sidx * A.n_units + a;      // hand-off record, indexed by launch position
+  const int64_t so = GAT_REC(A, sidx, a);                // hand-off record, indexed by launch position
 
   // wave-uniform draw parameters (numpy masked rejection: accept (y & mask) <= range)
   constexpr bool kind1 = KIND == 1;           // SamplerSegments: fixed number of placements, no trigger
@@ -397,7 +405,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     const bool fin = kind1 && put && nS == target;                                                             \
     len = isL ? (LR1) : len;                                                                                   \
     pend = trig ? (int32_t)len : (fin ? -2 : pend);                                                            \
-    used = (trig || fin) ? (JJ) + 1u : used;                                                                   \
+    used = (trig || put) ? (JJ) + 1u : used;       /* (a lane that runs out of rows is resumed behind its last placement) */ \
     sL = (sL && !isL) || (put && !fin);                                                                        \
     sP = (sP && !isP) || (isL && !trig);                                                                       \
     sO = (sO && !isO) || isP;                                                                                  \
@@ -461,7 +469,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     flag |= full ? kStatusOverflow : 0;                                                                        \
     const bool fin = kind1 && put && nS == target;                                                             \
     pend = trig ? (int32_t)len : (fin ? -2 : pend);                                                            \
-    used = (trig || fin) ? (JJ) + 1u : used;                                                                   \
+    used = (trig || put) ? (JJ) + 1u : used;                                                                   \
     sstart = isP ? sstartP : sstart;                                                                           \
     omask = isP ? 0xffffffffu >> __builtin_clz(range3 | 1u) : omask;                                           \
     orange = isP ? range3 : orange;                                                                            \
@@ -662,8 +670,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   if (live) {
     const bool halted = !(sL || sB || sP || sO);
     for (int i = nF; i < nS; ++i) out[i] = l_out[i & 15][lane];   // what the last flush left
-    A.st[so] = make_int4(nS, rem, (halted && pend != -1 && flag == 0) ? pend : -1,   // rows ran out / overflow: full mode
-                         (int)used);
+    // halted at the trigger (pend > 0) or complete (-2); rows ran out with the lane still placing: -3, k_sampler goes on
+    // behind the last placement (nS segments, `rem`, `used` outputs); overflow (or SamplerSegments out of rows): -1, the unit
+    // is run in full
+    A.st[so] = make_int4(nS, rem, flag != 0 ? -1 : (halted ? (pend != -1 ? pend : -1) : (kind1 ? -1 : -3)), (int)used);
     if (flag) atomicOr(A.flags, flag);
   }
 }
@@ -725,7 +735,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   const int sidx = blockIdx.x, a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_long || (A.a_end > 0 && a >= A.a_end)) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
-  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx, a);
   const int4 pre = A.st[sa];
   const int n = pre.x;
   if (tid == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
@@ -948,18 +958,20 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   uint2* fin = (!HUGE && A.slab_final != nullptr) ? A.slab_final + (int64_t)sidx * A.slab_stride + Up->slab_off : out;
   uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + kMtLdsWords);
-  const int64_t so = (int64_t)sidx * A.n_units + u;
+  const int64_t so = (int64_t)sidx * A.n_units + u;     // unit_n: [sample][unit]
+  const int64_t sw = GAT_REC(A, sidx, u);                // ws_stat: [unit][sample]
 
   // per-unit stream: numpy.random.seed((seed + sample*n_units + unit) mod 2^32)
   const uint64_t sample_id = (uint64_t)(A.sample_begin + sidx);
   const uint32_t seed = (uint32_t)((uint64_t)A.seed + sample_id * (uint64_t)A.n_units + (uint64_t)u);
-  if (A.skip != nullptr && A.skip[((int64_t)sidx * A.n_units + a) * A.skip_stride] != 0) return;
+  if (A.skip != nullptr && A.skip[GAT_REC(A, sidx, a) * A.skip_stride] != 0) return;
   const bool have_pre = A.st != nullptr;
-  const int4 pre = have_pre ? A.st[(int64_t)sidx * A.n_units + a] : make_int4(0, 0, -1, 0);
+  const int4 pre = have_pre ? A.st[GAT_REC(A, sidx, a)] : make_int4(0, 0, -1, 0);
   const int32_t pre_len = pre.z;
 
   int nout = 0, status = 0, nuns = 0;
   uint32_t placed = 0, ndraws = 0, full_units = 0;
+  bool switched = false;       // the unit was resumed and its rows ran out: the stream went on from the in-LDS generator
 #ifdef GAT_DIAG
   unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_t;
   GAT_STAMP(dg_t);
@@ -1003,11 +1015,13 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     if (lane == 0) {
       A.unit_n[so] = status ? 0 : nout;
       if (status) atomicOr(A.flags, status);
-      *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(placed, ndraws, 0u, full_units);
+      *reinterpret_cast<uint4*>(A.ws_stat + sw * 4) = make_uint4(placed, ndraws, 0u, full_units);
     }
     return;
   }
-  for (int attempt = (pre_len >= 0 ? 0 : 1); attempt < 2; ++attempt) {
+  // (pre_len: > 0 the pending length at the first consolidation; -3: k_place ran out of rows while placing -- the loop goes
+  //  on behind its last placement; -1: the unit is run in full from its seed)
+  for (int attempt = ((pre_len >= 0 || pre_len == -3) ? 0 : 1); attempt < 2; ++attempt) {
     const bool resume = attempt == 0;
     WaveRng rng;
     rng.mt = mt;
@@ -1021,10 +1035,10 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     if (resume) {
       nS = pre.x;
       int4 pre2 = make_int4(0, 0, 0, 0);
-      if (!HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[(int64_t)sidx * A.n_units + a];
+      if (!HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[GAT_REC(A, sidx, a)];
       const int32_t* __restrict__ R = nullptr;
       if (BIG && !HUGE && A.tb != nullptr && pre2.w == 1) {
-        R = A.tb + ((int64_t)sidx * A.n_units + a) * A.skip_stride;
+        R = A.tb + GAT_REC(A, sidx, a) * A.skip_stride;
         if (R[kPatchState] == 1) return;                       // k_resume_big has finished the unit
         if (R[kPatchState] == 3) continue;                     // k_tail_big ran out of rows: the unit is redone from its seed
         if (R[kPatchState] != 2) R = nullptr;
@@ -1063,12 +1077,14 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
           nS = nSp;
         }
       } else
-      // (a list the counting sort will take straight from the slab need not be copied first)
-      if (!HUGE && !(BIG && nS > 1024 && A.big_buckets > 0) && !(nS > 512 && nS <= 1024))
+      // (a list the counting sort will take straight from the slab need not be copied first -- unless the unit goes on PLACING,
+      //  pre_len -3: what it places joins the list in LDS)
+      if (!HUGE && (pre_len == -3 || (!(BIG && nS > 1024 && A.big_buckets > 0) && !(nS > 512 && nS <= 1024))))
         for (int i = lane; i < nS; i += kWave) seg[i] = out[i];
       remaining = pre.y;
-      pending = pre_len;
+      pending = pre_len >= 0 ? pre_len : -1;
       rng.use_pre = true; rng.exhausted = false; rng.ndraws = (uint32_t)pre.w; rng.pos = 0; rng.rbuf = 0;
+      rng.seed = seed; rng.can_switch = true;        // (where the rows run out the stream goes on from the in-LDS generator)
       rng.pre_rows = (uint32_t)A.rng_rows[a];
       rng.pre_j = rng.ndraws;
       rng.pre_base = rng.pre_j - (uint32_t)kWave;     // forces the first prefetch
@@ -1153,7 +1169,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             dirty = false;
           }
           const int n = nU + nS;
-          if (BIG && !HUGE && resume && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
+          if (BIG && !HUGE && resume && pre_len >= 0 && nU == 0 && !dirty && n > 1024 && A.big_buckets > 0) {
             // long list straight from the slab k_place wrote: counting sort into LDS (it was not copied at resume)
             int nb = 1024;
             while (nb < n && nb < A.big_buckets) nb <<= 1;
@@ -1162,7 +1178,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
               for (int i = lane; i < n; i += kWave) seg[i] = out[i];
               wave_sort_by_start<HUGE>(seg, n, lane);
             }
-          } else if (!HUGE && resume && nU == 0 && !dirty && n > 512 && n <= 1024 && n == pre.x) {
+          } else if (!HUGE && resume && pre_len >= 0 && rng.use_pre && nU == 0 && !dirty && n > 512 && n <= 1024 && n == pre.x) {
             // 513..1024 segments, still where k_place wrote them: the same counting sort with 512 buckets (the bucket sort
             // that holds the whole list in registers needs 16 elements per lane here -- over a hundred registers, which cost
             // every wave of the kernel spills: 128 VGPRs + 76 bytes of scratch against 106 without)
@@ -1176,7 +1192,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             for (int done = 0; done < nS; done += kWave)
               wave_insert_sorted<HUGE>(seg, nU + done, nS - done < kWave ? nS - done : kWave, lane);
           } else
-          if (nU == 0 || nS > kWave || dirty) wave_sort_fast<8, HUGE>(seg, n, resume ? mt : nullptr, lane);   // SegmentList.sort of everything
+          if (nU == 0 || nS > kWave || dirty) wave_sort_fast<8, HUGE>(seg, n, (resume && rng.use_pre) ? mt : nullptr, lane);   // SegmentList.sort of everything
                                         // (the MT19937 words are idle scratch while the stream comes from k_rng)
           else if (nS > 0) wave_insert_sorted<HUGE>(seg, nU, nS, lane);         // same order, few new segments
           GAT_PHASE(1)                               // sort / insert
@@ -1334,6 +1350,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       GAT_PHASE(6)
     }
     ndraws = rng.ndraws;
+    switched = resume && !rng.use_pre;
     if (serial != nullptr) *serial = rng;
     GAT_PHASE(6)
     if (rng.use_pre && rng.exhausted) continue;       // rows ran out: redo this unit from its seed
@@ -1397,7 +1414,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
   if (lane == 0) {
     A.unit_n[so] = nout;
     if (status) atomicOr(A.flags, status);
-    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(placed, ndraws, (uint32_t)nuns, full_units);
+    *reinterpret_cast<uint4*>(A.ws_stat + sw * 4) = make_uint4(placed, ndraws, (uint32_t)nuns, full_units | (switched ? 0x10000u : 0u));
   }
 }
 
@@ -1459,27 +1476,29 @@ __global__ __launch_bounds__(64) void k_serial(SamplerArgs A) {
   if (lane == 0) A.serial_state[kMtN] = (uint32_t)rng.pos;
 }
 
-__global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict__ ws_stat, int64_t n,
+// (records [unit][rec_stride]: the nb samples of this batch are the first nb of every unit's row)
+__global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict__ ws_stat, int64_t nb, int64_t n_units, int64_t rec_stride,
                                                       unsigned long long* __restrict__ stat,
                                                       const int32_t* __restrict__ skip, int skip_stride) {
-  unsigned long long a0 = 0, a1 = 0, a2 = 0, a4 = 0, a3 = 0;
+  unsigned long long a0 = 0, a1 = 0, a2 = 0, a4 = 0, a3 = 0, a5 = 0;
+  const int64_t n = nb * n_units;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint4 v = *reinterpret_cast<const uint4*>(ws_stat + i * 4);
-    a0 += v.x; a1 += v.y; a2 += v.z; a4 += v.w;
+    const int64_t u = i / nb, r = u * rec_stride + (i - u * nb);
+    const uint4 v = *reinterpret_cast<const uint4*>(ws_stat + r * 4);
+    a0 += v.x; a1 += v.y; a2 += v.z; a4 += v.w & 0xffffu; a5 += v.w >> 16;   // (.w: run in full | resumed with a stream moved up << 16)
+    // work units finished on the split path (k_tail's records are indexed by launch position: n_units rows as well)
+    if (skip != nullptr) a3 += skip[r * skip_stride] != 0 ? 1 : 0;
   }
-  // work units finished on the split path (k_tail's records are indexed by launch position: n_units per sample as well)
-  if (skip != nullptr)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-      a3 += skip[i * skip_stride] != 0 ? 1 : 0;
-  __shared__ unsigned long long red[4][5];
+  __shared__ unsigned long long red[4][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     a0 += __shfl_xor(a0, d); a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); a4 += __shfl_xor(a4, d); a3 += __shfl_xor(a3, d);
+    a5 += __shfl_xor(a5, d);
   }
-  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; red[wave][4] = a4; }
+  if (lane == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; red[wave][4] = a4; red[wave][5] = a5; }
   __syncthreads();
-  if (threadIdx.x < 5) {
+  if (threadIdx.x < 6) {
     const unsigned long long t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     atomicAdd(&stat[threadIdx.x], t);
   }
@@ -1507,6 +1526,7 @@ struct ContigArgs {
   const int4* st2;                 // .x = merged segments
   const int32_t* patch;            // TailPatch records as words (layout: gat_tail.h), patch_stride words each
   int32_t patch_stride;
+  int32_t rec_stride;              // (GAT_REC: st2 / patch / ws_stat are [unit][rec_stride])
   uint32_t* ws_stat;               // per-unit statistics (k_finalize's job otherwise)
   // one launch per size class of contigs: launch position p of this launch is contig order[base + p]
   const int32_t* order;
@@ -1545,7 +1565,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
       my_u = rec.x;
       my_off = rec.y;
       const bool have_patch = A.slab_merged != nullptr && rec.z >= 0;
-      const int64_t sa = (int64_t)sidx * A.n_units + (have_patch ? rec.z : 0);
+      const int64_t sa = GAT_REC(A, sidx, have_patch ? rec.z : 0);
       int4 c2 = make_int4(0, 0, 0, 0);
       if (have_patch) {
         my_patch = A.patch + sa * A.patch_stride;
@@ -1603,7 +1623,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < nE) seg[my_dst + nU + j] = ex[j];
-        *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + my_u) * 4) = make_uint4(pw[0].z, pw[0].w, pw[1].x, 0u);
+        *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, my_u) * 4) = make_uint4(pw[0].z, pw[0].w, pw[1].x, 0u);
       }
       wave_sync<HUGE>();
     }
@@ -1676,6 +1696,7 @@ struct CountArgs {
   const int4* st2;            // .x = merged segments
   const int32_t* patch;       // TailPatch records as words (kPatch*), patch_stride words each
   int32_t patch_stride, n_units;
+  int32_t rec_stride;         // (GAT_REC: st2 / patch are [launch position][rec_stride])
 };
 
 struct AnnoView {
@@ -1807,7 +1828,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
       const int64_t s_ = s0 + sl_;
       m.n = A.n_arr[s_ * A.n_stride + nidx];
       if (PATCH && upos >= 0) {
-        const int64_t sa = s_ * A.n_units + upos;
+        const int64_t sa = GAT_REC(A, s_, upos);
         const int32_t* __restrict__ R = A.patch + sa * A.patch_stride;
         m.state = R[kPatchState]; m.nE = R[kPatchNExtra]; m.nM = A.st2[sa].x;
       }
@@ -1827,7 +1848,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
     if (PATCH && m.state == 1) {
       v.nU = m.nM; v.n = m.nM + m.nE;
       v.X = A.seg_merged + s_ * A.seg_stride + coff;
-      v.Rex = reinterpret_cast<const uint2*>(A.patch + (s_ * A.n_units + upos) * A.patch_stride + kPatchExtra) - m.nM;
+      v.Rex = reinterpret_cast<const uint2*>(A.patch + GAT_REC(A, s_, upos) * A.patch_stride + kPatchExtra) - m.nM;
     }
     return v;
   };
@@ -1952,7 +1973,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     int nU = n;
     const uint2* __restrict__ Rex = X;
     if (PATCH && upos >= 0) {
-      const int64_t sa = (int64_t)s * A.n_units + upos;
+      const int64_t sa = GAT_REC(A, s, upos);
       const int32_t* __restrict__ R = A.patch + sa * A.patch_stride;
       if (R[kPatchState] == 1) {
         nU = A.st2[sa].x;

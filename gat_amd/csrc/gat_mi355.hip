@@ -453,6 +453,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       gat::SamplerArgs A;
       memset(&A, 0, sizeof(A));
       A.units = P->d_units.p; A.units_o = P->d_units_o.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
+      A.rec_stride = (int32_t)P->batch;                  // (the scratch's size in samples: the records' row length in every batch)
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
@@ -746,6 +747,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       B.unit_n = P->d_unit_n.p; B.contig_n = P->d_contig_n.p; B.stat = P->d_stat.p;
       B.slab_merged = nullptr; B.unit_pos = P->d_unit_pos.p; B.st2 = nullptr; B.patch = nullptr; B.patch_stride = 0;
       B.ws_stat = P->d_ws_stat.p;
+      B.rec_stride = (int32_t)P->batch;
       if (P->split_ran && P->patched_contigs) {
         B.slab_merged = P->d_slab.p;
         B.st2 = P->d_st2.p;
@@ -778,7 +780,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (!P->h_order.empty()) {
       // (behind k_contig: on isochore problems it is k_contig that writes the statistics of the units k_tail finished)
       hipLaunchKernelGGL(gat::k_reduce_stats, dim3(256), dim3(256), 0, ctx->stream, (const uint32_t*)P->d_ws_stat.p,
-                         (int64_t)nb * P->n_units, P->d_stat.p, skip_ptr, skip_stride);
+                         (int64_t)nb, (int64_t)P->n_units, (int64_t)P->batch, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
     HIPCHK(ctx, hipMemcpyAsync(h_stat, P->d_stat.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -837,6 +839,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       st->n_tail_units += (int64_t)stat[3];
       if (P->split_ran && (P->patched_contigs || P->patched_counts)) st->lists_from_records += 1;
       st->n_full_units += (int64_t)stat[4];
+      st->n_resumed_units += (int64_t)stat[5];
       if (timed) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -883,6 +886,7 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
     A.patch = reinterpret_cast<const int32_t*>(P->d_patch.p);
     A.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
     A.n_units = P->n_units;
+    A.rec_stride = (int32_t)P->batch;
   }
 }
 

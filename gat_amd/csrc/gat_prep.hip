@@ -18,7 +18,9 @@
 // the device-memory pool behind DevBuf (gat_host.h)
 namespace {
 struct PoolBlock { void* p; size_t bytes; };
-struct DevPool { std::vector<PoolBlock> blocks; size_t held = 0; };
+// blocks: idle ones; out: what the blocks handed out really hold (a request is served by a block up to a quarter larger: it
+// comes back under its own size, not the request's, so the books -- held, the GAT_POOL_BYTES cap, dev_pool_held() -- stay true)
+struct DevPool { std::vector<PoolBlock> blocks; size_t held = 0; std::map<void*, size_t> out; };
 std::mutex g_pool_mutex;
 std::map<int, DevPool> g_pools;
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
@@ -59,6 +61,7 @@ hipError_t dev_pool_alloc(void** out, size_t bytes) {
     if (best != P.blocks.size()) {
       *out = P.blocks[best].p;
       P.held -= P.blocks[best].bytes;
+      P.out[*out] = P.blocks[best].bytes;
       P.blocks[best] = P.blocks.back();
       P.blocks.pop_back();
       return hipSuccess;
@@ -77,20 +80,27 @@ hipError_t dev_pool_alloc(void** out, size_t bytes) {
       e = hipMalloc(out, want);
     }
   }
+  if (e == hipSuccess) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pools[dev].out[*out] = want;
+  }
   return e;
 }
 
-// (a large block comes back under the size it was handed out for -- at most a quarter below its own -- so it may shrink in
-//  the books; the driver frees what it allocated)
+// A block goes back idle: every caller frees behind a synchronisation of the stream it used the block on (a problem's
+// destruction, the end of a blocking call), so an idle block may be handed to ANY context of the device -- the contexts of
+// a device (the caller's, the observed counts', the annotation build's) run on streams of their own.
 void dev_pool_free(void* p, size_t bytes) {
   if (!p) return;
-  const size_t cls = pool_class(bytes);
+  size_t cls = pool_class(bytes);
   hipPointerAttribute_t attr;
   int dev = 0;
   if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device; else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     DevPool& P = g_pools[dev];
+    auto it = P.out.find(p);
+    if (it != P.out.end()) { cls = it->second; P.out.erase(it); }     // (the block's own size)
     if (P.held + cls <= pool_limit() && P.blocks.size() < 4096) {
       P.blocks.push_back(PoolBlock{p, cls});
       P.held += cls;
@@ -1090,14 +1100,20 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       // by ONE wave, placement by placement, and such a straggler (0.5 ms) is now longer than the rest of the sampler.
       const double nplace = P->sampler == GAT_SAMPLER_SEGMENTS ? (double)U.n_target : (double)U.hist_total;
       const double var_n = P->sampler == GAT_SAMPLER_SEGMENTS ? 0.0 : len_cv2[(size_t)u] * e * e;
-      // (the multiple follows what running out costs: ONE wave redoing the unit placement by placement -- 0.5 ms for 800
-      //  segments, a few dozen us for 50, where five sigma are plenty and the rows saved are a sixth of k_rng's work)
+      // The multiple follows what running out costs.  A unit of the split path (lists the wave sorts hold) that runs out of
+      // rows is RESUMED by k_sampler where its lane stopped -- behind k_place's last placement, or at the consolidation k_tail
+      // would have continued from -- with the stream moved up to its position by the in-LDS generator (rng_switch: the
+      // seeding chain + a twist per 624 outputs, ~10 us): 3.5 sigma and 32 rows for the tail (one stream in two thousand runs
+      // out; round 3's 5-7.5 sigma + 96, sized for a redo of every placement from the seed at 0.5 ms, generated 1.4x the rows
+      // that were consumed: k_rng 0.48 -> 0.43 ms on config 2, 1.07 -> 0.92 on config 3).  A long list that runs out behind
+      // k_tail_big's in-place unions is still redone from its seed -- milliseconds for thousands of placements: 7.5 sigma + 96.
       const char* env_s0 = getenv("GAT_RNG_SIGMA_MIN");
       const char* env_s1 = getenv("GAT_RNG_SIGMA_MAX");
       const char* env_tr = getenv("GAT_RNG_TAIL_ROWS");
-      const double s_min = env_s0 ? atof(env_s0) : 5.0, s_max = env_s1 ? atof(env_s1) : 7.5;
-      const double sigmas = std::min(s_max, std::max(s_min, s_min - 0.5 + nplace / 130.0));
-      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + (env_tr ? atof(env_tr) : 96.0);
+      const double s_min = env_s0 ? atof(env_s0) : 3.5, s_max = env_s1 ? atof(env_s1) : 7.5;
+      const bool long_list = U.hist_total + U.hist_total / 8 > 1024 || P->sampler == GAT_SAMPLER_SEGMENTS;
+      const double sigmas = long_list ? s_max : s_min;
+      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + (env_tr ? atof(env_tr) : (long_list ? 96.0 : 32.0));
       int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);
@@ -1191,6 +1207,8 @@ extern "C" int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t*
   }
   return GAT_OK;
 }
+
+extern "C" int64_t gat_problem_rng_rows(const gat_problem* p) { return p ? p->rng_rows_total : 0; }
 
 // ------------------------------------------------------------------------------------------
 // sizes of dictionary intersections for the overlap_* columns of the result rows (AnnotatorResultExtended.__init__,

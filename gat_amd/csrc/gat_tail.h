@@ -54,7 +54,7 @@ static_assert(sizeof(TailPatch) == kPatchWords * 4 && offsetof(TailPatch, extra)
 struct TailArgs {
   SamplerArgs S;
   uint32_t* cum;          // [batch][slab_stride]: inclusive running length of the merged list, parallel to the slab
-  TailPatch* patch;       // [batch][n_units] by launch position
+  TailPatch* patch;       // [launch position][rec_stride] (GAT_REC)
   uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
   int32_t loose_ok;       // k_resume_big: the lists' only readers are the segment-side count kernels (or k_contig, which
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const int a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_active || (A.a_end > 0 && a >= A.a_end)) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
-  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx, a);
   const int4 pre = A.st[sa];
   if (lane == 0) T.patch[sa].state = 0;
   // (launched behind k_merge_big when the problem has long lists: launch positions below n_long carry its verdict)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   __syncthreads();
   const int sidx = sb * kWave + lane;
   if (sidx >= A.batch) return;
-  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx, a);
   const int4 pre = A.st[sa];
   const int4 c2 = A.st2[sa];
   const uint32_t qe = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   for (int j = 0; j < kTailMaxExtra; ++j) { P->extra[j] = ex[j]; P->pos[j] = epos[j]; }
   P->state = 1;
   // (the unit's statistics: its consumers may take the record as it is, without k_finalize)
-  *reinterpret_cast<uint4*>(A.ws_stat + ((int64_t)sidx * A.n_units + Up->pad) * 4) = make_uint4(placed, rng.used, (uint32_t)nuns, 0u);
+  *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, Up->pad) * 4) = make_uint4(placed, rng.used, (uint32_t)nuns, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
   const int sidx = sb * kWave + lane;
-  const int64_t sa = (int64_t)(sidx < A.batch ? sidx : 0) * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx < A.batch ? sidx : 0, a);
   TailPatch* P = T.patch + sa;
   if (sidx < A.batch) P->state = 0;
   if (nws > kTailMaxWs) return;                        // long workspace: k_sampler's (search trees)
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   const int sidx = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_long) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
-  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx, a);
   int32_t* R = reinterpret_cast<int32_t*>(T.patch + sa);
   if (R[kPatchState] != 2) return;
   const int nE = R[kPatchNExtra];
@@ -792,6 +792,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
 
   WaveRng rng;
   rng.mt = nullptr;
+  rng.can_switch = false; rng.seed = 0u;               // (no LDS words for a generator here: out of rows = redo, state 3)
   rng.use_pre = true; rng.exhausted = false; rng.ndraws = (uint32_t)R[kPatchNdraws]; rng.pos = 0; rng.rbuf = 0;
   rng.pre_rows = (uint32_t)A.rng_rows[a];
   rng.pre_j = rng.ndraws;
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   if (lane == 0) {
     A.unit_n[so] = tsum > 0 ? nout : 0;
     if (!(tsum > 0)) atomicOr(A.flags, kStatusAssert);
-    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4((uint32_t)R[kPatchPlaced], rng.ndraws, (uint32_t)nuns, 0u);
+    *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, u) * 4) = make_uint4((uint32_t)R[kPatchPlaced], rng.ndraws, (uint32_t)nuns, 0u);
     R[kPatchState] = 1;
   }
 }
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
   const int sidx = blockIdx.x;
   const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
   if (a >= A.n_active) return;
-  const int64_t sa = (int64_t)sidx * A.n_units + a;
+  const int64_t sa = GAT_REC(A, sidx, a);
   const TailPatch* __restrict__ P = T.patch + sa;
   if (P->state != 1) return;                             // (k_tail queued it for k_sampler)
   const UnitDev* __restrict__ Up = A.units_o + a;
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
     const int64_t so = (int64_t)sidx * A.n_units + u;
     A.unit_n[so] = nout;
     if (!(total > 0)) atomicOr(A.flags, kStatusAssert);
-    *reinterpret_cast<uint4*>(A.ws_stat + so * 4) = make_uint4(P->placed, P->ndraws, P->nuns, 0u);
+    *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, u) * 4) = make_uint4(P->placed, P->ndraws, P->nuns, 0u);
   }
 }
 

@@ -148,6 +148,8 @@ typedef struct {
   int64_t n_batches;            /* batches the call was cut into (the scratch budget decides how many samples one holds)   */
   int64_t merged_form;          /* k_count_merged: how its scans fetched the index: 8 blocks of eight entries, 2 pairs,    */
                                 /* 1 the grid cell's record (its first two entries) + pairs; 0: the kernel did not run     */
+  int64_t n_resumed_units;      /* work units whose pre-generated random rows ran out and whose stream went on from the     */
+                                /* generator moved up to its position (instead of a run in full: n_full_units)              */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0
@@ -326,6 +328,10 @@ int gat_allgather_counts(gat_ctx* ctx, gat_comm* comm, const void* send_dev, voi
 /* queries */
 int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,
                      int64_t* slab_segments_per_sample, int64_t* algorithmic_bytes_per_sample);
+
+/* raw MT19937 outputs generated ahead per sample (over all units: the rows of k_rng), to set against gat_stats.n_draws, the
+ * outputs the samples consumed */
+int64_t gat_problem_rng_rows(const gat_problem* p);
 
 #ifdef __cplusplus
 }

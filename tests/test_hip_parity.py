@@ -301,7 +301,9 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     seg, off = P.sample(99, 3, 3 + S)
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     if case == "rows_run_out":
-        assert st["n_full_units"] > 0
+        # (a stream that runs out of pre-generated rows goes on from the generator moved up to its position; only SamplerSegments
+        #  and long lists behind k_tail_big are still run in full)
+        assert st["n_resumed_units"] > 0 and st["n_full_units"] == 0
     if case in ("large_units", "large_units_one_workspace_segment"):
         # long lists: k_merge_big, then k_tail_big carries the units through their placement rounds
         assert st["n_tail_units"] > 0.5 * S * flat["n_units"], st["n_tail_units"]
@@ -775,6 +777,31 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["allgather"]["bytes_per_rank"] == 2000 * 8
     assert "cpu_baseline" not in out and "api" not in out # reported at N = 1 only
     assert out["sustained"]["seconds"] >= 0.2 and out["sustained"]["min"] <= out["sustained_value"] <= out["sustained"]["max"]
+
+
+def test_bench_eight_ranks_on_one_gpu(tmp_path):
+    """the launch the driver's scaling run makes -- eight ranks under torch.distributed.run -- on this box's one GPU (gloo
+    instead of RCCL): every rank its own sample range, the gathered matrix of the last step against the oracle's columns"""
+    import subprocess
+    import sys
+    from gat_amd import problem
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
+    dump = str(tmp_path / "counts8.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
+           "--warmup", "1", "--samples", "64", "--extra", "", "--no-strong", "--sustain-seconds", "0", "--dump-counts", dump]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["distributed"]["world_size"] == 8 and out["value"] > 0
+    z = np.load(dump)
+    cfg = synthetic.config("config2")
+    flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
+    first, S = int(z["first_sample"]), int(z["samples_per_rank"])
+    want, _ = O.run_samples(flat, ["nucleotide-overlap"], int(z["seed"]), 1, first, first + 8 * S)
+    for rk in range(8):
+        assert np.array_equal(z["counts"][rk], want[0][:, rk * S:(rk + 1) * S]), rk
 
 
 def test_bench_starts_its_own_ranks():

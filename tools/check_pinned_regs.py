@@ -25,7 +25,7 @@ def touches(line):
 
 
 def main(path):
-    kernel, inside, regions, bad = None, False, 0, []
+    kernel, inside, regions, bad, nloads = None, False, 0, [], {}
     for no, line in enumerate(open(path, errors="replace"), 1):
         code = line.split("//")[0]
         m = re.match(r"^(_ZN3gat\w+):", line)
@@ -39,6 +39,14 @@ def main(path):
             continue
         if not inside or not code.strip() or code.lstrip().startswith((";", ".")):
             continue
+        # the loop's wait counts (s_waitcnt vmcnt(24): three chunks of eight row loads on their way) assume that the pinned
+        # loads are the loop's only LOADS: stores in between make a wait stricter, a spill's reload or any other load would too,
+        # but a loop that spills no longer fits the registers below v96 anyway -- refused as well
+        if re.match(r"^\s*(scratch_|buffer_)", code):
+            bad.append((kernel, no, code.strip() + "   <- scratch / buffer access inside a pinned loop"))
+            continue
+        if LOAD.match(code):
+            nloads[regions] = nloads.get(regions, 0) + 1
         if touches(code):
             t = TAKE.match(code)
             if LOAD.match(code) or (t and int(t.group(2)) < 96):
@@ -51,6 +59,9 @@ def main(path):
             sys.stderr.write("%s:%d: %s  [%s]\n" % (path, no, code, k))
         sys.exit("check_pinned_regs: %d instruction(s) inside a pinned-register loop use v96..v127: the loop's values no "
                  "longer fit below v96 -- lower the pressure or take the loop off the pipe" % len(bad))
+    odd = [r for r, n in nloads.items() if n % 8 != 0 or n == 0]
+    if odd or len(nloads) != regions:
+        sys.exit("check_pinned_regs: pinned loops with a number of row loads that is not a multiple of the chunk (8): %r" % (nloads,))
     print("check_pinned_regs: %d pinned-register loops clean" % regions)
 
 

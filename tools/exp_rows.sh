@@ -1,12 +1,17 @@
 #!/bin/bash
-cd ${GRAFT_REPO_ROOT:-$(pwd)}
-run() { echo "== $1"; env $1 python3 bench.py --no-cpu-baseline --no-api --no-strong --sustain-seconds 0 --extra config3,config5 > /tmp/b.json 2>/dev/null; python3 tools/show_bench.py /tmp/b.json; python3 - <<'PY'
-import json
-d=[json.loads(l) for l in open('/tmp/b.json') if l.startswith('{')][-1]
-print("   full units:", d["sampler"]["units_run_in_full"], [v["sampler"]["units_run_in_full"] for v in d["configs"].values()])
-PY
+# the row budget of k_rng (rows generated per stream = expected consumption + sigmas x spread + tail rows) against what the
+# streams that run out cost: k_rng / k_sampler times and units run in full, per setting.  usage: bash tools/exp_rows.sh
+run() {
+  for CFG in config2:10000 config3:10000; do
+    python bench.py --config ${CFG%%:*} --samples ${CFG##*:} --steps 10 --warmup 2 --no-api --no-strong --no-cpu-baseline --extra "" --sustain-seconds 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); k=d['kernels']; s=d['sampler']
+print('  %-8s %9.0f samples/s %.3f ms | rng %.3f place %.3f merge %.3f tail %.3f sampler %.3f | full %d retried %d' % ('${CFG%%:*}', d['value'], d['ms_per_step'], k['k_rng_ms'], k['k_place_ms'], k['k_merge_ms'], k['k_tail_ms'], k['k_sampler_ms'], s['units_run_in_full'], s['units_retried']))"
+  done
 }
-run "GAT_NOP=1"
-run "GAT_RNG_SIGMA_MIN=4.0 GAT_RNG_SIGMA_MAX=6.5 GAT_RNG_TAIL_ROWS=64"
-run "GAT_RNG_SIGMA_MIN=3.5 GAT_RNG_SIGMA_MAX=6.0 GAT_RNG_TAIL_ROWS=64"
-run "GAT_RNG_SIGMA_MIN=3.0 GAT_RNG_SIGMA_MAX=6.0 GAT_RNG_TAIL_ROWS=48"
+echo "default"; run
+for SET in "4 6 64" "3 5 48" "3 4 32" "2.5 3.5 32" "2 3 24"; do
+  set -- $SET
+  echo "GAT_RNG_SIGMA_MIN=$1 GAT_RNG_SIGMA_MAX=$2 GAT_RNG_TAIL_ROWS=$3"
+  GAT_RNG_SIGMA_MIN=$1 GAT_RNG_SIGMA_MAX=$2 GAT_RNG_TAIL_ROWS=$3 run
+done

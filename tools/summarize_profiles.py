@@ -26,6 +26,16 @@ STREAMING = ("k_place", "k_rng", "k_seed", "k_finalize", "k_consolidate", "k_mer
              "k_sampler", "k_count_swap", "k_null_stats")
 HBM_ACHIEVABLE_GBPS = 6290.0
 
+def kernel_sources_sha(root):
+    """what the committed counters belong to: the kernels' sources at the time of the collection (bench.py compares it with
+    the tree it runs from and quotes no counter of other kernels)"""
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("gat_kernels.h", "gat_tail.h", "gat_device.h", "gat_stats.h", "gat_types.h"):
+        h.update(open(os.path.join(root, "gat_amd", "csrc", fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
@@ -44,6 +54,7 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
             res[n][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[n][r["Counter_Name"]] += 1
     stats = {}
+    ncalls = {}
     ks = os.path.join(d, "kernel_stats.csv")
     if os.path.exists(ks):
         rows = [r for r in csv.DictReader(open(ks)) if "gat::" in r["Name"]]
@@ -53,6 +64,7 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
             for r in rows:
                 w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
                 stats[r["Name"]] = float(r["AverageNs"])
+                ncalls[r["Name"]] = int(r["Calls"])
     bj = os.path.join(d, "bench.json")
     S = None
     if os.path.exists(bj) and os.path.getsize(bj):
@@ -105,7 +117,19 @@ for d in sorted(glob.glob(os.path.join(src, "*"))):
         if count:
             main = max(count, key=lambda n: per_kernel[n].get("avg_ns") or 0)
             entry["count_kernel"] = dict(per_kernel[main], name=main)
+            # the whole step: every kernel's bytes x its launches per step (launches of the main count kernel = batches = steps
+            # here: one batch per step at these sizes)
+            steps = float(max(1, ncalls.get(main, 1)))
+            tot, tot_ns = 0.0, 0.0
+            for n, rec in per_kernel.items():
+                per_step = ncalls.get(n, 0) / steps
+                rec["launches_per_step"] = per_step
+                tot += rec["hbm_bytes_per_launch"] * per_step
+                tot_ns += (rec.get("avg_ns") or 0.0) * per_step
+            entry["step"] = {"hbm_bytes": tot, "kernel_ns": tot_ns, "hbm_GBps_over_kernel_time": tot / tot_ns if tot_ns else None}
         counters_json["%s:%d" % (cfg, S)] = entry
+counters_json["_meta"] = {"tag": tag, "kernel_sources_sha": kernel_sources_sha(root),
+                          "collected_by": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter group)"}
 with open(os.path.join(dst, "%s_kernel_counters.json" % tag), "w") as f:
     json.dump(counters_json, f, indent=1, sort_keys=True)
-print("wrote", sorted(counters_json))
+print("wrote", sorted(k for k in counters_json if k != "_meta"))
