@@ -608,7 +608,8 @@ def test_pinned_register_check_catches_a_stray_use(tmp_path):
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     tool = os.path.join(root, "tools", "check_pinned_regs.py")
     head = "_ZN3gat12k_place_pipeILi0ELi1ELi0EEEvNS_11SamplerArgsE:\n\tv_add_u32_e32 v97, s3, v82\n\t; GAT_PINNED_BEGIN\n"
-    body = ("\tglobal_load_dword v96, v[2:3], off\n\tglobal_load_dword v127, v[2:3], off offset:1792\n"
+    loads = "".join("\tglobal_load_dword v%d, v[2:3], off offset:%d\n" % (96 + q, 256 * q) for q in range(7))
+    body = (loads + "\tglobal_load_dword v127, v[2:3], off offset:1792\n"
             "\ts_waitcnt vmcnt(24)\n\tv_mov_b32 v5, v96\n\tv_add_u32_e32 v6, v5, v7\n")
     tail = "\t; GAT_PINNED_END\n\tds_read_b32 v100, v3\n\ts_endpgm\n"
 
@@ -621,6 +622,9 @@ def test_pinned_register_check_catches_a_stray_use(tmp_path):
     for stray in ("\tv_add_u32_e32 v97, s3, v82\n", "\tds_read_b128 v[94:97], v3\n", "\tv_mov_b32 v100, v96\n"):
         r = run(head + body + stray + tail)
         assert r.returncode != 0 and "pinned-register loop" in (r.stderr + r.stdout), stray
+    # the waits count the loop's loads: a spill (scratch / buffer access) or a chunk that is not eight loads fails too
+    assert run(head + body + "\tscratch_load_dword v3, off, s32 offset:4\n" + tail).returncode != 0
+    assert run(head + body.replace("\tglobal_load_dword v127, v[2:3], off offset:1792\n", "") + tail).returncode != 0
     assert run("\tv_mov_b32 v1, v2\n").returncode != 0            # no markers: the wrong file
 
 
