@@ -525,6 +525,46 @@ def api_block(args, repeats=5):
                      "inputs_ms": t_inputs * 1e3, "isochore_split_ms": t_iso * 1e3,
                      "includes": "computeCounts (observed), gat_problem_create, gat_sample_and_count, gat_null_stats, D2H of the "
                                  "count matrix, AnnotatorResultExtended rows; excludes building the collections (inputs_ms)"}
+    # sixteen segment tracks against config 3's annotations (gat/__init__.py:971-1010 loops the tracks): the annotation tables
+    # are made once (gat_annotations_create) and shared, a track's sampling is enqueued while the previous one's rows are made
+    cfg = synthetic.config("config3")
+    cfg16 = dict(cfg, segment_tracks=[("track%02d" % i, synthetic.random_segments(synthetic.HG19, 10000, 500, 11 + i)) for i in range(16)])
+    segments, annotations, workspace, _ = synthetic.as_collections(cfg16)
+    counters = [gat_amd.COUNTERS[cfg["counter"]]()]
+
+    def call16():
+        t = time.perf_counter()
+        rows = gat_amd.run(segments, annotations, workspace, gat_amd.SamplerAnnotator(bucket_size=1, nbuckets=100000), counters,
+                           gat_amd.UnconditionalWorkspace(), num_samples=10000, random_seed=args.seed)
+        return time.perf_counter() - t, len(rows)
+    call16()
+    gc.collect()
+    gc.disable()
+    try:
+        ts = sorted(call16()[0] for _ in range(3))
+    finally:
+        gc.enable()
+    n_rows = call16()[1]
+    # what a later track's problem costs to create when the annotation tables exist (and what the first one costs with them)
+    from gat_amd import _lib, problem
+    ctx = gat_amd.get_context()
+    flat = problem.flatten_dictionaries(segments["track00"], workspace, annotations, list(annotations.tracks), 1, 100000)
+    t0 = time.perf_counter()
+    A = _lib.Annotations(ctx, flat)
+    t_annos = time.perf_counter() - t0
+    units = dict(flat, annos=None, anno_off=None, anno_end=None, anno_group=None)
+    tc = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        P = _lib.Problem(ctx, units, annotations=A)
+        tc.append(time.perf_counter() - t0)
+        P.close()
+    A.close()
+    med = ts[len(ts) // 2]
+    out["config3_16_segment_tracks"] = {"ms_per_run": med * 1e3, "ms_per_track": med * 1e3 / 16, "repeats": 3, "result_rows": n_rows,
+                                        "samples_per_s": 16 * 10000 / med, "num_samples": 10000, "segment_tracks": 16,
+                                        "annotation_tables_once_ms": t_annos * 1e3,
+                                        "problem_create_with_shared_tables_ms": sorted(tc)[len(tc) // 2] * 1e3}
     return out
 
 

@@ -335,6 +335,7 @@ struct gat_problem {
   DevBuf<int4> d_st2;                    // k_merge_big -> k_sampler hand-off (first consolidation of the long lists)
 #ifdef GAT_DIAG
   DevBuf<unsigned long long> d_diag;     // diagnostic build: per work unit, cycles per phase of k_sampler
+  DevBuf<unsigned long long> d_diag_place;   // ... per launch position, cycles per phase of k_place's loop
 #endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;

@@ -65,6 +65,7 @@ struct SamplerArgs {
   uint32_t* serial_state;
   const int32_t* unit_pos;    // unit id -> launch position, -1: inactive (k_serial walks the units in the reference's order)
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
+  unsigned long long* diag_place;   // ... and [launch position][8]: k_place's cycles per phase of its loop, summed over the unit's tiles
 };
 
 // The hand-over records between the sampler's kernels -- st, st2, TailPatch by launch position, ws_stat by unit id -- are laid
@@ -86,7 +87,12 @@ constexpr int kTbTrueRemaining = kPatchPad, kTbNSampled = kPatchPos, kTbSampledA
 #ifdef GAT_DIAG
 #define GAT_STAMP(T) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); }
 #define GAT_PHASE(K) { unsigned long long t__; GAT_STAMP(t__); dg[K] += t__ - dg_t; dg_t = t__; }
+// k_place's loop (tools/diag_place.sh): 0 row wait (the hand-pipelined loads' s_waitcnt + takes, or the compiler's), 1 the
+// chunk's look-ups (rank lengths from LDS / workspace segments), 2 the eight steps of the state machine incl. ring stores,
+// 3 the flush of the ring, 4 loop control (ballot, branch, the next chunk's loads issued)
+#define GAT_PSTAMP(K) { unsigned long long t__; GAT_STAMP(t__); pdg[K] += t__ - pdg_t; pdg_t = t__; }
 #else
+#define GAT_PSTAMP(K)
 #define GAT_PHASE(K) {}
 #endif
 
@@ -413,8 +419,12 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 
   // rows are consumed in chunks of kPlaceChunk; the next chunk is in flight while this one is worked on
   // (few waves per SIMD: nothing else hides the load latency)
-  // a placement takes at least two accepted outputs, so a chunk adds at most kPlaceChunk/2 = 4 segments to the
-  // at most 7 left by the previous flush: the ring of 16 never wraps onto unwritten segments
+  // The ring is flushed behind every SECOND chunk: a placement takes at least two accepted outputs, so two chunks add at
+  // most kPlaceChunk = 8 segments to the at most 7 a flush leaves -- 15 of the ring's 16 slots, the one left is where the
+  // next segment goes (k_place_wide writes it unconditionally).  In-kernel stamps (tools/diag_place.sh,
+  // profiles/r04_k_place_phases.txt) had the flush at a quarter of a wave's cycles per row: it runs whenever ANY lane has
+  // eight segments waiting -- with 64 lanes out of step that is every chunk -- and its eight LDS reads stand in front of the
+  // stores with nothing to overlap them (the row loads' asm statements fence the schedule)
   int nF = 0;                  // segments already written to the slab (multiple of 8)
   auto flush = [&]() __attribute__((always_inline)) {
 #ifdef GAT_EXP_NOFLUSH
@@ -545,6 +555,13 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE_B((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
 #define GAT_ALIVE_TB (sL || sB || sP || sO)
   // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
+#ifdef GAT_DIAG
+  unsigned long long pdg[5] = {0, 0, 0, 0, 0}, pdg_t, pdg_rows = 0;
+  GAT_STAMP(pdg_t);
+#define GAT_PROWS pdg_rows += kPlaceChunk;
+#else
+#define GAT_PROWS
+#endif
   // Two loops.  GAT_PLACE_LOOP: two chunk buffers, loads left to the compiler -- which, for a register loaded in one
   // trip and used in the next, waits for EVERYTHING in flight (loads and stores share one in-order counter, vmcnt, and the
   // flush above stores under a lane-dependent condition, so it cannot count): every chunk then exposes a round trip to
@@ -575,9 +592,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
                : "=v"(ya[0]), "=v"(ya[1]), "=v"(ya[2]), "=v"(ya[3]), "=v"(ya[4]), "=v"(ya[5]), "=v"(ya[6]), "=v"(ya[7]) \
                :: "memory");
 #define GAT_PLACE_CHUNK(PRE, ONE, K)                                                                         \
+  GAT_PSTAMP(0)                                                                                              \
   PRE(ya)                                                                                                    \
+  GAT_PSTAMP(1)                                                                                              \
   _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + (K) * kPlaceChunk + c))  \
-  flush();
+  GAT_PSTAMP(2)                                                                                              \
+  if ((K) & 1) flush();                /* every second chunk: see flush */                                   \
+  GAT_PSTAMP(3)                                                                                              \
+  GAT_PROWS
 #define GAT_PLACE_LOOP_PIPE(PRE, ONE, ALIVE)                                                                 \
   {                                                                                                          \
     static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
@@ -587,18 +609,22 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, 2 * kPlaceChunk)                                    \
     for (int j = 0; j < rows; j += 4 * kPlaceChunk) {                                                        \
       if (__ballot(ALIVE) == 0) break;                                                                       \
+      GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
       GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
       GAT_PLACE_CHUNK(PRE, ONE, 0)                                                                           \
       if (j + 1 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
       GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
       GAT_PLACE_CHUNK(PRE, ONE, 1)                                                                           \
       if (j + 2 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
       GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
       GAT_PLACE_CHUNK(PRE, ONE, 2)                                                                           \
       if (j + 3 * kPlaceChunk >= rows || __ballot(ALIVE) == 0) break;                                        \
+      GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
       GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
       GAT_PLACE_CHUNK(PRE, ONE, 3)                                                                           \
@@ -611,21 +637,31 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rq[c * kWave];                             \
     for (int j = 0; j < rows; j += 2 * kPlaceChunk) {                                                          \
       if (__ballot(ALIVE) == 0) break;                                                                         \
+      GAT_PSTAMP(4)                                                                                            \
       const bool more_b = j + kPlaceChunk < rows;                                                              \
       if (more_b) {                                                                                            \
         _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rq[(kPlaceChunk + c) * kWave];         \
       }                                                                                                        \
+      GAT_PSTAMP(0)                                                                                            \
       PRE(ya)                                                                                                  \
+      GAT_PSTAMP(1)                                                                                            \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + c))                    \
-      flush();                                                                                                 \
+      GAT_PSTAMP(2)                                                                                            \
+      GAT_PSTAMP(3)                                                                                            \
+      GAT_PROWS                                                                                                \
       if (!more_b || __ballot(ALIVE) == 0) break;                                                              \
       if (j + 2 * kPlaceChunk < rows) {                                                                        \
         _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ya[c] = rq[(2 * kPlaceChunk + c) * kWave];     \
       }                                                                                                        \
       rq += 2 * kPlaceChunk * kWave;                                                                           \
+      GAT_PSTAMP(0)                                                                                            \
       PRE(yb)                                                                                                  \
+      GAT_PSTAMP(1)                                                                                            \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb, c, (uint32_t)(j + kPlaceChunk + c))      \
+      GAT_PSTAMP(2)                                                                                            \
       flush();                                                                                                 \
+      GAT_PSTAMP(3)                                                                                            \
+      GAT_PROWS                                                                                                \
     }                                                                                                          \
   }
   if constexpr (MODE == 3) {
@@ -645,6 +681,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       }
     }
   }
+#undef GAT_PROWS
+#ifdef GAT_DIAG
+  if (lane == 0 && A.diag_place != nullptr && sb_own < n_tiles) {
+    for (int k = 0; k < 5; ++k) atomicAdd(&A.diag_place[(int64_t)a * 8 + k], pdg[k]);
+    atomicAdd(&A.diag_place[(int64_t)a * 8 + 5], pdg_rows);
+    atomicAdd(&A.diag_place[(int64_t)a * 8 + 6], 1ull);
+  }
+#endif
 #undef GAT_PLACE_LOOP
 #undef GAT_PLACE_LOOP_PIPE
 #undef GAT_PLACE_CHUNK

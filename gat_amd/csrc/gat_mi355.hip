@@ -464,6 +464,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         if (P->d_diag.n < nd) HIPCHK(ctx, P->d_diag.alloc(nd));
         HIPCHK(ctx, hipMemsetAsync(P->d_diag.p, 0, nd * 8, ctx->stream));
         A.diag = P->d_diag.p;
+        const size_t np = std::max<size_t>(1, P->h_order.size()) * 8;
+        if (P->d_diag_place.n < np) HIPCHK(ctx, P->d_diag_place.alloc(np));
+        HIPCHK(ctx, hipMemsetAsync(P->d_diag_place.p, 0, np * 8, ctx->stream));
+        A.diag_place = P->d_diag_place.p;
       }
 #endif
       // the units' launch positions are spread over grid y and z (each <= 65535)
@@ -828,6 +832,18 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
         fprintf(f, "{\"work_units\": %lld, \"cycles\": {\"prologue\": %.0f, \"sort\": %.0f, \"merge\": %.0f, \"coverage\": %.0f, "
                    "\"fast_paths\": %.0f, \"trim\": %.0f, \"draws_placement\": %.0f, \"final_filter_write\": %.0f}}\n",
                 (long long)nb * (long long)P->h_order.size(), sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], sum[6], sum[7]);
+        if (P->d_diag_place.n >= P->h_order.size() * 8 && !P->h_order.empty()) {
+          // k_place's loop, per phase: over all tiles, and for the largest unit alone (launch position 0: the tile the kernel ends with)
+          std::vector<unsigned long long> hp(P->h_order.size() * 8);
+          if (staged_d2h(ctx, hp.data(), P->d_diag_place.p, hp.size() * 8) == hipSuccess) {
+            double all[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (size_t i = 0; i < hp.size(); ++i) all[i & 7] += (i & 7) < 7 ? (double)hp[i] : 0.0;
+            fprintf(f, "{\"k_place\": {\"all_tiles\": {\"row_wait\": %.0f, \"lookups\": %.0f, \"steps\": %.0f, \"flush\": %.0f, \"loop_control\": %.0f, "
+                       "\"rows\": %.0f, \"tiles\": %.0f}, \"largest_unit\": {\"row_wait\": %llu, \"lookups\": %llu, \"steps\": %llu, \"flush\": %llu, "
+                       "\"loop_control\": %llu, \"rows\": %llu, \"tiles\": %llu}}}\n",
+                    all[0], all[1], all[2], all[3], all[4], all[5], all[6], hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6]);
+          }
+        }
         fclose(f);
       }
     }

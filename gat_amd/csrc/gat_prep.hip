@@ -1112,8 +1112,12 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       const char* env_tr = getenv("GAT_RNG_TAIL_ROWS");
       const double s_min = env_s0 ? atof(env_s0) : 3.5, s_max = env_s1 ? atof(env_s1) : 7.5;
       const bool long_list = U.hist_total + U.hist_total / 8 > 1024 || P->sampler == GAT_SAMPLER_SEGMENTS;
-      const double sigmas = long_list ? s_max : s_min;
-      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + (env_tr ? atof(env_tr) : (long_list ? 96.0 : 32.0));
+      // (a resumed unit goes through k_sampler's wave-per-unit consolidation and tail: tens of microseconds for hundreds of
+      //  segments, a few for fifty -- up to five sigma for the larger units of the split path: config 2, k_rng + k_sampler
+      //  0.55 -> 0.51 ms, where 3.5 sigma throughout gave back in k_sampler what it saved in k_rng)
+      const double sigmas = long_list ? s_max : std::min(std::max(s_min, 5.0), std::max(s_min, s_min - 0.5 + nplace / 130.0));
+      const double tail_rows = env_tr ? atof(env_tr) : (long_list ? 96.0 : (nplace < 128 ? 32.0 : 48.0));
+      const double need = e * nplace * slack + sigmas * std::sqrt(nplace * (v + 0.5 + var_n)) + tail_rows;
       int64_t rows = ((int64_t)std::ceil(need / 16.0)) * 16;        // whole k_place chunks (8) and k_rng read groups (16)
       rows = std::min<int64_t>(rows, (int64_t)gat::kMtN * 2048);
       P->h_rng_rows.push_back((int32_t)rows);

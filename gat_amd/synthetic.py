@@ -163,7 +163,7 @@ def as_collections(cfg):
                 c.add(t, contig, s)
         return c
 
-    segments = coll([("merged", cfg["segments"])])
+    segments = coll(cfg.get("segment_tracks") or [("merged", cfg["segments"])])
     annotations = coll(cfg["annotations"])
     workspaces = coll([("ws", cfg["workspace"])])
     workspaces.collapse()
