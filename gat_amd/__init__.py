@@ -495,6 +495,34 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
                 outf.close()
         if r is not None:
             sampled_counts[track] = r
+            # the track's result rows now, while the device samples the next track (assembled in the reference's order --
+            # counter, track, annotation, gat/__init__.py:1040-1068 -- at the end)
+            for counter_id in range(len(counters)):
+                if track in observed()[counter_id]:
+                    rows_by[(counter_id, track)] = make_rows(counter_id, track)
+
+    rows_by = {}
+    keep = []                        # the generated dictionaries stay alive so that their ids stay theirs
+
+    def make_rows(counter_id, track):
+        counter, rows = counters[counter_id], []
+        for annotation, observed_value in observed()[counter_id][track].items():
+            temp_segs, temp_annos, temp_workspace = workspace_generator(segments[track], annotations[annotation], workspace)
+            keep.append((temp_segs, temp_annos, temp_workspace))
+            if id(temp_workspace) not in sizes:
+                sizes[id(temp_workspace)] = (temp_workspace.counts(), temp_workspace.sum())
+            if sizes[id(temp_workspace)][1] == 0:
+                continue
+            ref = reference[track][annotation] if reference else None
+            dev_stats = getattr(sampled_counts[track], "stats", None)
+            rows.append(AnnotatorResultExtended(
+                track=track, annotation=annotation, counter=counter.name, observed=observed_value,
+                samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
+                annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
+                pseudo_count=pseudo_count, _sizes=sizes,
+                _stats=dev_stats[counter_id][annotation] if dev_stats else None,
+                _overlap=overlaps[track].get(annotation) if overlaps.get(track) else None))
+        return rows
 
     inflight = collections.deque()
     try:
@@ -552,27 +580,10 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
     observed_counts = observed()
 
     annotator_results = []
-    keep = []                        # the generated dictionaries stay alive so that their ids stay theirs
     for counter_id, (counter, observed_count) in enumerate(zip(counters, observed_counts)):
-        for track, r in observed_count.items():
-            if track not in sampled_counts:
-                continue
-            for annotation, observed in r.items():
-                temp_segs, temp_annos, temp_workspace = workspace_generator(segments[track], annotations[annotation], workspace)
-                keep.append((temp_segs, temp_annos, temp_workspace))
-                if id(temp_workspace) not in sizes:
-                    sizes[id(temp_workspace)] = (temp_workspace.counts(), temp_workspace.sum())
-                if sizes[id(temp_workspace)][1] == 0:
-                    continue
-                ref = reference[track][annotation] if reference else None
-                dev_stats = getattr(sampled_counts[track], "stats", None)
-                annotator_results.append(AnnotatorResultExtended(
-                    track=track, annotation=annotation, counter=counter.name, observed=observed,
-                    samples=sampled_counts[track][counter_id][annotation], track_segments=temp_segs,
-                    annotation_segments=temp_annos, workspace=temp_workspace, reference=ref,
-                    pseudo_count=pseudo_count, _sizes=sizes,
-                    _stats=dev_stats[counter_id][annotation] if dev_stats else None,
-                    _overlap=overlaps[track].get(annotation) if overlaps.get(track) else None))
+        for track in observed_count:
+            if track in sampled_counts:
+                annotator_results.extend(rows_by[(counter_id, track)] if (counter_id, track) in rows_by else make_rows(counter_id, track))
     if output_counts_pattern and rank == 0:               # (every rank holds the gathered matrix: one writer)
         for counter in counters:
             with open(re.sub("%s", counter.name, output_counts_pattern), "w") as outfile:

@@ -257,7 +257,11 @@ struct gat_annotations {
   std::atomic<int> ready{1};       // 0 while the worker runs
   int build_rc = 0;
   std::string build_err;
-  bool will_merge = false;         // known before the build: the merged index will exist (decides the count kernel's route)
+  // known before the build (shape_known): whether the merged index will exist and how many intervals the tables will hold --
+  // what decides the count kernel's route, and with it the sampler's last steps.  With four tracks or more the index exists
+  // whatever the lists hold; lists that pass through ungrouped (no fromIsochores merge) have their sizes in the desc
+  bool shape_known = false, will_merge = false;
+  int64_t total_known = -1;        // intervals of the tables, or -1 (merged groups: known when built)
 };
 void annotations_release(gat_annotations* a);     // gat_prep.hip
 inline bool annotations_ready(const gat_annotations* a) { return a->ready.load(std::memory_order_acquire) != 0; }

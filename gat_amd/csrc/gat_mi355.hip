@@ -247,11 +247,11 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
 }
 
 // which kernel serves the segment-side counters (the choice launch_count makes)
-static int count_route(const gat_ctx* ctx, const AnnoDev& annos, const Counters& C, int n_contigs, int n_tracks, int swap_capx) {
+static int count_route(const gat_ctx* ctx, bool has_merged, const Counters& C, int n_contigs, int n_tracks, int swap_capx) {
   if (!C.any_seg || n_contigs <= 0) return GAT_COUNT_KERNEL_NONE;
   const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
   const size_t lds_merged = (size_t)n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-  if (only_overlap && annos.has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED"))
+  if (only_overlap && has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED"))
     return GAT_COUNT_KERNEL_MERGED;
   if (swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) return GAT_COUNT_KERNEL_SWAP;
   return GAT_COUNT_KERNEL_SEG;
@@ -306,7 +306,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), gpy, gpz);
     const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
     const size_t lds_merged = (size_t)A.n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-    const int route = count_route(ctx, annos, C, A.n_contigs, A.n_tracks, swap_capx);
+    const int route = count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx);
     if (route == GAT_COUNT_KERNEL_MERGED) {
       // several tracks: one look-up per sample segment in the merged index of all tracks
       A.mz = annos.mz.p; A.mz_off = annos.mz_off.p; A.mfirst = annos.mfirst.p; A.mf_off = annos.mf_off.p;
@@ -917,8 +917,9 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
 static void decide_swap(gat_problem* P) {
   if (P->swap_decided) return;
   P->swap_decided = true;
+  const int64_t total = annotations_ready(P->anno) ? P->anno->dev.total : P->anno->total_known;   // (callers: ready, or total_known >= 0)
   const double avg_n = P->n_contigs ? (double)P->n_seg_total / P->n_contigs : 0.0;
-  const double avg_m = (P->n_contigs && P->n_tracks) ? (double)P->anno->dev.total / ((double)P->n_contigs * P->n_tracks) : 0.0;
+  const double avg_m = (P->n_contigs && P->n_tracks) ? (double)total / ((double)P->n_contigs * P->n_tracks) : 0.0;
   if (avg_m > 0 && avg_n > 3.0 * avg_m) P->swap_capx = 1;       // capacity is taken from the slab layout at launch
 }
 
@@ -987,17 +988,20 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
     if (annotations_ready(P->anno)) {
       if ((rc = annotations_wait(ctx, P->anno))) return rc;
       decide_swap(P);
-      route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+      route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
     } else {
       const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
       const size_t lds_merged = (size_t)P->n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
       if (C.any_seg && P->n_contigs > 0 && only_overlap && P->anno->will_merge && (int64_t)lds_merged + 1024 <= ctx->max_lds &&
           !getenv("GAT_COUNT_NO_MERGED")) {
-        route = GAT_COUNT_KERNEL_MERGED;
+        route = GAT_COUNT_KERNEL_MERGED;                       // (whatever the swap decision would be)
+      } else if (P->anno->shape_known && P->anno->total_known >= 0) {
+        decide_swap(P);                                        // (from the sizes announced before the build)
+        route = count_route(ctx, P->anno->will_merge, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
       } else {
         if ((rc = annotations_wait(ctx, P->anno))) return rc;
         decide_swap(P);
-        route = count_route(ctx, P->anno->dev, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+        route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
       }
     }
     // the scratch is sized while nothing of this problem is in flight; batches behind the first fit by construction

@@ -808,6 +808,10 @@ static int annotations_build(gat_ctx* ctx, gat_annotations* A, const gat_annotat
   if (rc) return rc;
   HIPCHK(ctx, stage_flush(ctx));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // (the tables are resident when the build is reported done)
+  if (A->shape_known && (A->dev.has_merged != A->will_merge || (A->total_known >= 0 && A->dev.total != A->total_known)))
+    return set_err(ctx, GAT_ERR_DEVICE, "internal: the annotation tables are not of the shape announced before their build "
+                   "(merged index %d / %d, %lld / %lld intervals)", (int)A->dev.has_merged, (int)A->will_merge,
+                   (long long)A->dev.total, (long long)A->total_known);
   return GAT_OK;
 }
 
@@ -849,9 +853,36 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
   // whether the merged index will exist is known from the shape alone when there are enough tracks (build_annos): only then
   // may a problem sample before the tables are there (the sampler's last steps depend on the count kernel that follows)
   const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  const int64_t n_groups_all = (int64_t)d->n_tracks * d->n_contigs;
   A->will_merge = d->n_contigs > 0 && d->n_tracks >= (env_mm ? atoi(env_mm) : 4) && d->n_tracks <= 65535;
+  A->shape_known = A->will_merge;
+  if (!d->merge_contigs && d->anno_off != nullptr && n_groups_all > 0) {
+    // the lists pass through as they are (a key is its contig; of several lists of a group the last one stays): their
+    // lengths are in the desc, and with them everything build_annos decides the tables' form by
+    std::vector<int64_t> len((size_t)n_groups_all, 0);
+    bool ok = true;
+    if (d->anno_group != nullptr) {
+      for (int64_t l = 0; l < d->n_anno_lists && ok; ++l) {
+        const int32_t g = d->anno_group[l];
+        if (g < -1 || g >= n_groups_all) { ok = false; break; }
+        if (g >= 0) len[(size_t)g] = (d->anno_end ? d->anno_end[l] : d->anno_off[l + 1]) - d->anno_off[l];
+      }
+    } else
+      for (int64_t g = 0; g < n_groups_all; ++g) len[(size_t)g] = d->anno_off[g + 1] - d->anno_off[g];
+    if (ok) {
+      int64_t total = 0, max_m = 0;
+      for (int64_t g = 0; g < n_groups_all; ++g) { if (len[(size_t)g] < 0) ok = false; total += len[(size_t)g]; max_m = std::max(max_m, len[(size_t)g]); }
+      if (ok) {
+        const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
+        const bool unstaged = max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+        A->will_merge = d->n_contigs > 0 && d->n_tracks <= 65535 && (d->n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged);
+        A->total_known = total;
+        A->shape_known = true;
+      }
+    }
+  }
   const char* env_a = getenv("GAT_ANNOTATIONS_SYNC");
-  const bool async = (d->flags & GAT_ANNOTATIONS_ASYNC) != 0 && A->will_merge && !(env_a && atoi(env_a) != 0);
+  const bool async = (d->flags & GAT_ANNOTATIONS_ASYNC) != 0 && A->shape_known && !(env_a && atoi(env_a) != 0);
   if (!async) {
     int rc = annotations_build(ctx, A.get(), d);
     if (rc) return rc;

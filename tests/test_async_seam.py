@@ -151,7 +151,7 @@ def test_context_closed_before_its_problem():
     P.close()
 
 
-@pytest.mark.parametrize("n_tracks,isochores", [(6, True), (5, False), (2, True)])
+@pytest.mark.parametrize("n_tracks,isochores", [(6, True), (5, False), (2, True), (1, False), (3, False)])
 def test_annotation_tables_built_while_the_device_samples(ctx, n_tracks, isochores):
     """gat_annotations_create with GAT_ANNOTATIONS_ASYNC: the problem is sampled at once, the count kernels follow when the
     tables are there; fewer than four tracks: the build is synchronous (the count kernel's route is not known beforehand).
