@@ -950,13 +950,24 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   std::vector<std::vector<int32_t>> per_contig((size_t)d->n_contigs);
   std::vector<double> len_cv2((size_t)std::max(1, d->n_units), 0.0);
 
+  // Per unit, on the host threads (192 isochore units x ~50 segments, or 24 contigs x hundreds: the overlaps with the
+  // workspace, the rank table -- a sort of the unit's lengths --, the search trees): everything a unit needs by itself into a
+  // record of its own; the offsets into the shared tables are dealt out in unit order behind it.
+  struct UnitPrep {
+    int rc = 0;
+    std::string err;
+    bool active = false;
+    std::vector<uint32_t> rank;          // rank 0 (never drawn) + the bucket indices in ascending order
+    std::vector<uint2> ws;
+    std::vector<uint32_t> cdf, tree_start, tree_cdf;
+    int64_t nwork = 0;
+    double cv2 = 0.0;
+  };
+  std::vector<UnitPrep> prep((size_t)std::max(0, d->n_units));
   for (int u = 0; u < d->n_units; ++u) {
     UnitDev& U = P->h_units[u];
     memset(&U, 0, sizeof(U));
-    const gat_segment* us = d->segs + d->seg_off[u];
-    const int64_t nus = d->seg_off[u + 1] - d->seg_off[u];
-    const gat_segment* uw = d->ws + d->ws_off[u];
-    const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+    const int64_t nus = d->seg_off[u + 1] - d->seg_off[u], nuw = d->ws_off[u + 1] - d->ws_off[u];
     const int c = d->unit_contig[u];
     U.contig = c;
     P->n_seg_total += nus;
@@ -964,11 +975,29 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     if (c >= d->n_contigs || (c < 0 && !skipped))
       return set_err(ctx, GAT_ERR_ARG, "unit %d: contig index %d invalid (skipped units carry -1)", u, c);
     if (skipped) continue;
-    if (c < 0) return set_err(ctx, GAT_ERR_ARG, "unit %d is not skipped by computeSample but has contig -1", u);
     per_contig[(size_t)c].push_back(u);
-    int rc;
-    if ((rc = check_list(ctx, us, nus, "segment", u))) return rc;     // gat/Engine.pyx:535
-    if ((rc = check_list(ctx, uw, nuw, "workspace", u))) return rc;   // gat/Engine.pyx:536
+  }
+  auto fail_unit = [&](UnitPrep& R, int code, const char* fmt, auto... args) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), fmt, args...);
+    R.rc = code; R.err = buf;
+  };
+  parallel_for((d->n_units + 7) / 8, [&](int64_t blk) {
+  for (int u = (int)blk * 8; u < std::min<int>(d->n_units, (int)blk * 8 + 8); ++u) {
+    UnitDev& U = P->h_units[u];
+    UnitPrep& R = prep[(size_t)u];
+    const gat_segment* us = d->segs + d->seg_off[u];
+    const int64_t nus = d->seg_off[u + 1] - d->seg_off[u];
+    const gat_segment* uw = d->ws + d->ws_off[u];
+    const int64_t nuw = d->ws_off[u + 1] - d->ws_off[u];
+    if (nus == 0 || nuw == 0) continue;
+    for (int pass = 0; pass < 2 && R.rc == 0; ++pass) {              // gat/Engine.pyx:535-536: both lists normalized
+      const gat_segment* l = pass ? uw : us;
+      const int64_t nl = pass ? nuw : nus;
+      for (int64_t i = 0; i < nl; ++i)
+        if (l[i].start >= l[i].end || l[i].end >= 0x80000000u || (i > 0 && l[i - 1].end > l[i].start)) { R.rc = GAT_ERR_ASSERT; R.err = pass ? "workspace" : "segment"; break; }
+    }
+    if (R.rc) continue;                                              // (the message comes from check_list below, in unit order)
     // working = segments.filter(workspace); ltotal = working.intersect(workspace).sum()
     uint32_t ltotal = 0, maxlen = 0;
     int64_t nwork = 0;
@@ -989,65 +1018,91 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     if (bucket == 0) bucket = (int64_t)std::ceil((double)(int32_t)maxlen / (double)d->nbuckets);
     // the histogram over the buckets, cumulated, read as "rank r -> bucket": the bucket indices in ascending order (a sort
     // of the unit's lengths; a std::map insertion per segment was most of this stage: 0.8 of config 2's 1.2 ms)
-    U.rank_off = (int32_t)h_rank_len.size();
-    h_rank_len.push_back(0u);                       // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
+    R.rank.reserve(lens.size() + 1);
+    R.rank.push_back(0u);                           // rank 0 is never drawn (r >= 1, gat/Engine.pyx:419-422)
     for (uint32_t l : lens) {
       const int64_t i = ((int64_t)l + bucket - 1) / bucket;
-      if (i >= d->nbuckets)
-        return set_err(ctx, GAT_ERR_VALUE, "unit %d: segment of length %u too large: increase nbuckets (%d) or bucket_size (%lld)",
-                       u, l, d->nbuckets, (long long)bucket);
-      h_rank_len.push_back((uint32_t)i);
+      if (i >= d->nbuckets) {
+        fail_unit(R, GAT_ERR_VALUE, "unit %d: segment of length %u too large: increase nbuckets (%d) or bucket_size (%lld)",
+                  u, l, d->nbuckets, (long long)bucket);
+        break;
+      }
+      R.rank.push_back((uint32_t)i);
     }
-    std::sort(h_rank_len.begin() + U.rank_off + 1, h_rank_len.end());           // ranks (cum-count, cum] of a bucket hold it
-    const uint32_t cum = (uint32_t)lens.size();
-    U.hist_total = cum;
+    if (R.rc) continue;
+    std::sort(R.rank.begin() + 1, R.rank.end());                    // ranks (cum-count, cum] of a bucket hold it
+    U.hist_total = (uint32_t)lens.size();
     U.bucket = (uint32_t)bucket;
     {
       double m1 = 0, m2 = 0;                               // squared coefficient of variation of the lengths drawn
       for (uint32_t l : lens) { m1 += (double)l; m2 += (double)l * (double)l; }
       m1 /= (double)lens.size(); m2 /= (double)lens.size();
-      len_cv2[(size_t)u] = m1 > 0 ? std::max(0.0, m2 / (m1 * m1) - 1.0) : 0.0;
+      R.cv2 = m1 > 0 ? std::max(0.0, m2 / (m1 * m1) - 1.0) : 0.0;
     }
     // SegmentListSampler(workspace) (gat/Engine.pyx:261-277)
     U.n_ws = (int32_t)nuw;
-    U.ws_off = (int32_t)h_ws.size();
     uint32_t tot = 0;
+    R.ws.reserve((size_t)nuw); R.cdf.reserve((size_t)nuw);
     for (int64_t i = 0; i < nuw; ++i) {
       tot += uw[i].end - uw[i].start;
-      h_ws.push_back(make_uint2(uw[i].start, uw[i].end));
-      h_ws_cdf.push_back(tot - 1u);
+      R.ws.push_back(make_uint2(uw[i].start, uw[i].end));
+      R.cdf.push_back(tot - 1u);
     }
     U.ws_total = tot;
     // long workspaces: 16-ary search trees (gat_device.h, WsTree) over the starts and over the cumulated lengths
     U.tree_start_off = -1;
     U.tree_cdf_off = -1;
-    if (nuw > ((int64_t)1 << (4 * gat::kWsTreeLevels)))
-      return set_err(ctx, GAT_ERR_CAPACITY, "unit %d: %lld workspace segments (> %lld)", u, (long long)nuw,
-                     (long long)((int64_t)1 << (4 * gat::kWsTreeLevels)));
+    if (nuw > ((int64_t)1 << (4 * gat::kWsTreeLevels))) {
+      fail_unit(R, GAT_ERR_CAPACITY, "unit %d: %lld workspace segments (> %lld)", u, (long long)nuw, (long long)((int64_t)1 << (4 * gat::kWsTreeLevels)));
+      continue;
+    }
     if (nuw > gat::kWsTreeMin) {
-      auto build = [&](auto key, uint32_t pad) {
-        const int32_t off = (int32_t)h_ws_tree.size();
+      auto build = [&](std::vector<uint32_t>& tree, auto key, uint32_t pad) {
         std::vector<uint32_t> level((size_t)nuw);
         for (int64_t i = 0; i < nuw; ++i) level[(size_t)i] = key(i);
         for (;;) {
           const size_t n = level.size(), nodes = (n + 15) / 16;
-          h_ws_tree.insert(h_ws_tree.end(), level.begin(), level.end());
-          h_ws_tree.insert(h_ws_tree.end(), nodes * 16 - n, pad);
+          tree.insert(tree.end(), level.begin(), level.end());
+          tree.insert(tree.end(), nodes * 16 - n, pad);
           if (n <= 16) break;
           std::vector<uint32_t> up(nodes);
           for (size_t j = 0; j < nodes; ++j) up[j] = level[std::min(16 * j + 15, n - 1)];   // largest key of node j
           level.swap(up);
         }
-        return off;
       };
-      U.tree_start_off = build([&](int64_t i) { return uw[i].start; }, 0xffffffffu);
-      const size_t base = h_ws_cdf.size() - (size_t)nuw;
-      U.tree_cdf_off = build([&](int64_t i) { return h_ws_cdf[base + (size_t)i]; }, 0x7fffffffu);
+      build(R.tree_start, [&](int64_t i) { return uw[i].start; }, 0xffffffffu);
+      build(R.tree_cdf, [&](int64_t i) { return R.cdf[(size_t)i]; }, 0x7fffffffu);
     }
     U.ltotal = (int32_t)ltotal;
     U.n_target = (int32_t)nus;                       // SamplerSegments places len(segments) segments
-    P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(nwork, nus) : nwork);
-    work.push_back(std::make_pair(nwork, (int32_t)u));
+    R.nwork = nwork;
+    R.active = true;
+  }
+  });
+  for (int u = 0; u < d->n_units; ++u) {
+    UnitPrep& R = prep[(size_t)u];
+    UnitDev& U = P->h_units[u];
+    if (R.rc == GAT_ERR_ASSERT) {                    // (the first offender in unit order, with the reference's message)
+      int rc;
+      if ((rc = check_list(ctx, d->segs + d->seg_off[u], d->seg_off[u + 1] - d->seg_off[u], "segment", u))) return rc;     // gat/Engine.pyx:535
+      if ((rc = check_list(ctx, d->ws + d->ws_off[u], d->ws_off[u + 1] - d->ws_off[u], "workspace", u))) return rc;       // gat/Engine.pyx:536
+    }
+    if (R.rc) return set_err(ctx, R.rc, "%s", R.err.c_str());
+    if (!R.active) continue;
+    U.rank_off = (int32_t)h_rank_len.size();
+    h_rank_len.insert(h_rank_len.end(), R.rank.begin(), R.rank.end());
+    U.ws_off = (int32_t)h_ws.size();
+    h_ws.insert(h_ws.end(), R.ws.begin(), R.ws.end());
+    h_ws_cdf.insert(h_ws_cdf.end(), R.cdf.begin(), R.cdf.end());
+    if (!R.tree_start.empty()) {
+      U.tree_start_off = (int32_t)h_ws_tree.size();
+      h_ws_tree.insert(h_ws_tree.end(), R.tree_start.begin(), R.tree_start.end());
+      U.tree_cdf_off = (int32_t)h_ws_tree.size();
+      h_ws_tree.insert(h_ws_tree.end(), R.tree_cdf.begin(), R.tree_cdf.end());
+    }
+    len_cv2[(size_t)u] = R.cv2;
+    P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(R.nwork, d->seg_off[u + 1] - d->seg_off[u]) : R.nwork);
+    work.push_back(std::make_pair(R.nwork, (int32_t)u));
   }
   // contig -> units (reference order)
   P->h_contig_unit_off.assign((size_t)d->n_contigs + 1, 0);

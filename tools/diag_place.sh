@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic build of the library with in-kernel stamps (-DGAT_DIAG): where k_place's loop spends a wave's cycles -- waiting
 # for its rows, the chunk's look-ups, the eight steps of the state machine, the flush of the ring, loop control -- over all
-# tiles and for the largest unit's tiles (the ones the kernel ends with).  s_memtime counts at 100 MHz (10 ns); the stamps
+# tiles and for the largest unit's tiles (the ones the kernel ends with).  s_memtime counts shader-clock cycles; the stamps
 # fence the schedule (every stamp waits for the scalar and LDS queues): read the SHARES and the per-row figures as bounds.
 # usage (GPU box): bash tools/diag_place.sh <tag> [config:samples ...]
 set -u
@@ -25,10 +25,10 @@ for l in open(sys.argv[1]):
     if "k_place" not in d: continue
     for which in tot:
         for k, v in d["k_place"][which].items(): tot[which][k] = tot[which].get(k, 0) + v
-print("k_place, %s at %s samples per call (s_memtime ticks of 10 ns)" % (sys.argv[2], sys.argv[3]))
+print("k_place, %s at %s samples per call (cycles)" % (sys.argv[2], sys.argv[3]))
 for which in ("all_tiles", "largest_unit"):
     t = tot[which]; s = sum(t[n] for n in names)
-    print("  %-13s %d tiles, %.0f rows per tile, %.1f ns per row of 64 lanes" % (which, t["tiles"], t["rows"] / max(1, t["tiles"]), 10.0 * s / max(1, t["rows"])))
-    for n in names: print("      %-13s %5.1f %%   %6.1f ns per row" % (n, 100.0 * t[n] / s, 10.0 * t[n] / max(1, t["rows"])))
+    print("  %-13s %d tiles, %.0f rows per tile, %.0f cycles per row of 64 lanes" % (which, t["tiles"], t["rows"] / max(1, t["tiles"]), s / max(1, t["rows"])))
+    for n in names: print("      %-13s %5.1f %%   %6.1f cycles per row" % (n, 100.0 * t[n] / s, t[n] / max(1, t["rows"])))
 PY
 done
