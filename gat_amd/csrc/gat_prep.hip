@@ -17,17 +17,17 @@
 // ------------------------------------------------------------------------------------------
 // the device-memory pool behind DevBuf (gat_host.h)
 namespace {
-struct PoolBlock { void* p; size_t bytes; };
+struct PoolBlock { void* p; size_t bytes; unsigned long long stamp; };
 // blocks: idle ones; out: what the blocks handed out really hold (a request is served by a block up to a quarter larger: it
 // comes back under its own size, not the request's, so the books -- held, the GAT_POOL_BYTES cap, dev_pool_held() -- stay true)
-struct DevPool { std::vector<PoolBlock> blocks; size_t held = 0; std::map<void*, size_t> out; };
+struct DevPool { std::vector<PoolBlock> blocks; size_t held = 0; std::map<void*, size_t> out; unsigned long long clock = 0; };
 std::mutex g_pool_mutex;
 std::map<int, DevPool> g_pools;
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
 size_t pool_limit() {
   static const size_t limit = [] {
     const char* env = getenv("GAT_POOL_BYTES");
-    return env ? (size_t)atof(env) : (size_t)64 << 30;
+    return env ? (size_t)atof(env) : (size_t)96 << 30;
   }();
   return limit;
 }
@@ -96,18 +96,34 @@ void dev_pool_free(void* p, size_t bytes) {
   hipPointerAttribute_t attr;
   int dev = 0;
   if (hipPointerGetAttributes(&attr, p) == hipSuccess) dev = attr.device; else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
+  std::vector<void*> evict;
+  bool kept = false;
   {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     DevPool& P = g_pools[dev];
     auto it = P.out.find(p);
     if (it != P.out.end()) { cls = it->second; P.out.erase(it); }     // (the block's own size)
-    if (P.held + cls <= pool_limit() && P.blocks.size() < 4096) {
-      P.blocks.push_back(PoolBlock{p, cls});
+    if (cls <= pool_limit() && P.blocks.size() < 4096) {
+      // the block just freed is the one most likely to be asked for again (a host that creates problem after problem):
+      // it stays, and what has lain idle longest goes back to the driver until the pool is within its limit -- refusing
+      // the NEW block instead made a run over 16 segment tracks allocate and free its 15 GB of scratch per track (78 ms
+      // each) once blocks of earlier, larger problems had filled the pool
+      P.blocks.push_back(PoolBlock{p, cls, ++P.clock});
       P.held += cls;
-      return;
+      while (P.held > pool_limit() && P.blocks.size() > 1) {
+        size_t old = 0;
+        for (size_t i = 1; i < P.blocks.size(); ++i) if (P.blocks[i].stamp < P.blocks[old].stamp) old = i;
+        if (P.blocks[old].p == p) break;
+        evict.push_back(P.blocks[old].p);
+        P.held -= P.blocks[old].bytes;
+        P.blocks[old] = P.blocks.back();
+        P.blocks.pop_back();
+      }
+      kept = true;
     }
   }
-  (void)hipFree(p);
+  for (void* q : evict) (void)hipFree(q);            // (outside the lock: hipFree waits for the device)
+  if (!kept) (void)hipFree(p);
 }
 
 size_t dev_pool_held() {
