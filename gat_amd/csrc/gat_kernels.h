@@ -380,6 +380,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // the vector work (51 -> 3x vector instructions per output).  LR1 = the length of rank 1 + (y & maskL), read for the
   // whole chunk up front (one exposed latency per chunk instead of one per output).
   bool sL = live, sP = false, sO = false;
+  uint32_t omaskS = 0u, orangeS = 0u;
   const int32_t c_ss = (int32_t)ws0.x + 1;               // sampling_start = ws.start - length + 1 (:318)
   const uint32_t c_r3 = ws0.y - ws0.x - 2u;              // its range: ws.end - 1 - sampling_start = c_r3 + length
 #define GAT_STEP_SIMPLE_B(Y, LR1, JJ)                                                                          \
@@ -389,10 +390,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
        offset's range follows from the length drawn last: sampling_start = c_ss - len, range c_r3 + len) */    \
     const bool accL = (y_ & maskL) <= rangeL;                                                                  \
     const bool accP = (y_ & maskP) <= rangeP;                                                                  \
-    const uint32_t range3 = c_r3 + len;                                                                        \
-    const uint32_t vO = y_ & (0xffffffffu >> __builtin_clz(range3 | 1u));                                      \
-    const bool accO = vO <= range3;                                                                            \
+    /* (the offset draw's mask and range are kept from the position draw on, as the general step does: the chain          \
+        length -> range -> leading zeros -> mask -> value -> test is off the row's critical path) */          \
+    const uint32_t vO = y_ & omaskS;                                                                           \
+    const bool accO = vO <= orangeS;                                                                           \
     const bool isL = sL && accL, isP = sP && accP, isO = sO && accO;                                           \
+    const uint32_t range3 = c_r3 + len;                                                                        \
+    omaskS = isP ? 0xffffffffu >> __builtin_clz(range3 | 1u) : omaskS;                                         \
+    orangeS = isP ? range3 : orangeS;                                                                          \
     const bool trig = isL && !kind1 && rem <= (int32_t)(LR1);          /* :582 -> consolidate */               \
     const int32_t q = c_ss - (int32_t)len + (int32_t)vO;                                                       \
     const uint32_t start = (uint32_t)(q > 0 ? q : 0);                                                          \
