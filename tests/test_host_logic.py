@@ -692,3 +692,117 @@ def test_bed_table_reader_over_several_files(tmp_path, monkeypatch):
         got = _read_bed_either_way(monkeypatch, [str(a), str(b)], False, **kw)
         assert got == want, kw
     assert _read_bed_either_way(monkeypatch, [str(a), str(b)], False, allow_multiple=False) == "ValueError"
+
+
+def test_list_sums_equal_segmentlist_sum():
+    """gat_list_sums (the *_size columns of a run over 10^4 lists): SegmentList.sum() per list -- a uint32 accumulator,
+    gat/SegmentList.pyx:1607 -- for lists given as ranges of one array"""
+    from gat_amd import _lib, intervals as iv
+    rs = np.random.RandomState(5)
+    lists = []
+    for _ in range(40):
+        n = int(rs.randint(0, 50))
+        s = np.sort(rs.randint(0, 1 << 20, n))
+        lists.append(iv.normalize(iv.make(s, s + rs.randint(1, 3000, n))))
+    lists.append(iv.make([0, 1 << 31], [(1 << 31) - 1, 0xffffffff]))          # sums beyond 2^32 wrap like the reference's accumulator
+    data = np.concatenate(lists)
+    end = np.cumsum([len(x) for x in lists])
+    got = _lib.list_sums(data, end - [len(x) for x in lists], end)
+    for g, x in zip(got.tolist(), lists):
+        assert g == int((x["end"].astype(np.int64) - x["start"]).sum() & 0xFFFFFFFF)
+
+
+def test_contig_list_lengths_equal_from_isochores():
+    """problem.contig_list_lengths -- len(dictionary.fromIsochores()[contig]) for every contig in one vectorised pass (the
+    density counter's divisor, gat/Engine.pyx:1437) -- against problem.from_isochores on the arrays: touching and overlapping
+    pieces merge (merge(0)), empty segments vanish, keys without a dot pass through"""
+    import gat_amd
+    rs = np.random.RandomState(8)
+    for case in range(30):
+        d = gat_amd.IntervalDictionary()
+        dotted = case % 3 != 0
+        for c in range(int(rs.randint(1, 5))):
+            for k in range(int(rs.randint(1, 5)) if dotted else 1):
+                n = int(rs.randint(0, 30))
+                s = np.sort(rs.randint(0, 2000, n))
+                e = s + rs.randint(0, 120, n)                          # zero-length ones included
+                sl = gat_amd.SegmentList(array=iv.make(s, e))
+                d.add("chr%d.iso%d" % (c, k) if dotted else "chr%d" % c, sl)
+        want = dict((c, len(a)) for c, a in problem.from_isochores(d.asArrays()).items())
+        got = problem.contig_list_lengths(d)
+        if dotted:
+            assert dict(got) == want, case
+        else:
+            assert dict(got) == dict((c, len(a)) for c, a in d.asArrays().items()), case
+        assert list(got.keys()) == list(want.keys())
+
+
+def test_collection_ranges_equal_the_dictionaries_ranges():
+    """IntervalCollection._ranges (where the lists of given keys lie in the collection's one array; kept for the length of a
+    run()) against _DictFlat.ranges dictionary by dictionary: same keys, keys in another order, keys a dictionary lacks"""
+    _, cfg = synthetic.small_genome()
+    segments, annotations, workspace, _ = synthetic.as_collections(cfg)
+    tracks = list(annotations.tracks)
+    aflat = annotations._flat(tracks)
+    keys = list(annotations[tracks[0]].keys())
+    annotations._ranges_memo = {}
+    try:
+        for target in (keys, keys[::-1], keys[:3] + ["nowhere.iso9"] + keys[3:]):
+            b, e = annotations._ranges(aflat, target)
+            bb, ee = zip(*[f.ranges(target, base) for f, base in zip(aflat[2], aflat[1])])
+            assert np.array_equal(b, np.concatenate(bb)) and np.array_equal(e, np.concatenate(ee))
+            b2, e2 = annotations._ranges(aflat, target)                # (from the memo)
+            assert b2 is b and e2 is e
+    finally:
+        annotations._ranges_memo = None
+    # a dictionary whose keys differ from the others' takes the general path
+    del annotations[tracks[1]][keys[0]]
+    aflat = annotations._flat(tracks)
+    b, e = annotations._ranges(aflat, keys)
+    bb, ee = zip(*[f.ranges(keys, base) for f, base in zip(aflat[2], aflat[1])])
+    assert np.array_equal(b, np.concatenate(bb)) and np.array_equal(e, np.concatenate(ee))
+
+
+def test_result_rows_keep_the_device_rows_until_asked():
+    """AnnotatorResult with the device's statistics keeps the row as it came (int64, or a row that fetches the matrix from the
+    device on demand) and makes the float copy the reference holds when somebody asks: same samples, same p-values"""
+    import gat_amd
+    rs = np.random.RandomState(4)
+    row = rs.randint(0, 500, 1000).astype(np.int64)
+    observed = 260.0
+    eager = gat_amd.AnnotatorResult("t", "a", "c", observed, row)
+    srt = np.sort(row)
+    off = int(0.05 * len(row))
+    stats = (float(np.mean(row.astype(np.float64))), float(np.std(row.astype(np.float64))), float(srt[off]), float(srt[len(row) - off]),
+             int((row < observed).sum()), int((row == observed).sum()))
+    fetched = []
+
+    class Row(object):                                   # stands in for gat_amd._DeviceRow
+        def __len__(self):
+            return len(row)
+
+        def __array__(self, dtype=None, copy=None):
+            fetched.append(1)
+            return row.astype(dtype) if dtype is not None else row
+
+    for samples in (row, Row()):
+        lazy = gat_amd.AnnotatorResult("t", "a", "c", observed, samples, _stats=stats)
+        assert str(lazy) == str(eager) and not fetched
+        assert lazy.getEmpiricalPValue(observed) == eager.getEmpiricalPValue(observed) and not fetched   # (counted on the device)
+        assert lazy.getEmpiricalPValue(100.0) == eager.getEmpiricalPValue(100.0)                           # (another value: the samples)
+        assert np.array_equal(lazy.samples, eager.samples) and lazy.getSample(7) == eager.getSample(7)
+    assert fetched
+
+
+def test_device_counts_rows_fetch_once():
+    """gat_amd._DeviceCounts (the gathered matrix under nccl): rank 0 reads it back at once, the other ranks' rows on demand,
+    once for all rows"""
+    torch = pytest.importorskip("torch")
+    import gat_amd
+    m = np.arange(2 * 3 * 5, dtype=np.int64).reshape(2, 3, 5)
+    counts = gat_amd._DeviceCounts(torch.from_numpy(m.copy()), ["nucleotide-overlap", "segment-overlap"])
+    rows = counts.rows(1, 3, True)
+    assert counts.host is None and len(rows[2]) == 5
+    assert np.array_equal(np.array(rows[2], dtype=np.float64), m[1, 2].astype(np.float64))
+    assert counts.host is not None and counts.tensor is None
+    assert np.array_equal(counts.rows(0, 3, False)[1], m[0, 1]) and list(rows[0]) == m[1, 0].tolist() and rows[1][3] == m[1, 1, 3]
