@@ -836,7 +836,10 @@ static void annotations_build_worker(gat_annotations* A, gat_annotations_desc d)
   gat_ctx* b = A->ctx->build_ctx;
   int rc = GAT_OK;
   if (hipSetDevice(b->device) != hipSuccess) rc = set_err(b, GAT_ERR_DEVICE, "hipSetDevice failed in the annotation build");
-  if (rc == GAT_OK) rc = annotations_build(b, A, &d);
+  if (rc == GAT_OK) {
+    try { rc = annotations_build(b, A, &d); }
+    catch (const std::exception& e) { rc = set_err(b, GAT_ERR_MEMORY, "annotation build: %s", e.what()); }   // (bad_alloc: reported, not fatal)
+  }
   A->build_rc = rc;
   if (rc) A->build_err = b->err;
   A->ready.store(1, std::memory_order_release);
