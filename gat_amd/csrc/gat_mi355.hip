@@ -495,7 +495,12 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[0], ctx->stream));
         const dim3 gp(nsb, gy, gz);
-        const int mode = P->all_simple ? (getenv("GAT_PLACE_WIDE") ? 3 : 1)
+        // (small calls of a problem of simple units -- about a wave per SIMD or less, e.g. the metric's 10 000 samples cut over
+        //  eight GPUs -- take the wide kernel as well: its loop stores unconditionally and four tiles share a rank table; config 2,
+        //  k_place at 1 250 / 2 500 / 5 000 samples: 0.46 / 0.47 / 0.56 ms against the lean kernel's 0.52 / 0.53 / 0.57, at 10 000
+        //  1.05 against 0.92)
+        const bool small_call = (int64_t)nsb * (int64_t)n_act <= 1536 && !getenv("GAT_PLACE_NO_WIDE");
+        const int mode = P->all_simple ? ((getenv("GAT_PLACE_WIDE") || small_call) ? 3 : 1)
                                        : (P->all_one_ws && !getenv("GAT_PLACE_NO_WIDE") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
         // (k_place_wide: kPlaceWide tiles per workgroup, the largest unit's rank table beside their rings)
         const dim3 gw((nsb + gat::kPlaceWide - 1) / gat::kPlaceWide, gy, gz);

@@ -14,7 +14,11 @@ constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so
 
 constexpr int kPlaceWsLds = 256;      // k_place: workspace segments kept in LDS (16 B each)
 constexpr int kPlaceRankLds = 1024;   // k_place: length-rank table entries kept in LDS
-constexpr int kPlaceWide = 8;          // k_place_wide: tiles (waves) of a workgroup, sharing one unit's rank table in LDS
+#ifndef GAT_PLACE_WIDE_TILES
+#define GAT_PLACE_WIDE_TILES 4         // (tuning builds: -DGAT_PLACE_WIDE_TILES=2 / 8; tools/exp_wide_tiles*.sh: config-4 shape k_place_wide
+                                       //  10.7 ms with 8, 9.2 with 4, 11.4 with 2)
+#endif
+constexpr int kPlaceWide = GAT_PLACE_WIDE_TILES;   // k_place_wide: tiles (waves) of a workgroup, sharing one unit's rank table in LDS
 constexpr int kPlaceWideMaxRank = 20480;  // ... whose size is bounded by the LDS beside the eight 8 KB rings (80 KB of 160)
 constexpr int kTailMaxWs = 64;        // workspace segments k_tail scans linearly (wave-uniform loop)
 constexpr int kMergedSlots = 8;       // k_count_merged: contigs are dealt to this many slots (blockIdx % 8: the XCD stride)

@@ -1,0 +1,4 @@
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+echo "default (lean k_place_pipe)"; python tools/place_scaling.py config2 1250 10000 20000 2>&1 | tail -3
+for W in w2 w4; do echo "k_place_wide, $W tiles per workgroup"; GAT_PLACE_WIDE=1 GAT_LIB_PATH=$PWD/build/$W/libgat_$W.so python tools/place_scaling.py config2 1250 10000 20000 2>&1 | tail -3; done
+echo "k_place_wide, 8"; GAT_PLACE_WIDE=1 python tools/place_scaling.py config2 1250 10000 20000 2>&1 | tail -3
