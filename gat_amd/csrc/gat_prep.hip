@@ -614,11 +614,12 @@ static int group_annotations(gat_ctx* ctx, const gat_problem_desc* d, std::vecto
   buf.resize((size_t)size[(size_t)n_groups]);
   gbeg.assign(size.begin(), size.end() - 1);
   gend = gbeg;
-  constexpr int64_t kBlock = 64;                                    // groups per task
+  constexpr int64_t kBlock = 16;                                    // groups per task
   const int64_t nblocks = (n_groups + kBlock - 1) / kBlock;
   std::vector<int64_t> bad((size_t)std::max<int64_t>(1, nblocks), -1);
   parallel_for(nblocks, [&](int64_t blk) {
-    std::vector<uint64_t> keys;
+    std::vector<uint64_t> keys, tmp;
+    std::vector<size_t> runs, nruns;
     for (int64_t g = blk * kBlock; g < std::min(n_groups, (blk + 1) * kBlock); ++g) {
       gat_segment* out = buf.data() + gbeg[(size_t)g];
       const int64_t m0 = cnt[(size_t)g], m1 = cnt[(size_t)g + 1];
@@ -632,22 +633,47 @@ static int group_annotations(gat_ctx* ctx, const gat_problem_desc* d, std::vecto
         gend[(size_t)g] = gbeg[(size_t)g] + n;
         continue;
       }
-      // concatenate, sort by start (one member, or members that follow one another, are sorted already), merge(0)
+      // concatenate, sort by start (one member, or members that follow one another, are sorted already), merge(0).  The
+      // members are sorted lists themselves (the isochore pieces of a contig's track): runs that are merged pairwise -- three
+      // passes over a contig's 400 intervals for eight isochore classes -- instead of sorted from scratch (1.7 of the 3.2 ms
+      // this step took on config 3); a member that is not sorted sends the group to std::sort
       keys.clear();
-      bool sorted = true;
+      runs.clear();
+      bool sorted = true, runs_sorted = true;
       uint32_t last = 0;
       for (int64_t q = m0; q < m1; ++q) {
         const int64_t l = member[(size_t)q];
+        runs.push_back(keys.size());
+        uint32_t last_in_run = 0;
         for (int64_t i = lb(l); i < le(l); ++i) {
           const gat_segment x = d->annos[i];
           if (x.start > x.end || x.end >= 0x80000000u) { bad[(size_t)blk] = l; return; }
           if (x.start == x.end) continue;                            // merge() drops empty segments
           sorted = sorted && x.start >= last;
+          runs_sorted = runs_sorted && x.start >= last_in_run;
           last = x.start;
+          last_in_run = x.start;
           keys.push_back(((uint64_t)x.start << 32) | x.end);
         }
       }
-      if (!sorted) std::sort(keys.begin(), keys.end());
+      runs.push_back(keys.size());
+      if (!sorted) {
+        if (!runs_sorted) std::sort(keys.begin(), keys.end());
+        else {
+          tmp.resize(keys.size());
+          while (runs.size() > 2) {                                  // pairwise merges of neighbouring runs
+            nruns.clear();
+            for (size_t r = 0; r + 1 < runs.size(); r += 2) {
+              const size_t a = runs[r], b = runs[r + 1], c = r + 2 < runs.size() ? runs[r + 2] : runs[r + 1];
+              std::merge(keys.begin() + (long)a, keys.begin() + (long)b, keys.begin() + (long)b, keys.begin() + (long)c, tmp.begin() + (long)a);
+              nruns.push_back(a);
+            }
+            nruns.push_back(keys.size());
+            keys.swap(tmp);
+            runs.swap(nruns);
+          }
+        }
+      }
       int64_t n = 0;
       for (size_t i = 0; i < keys.size(); ++i) {
         const uint32_t s0 = (uint32_t)(keys[i] >> 32), e0 = (uint32_t)keys[i];
