@@ -312,6 +312,46 @@ __device__ __forceinline__ void sort_stage_lanes(uint32_t (&ks)[E], uint32_t (&k
     ke[r] = take ? pe : ke[r];
   }
 }
+// One list of at most 64 segments, one per lane: the same network (21 stages) with the partner of a stage fetched by a DPP
+// modifier wherever it lies within the lane's row of 16 -- 18 stages: quad permutes (xor 1, 2, 3), row_half_mirror (xor 7),
+// row_mirror (xor 15), row_ror:8 (xor 8), a shift pair under bank masks (xor 4) -- and by ds_bpermute only across rows (xor 16,
+// 31, 63): 6 LDS permutes per list instead of 42.  CTRL: the DPP control word; CTRL2 != 0: second half of the xor-4 pair.
+template <int CTRL, int BANK = 0xf, int CTRL2 = 0, int BANK2 = 0>
+__device__ __forceinline__ uint32_t lane_partner_dpp(uint32_t v) {
+  uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, BANK, false);
+  if constexpr (CTRL2 != 0) r = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)v, CTRL2, 0xf, BANK2, false);
+  return r;
+}
+__device__ __forceinline__ void sort64_exchange(uint32_t& ks, uint32_t& ke, uint32_t ps, uint32_t pe, bool lower) {
+  const bool take = lower ? (ps < ks) : (ps > ks);              // equal starts: neither side moves
+  ks = take ? ps : ks;
+  ke = take ? pe : ke;
+}
+template <int HB, int CTRL, int BANK = 0xf, int CTRL2 = 0, int BANK2 = 0>
+__device__ __forceinline__ void sort64_stage_dpp(uint32_t& ks, uint32_t& ke, int lane) {
+  const uint32_t ps = lane_partner_dpp<CTRL, BANK, CTRL2, BANK2>(ks), pe = lane_partner_dpp<CTRL, BANK, CTRL2, BANK2>(ke);
+  sort64_exchange(ks, ke, ps, pe, (lane & (1 << HB)) == 0);
+}
+template <int HB, int ML>
+__device__ __forceinline__ void sort64_stage_perm(uint32_t& ks, uint32_t& ke, int lane) {
+  const int src = (lane ^ ML) << 2;
+  const uint32_t ps = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ks), pe = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ke);
+  sort64_exchange(ks, ke, ps, pe, (lane & (1 << HB)) == 0);
+}
+__device__ __forceinline__ void sort64_by_start(uint32_t& ks, uint32_t& ke, int lane) {
+  constexpr int X1 = 0xB1, X2 = 0x4E, X3 = 0x1B, X7 = 0x141, X15 = 0x140, X8 = 0x128, SHL4 = 0x104, SHR4 = 0x114;
+  auto x1 = [&]() { sort64_stage_dpp<0, X1>(ks, ke, lane); };
+  auto x2 = [&]() { sort64_stage_dpp<1, X2>(ks, ke, lane); };
+  auto x4 = [&]() { sort64_stage_dpp<2, SHL4, 0x5, SHR4, 0xA>(ks, ke, lane); };
+  auto x8 = [&]() { sort64_stage_dpp<3, X8>(ks, ke, lane); };
+  x1();                                                                        // blocks of 2: flip
+  sort64_stage_dpp<1, X3>(ks, ke, lane); x1();                                 // 4: flip, disperse 1
+  sort64_stage_dpp<2, X7>(ks, ke, lane); x2(); x1();                           // 8
+  sort64_stage_dpp<3, X15>(ks, ke, lane); x4(); x2(); x1();                    // 16
+  sort64_stage_perm<4, 31>(ks, ke, lane); x8(); x4(); x2(); x1();              // 32
+  sort64_stage_perm<5, 63>(ks, ke, lane); sort64_stage_perm<4, 16>(ks, ke, lane); x8(); x4(); x2(); x1();   // 64
+}
+
 // partner differs in register index (RMASK) and, for the flip steps, mirrors the lane (xor 63)
 template <int E, int RMASK, bool MIRROR>
 __device__ __forceinline__ void sort_stage_regs(uint32_t (&ks)[E], uint32_t (&ke)[E], int lane) {

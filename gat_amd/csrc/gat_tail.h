@@ -95,10 +95,14 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     // running maximum in front of the next head --, coverage and running lengths on the head lanes, one store.
     const uint2 x = lane < n ? out[lane] : make_uint2(0xffffffffu, 0xffffffffu);
     uint32_t ks[1] = {x.x}, ke[1] = {x.y};
+#ifdef GAT_SORT64_BPERMUTE
     for (int lk = 1; lk <= 6; ++lk) {
       sort_stage_lanes<1>(ks, ke, (1 << lk) - 1, lk - 1, lane);   // flip
       sort_disperse_below64<1>(ks, ke, lk - 2, lane);
     }
+#else
+    sort64_by_start(ks[0], ke[0], lane);                          // (partners within a row of 16 lanes by DPP modifiers)
+#endif
     const bool valid = ks[0] != ke[0];                            // (empty segments are dropped; the padding is empty)
     const int32_t m = wave_incl_max_i32(valid ? (int32_t)ke[0] : INT32_MIN, lane);
     const int32_t excl = __builtin_amdgcn_update_dpp(INT32_MIN, m, 0x138, 0xf, 0xf, false);   // wave_shr:1
