@@ -1,3 +1,4 @@
+# k_place_wide's tiles per workgroup on the config-4 shape; tuning builds as for tools/exp_wide_tiles.sh
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 for W in default w4 w2; do
   echo "config-4 shape, k_place_wide tiles per workgroup: $W"
