@@ -340,6 +340,7 @@ struct gat_problem {
 #ifdef GAT_DIAG
   DevBuf<unsigned long long> d_diag;     // diagnostic build: per work unit, cycles per phase of k_sampler
   DevBuf<unsigned long long> d_diag_place;   // ... per launch position, cycles per phase of k_place's loop
+  DevBuf<unsigned long long> d_diag_tiles;   // ... per tile of k_place, begin and end (s_memrealtime)
 #endif
   DevBuf<int64_t> d_rng_off;
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;

@@ -66,6 +66,7 @@ struct SamplerArgs {
   const int32_t* unit_pos;    // unit id -> launch position, -1: inactive (k_serial walks the units in the reference's order)
   unsigned long long* diag;   // diagnostic build (-DGAT_DIAG) only: [work unit][8] shader cycles per phase of k_sampler
   unsigned long long* diag_place;   // ... and [launch position][8]: k_place's cycles per phase of its loop, summed over the unit's tiles
+  unsigned long long* diag_tiles;   // ... and [launch position][sample block][2]: when a tile of k_place began and ended (s_memrealtime, 100 MHz)
 };
 
 // The hand-over records between the sampler's kernels -- st, st2, TailPatch by launch position, ws_stat by unit id -- are laid
@@ -561,7 +562,8 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_ALIVE_TB (sL || sB || sP || sO)
   // (macros, not a lambda taking the step closure: that form kept the closures in scratch memory)
 #ifdef GAT_DIAG
-  unsigned long long pdg[5] = {0, 0, 0, 0, 0}, pdg_t, pdg_rows = 0;
+  unsigned long long pdg[5] = {0, 0, 0, 0, 0}, pdg_t, pdg_rows = 0, tile_t0;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tile_t0) :: "memory");
   GAT_STAMP(pdg_t);
 #define GAT_PROWS pdg_rows += kPlaceChunk;
 #else
@@ -692,6 +694,12 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     for (int k = 0; k < 5; ++k) atomicAdd(&A.diag_place[(int64_t)a * 8 + k], pdg[k]);
     atomicAdd(&A.diag_place[(int64_t)a * 8 + 5], pdg_rows);
     atomicAdd(&A.diag_place[(int64_t)a * 8 + 6], 1ull);
+    if (A.diag_tiles != nullptr) {
+      unsigned long long tile_t1;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tile_t1) :: "memory");
+      A.diag_tiles[((int64_t)a * n_tiles + sb_own) * 2] = tile_t0;
+      A.diag_tiles[((int64_t)a * n_tiles + sb_own) * 2 + 1] = tile_t1;
+    }
   }
 #endif
 #undef GAT_PLACE_LOOP

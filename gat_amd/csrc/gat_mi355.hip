@@ -468,6 +468,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         if (P->d_diag_place.n < np) HIPCHK(ctx, P->d_diag_place.alloc(np));
         HIPCHK(ctx, hipMemsetAsync(P->d_diag_place.p, 0, np * 8, ctx->stream));
         A.diag_place = P->d_diag_place.p;
+        const size_t nt = std::max<size_t>(1, P->h_order.size()) * (size_t)((nb + 63) / 64) * 2;
+        if (P->d_diag_tiles.n < nt) HIPCHK(ctx, P->d_diag_tiles.alloc(nt));
+        HIPCHK(ctx, hipMemsetAsync(P->d_diag_tiles.p, 0, nt * 8, ctx->stream));
+        A.diag_tiles = P->d_diag_tiles.p;
       }
 #endif
       // the units' launch positions are spread over grid y and z (each <= 65535)
@@ -847,6 +851,30 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
                        "\"rows\": %.0f, \"tiles\": %.0f}, \"largest_unit\": {\"row_wait\": %llu, \"lookups\": %llu, \"steps\": %llu, \"flush\": %llu, "
                        "\"loop_control\": %llu, \"rows\": %llu, \"tiles\": %llu}}}\n",
                     all[0], all[1], all[2], all[3], all[4], all[5], all[6], hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6]);
+          }
+        }
+        {
+          // k_place's tiles in time: per unit (launch position) the first begin, the median begin, the median and the last end of
+          // its tiles, in microseconds from the kernel's first begin
+          const size_t n_act = P->h_order.size(), ntl = (size_t)((nb + 63) / 64);
+          std::vector<unsigned long long> ht(n_act * ntl * 2);
+          if (n_act && ntl && P->d_diag_tiles.n >= ht.size() && staged_d2h(ctx, ht.data(), P->d_diag_tiles.p, ht.size() * 8) == hipSuccess) {
+            unsigned long long t_min = ~0ull;
+            for (size_t i = 0; i < ht.size(); i += 2) if (ht[i] && ht[i] < t_min) t_min = ht[i];
+            fprintf(f, "{\"k_place_tiles\": [");
+            for (size_t a = 0; a < n_act; ++a) {
+              std::vector<double> b0, e0;
+              for (size_t t = 0; t < ntl; ++t) {
+                const unsigned long long x = ht[(a * ntl + t) * 2], y = ht[(a * ntl + t) * 2 + 1];
+                if (x && y) { b0.push_back((double)(x - t_min) / 100.0); e0.push_back((double)(y - t_min) / 100.0); }
+              }
+              if (b0.empty()) continue;
+              std::sort(b0.begin(), b0.end()); std::sort(e0.begin(), e0.end());
+              fprintf(f, "%s{\"a\": %zu, \"segments\": %u, \"tiles\": %zu, \"begin_first\": %.1f, \"begin_median\": %.1f, \"begin_last\": %.1f, "
+                         "\"end_first\": %.1f, \"end_median\": %.1f, \"end_last\": %.1f}", a ? ", " : "", a,
+                      P->h_units[(size_t)P->h_order[a]].hist_total, b0.size(), b0.front(), b0[b0.size() / 2], b0.back(), e0.front(), e0[e0.size() / 2], e0.back());
+            }
+            fprintf(f, "]}\n");
           }
         }
         fclose(f);
