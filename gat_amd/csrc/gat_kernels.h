@@ -50,6 +50,7 @@ struct SamplerArgs {
                               //   z = the pending length (>0), -1: run the unit in full, -2: SamplerSegments complete,
                               //   w = raw outputs consumed so far
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
+  int32_t place_plain_step;   // != 0: k_place runs GAT_STEP_SIMPLE_B where GAT_STEP_SIMPLE_C would do (GAT_PLACE_NO_CM: tests, A/B)
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
   int32_t a_base, a_end;      // k_sampler / k_merge_big / k_consolidate: the launch covers launch positions [a_base, a_end) -- one
@@ -267,7 +268,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   constexpr int WIDE = MODE == 3 ? kPlaceWide : 1;                         // tiles (waves) of a workgroup
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank_tab[kRankTab];
-  __shared__ uint2 l_out_all[WIDE][16][kWave];   // ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
+  __shared__ __attribute__((aligned(8192))) uint2 l_out_all[WIDE][16][kWave];   // (8 KB-aligned: GAT_STEP_SIMPLE_ASM) ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   extern __shared__ __attribute__((aligned(16))) uint32_t l_rank_wide[];   // MODE 3: the unit's rank table, entry v = length of rank 1 + v
   uint32_t* const l_rank = MODE == 3 ? l_rank_wide : l_rank_tab;
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -423,6 +424,75 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     sO = (sO && !isO) || isP;                                                                                  \
   }
 
+  // The same step where the offset draw's MASK does not depend on the length drawn: its range is c_r3 + length, the position
+  // draw's c_r3 + 1, and unless a power of two lies between c_r3 + 1 and c_r3 + the unit's longest length every length gives
+  // the position draw's mask (a contig of 50-250 Mb against segments of hundreds of bases: cm_ok below; a unit where it does
+  // not hold takes the step above).  Then y & maskP serves both tests, the chain length -> range -> leading zeros -> mask and
+  // its two selects per row are gone, and what only an accepted offset draw needs -- position, clipping, overlap, the ring
+  // store, the counters -- stands inside `if (isO)`: one skipped region instead of selects per row.  The slab's capacity is not
+  // tested per row either: a lane that runs past it keeps counting (the ring is LDS; flush() stops at the capacity) and is
+  // flagged after the loop -- the unit is run again either way.  A triggered lane's pending length is the length it holds
+  // when the loop ends (nothing changes it once the lane is in no state).
+  const uint32_t lmaxS = rank_len[1u + rangeL];           // (the table ascends: the longest length that can be drawn)
+  const bool cm_ok = A.place_plain_step == 0 && (uint64_t)c_r3 + (uint64_t)lmaxS <= (uint64_t)maskP;
+  // The step itself is written out (one asm statement per row): the compiler's form of the same logic costs a lone wave ~8
+  // cycles per instruction (every v_cmp -> s_and -> v_cndmask hop waits out its predecessor; tools/ubench/valu_issue.hip:
+  // that chain alone runs at 8.1 cycles per instruction for one wave, independent instructions at 4.6), here the four
+  // compares are issued back to back, the lane-mask logic follows as one scalar block, and what only an accepted offset draw
+  // needs runs with exec = those lanes (no branch: with 64 lanes some lane places in nearly every row).  18 vector, 13
+  // scalar, one LDS instruction per row.  State: mL / mP / mO lane masks (in L / in P / in O), len, rem, nS9 = segments
+  // placed << 9 (the ring slot's byte offset is nS9 & 0x1e00: the ring is 8 KB-aligned), used_lo = 1 + the row within the
+  // current trip of 32 rows at which the lane last placed or triggered (an inline constant; folded into `used` per trip).
+  // overlap = min(ws.end, end) - max(ws.start, start) is at least 1 for an accepted offset (q in [ws.start + 1 - len,
+  // ws.end - 1], coordinates below 2^31: gat_problem_create), so the reference's max(0, .) (gat/Engine.pyx:340-342) is not taken.
+  uint64_t mL = 0, mP = 0, mO = 0;
+  uint32_t nS9 = 0, used_lo = 0;
+  const uint32_t lane_ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&l_out[0][lane];
+#define GAT_STEP_SIMPLE_ASM(Y, LR1, JJ1)                                                                       \
+  {                                                                                                            \
+    uint32_t t0_, t1_, t2_, t3_;                                                                               \
+    uint64_t sa_, sb_, sc_;                                                                                    \
+    asm volatile(                                                                                              \
+        "v_and_b32 %7, %16, %14\n\t"                  /* vO = y & maskP */                                     \
+        "v_and_b32 %8, %26, %14\n\t"                  /* y & maskL */                                          \
+        "v_cmp_ge_u32_e64 %12, %17, %7\n\t"           /* accP: vO <= rangeP */                                 \
+        "v_add_u32 %9, %19, %0\n\t"                   /* c_r3 + len */                                         \
+        "v_cmp_ge_u32 vcc, %18, %8\n\t"               /* accL */                                               \
+        "v_cmp_le_u32_e64 %13, %7, %9\n\t"            /* accO: vO <= c_r3 + len */                             \
+        "s_and_b64 %11, %4, vcc\n\t"                  /* isL */                                                \
+        "v_cmp_le_i32 vcc, %1, %15\n\t"               /* remaining <= length of this rank */                   \
+        "s_and_b64 %12, %5, %12\n\t"                  /* isP */                                                \
+        "s_and_b64 %13, %6, %13\n\t"                  /* isO */                                                \
+        "s_and_b64 vcc, %11, vcc\n\t"                 /* trigger = isL && remaining <= length (:582) */        \
+        "v_cndmask_b32_e64 %0, %0, %15, %11\n\t"      /* len = isL ? length : len */                           \
+        "v_cndmask_b32_e64 %3, %3, %25, vcc\n\t"      /* used_lo = trigger ? row + 1 : used_lo */              \
+        "s_xor_b64 %4, %4, %11\n\t"                                                                            \
+        "s_andn2_b64 %11, %11, vcc\n\t"               /* isL && !trigger */                                    \
+        "s_xor_b64 %5, %5, %12\n\t"                                                                            \
+        "s_xor_b64 %6, %6, %13\n\t"                                                                            \
+        "s_or_b64 %4, %4, %13\n\t"                    /* L: left by an accepted rank draw, entered by a placement */ \
+        "s_or_b64 %5, %5, %11\n\t"                    /* P: ... position draw / rank draw without trigger */   \
+        "s_or_b64 %6, %6, %12\n\t"                    /* O: ... offset draw / position draw */                 \
+        "s_and_saveexec_b64 %11, %13\n\t"             /* the lanes that place (:318-340) */                    \
+        "v_add_u32 %9, %20, %7\n\t"                   /* end = sampling_start + offset + len = c_ss + vO */    \
+        "v_and_or_b32 %8, %2, %23, %24\n\t"           /* ring slot */                                          \
+        "v_sub_u32 %7, %9, %0\n\t"                    /* q = end - len */                                      \
+        "v_add_u32 %2, 0x200, %2\n\t"                                                                          \
+        "v_min_i32 %10, %22, %9\n\t"                  /* min(ws.end, end) */                                   \
+        "v_max_i32 %7, 0, %7\n\t"                     /* start = max(q, 0) */                                  \
+        "v_sub_u32 %1, %1, %10\n\t"                   /* remaining -= overlap = min(..) - max(..) */           \
+        "v_max_i32 %10, %21, %7\n\t"                  /* max(ws.start, start) */                               \
+        "ds_write2_b32 %8, %7, %9 offset1:1\n\t"                                                               \
+        "v_mov_b32 %3, %25\n\t"                                                                                \
+        "v_add_u32 %1, %1, %10\n\t"                                                                            \
+        "s_mov_b64 exec, %11"                                                                                  \
+        : "+v"(len), "+v"(rem), "+v"(nS9), "+v"(used_lo), "+s"(mL), "+s"(mP), "+s"(mO),                        \
+          "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_), "=&s"(sa_), "=&s"(sb_), "=&s"(sc_)                   \
+        : "v"(Y), "v"(LR1), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(c_r3), "s"(c_ss), "s"(ws0.x), "s"(ws0.y), \
+          "s"(0x1e00u), "v"(lane_ring), "n"(JJ1), "s"(maskL)                                                   \
+        : "vcc", "scc", "memory");                                                                             \
+  }
+
   // rows are consumed in chunks of kPlaceChunk; the next chunk is in flight while this one is worked on
   // (few waves per SIMD: nothing else hides the load latency)
   // The ring is flushed behind every SECOND chunk: a placement takes at least two accepted outputs, so two chunks add at
@@ -436,7 +506,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #ifdef GAT_EXP_NOFLUSH
     if (nS - nF >= 8) { nF += 8; return; }
 #endif
-    if (nS - nF >= 8) {
+    if (nS - nF >= 8 && nF + 8 <= cap) {                  // (beyond the capacity: GAT_STEP_SIMPLE_ASM's lanes run on, flagged below)
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
       const int w0 = nF & 15;
 #pragma unroll
@@ -582,14 +652,17 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // load is always issued (rows beyond the tile's end re-read its last chunk and are not used), so the count holds.
   // (The same with the buffers as asm operands did not work: the compiler copies them around the loop's back edge while
   // loads are on their way into them.)
+#ifndef GAT_ROW_NT
+#define GAT_ROW_NT " nt"              /* the rows are read once: streamed past the L2's lines (the ring's half-written ones stay) */
+#endif
 #define GAT_PIN_LOAD(R0, R1, R2, R3, R4, R5, R6, R7, ROW0)                                                     \
   {                                                                                                            \
     const int r0_ = (int)(ROW0) < rows - kPlaceChunk ? (int)(ROW0) : rows - kPlaceChunk;                       \
     const uint32_t* p_ = rp + (int64_t)r0_ * kWave;                                                            \
-    asm volatile("global_load_dword v" #R0 ", %0, off\n\tglobal_load_dword v" #R1 ", %0, off offset:256\n\t" \
-                 "global_load_dword v" #R2 ", %0, off offset:512\n\tglobal_load_dword v" #R3 ", %0, off offset:768\n\t" \
-                 "global_load_dword v" #R4 ", %0, off offset:1024\n\tglobal_load_dword v" #R5 ", %0, off offset:1280\n\t" \
-                 "global_load_dword v" #R6 ", %0, off offset:1536\n\tglobal_load_dword v" #R7 ", %0, off offset:1792" \
+    asm volatile("global_load_dword v" #R0 ", %0, off" GAT_ROW_NT "\n\tglobal_load_dword v" #R1 ", %0, off offset:256" GAT_ROW_NT "\n\t" \
+                 "global_load_dword v" #R2 ", %0, off offset:512" GAT_ROW_NT "\n\tglobal_load_dword v" #R3 ", %0, off offset:768" GAT_ROW_NT "\n\t" \
+                 "global_load_dword v" #R4 ", %0, off offset:1024" GAT_ROW_NT "\n\tglobal_load_dword v" #R5 ", %0, off offset:1280" GAT_ROW_NT "\n\t" \
+                 "global_load_dword v" #R6 ", %0, off offset:1536" GAT_ROW_NT "\n\tglobal_load_dword v" #R7 ", %0, off offset:1792" GAT_ROW_NT \
                  :: "v"(p_) : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3, "v" #R4, "v" #R5, "v" #R6, "v" #R7); \
   }
 #define GAT_PIN_TAKE(R0, R1, R2, R3, R4, R5, R6, R7)                                                           \
@@ -638,6 +711,59 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     }                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");   /* nothing on its way into a register at the end */\
   }
+  // the same loop around GAT_STEP_SIMPLE_ASM: the state is lane masks (the loop ends when no lane is in a state), a trip's
+  // events are folded into `used` at the next trip's head and behind the loop
+#define GAT_PLACE_CHUNK_ASM(PRE, K)                                                                          \
+  GAT_PSTAMP(0)                                                                                              \
+  PRE(ya)                                                                                                    \
+  GAT_PSTAMP(1)                                                                                              \
+  GAT_STEP_SIMPLE_ASM(ya[0], lr[0], (K) * 8 + 1) GAT_STEP_SIMPLE_ASM(ya[1], lr[1], (K) * 8 + 2)              \
+  GAT_STEP_SIMPLE_ASM(ya[2], lr[2], (K) * 8 + 3) GAT_STEP_SIMPLE_ASM(ya[3], lr[3], (K) * 8 + 4)              \
+  GAT_STEP_SIMPLE_ASM(ya[4], lr[4], (K) * 8 + 5) GAT_STEP_SIMPLE_ASM(ya[5], lr[5], (K) * 8 + 6)              \
+  GAT_STEP_SIMPLE_ASM(ya[6], lr[6], (K) * 8 + 7) GAT_STEP_SIMPLE_ASM(ya[7], lr[7], (K) * 8 + 8)              \
+  GAT_PSTAMP(2)                                                                                              \
+  if ((K) & 1) { nS = (int)(nS9 >> 9); flush(); }                                                            \
+  GAT_PSTAMP(3)                                                                                              \
+  GAT_PROWS
+#define GAT_FOLD_USED(BASE) { used = used_lo != 0u ? (uint32_t)(BASE) + used_lo : used; used_lo = 0u; }
+#define GAT_PLACE_LOOP_PIPE_ASM(PRE)                                                                         \
+  {                                                                                                          \
+    static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
+    mL = __ballot(sL); mP = 0; mO = 0;                                                                       \
+    int jbase = 0;                                                                                           \
+    asm volatile("; GAT_PINNED_BEGIN" ::: "memory");                                                         \
+    GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, 0)                                                      \
+    GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, kPlaceChunk)                                        \
+    GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, 2 * kPlaceChunk)                                    \
+    for (int j = 0; j < rows; j += 4 * kPlaceChunk) {                                                        \
+      if ((mL | mP | mO) == 0) break;                                                                        \
+      GAT_PSTAMP(4)                                                                                          \
+      GAT_FOLD_USED(jbase)                                                                                   \
+      jbase = j;                                                                                             \
+      GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
+      GAT_PLACE_CHUNK_ASM(PRE, 0)                                                                            \
+      if (j + 1 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_PSTAMP(4)                                                                                          \
+      GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
+      GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
+      GAT_PLACE_CHUNK_ASM(PRE, 1)                                                                            \
+      if (j + 2 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_PSTAMP(4)                                                                                          \
+      GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
+      GAT_PLACE_CHUNK_ASM(PRE, 2)                                                                            \
+      if (j + 3 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_PSTAMP(4)                                                                                          \
+      GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
+      GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
+      GAT_PLACE_CHUNK_ASM(PRE, 3)                                                                            \
+    }                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");                                     \
+    GAT_FOLD_USED(jbase)                                                                                     \
+    nS = (int)(nS9 >> 9);                                                                                    \
+    sL = (mL >> lane) & 1; sP = (mP >> lane) & 1; sO = (mO >> lane) & 1;                                     \
+  }
 #define GAT_PLACE_LOOP(PRE, ONE, ALIVE)                                                                        \
   {                                                                                                            \
     const uint32_t* __restrict__ rq = rp;                                                                      \
@@ -671,12 +797,16 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       GAT_PROWS                                                                                                \
     }                                                                                                          \
   }
+  bool plain_step = true;                    // false: GAT_STEP_SIMPLE_ASM ran -- the pending length and the capacity are settled below
   if constexpr (MODE == 3) {
     static_assert(PIPE, "k_place_wide runs the hand-pipelined loop");
-    GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_W, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_W) }
+    else GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_W, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
   } else if (simple_lds) {
-    if constexpr (PIPE) GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
-    else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    if constexpr (PIPE) {
+      if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_L) }
+      else GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
+    } else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
   } else if constexpr (!ALL_SIMPLE) {
     if (simple_shape) GAT_PLACE_LOOP(GAT_PRE_SIMPLE_G, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
     else {
@@ -711,6 +841,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_ONE_SIMPLE_B
 #undef GAT_ALIVE_B
 #undef GAT_STEP_SIMPLE_B
+#undef GAT_STEP_SIMPLE_ASM
+#undef GAT_PLACE_LOOP_PIPE_ASM
+#undef GAT_PLACE_CHUNK_ASM
+#undef GAT_FOLD_USED
 #undef GAT_PRE_TABLE_GG
 #undef GAT_PRE_TABLE_LG
 #undef GAT_PRE_TABLE_GL
@@ -726,6 +860,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_ALIVE_TB
   if (live) {
     const bool halted = !(sL || sB || sP || sO);
+    if (!plain_step) {
+      if (!kind1 && halted) pend = (int32_t)len;                  // (only the trigger halts a lane of that loop)
+      if (nS > cap) { flag |= kStatusOverflow; nS = nF; }
+    }
     for (int i = nF; i < nS; ++i) out[i] = l_out[i & 15][lane];   // what the last flush left
     // halted at the trigger (pend > 0) or complete (-2); rows ran out with the lane still placing: -3, k_sampler goes on
     // behind the last placement (nS segments, `rem`, `used` outputs); overflow (or SamplerSegments out of rows): -1, the unit

@@ -456,6 +456,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.rec_stride = (int32_t)P->batch;                  // (the scratch's size in samples: the records' row length in every batch)
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
+      A.place_plain_step = getenv("GAT_PLACE_NO_CM") ? 1 : 0;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->flags_dev(); A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
 #ifdef GAT_DIAG
@@ -851,6 +852,29 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
                        "\"rows\": %.0f, \"tiles\": %.0f}, \"largest_unit\": {\"row_wait\": %llu, \"lookups\": %llu, \"steps\": %llu, \"flush\": %llu, "
                        "\"loop_control\": %llu, \"rows\": %llu, \"tiles\": %llu}}}\n",
                     all[0], all[1], all[2], all[3], all[4], all[5], all[6], hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6]);
+          }
+        }
+        {
+          // k_place's hand-over records by kind: pending length (triggered), -1 run in full, -2 complete, -3 resume
+          const size_t n_act = P->h_order.size();
+          std::vector<int4> hs(n_act * (size_t)P->batch);
+          if (n_act && P->d_st.n >= hs.size() && staged_d2h(ctx, hs.data(), P->d_st.p, hs.size() * sizeof(int4)) == hipSuccess) {
+            long long kinds[5] = {0, 0, 0, 0, 0};
+            int shown = 0;
+            fprintf(f, "{\"k_place_handover_examples\": [");
+            for (size_t a = 0; a < n_act; ++a)
+              for (int64_t i = 0; i < nb; ++i) {
+                const int4 r = hs[a * (size_t)P->batch + (size_t)i];
+                kinds[r.z > 0 ? 0 : (r.z == -1 ? 1 : (r.z == -2 ? 2 : (r.z == -3 ? 3 : 4)))]++;
+                if (r.z <= 0 && shown < 12) fprintf(f, "%s[%zu, %lld, %d, %d, %d, %d, %d]", shown++ ? ", " : "", a, (long long)i, r.x, r.y, r.z, r.w, P->h_rng_rows.empty() ? -1 : P->h_rng_rows[a]);
+              }
+            {
+              long long sx = 0, sy = 0, sz = 0, sw = 0;
+              for (size_t a = 0; a < n_act; ++a) for (int64_t i = 0; i < nb; ++i) { const int4 r = hs[a * (size_t)P->batch + (size_t)i]; sx += r.x; sy += r.y; sz += r.z; sw += r.w; }
+              fprintf(f, "], \"k_place_handover_sums\": [%lld, %lld, %lld, %lld", sx, sy, sz, sw);
+            }
+            fprintf(f, "], \"k_place_handover\": {\"triggered\": %lld, \"in_full\": %lld, \"complete\": %lld, \"resume\": %lld, \"other\": %lld}}\n",
+                    kinds[0], kinds[1], kinds[2], kinds[3], kinds[4]);
           }
         }
         {

@@ -10,7 +10,7 @@ import re
 import sys
 
 PINNED = re.compile(r"\bv(9[6-9]|1[01][0-9]|12[0-7])\b|\bv\[(\d+):(\d+)\]")
-LOAD = re.compile(r"^\s*global_load_dword v(9[6-9]|1[01][0-9]|12[0-7]), v\[\d+:\d+\], off( offset:\d+)?\s*$")
+LOAD = re.compile(r"^\s*global_load_dword v(9[6-9]|1[01][0-9]|12[0-7]), v\[\d+:\d+\], off( offset:\d+)?( nt)?\s*$")
 TAKE = re.compile(r"^\s*v_mov_b32(_e32)? v(\d+), v(9[6-9]|1[01][0-9]|12[0-7])\s*$")
 
 
