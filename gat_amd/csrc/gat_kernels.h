@@ -507,12 +507,27 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     if (nS - nF >= 8) { nF += 8; return; }
 #endif
     if (nS - nF >= 8 && nF + 8 <= cap) {                  // (beyond the capacity: GAT_STEP_SIMPLE_ASM's lanes run on, flagged below)
+#if defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 4
+      uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (nF & 8));
+#else
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
+#endif
       const int w0 = nF & 15;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
+#if defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 1
+        dst[w] = make_uint4(nF, w, nS, lane);
+#elif defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 2
+        const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
+        asm volatile("" :: "v"(e0.x), "v"(e0.y), "v"(e1.x), "v"(e1.y));
+#elif defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 3
+        const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store((v4u){e0.x, e0.y, e1.x, e1.y}, reinterpret_cast<v4u*>(dst + w));
+#else
         const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
         dst[w] = make_uint4(e0.x, e0.y, e1.x, e1.y);
+#endif
       }
       nF += 8;
     }
@@ -568,6 +583,73 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   uint32_t ya[kPlaceChunk], yb[kPlaceChunk], lr[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t pcs[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0}, pce[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0},
            ppe[kPlaceChunk] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // The general step written out like GAT_STEP_SIMPLE_ASM, for units without a bucket draw (bucket size 1: every problem
+  // whose longest segment is below nbuckets): the acceptance tests and the lane-mask logic, then what an accepted POSITION
+  // draw needs with exec = those lanes (the chosen workspace segment, sampling_start = max(previous end, start - len + 1)
+  // (:318-325), the offset draw's range and mask; a range of 0 places at once: randint consumes nothing), then what a
+  // placement needs with exec = the lanes that place.  31 vector + 19 scalar + one LDS instruction per row.  The overlap with
+  // the chosen segment is at least 1 (q in [sampling_start, segment end - 1], sampling_start >= segment start - len + 1).
+#define GAT_STEP_TABLE_ASM(Y, LR1, PCS, PCE, PPE, JJ1)                                                         \
+  {                                                                                                            \
+    uint32_t t0_, t1_, t2_, t3_;                                                                               \
+    uint64_t sa_, sb_, sc_;                                                                                    \
+    asm volatile(                                                                                              \
+        "v_and_b32 %12, %24, %19\n\t"                 /* y & maskP */                                          \
+        "v_and_b32 %13, %27, %19\n\t"                 /* y & maskL */                                          \
+        "v_and_b32 %14, %8, %19\n\t"                  /* vO = y & the offset draw's mask */                    \
+        "v_cmp_ge_u32_e64 %17, %25, %12\n\t"          /* accP */                                               \
+        "v_cmp_ge_u32 vcc, %26, %13\n\t"              /* accL */                                               \
+        "v_cmp_le_u32_e64 %18, %14, %9\n\t"           /* accO: vO <= its range */                              \
+        "s_and_b64 %16, %4, vcc\n\t"                  /* isL */                                                \
+        "v_cmp_le_i32 vcc, %1, %20\n\t"               /* remaining <= length of this rank */                   \
+        "s_and_b64 %17, %5, %17\n\t"                  /* isP */                                                \
+        "s_and_b64 %18, %6, %18\n\t"                  /* isO */                                                \
+        "s_and_b64 vcc, %16, vcc\n\t"                 /* trigger (:582) */                                     \
+        "v_cndmask_b32_e64 %0, %0, %20, %16\n\t"      /* len */                                                \
+        "v_cndmask_b32_e64 %3, %3, %30, vcc\n\t"      /* used_lo */                                            \
+        "s_xor_b64 %4, %4, %16\n\t"                                                                            \
+        "s_andn2_b64 %16, %16, vcc\n\t"               /* isL && !trigger */                                    \
+        "s_xor_b64 %5, %5, %17\n\t"                                                                            \
+        "s_xor_b64 %6, %6, %18\n\t"                                                                            \
+        "s_or_b64 %5, %5, %16\n\t"                    /* P entered by a rank draw without trigger */           \
+        "s_and_saveexec_b64 %16, %17\n\t"             /* the lanes whose position draw is accepted */          \
+        "v_sub_u32 %12, %21, %0\n\t"                  /* segment start - len */                                \
+        "v_mov_b32 %10, %21\n\t"                      /* cs */                                                 \
+        "v_add_u32 %12, 1, %12\n\t"                                                                            \
+        "v_mov_b32 %11, %22\n\t"                      /* ce */                                                 \
+        "v_max_i32 %7, %23, %12\n\t"                  /* sampling_start */                                     \
+        "v_mov_b32 %14, 0\n\t"                        /* (an immediate placement is at sampling_start) */      \
+        "v_sub_u32 %12, %22, %7\n\t"                                                                           \
+        "v_add_u32 %9, -1, %12\n\t"                   /* range of the offset draw = ce - 1 - sampling_start */ \
+        "v_or_b32 %12, 1, %9\n\t"                                                                              \
+        "v_ffbh_u32 %12, %12\n\t"                                                                              \
+        "v_cmp_eq_u32 vcc, 0, %9\n\t"                 /* range 0: placed at once */                            \
+        "v_lshrrev_b32_e64 %8, %12, -1\n\t"           /* its mask */                                           \
+        "s_mov_b64 exec, %16\n\t"                                                                              \
+        "s_andn2_b64 %17, %17, vcc\n\t"               /* isP && !immediate */                                  \
+        "s_or_b64 %18, %18, vcc\n\t"                  /* the lanes that place */                               \
+        "s_or_b64 %6, %6, %17\n\t"                    /* O entered by a position draw */                       \
+        "s_or_b64 %4, %4, %18\n\t"                    /* L entered by a placement */                           \
+        "s_and_saveexec_b64 %16, %18\n\t"                                                                      \
+        "v_add_u32 %12, %7, %14\n\t"                  /* q = sampling_start + offset */                        \
+        "v_and_or_b32 %13, %2, %28, %29\n\t"          /* ring slot */                                          \
+        "v_add_u32 %15, %12, %0\n\t"                  /* end = q + len */                                      \
+        "v_max_i32 %12, 0, %12\n\t"                   /* start = max(q, 0) */                                  \
+        "v_add_u32 %2, 0x200, %2\n\t"                                                                          \
+        "v_min_i32 %14, %11, %15\n\t"                 /* min(ce, end) */                                       \
+        "v_sub_u32 %1, %1, %14\n\t"                   /* remaining -= overlap */                               \
+        "v_max_i32 %14, %10, %12\n\t"                 /* max(cs, start) */                                     \
+        "ds_write2_b32 %13, %12, %15 offset1:1\n\t"                                                            \
+        "v_mov_b32 %3, %30\n\t"                                                                                \
+        "v_add_u32 %1, %1, %14\n\t"                                                                            \
+        "s_mov_b64 exec, %16"                                                                                  \
+        : "+v"(len), "+v"(rem), "+v"(nS9), "+v"(used_lo), "+s"(mL), "+s"(mP), "+s"(mO),                        \
+          "+v"(sstart), "+v"(omask), "+v"(orange), "+v"(cs), "+v"(ce),                                         \
+          "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_), "=&s"(sa_), "=&s"(sb_), "=&s"(sc_)                   \
+        : "v"(Y), "v"(LR1), "v"(PCS), "v"(PCE), "v"(PPE), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(maskL),    \
+          "s"(0x1e00u), "v"(lane_ring), "n"(JJ1)                                                               \
+        : "vcc", "scc", "memory");                                                                             \
+  }
   // per-chunk look-ups that depend only on the output value: length of rank 1 + (y & maskL), from the LDS copy of the
   // table or (units with >= kPlaceRankLds segments) from global memory ...
 #define GAT_PRE_RANK_L(Y)                                                                                      \
@@ -713,20 +795,20 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   }
   // the same loop around GAT_STEP_SIMPLE_ASM: the state is lane masks (the loop ends when no lane is in a state), a trip's
   // events are folded into `used` at the next trip's head and behind the loop
-#define GAT_PLACE_CHUNK_ASM(PRE, K)                                                                          \
+#define GAT_ONE_SIMPLE_ASM(C, JJ1) GAT_STEP_SIMPLE_ASM(ya[C], lr[C], JJ1)
+#define GAT_ONE_TABLE_ASM(C, JJ1) GAT_STEP_TABLE_ASM(ya[C], lr[C], pcs[C], pce[C], ppe[C], JJ1)
+#define GAT_PLACE_CHUNK_ASM(PRE, ONE, K)                                                                     \
   GAT_PSTAMP(0)                                                                                              \
   PRE(ya)                                                                                                    \
   GAT_PSTAMP(1)                                                                                              \
-  GAT_STEP_SIMPLE_ASM(ya[0], lr[0], (K) * 8 + 1) GAT_STEP_SIMPLE_ASM(ya[1], lr[1], (K) * 8 + 2)              \
-  GAT_STEP_SIMPLE_ASM(ya[2], lr[2], (K) * 8 + 3) GAT_STEP_SIMPLE_ASM(ya[3], lr[3], (K) * 8 + 4)              \
-  GAT_STEP_SIMPLE_ASM(ya[4], lr[4], (K) * 8 + 5) GAT_STEP_SIMPLE_ASM(ya[5], lr[5], (K) * 8 + 6)              \
-  GAT_STEP_SIMPLE_ASM(ya[6], lr[6], (K) * 8 + 7) GAT_STEP_SIMPLE_ASM(ya[7], lr[7], (K) * 8 + 8)              \
+  ONE(0, (K) * 8 + 1) ONE(1, (K) * 8 + 2) ONE(2, (K) * 8 + 3) ONE(3, (K) * 8 + 4)                            \
+  ONE(4, (K) * 8 + 5) ONE(5, (K) * 8 + 6) ONE(6, (K) * 8 + 7) ONE(7, (K) * 8 + 8)                            \
   GAT_PSTAMP(2)                                                                                              \
   if ((K) & 1) { nS = (int)(nS9 >> 9); flush(); }                                                            \
   GAT_PSTAMP(3)                                                                                              \
   GAT_PROWS
 #define GAT_FOLD_USED(BASE) { used = used_lo != 0u ? (uint32_t)(BASE) + used_lo : used; used_lo = 0u; }
-#define GAT_PLACE_LOOP_PIPE_ASM(PRE)                                                                         \
+#define GAT_PLACE_LOOP_PIPE_ASM(PRE, ONE)                                                                       \
   {                                                                                                          \
     static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
     mL = __ballot(sL); mP = 0; mO = 0;                                                                       \
@@ -742,22 +824,22 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       jbase = j;                                                                                             \
       GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
       GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
-      GAT_PLACE_CHUNK_ASM(PRE, 0)                                                                            \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 0)                                                                           \
       if (j + 1 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
       GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, 1)                                                                            \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 1)                                                                           \
       if (j + 2 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
       GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, 2)                                                                            \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 2)                                                                           \
       if (j + 3 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
       GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, 3)                                                                            \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 3)                                                                           \
     }                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");                                     \
     GAT_FOLD_USED(jbase)                                                                                     \
@@ -800,11 +882,11 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   bool plain_step = true;                    // false: GAT_STEP_SIMPLE_ASM ran -- the pending length and the capacity are settled below
   if constexpr (MODE == 3) {
     static_assert(PIPE, "k_place_wide runs the hand-pipelined loop");
-    if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_W) }
+    if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_W, GAT_ONE_SIMPLE_ASM) }
     else GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_W, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
   } else if (simple_lds) {
     if constexpr (PIPE) {
-      if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_L) }
+      if (!kind1 && cm_ok) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_ASM) }
       else GAT_PLACE_LOOP_PIPE(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
     } else GAT_PLACE_LOOP(GAT_PRE_SIMPLE_L, GAT_ONE_SIMPLE_B, GAT_ALIVE_B)
   } else if constexpr (!ALL_SIMPLE) {
@@ -812,7 +894,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     else {
       if (ws_lds) {
         // (not through the pinned registers: a chunk of this loop has more values in flight than the 96 registers below them hold)
-        if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_TB)
+        if (rank_lds) {
+          if (!kind1 && !drawB && A.place_plain_step == 0) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_TABLE_LL, GAT_ONE_TABLE_ASM) }
+          else GAT_PLACE_LOOP(GAT_PRE_TABLE_LL, GAT_ONE_TABLE, GAT_ALIVE_TB)
+        } else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_TB)
       } else if constexpr (TREES) {
         if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_TB)
       }
@@ -842,6 +927,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_ALIVE_B
 #undef GAT_STEP_SIMPLE_B
 #undef GAT_STEP_SIMPLE_ASM
+#undef GAT_STEP_TABLE_ASM
+#undef GAT_ONE_SIMPLE_ASM
+#undef GAT_ONE_TABLE_ASM
 #undef GAT_PLACE_LOOP_PIPE_ASM
 #undef GAT_PLACE_CHUNK_ASM
 #undef GAT_FOLD_USED
