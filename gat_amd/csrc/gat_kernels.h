@@ -448,13 +448,13 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   uint64_t mL = 0, mP = 0, mO = 0;
   uint32_t nS9 = 0, used_lo = 0;
   const uint32_t lane_ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&l_out[0][lane];
-#define GAT_STEP_SIMPLE_ASM(Y, LR1, JJ1)                                                                       \
+#define GAT_STEP_SIMPLE_ASM(YREG, LR1, JJ1)                                                                       \
   {                                                                                                            \
     uint32_t t0_, t1_, t2_, t3_;                                                                               \
     uint64_t sa_, sb_, sc_;                                                                                    \
     asm volatile(                                                                                              \
-        "v_and_b32 %7, %16, %14\n\t"                  /* vO = y & maskP */                                     \
-        "v_and_b32 %8, %26, %14\n\t"                  /* y & maskL */                                          \
+        "v_and_b32 %7, %16, v" #YREG "\n\t"                /* vO = y & maskP */                                     \
+        "v_and_b32 %8, %26, v" #YREG "\n\t"                /* y & maskL */                                          \
         "v_cmp_ge_u32_e64 %12, %17, %7\n\t"           /* accP: vO <= rangeP */                                 \
         "v_add_u32 %9, %19, %0\n\t"                   /* c_r3 + len */                                         \
         "v_cmp_ge_u32 vcc, %18, %8\n\t"               /* accL */                                               \
@@ -488,7 +488,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
         "s_mov_b64 exec, %11"                                                                                  \
         : "+v"(len), "+v"(rem), "+v"(nS9), "+v"(used_lo), "+s"(mL), "+s"(mP), "+s"(mO),                        \
           "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_), "=&s"(sa_), "=&s"(sb_), "=&s"(sc_)                   \
-        : "v"(Y), "v"(LR1), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(c_r3), "s"(c_ss), "s"(ws0.x), "s"(ws0.y), \
+        : "n"(0), "v"(LR1), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(c_r3), "s"(c_ss), "s"(ws0.x), "s"(ws0.y), \
           "s"(0x1e00u), "v"(lane_ring), "n"(JJ1), "s"(maskL)                                                   \
         : "vcc", "scc", "memory");                                                                             \
   }
@@ -589,14 +589,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // (:318-325), the offset draw's range and mask; a range of 0 places at once: randint consumes nothing), then what a
   // placement needs with exec = the lanes that place.  31 vector + 19 scalar + one LDS instruction per row.  The overlap with
   // the chosen segment is at least 1 (q in [sampling_start, segment end - 1], sampling_start >= segment start - len + 1).
-#define GAT_STEP_TABLE_ASM(Y, LR1, PCS, PCE, PPE, JJ1)                                                         \
+#define GAT_STEP_TABLE_ASM(YREG, LR1, PCS, PCE, PPE, JJ1)                                                         \
   {                                                                                                            \
     uint32_t t0_, t1_, t2_, t3_;                                                                               \
     uint64_t sa_, sb_, sc_;                                                                                    \
     asm volatile(                                                                                              \
-        "v_and_b32 %12, %24, %19\n\t"                 /* y & maskP */                                          \
-        "v_and_b32 %13, %27, %19\n\t"                 /* y & maskL */                                          \
-        "v_and_b32 %14, %8, %19\n\t"                  /* vO = y & the offset draw's mask */                    \
+        "v_and_b32 %12, %24, v" #YREG "\n\t"               /* y & maskP */                                          \
+        "v_and_b32 %13, %27, v" #YREG "\n\t"               /* y & maskL */                                          \
+        "v_and_b32 %14, %8, v" #YREG "\n\t"                /* vO = y & the offset draw's mask */                    \
         "v_cmp_ge_u32_e64 %17, %25, %12\n\t"          /* accP */                                               \
         "v_cmp_ge_u32 vcc, %26, %13\n\t"              /* accL */                                               \
         "v_cmp_le_u32_e64 %18, %14, %9\n\t"           /* accO: vO <= its range */                              \
@@ -646,7 +646,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
         : "+v"(len), "+v"(rem), "+v"(nS9), "+v"(used_lo), "+s"(mL), "+s"(mP), "+s"(mO),                        \
           "+v"(sstart), "+v"(omask), "+v"(orange), "+v"(cs), "+v"(ce),                                         \
           "=&v"(t0_), "=&v"(t1_), "=&v"(t2_), "=&v"(t3_), "=&s"(sa_), "=&s"(sb_), "=&s"(sc_)                   \
-        : "v"(Y), "v"(LR1), "v"(PCS), "v"(PCE), "v"(PPE), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(maskL),    \
+        : "n"(0), "v"(LR1), "v"(PCS), "v"(PCE), "v"(PPE), "s"(maskP), "s"(rangeP), "s"(rangeL), "s"(maskL),    \
           "s"(0x1e00u), "v"(lane_ring), "n"(JJ1)                                                               \
         : "vcc", "scc", "memory");                                                                             \
   }
@@ -795,14 +795,14 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   }
   // the same loop around GAT_STEP_SIMPLE_ASM: the state is lane masks (the loop ends when no lane is in a state), a trip's
   // events are folded into `used` at the next trip's head and behind the loop
-#define GAT_ONE_SIMPLE_ASM(C, JJ1) GAT_STEP_SIMPLE_ASM(ya[C], lr[C], JJ1)
-#define GAT_ONE_TABLE_ASM(C, JJ1) GAT_STEP_TABLE_ASM(ya[C], lr[C], pcs[C], pce[C], ppe[C], JJ1)
-#define GAT_PLACE_CHUNK_ASM(PRE, ONE, K)                                                                     \
+#define GAT_ONE_SIMPLE_ASM(C, JJ1, YREG) GAT_STEP_SIMPLE_ASM(YREG, lr[C], JJ1)
+#define GAT_ONE_TABLE_ASM(C, JJ1, YREG) GAT_STEP_TABLE_ASM(YREG, lr[C], pcs[C], pce[C], ppe[C], JJ1)
+#define GAT_PLACE_CHUNK_ASM(PRE, ONE, K, R0, R1, R2, R3, R4, R5, R6, R7)                                     \
   GAT_PSTAMP(0)                                                                                              \
   PRE(ya)                                                                                                    \
   GAT_PSTAMP(1)                                                                                              \
-  ONE(0, (K) * 8 + 1) ONE(1, (K) * 8 + 2) ONE(2, (K) * 8 + 3) ONE(3, (K) * 8 + 4)                            \
-  ONE(4, (K) * 8 + 5) ONE(5, (K) * 8 + 6) ONE(6, (K) * 8 + 7) ONE(7, (K) * 8 + 8)                            \
+  ONE(0, (K) * 8 + 1, R0) ONE(1, (K) * 8 + 2, R1) ONE(2, (K) * 8 + 3, R2) ONE(3, (K) * 8 + 4, R3)            \
+  ONE(4, (K) * 8 + 5, R4) ONE(5, (K) * 8 + 6, R5) ONE(6, (K) * 8 + 7, R6) ONE(7, (K) * 8 + 8, R7)            \
   GAT_PSTAMP(2)                                                                                              \
   if ((K) & 1) { nS = (int)(nS9 >> 9); flush(); }                                                            \
   GAT_PSTAMP(3)                                                                                              \
@@ -824,22 +824,22 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       jbase = j;                                                                                             \
       GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
       GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
-      GAT_PLACE_CHUNK_ASM(PRE, ONE, 0)                                                                           \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 0, 96, 97, 98, 99, 100, 101, 102, 103)                                                                           \
       if (j + 1 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
       GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, ONE, 1)                                                                           \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 1, 104, 105, 106, 107, 108, 109, 110, 111)                                                                           \
       if (j + 2 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
       GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, ONE, 2)                                                                           \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 2, 112, 113, 114, 115, 116, 117, 118, 119)                                                                           \
       if (j + 3 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
       GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
-      GAT_PLACE_CHUNK_ASM(PRE, ONE, 3)                                                                           \
+      GAT_PLACE_CHUNK_ASM(PRE, ONE, 3, 120, 121, 122, 123, 124, 125, 126, 127)                                                                           \
     }                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");                                     \
     GAT_FOLD_USED(jbase)                                                                                     \
@@ -962,13 +962,17 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 }
 
 template <int KIND, int MODE, int SMALL = 0>
-__global__ __launch_bounds__(64) void k_place(SamplerArgs A) { place_body<KIND, MODE, SMALL, false>(A); }
+// (SMALL 1 -- 10 KB of LDS, sixteen waves per CU -- is asked for four waves per SIMD: without the hint the register that holds
+//  spilled scalars lands behind the pinned rows, v128, and a fourth wave no longer fits)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == 0 && SMALL == 1 ? 4 : 1))) void k_place(SamplerArgs A) {
+  place_body<KIND, MODE, SMALL, false>(A);
+}
 
 // the single-workspace-segment units' rows pipelined through v96..v127 by hand (MODE 1, or MODE 0 where such units hold
 // most of the working segments: gat_problem::pipe_pays).  (amdgpu_num_vgpr does NOT keep the compiler below v96 on
 // gfx950 -- the unified register file doubles the number -- it is kept because the allocation it was tuned with is.)
 template <int KIND, int MODE, int SMALL = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96))) void k_place_pipe(SamplerArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96), amdgpu_waves_per_eu(MODE == 0 && SMALL == 1 ? 4 : 1))) void k_place_pipe(SamplerArgs A) {
   place_body<KIND, MODE, SMALL, true>(A);
 }
 

@@ -3,8 +3,9 @@
 flight into v96..v127 and nothing tells the register allocator so -- it stays below v96 only because the loop's own values fit
 there (the amdgpu_num_vgpr attribute does not bind on gfx950).  This script reads the device assembly the compile leaves
 behind (-save-temps=obj) and fails the build if, between the markers GAT_PINNED_BEGIN / GAT_PINNED_END the loop emits, any
-instruction other than the loop's own loads (global_load_dword v9x, ..., off) and takes (v_mov_b32 vN, v9x) names one of
-those registers; a silent corruption of the random rows becomes a build error.
+COMPILER-GENERATED instruction names one of those registers (the loop's own asm statements -- the row loads, the takes
+v_mov_b32 vN, v9x, the written-out steps that read a row register in place -- stand between ;;#ASMSTART / ;;#ASMEND and are
+the author's business); a silent corruption of the random rows becomes a build error.
 usage: tools/check_pinned_regs.py <device .s>"""
 import re
 import sys
@@ -25,12 +26,15 @@ def touches(line):
 
 
 def main(path):
-    kernel, inside, regions, bad, nloads = None, False, 0, [], {}
+    kernel, inside, regions, bad, nloads, in_asm = None, False, 0, [], {}, False
     for no, line in enumerate(open(path, errors="replace"), 1):
         code = line.split("//")[0]
         m = re.match(r"^(_ZN3gat\w+):", line)
         if m:
             kernel, inside = m.group(1), False
+        if "#ASMSTART" in line or "#ASMEND" in line:
+            in_asm = "#ASMSTART" in line
+            continue
         if "GAT_PINNED_BEGIN" in line:
             inside, regions = True, regions + 1
             continue
@@ -51,6 +55,9 @@ def main(path):
             t = TAKE.match(code)
             if LOAD.match(code) or (t and int(t.group(2)) < 96):
                 continue
+            if in_asm and not re.match(r"^\s*(global_|flat_|buffer_|scratch_|ds_read|ds_load)", code) and \
+                    not re.match(r"^\s*\S+\s+v(9[6-9]|1[01][0-9]|12[0-7])\b", code):
+                continue                  # a hand-written instruction READING a row register (never a load into one, never its destination)
             bad.append((kernel, no, code.strip()))
     if regions == 0:
         sys.exit("check_pinned_regs: no GAT_PINNED_BEGIN marker in %s (wrong file?)" % path)
