@@ -488,6 +488,10 @@ def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
     if seed % 2 == 1:
         # (a call of a few samples of simple units takes k_place_wide by itself: every other seed keeps the lean kernels)
         monkeypatch.setenv("GAT_PLACE_NO_WIDE", "1")
+    if seed % 4 >= 2:
+        # (k_place's written-out steps take every unit they can: half the seeds keep the compiler's form of the same steps,
+        #  which is what units with a bucket draw, SamplerSegments and offset masks that depend on the length still run)
+        monkeypatch.setenv("GAT_PLACE_NO_CM", "1")
     rs = np.random.RandomState(seed)
     n_contigs = int(rs.randint(1, 4))
     contigs = collections.OrderedDict(("f%d" % i, int(rs.randint(200000, 3000000))) for i in range(n_contigs))
