@@ -507,27 +507,12 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     if (nS - nF >= 8) { nF += 8; return; }
 #endif
     if (nS - nF >= 8 && nF + 8 <= cap) {                  // (beyond the capacity: GAT_STEP_SIMPLE_ASM's lanes run on, flagged below)
-#if defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 4
-      uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + (nF & 8));
-#else
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
-#endif
       const int w0 = nF & 15;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-#if defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 1
-        dst[w] = make_uint4(nF, w, nS, lane);
-#elif defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 2
-        const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
-        asm volatile("" :: "v"(e0.x), "v"(e0.y), "v"(e1.x), "v"(e1.y));
-#elif defined(GAT_EXP_FLUSH) && GAT_EXP_FLUSH == 3
-        const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
-        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store((v4u){e0.x, e0.y, e1.x, e1.y}, reinterpret_cast<v4u*>(dst + w));
-#else
         const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
         dst[w] = make_uint4(e0.x, e0.y, e1.x, e1.y);
-#endif
       }
       nF += 8;
     }
