@@ -626,6 +626,16 @@ def test_pinned_register_check_catches_a_stray_use(tmp_path):
     assert run(head + body + "\tscratch_load_dword v3, off, s32 offset:4\n" + tail).returncode != 0
     assert run(head + body.replace("\tglobal_load_dword v127, v[2:3], off offset:1792\n", "") + tail).returncode != 0
     assert run("\tv_mov_b32 v1, v2\n").returncode != 0            # no markers: the wrong file
+    # the loop's own asm statements (;;#ASMSTART .. ;;#ASMEND) may READ a row register in place -- the written-out steps do --
+    # but never write one or load into one; the same instruction from the compiler is a stray use
+    def asm(t):
+        return "\t;;#ASMSTART\n" + t + "\t;;#ASMEND\n"
+    assert run(head + body + asm("\tv_and_b32 v40, s60, v96\n\tv_cmp_ge_u32 vcc, s54, v40\n") + tail).returncode == 0
+    assert run(head + body + "\tv_and_b32 v40, s60, v96\n" + tail).returncode != 0
+    assert run(head + body + asm("\tv_mov_b32 v96, v1\n") + tail).returncode != 0
+    assert run(head + body + asm("\tds_read_b32 v97, v3\n") + tail).returncode != 0
+    assert run(head + asm(loads + "\tglobal_load_dword v127, v[2:3], off offset:1792 nt\n") +
+               asm("\ts_waitcnt vmcnt(24)\n\tv_mov_b32 v5, v96\n") + tail).returncode == 0
 
 
 _BED_CASES = {
