@@ -228,7 +228,15 @@ __global__ __launch_bounds__(kRngThreads) void k_rng(SamplerArgs A) {
 #pragma unroll
           for (int q = 0; q < kGroup; ++q) w[q] = src[(k + q) * kWave];
 #pragma unroll
-          for (int q = 0; q < kGroup; ++q) dst[(k + q) * kWave] = mt_temper(w[q]);
+          for (int q = 0; q < kGroup; ++q) {
+#ifndef GAT_RNG_NO_NT
+            // written once, read once and gigabytes later: past the L2 (config 2: k_rng 0.44 -> 0.49 ms but k_place, which no
+            // longer shares the memory system with these lines' write-back, 0.84 -> 0.75; config 3 0.94 -> 0.88 and 0.96 -> 0.89)
+            __builtin_nontemporal_store(mt_temper(w[q]), &dst[(k + q) * kWave]);
+#else
+            dst[(k + q) * kWave] = mt_temper(w[q]);
+#endif
+          }
         }
       }
     }
