@@ -2054,6 +2054,12 @@ constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per
 // PATCH: the unit lists are taken as k_tail left them -- merged list (trimmed in place, emptied segments read as padding)
 // + the record's extras -- so k_finalize and its round trip of the lists through HBM are not needed when only counts are
 // asked for.  The sums do not depend on the order or on the padding; the elements are those k_finalize would write.
+// a sampled list is read once by a count kernel: non-temporal, so that it does not push the annotation index out of the L2
+__device__ __forceinline__ uint2 ld_list_nt(const uint2* p) {
+  typedef uint32_t v2u_ __attribute__((ext_vector_type(2)));
+  const v2u_ t = __builtin_nontemporal_load(reinterpret_cast<const v2u_*>(p));
+  return make_uint2(t.x, t.y);
+}
 template <bool STAGED, bool WANT_HITS, bool PATCH = false>
 __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2134,7 +2140,7 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   };
   auto load = [&](const View& v, int i) -> uint2 {
     if (i >= v.n) return kPad;
-    if (!PATCH) return v.X[i];
+    if (!PATCH) return v.X[i];                                // (non-temporal here: 0.288 -> 0.283 ms on config 2, not worth a second form)
     const uint2 y = *(i < v.nU ? v.X + i : v.Rex + i);
     return y.x == y.y ? kPad : y;                            // (emptied by the trim: merge(0) drops it)
   };
@@ -2228,6 +2234,11 @@ constexpr int kMergedThreads = GAT_MERGED_THREADS;
 // entries out of the grid cell's own 32-byte record, pairs behind them.  The host picks by how many entries a scan is
 // expected to pass (AnnoDev::merged_block): config 3 / config 5 pass 3 (blocks: 1.27 -> 1.49 ms and 1.76 -> 2.21 ms; cell
 // records: see DESIGN.md), the config-4 shape passes 15 and takes blocks (48.7 -> 37.0 ms per 12 500 samples).
+#ifndef GAT_MERGED_NO_NT
+#define GAT_LD_LIST(P) ld_list_nt(P)     /* config-4 shape: k_count_merged 34.4 -> 32.9 ms; with its partial sums stored the same way 29.6 */
+#else
+#define GAT_LD_LIST(P) (*(P))
+#endif
 template <bool PATCH, int BLK>
 __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2273,7 +2284,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
         // (an empty segment -- padding, or what a trim emptied -- meets nothing: start < 0 never holds)
-        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
+        x[r] = i < n ? GAT_LD_LIST(PATCH ? (i < nU ? X + i : Rex + i) : X + i) : make_uint2(0u, 0u);
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }
@@ -2331,7 +2342,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
-        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
+        x[r] = i < n ? GAT_LD_LIST(PATCH ? (i < nU ? X + i : Rex + i) : X + i) : make_uint2(0u, 0u);
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
@@ -2388,7 +2399,7 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
       for (int r = 0; r < kR; ++r) {
         const int i = base + r * kWave + lane;
         // (an empty segment -- padding, or what a trim emptied -- meets nothing: start < 0 never holds)
-        x[r] = i < n ? (PATCH ? *(i < nU ? X + i : Rex + i) : X[i]) : make_uint2(0u, 0u);
+        x[r] = i < n ? GAT_LD_LIST(PATCH ? (i < nU ? X + i : Rex + i) : X + i) : make_uint2(0u, 0u);
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) { const uint32_t g = x[r].x >> shift; k[r] = F[g < last ? g : last]; }
@@ -2425,7 +2436,12 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     }
     wave_fence();
     uint32_t* __restrict__ dst = A.part + ((int64_t)c * A.n_samples + s) * T;
+#ifndef GAT_MERGED_NO_NT
+    // (1.2 GB of partial sums per launch on the config-4 shape, read once by k_count_merged_finish: past the L2, where the index lives)
+    for (int t = lane; t < T; t += kWave) { __builtin_nontemporal_store(acc[t], &dst[t]); acc[t] = 0u; }
+#else
     for (int t = lane; t < T; t += kWave) { dst[t] = acc[t]; acc[t] = 0u; }
+#endif
     wave_fence();
   }
 }
