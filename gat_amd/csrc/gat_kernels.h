@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       __syncthreads();
       uint32_t before = run, all = 0;
       for (int k = 0; k < kMergeWaves; ++k) { if (k < wave) before += red[k]; all += red[k]; }
-      if (i < count) cum[i] = before + incl;
+      if (i < count && ((i & 7) == 7 || i == count - 1)) cum[i >> 3] = before + incl;     // (per block of eight: k_tail)
       run += all;
     }
   }

@@ -121,7 +121,10 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     else if (nws <= kWsLoopMax) cov1 = ws_overlap_search(W, s1, e1);
     else if constexpr (TREE) { if (head) cov1 = seg_overlap_tree1(ws, ws_cdf, tree_start1, ws_tree_geom(nws), s1, e1); }
     const uint32_t incl1 = wave_incl_sum_u32(e1 - s1, lane);
-    if (head) { out[pos] = make_uint2(s1, e1); cum[pos] = incl1; }
+    if (head) {
+      out[pos] = make_uint2(s1, e1);
+      if ((pos & 7) == 7 || pos == nU1 - 1) cum[pos >> 3] = incl1;                     // (running lengths per block of eight: GAT_CUM8)
+    }
     cov1 = wave_total_u32(cov1);
     const uint32_t run1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, kWave - 1);
     if (lane == 0) A.st2[sa] = make_int4(nU1, (int)cov1, (int)run1, 1);
@@ -167,7 +170,10 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     else if (nws <= kWsLoopMax) cov += ws_overlap_search(W, v.x, v.y);
     else if constexpr (TREE) { if (i < nU) cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y); }
     const uint32_t incl = run + wave_incl_sum_u32(v.y - v.x, lane);
-    if (i < nU) { out[i] = v; cum[i] = incl; }
+    if (i < nU) {
+      out[i] = v;
+      if ((i & 7) == 7 || i == nU - 1) cum[i >> 3] = incl;
+    }
     run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
   }
   cov = wave_total_u32(cov);
@@ -340,14 +346,41 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       const uint32_t p = tail_range(rng, total - 1u);
       // leftmost element whose inclusive running length exceeds p (searchsorted over cdf = incl - 1)
       // ((int32_t)(c - 1 - p) >= 0 is c > p: running lengths stay below 2^31)
-      const int lo = interp_upper_bound(nU, p, [&](int i) -> uint32_t {
-        uint32_t c = cum[i];
+      // The running lengths are kept per BLOCK of eight merged segments (cum[b] = through element 8 b + 7, the last entry through
+      // the last element): an eighth of what k_consolidate used to write, and the search below touches the two lines that hold
+      // a list's block sums instead of a line per probe; the block found, its eight segments -- one 64-byte piece of the list
+      // -- are walked.  val(i) = merged running length through i + the extras in front of or at i, non-decreasing in i, so the
+      // first block whose last element exceeds p holds the answer.
+      const int nB = (nU + 7) >> 3;
+      const int bl = interp_upper_bound(nB, p, [&](int b) -> uint32_t {
+        const int last = b * 8 + 7 < nU - 1 ? b * 8 + 7 : nU - 1;
+        uint32_t c = cum[b];
 #pragma unroll
-        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= i) c += ex[j].y - ex[j].x;
+        for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= last) c += ex[j].y - ex[j].x;
         return c;
       });
+      int lo = nU;
+      uint32_t before = nB > 0 && bl > 0 ? cum[(bl < nB ? bl : nB) - 1] : 0u;      // merged running length in front of element lo
+      if (bl < nB) {
+        uint2 blk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) blk[q] = bl * 8 + q < nU ? U[bl * 8 + q] : make_uint2(0u, 0u);
+        uint32_t runm = before;
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int i = bl * 8 + q;
+          if (!hit && i < nU) {
+            uint32_t c = runm + (blk[q].y - blk[q].x);
+#pragma unroll
+            for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= i) c += ex[j].y - ex[j].x;
+            if (c > p) { hit = true; lo = i; before = runm; }
+            else runm += blk[q].y - blk[q].x;
+          }
+        }
+        if (!hit) before = runm;
+      }
       // extras standing right in front of merged-list element lo come first
-      uint32_t before = lo > 0 ? cum[lo - 1] : 0u;
       int nbefore = 0;
 #pragma unroll
       for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] < lo) { before += ex[j].y - ex[j].x; nbefore++; }
