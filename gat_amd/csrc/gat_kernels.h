@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   tot = block_reduce_u32(tot, red, tid, false, false);
   if (A.cum != nullptr) {
     // split path: the running lengths k_tail's position draw searches (block-wide inclusive scan, 256 elements a round)
-    uint32_t* __restrict__ cum = A.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+    uint32_t* __restrict__ cum = A.cum + (((int64_t)sidx * A.slab_stride + Up->slab_off) >> 3);
     uint32_t run = 0;
     for (int base = 0; base < count; base += kMergeThreads) {
       const int i = base + tid;

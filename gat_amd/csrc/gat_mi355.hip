@@ -191,7 +191,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   }
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
                              (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
-                             (P->split_path ? P->slab_stride * 12 + (int64_t)(sizeof(gat::TailPatch) + 4) * P->n_units : 0);
+                             (P->split_path ? P->slab_stride * 8 + P->slab_stride / 2 + (int64_t)(sizeof(gat::TailPatch) + 4) * P->n_units : 0);
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
@@ -219,7 +219,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
       HIPCHK(ctx, hipMemsetAsync(P->d_patch.p, 0, ns * sizeof(gat::TailPatch), ctx->stream));
     }
     if (P->split_path) {
-      HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride)));
+      HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride / 8 + 8)));      // (slab regions are multiples of 64 entries: cap_for)
       HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_patch.alloc(ns));
       HIPCHK(ctx, P->d_todo.alloc(ns));

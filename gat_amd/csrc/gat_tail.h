@@ -53,7 +53,7 @@ static_assert(sizeof(TailPatch) == kPatchWords * 4 && offsetof(TailPatch, extra)
 
 struct TailArgs {
   SamplerArgs S;
-  uint32_t* cum;          // [batch][slab_stride]: inclusive running length of the merged list, parallel to the slab
+  uint32_t* cum;          // [batch][slab_stride / 8]: inclusive running length of the merged list through every eighth element (and the last)
   TailPatch* patch;       // [launch position][rec_stride] (GAT_REC)
   uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   uint32_t* scratch = lds;                                          // bucket-sort scratch
   uint2* seg = reinterpret_cast<uint2*>(lds + kSortScratchWords);
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
-  uint32_t* cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  uint32_t* cum = T.cum + (((int64_t)sidx * A.slab_stride + Up->slab_off) >> 3);      // (one entry per block of eight slab entries)
   const int nws = Up->n_ws;
   const uint2* __restrict__ ws = A.ws + Up->ws_off;
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   // (every unit that is not finished here goes to k_sampler's queue)
   if (pre.z < 0 || c2.w != 1 || c2.x <= 0) { T.todo[atomicAdd(T.todo_count, 1u)] = qe; return; }   // not consolidated
   uint2* U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;     // (read; the trim is written into it at the very end)
-  const uint32_t* __restrict__ cum = T.cum + (int64_t)sidx * A.slab_stride + Up->slab_off;
+  const uint32_t* __restrict__ cum = T.cum + (((int64_t)sidx * A.slab_stride + Up->slab_off) >> 3);
   const int nU = c2.x;
   uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
 
