@@ -346,8 +346,6 @@ struct gat_problem {
   DevBuf<uint32_t> d_rng_out, d_ws_stat, d_part;
   DevBuf<uint32_t> d_rng_ckpt;           // k_seed -> k_rng: 16 checkpoints of every stream's seeded state (4 KB per tile)
   DevBuf<uint2> d_fslab;                 // split path: the units' final lists (k_finalize writes out of place)
-  DevBuf<uint32_t> d_tail_rows;          // split path: k_place -> k_tail, the rows around a lane's trigger (16 words per work unit)
-  DevBuf<int32_t> d_tail_rows_on;        // ... per launch position: written by this batch's k_place
   DevBuf<uint32_t> d_cum;                // split path: running lengths of the merged lists (parallel to the slab)
   DevBuf<gat::TailPatch> d_patch;        // ... and k_tail's record per work unit
   DevBuf<uint32_t> d_todo;               // ... and the units it leaves to k_sampler (their number: todo_count_dev())

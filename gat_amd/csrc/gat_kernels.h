@@ -51,10 +51,6 @@ struct SamplerArgs {
                               //   w = raw outputs consumed so far
   int32_t sampler_kind;       // 0 SamplerAnnotator, 1 SamplerSegments (st_length -2: unit complete after k_place)
   int32_t place_plain_step;   // != 0: k_place runs GAT_STEP_SIMPLE_B where GAT_STEP_SIMPLE_C would do (GAT_PLACE_NO_CM: tests, A/B)
-  uint32_t* tail_rows;        // split path: [launch position][rec_stride][16] -- the two chunks of rows around a lane's trigger, kept by
-                              //   k_place's written-out loops for k_tail (a lane's next rows are eight lines of k_rng's [row][lane]
-                              //   layout, 1 KB for 32 bytes; here they are one 64-byte record); nullptr: not kept
-  int32_t* tail_rows_on;      // [launch position]: 1 = the unit's records were written by this batch's k_place
   int32_t big_buckets;        // > 0: LDS holds that many + 1 scratch words behind the segment buffer (units > 1024 segments)
   int32_t lds_cap;            // segment capacity of the LDS buffer
   int32_t a_base, a_end;      // k_sampler / k_merge_big / k_consolidate: the launch covers launch positions [a_base, a_end) -- one
@@ -460,29 +456,6 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   uint64_t mL = 0, mP = 0, mO = 0;
   uint32_t nS9 = 0, used_lo = 0;
   const uint32_t lane_ring = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)&l_out[0][lane];
-  // k_tail's rows (SamplerArgs::tail_rows): a lane that triggers in a chunk leaves that chunk's eight rows and the next one's --
-  // both still in the pinned registers -- as one 64-byte record; k_tail's rows start at `used`, inside the first of the two
-  const bool keep_rows = A.tail_rows != nullptr;
-  uint32_t* const trow_ptr = A.tail_rows + (keep_rows ? GAT_REC(A, sidx, a) * 16 : 0);
-  uint64_t alive_prev = 0;
-#define GAT_KEEP_ROWS(A0, A3, A4, A7, B0, B3, B4, B7)                                                          \
-  {                                                                                                            \
-    const uint64_t alive_now_ = mL | mP | mO, newh_ = alive_prev & ~alive_now_;                                \
-    alive_prev = alive_now_;                                                                                   \
-    if (keep_rows && newh_ != 0) {                                                                             \
-      uint64_t sv_;                                                                                            \
-      const uint64_t newh_u_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(newh_ >> 32)) << 32) |   \
-                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)newh_);      \
-      asm volatile("s_waitcnt vmcnt(16)\n\t"             /* (the next chunk's rows have landed: two chunks may stay in flight) */ \
-                   "s_and_saveexec_b64 %0, %1\n\t"                                                             \
-                   "global_store_dwordx4 %2, v[" #A0 ":" #A3 "], off\n\t"                                      \
-                   "global_store_dwordx4 %2, v[" #A4 ":" #A7 "], off offset:16\n\t"                            \
-                   "global_store_dwordx4 %2, v[" #B0 ":" #B3 "], off offset:32\n\t"                            \
-                   "global_store_dwordx4 %2, v[" #B4 ":" #B7 "], off offset:48\n\t"                            \
-                   "s_mov_b64 exec, %0"                                                                        \
-                   : "=&s"(sv_) : "s"(newh_u_), "v"(trow_ptr) : "memory");                                       \
-    }                                                                                                          \
-  }
 #define GAT_STEP_SIMPLE_ASM(YREG, LR1, JJ1)                                                                       \
   {                                                                                                            \
     uint32_t t0_, t1_, t2_, t3_;                                                                               \
@@ -832,7 +805,6 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   {                                                                                                          \
     static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
     mL = __ballot(sL); mP = 0; mO = 0;                                                                       \
-    alive_prev = mL;                                                                                         \
     int jbase = 0;                                                                                           \
     asm volatile("; GAT_PINNED_BEGIN" ::: "memory");                                                         \
     GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, 0)                                                      \
@@ -846,25 +818,21 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       GAT_PIN_LOAD(120, 121, 122, 123, 124, 125, 126, 127, j + 3 * kPlaceChunk)                              \
       GAT_PIN_TAKE(96, 97, 98, 99, 100, 101, 102, 103)                                                       \
       GAT_PLACE_CHUNK_ASM(PRE, ONE, 0, 96, 97, 98, 99, 100, 101, 102, 103)                                                                           \
-      GAT_KEEP_ROWS(96, 99, 100, 103, 104, 107, 108, 111)                                                    \
       if (j + 1 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(96, 97, 98, 99, 100, 101, 102, 103, j + 4 * kPlaceChunk)                                  \
       GAT_PIN_TAKE(104, 105, 106, 107, 108, 109, 110, 111)                                                   \
       GAT_PLACE_CHUNK_ASM(PRE, ONE, 1, 104, 105, 106, 107, 108, 109, 110, 111)                                                                           \
-      GAT_KEEP_ROWS(104, 107, 108, 111, 112, 115, 116, 119)                                                  \
       if (j + 2 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(104, 105, 106, 107, 108, 109, 110, 111, j + 5 * kPlaceChunk)                              \
       GAT_PIN_TAKE(112, 113, 114, 115, 116, 117, 118, 119)                                                   \
       GAT_PLACE_CHUNK_ASM(PRE, ONE, 2, 112, 113, 114, 115, 116, 117, 118, 119)                                                                           \
-      GAT_KEEP_ROWS(112, 115, 116, 119, 120, 123, 124, 127)                                                  \
       if (j + 3 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
       GAT_PSTAMP(4)                                                                                          \
       GAT_PIN_LOAD(112, 113, 114, 115, 116, 117, 118, 119, j + 6 * kPlaceChunk)                              \
       GAT_PIN_TAKE(120, 121, 122, 123, 124, 125, 126, 127)                                                   \
       GAT_PLACE_CHUNK_ASM(PRE, ONE, 3, 120, 121, 122, 123, 124, 125, 126, 127)                                                                           \
-      GAT_KEEP_ROWS(120, 123, 124, 127, 96, 99, 100, 103)                                                    \
     }                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");                                     \
     GAT_FOLD_USED(jbase)                                                                                     \
@@ -958,7 +926,6 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PLACE_LOOP_PIPE_ASM
 #undef GAT_PLACE_CHUNK_ASM
 #undef GAT_FOLD_USED
-#undef GAT_KEEP_ROWS
 #undef GAT_PRE_TABLE_GG
 #undef GAT_PRE_TABLE_LG
 #undef GAT_PRE_TABLE_GL
@@ -972,7 +939,6 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PRE_RANK_L
 #undef GAT_STEP_TABLE_B
 #undef GAT_ALIVE_TB
-  if (lane == 0 && A.tail_rows_on != nullptr) A.tail_rows_on[a] = (keep_rows && !plain_step) ? 1 : 0;   // (every tile of the unit: the same value)
   if (live) {
     const bool halted = !(sL || sB || sP || sO);
     if (!plain_step) {

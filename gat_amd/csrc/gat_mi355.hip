@@ -191,7 +191,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   }
   const int64_t per_sample = P->slab_stride * 8 * (P->merge_contigs ? 2 : 1) + 4 * ((int64_t)P->n_units + P->n_contigs) +
                              (P->sampler_mode ? P->rng_rows_total * 4 + 16 * (int64_t)P->n_units : 0) +
-                             (P->split_path ? P->slab_stride * 8 + P->slab_stride / 2 + (int64_t)(sizeof(gat::TailPatch) + 4 + 64) * P->n_units : 0);
+                             (P->split_path ? P->slab_stride * 8 + P->slab_stride / 2 + (int64_t)(sizeof(gat::TailPatch) + 4) * P->n_units : 0);
   int64_t b = (int64_t)(budget / (double)per_sample);
   b = std::max<int64_t>(1, std::min<int64_t>(b, want));
   if (P->batch >= b) return GAT_OK;
@@ -223,9 +223,6 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
       HIPCHK(ctx, P->d_fslab.alloc((size_t)(b * P->slab_stride)));
       HIPCHK(ctx, P->d_patch.alloc(ns));
       HIPCHK(ctx, P->d_todo.alloc(ns));
-      HIPCHK(ctx, P->d_tail_rows.alloc(ns * 16));
-      HIPCHK(ctx, P->d_tail_rows_on.alloc((size_t)std::max(1, P->n_units)));
-      HIPCHK(ctx, hipMemsetAsync(P->d_tail_rows_on.p, 0, (size_t)std::max(1, P->n_units) * sizeof(int32_t), ctx->stream));
     }
   }
   P->batch = b;
@@ -460,10 +457,6 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.place_plain_step = getenv("GAT_PLACE_NO_CM") ? 1 : 0;
-      // (k_place's written-out loops keep the rows around a lane's trigger for k_tail: GAT_PLACE_NO_KEEP_ROWS leaves k_tail to k_rng's rows)
-      const bool keep_rows = P->split_path && P->d_tail_rows.p != nullptr && !getenv("GAT_PLACE_NO_KEEP_ROWS");
-      A.tail_rows = keep_rows ? P->d_tail_rows.p : nullptr;
-      A.tail_rows_on = keep_rows ? P->d_tail_rows_on.p : nullptr;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->flags_dev(); A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
 #ifdef GAT_DIAG

@@ -224,8 +224,6 @@ struct TailRng {
   const uint32_t* rp;     // the lane's column of the tile's rows
   uint32_t used, rows;    // raw outputs consumed / generated
   uint32_t buf[kTailRows];
-  const uint32_t* win;    // k_place's record of the rows around the lane's trigger (SamplerArgs::tail_rows): rows [win_base, win_base + win_n)
-  uint32_t win_base, win_n;
   uint32_t have;          // buf holds rows [base, base + have)
   uint32_t base;
   bool out_of_rows;
@@ -233,10 +231,7 @@ struct TailRng {
 __device__ __forceinline__ void tail_fetch(TailRng& r) {
   r.base = r.used;
 #pragma unroll
-  for (int k = 0; k < kTailRows; ++k) {
-    const uint32_t i = r.used + (uint32_t)k;
-    r.buf[k] = i < r.rows ? (i - r.win_base < r.win_n ? r.win[i - r.win_base] : r.rp[(size_t)i * kWave]) : 0u;
-  }
+  for (int k = 0; k < kTailRows; ++k) r.buf[k] = r.used + (uint32_t)k < r.rows ? r.rp[(size_t)(r.used + (uint32_t)k) * kWave] : 0u;
   r.have = kTailRows;
 }
 __device__ __forceinline__ uint32_t tail_next(TailRng& r) {
@@ -299,14 +294,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   rng.used = (uint32_t)pre.w;
   rng.out_of_rows = false;
   rng.have = 0; rng.base = rng.used;
-  rng.win = nullptr; rng.win_base = 0; rng.win_n = 0;
-  if (A.tail_rows != nullptr && A.tail_rows_on[a] != 0 && rng.used > 0) {
-    // k_place kept the chunk of rows the lane triggered in and the next one (the second only where the tile's rows go that far:
-    // behind the last whole chunk the loads re-read the tile's last rows)
-    rng.win = A.tail_rows + GAT_REC(A, sidx, a) * 16;
-    rng.win_base = (rng.used - 1u) & ~7u;
-    rng.win_n = rng.win_base + 16u <= rng.rows ? 16u : 8u;
-  }
 
   // bases of [s, e) inside the workspace (SegmentList.intersect(workspace).sum() of one segment)
   auto ws_overlap = [&](uint32_t s, uint32_t e) -> uint32_t {
@@ -615,7 +602,6 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
   rng.used = (uint32_t)pre.w;
   rng.out_of_rows = false;
   rng.have = 0; rng.base = rng.used;
-  rng.win = nullptr; rng.win_base = 0; rng.win_n = 0;
 
   auto ws_overlap = [&](uint32_t s, uint32_t e) -> uint32_t {
     uint32_t ov = 0;

@@ -5,7 +5,7 @@ there (the amdgpu_num_vgpr attribute does not bind on gfx950).  This script read
 behind (-save-temps=obj) and fails the build if, between the markers GAT_PINNED_BEGIN / GAT_PINNED_END the loop emits, any
 COMPILER-GENERATED instruction names one of those registers (the loop's own asm statements -- the row loads, the takes
 v_mov_b32 vN, v9x, the written-out steps that read a row register in place -- stand between ;;#ASMSTART / ;;#ASMEND and are
-the author's business -- they may read a row register in place, also as the data of a store, never write one); a silent corruption of the random rows becomes a build error.
+the author's business); a silent corruption of the random rows becomes a build error.
 usage: tools/check_pinned_regs.py <device .s>"""
 import re
 import sys
@@ -55,7 +55,7 @@ def main(path):
             t = TAKE.match(code)
             if LOAD.match(code) or (t and int(t.group(2)) < 96):
                 continue
-            if in_asm and not re.match(r"^\s*(global_load|global_atomic|flat_|buffer_|scratch_|ds_read|ds_load)", code) and \
+            if in_asm and not re.match(r"^\s*(global_|flat_|buffer_|scratch_|ds_read|ds_load)", code) and \
                     not re.match(r"^\s*\S+\s+v(9[6-9]|1[01][0-9]|12[0-7])\b", code):
                 continue                  # a hand-written instruction READING a row register (never a load into one, never its destination)
             bad.append((kernel, no, code.strip()))
