@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-api", action="store_true", help="skip the gat_amd.run() block")
     ap.add_argument("--dump-counts", default=None, help="rank 0 saves the gathered count matrix of the last step (tests)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block")
+    ap.add_argument("--details", default=None, help="where rank 0 writes the full report (default: bench_details.json beside bench.py)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scale", type=float, default=1.0, help="scale interval counts (debugging only)")
@@ -127,8 +128,8 @@ def cpu_baseline(flat, counters, seed, budget_s):
     nt = int(max(probe, min(2000 * threads, 0.5 * budget_s * probe / dtp)))
     dtt = run_threads(nt)
     return dict(value=nt / dtt, unit="samples/s", cores=threads, kind="port",
-                sample="%d samples of the same workload on %d threads in %.1f s (oracle/gat_oracle.c); one thread: "
-                       "%.1f samples/s (%d samples, %.1f s)" % (nt, threads, dtt, n1 / dt1, n1, dt1),
+                sample="%d samples of this workload, %d threads, %.1f s (oracle/gat_oracle.c); 1 thread: %d samples, %.1f s"
+                       % (nt, threads, dtt, n1, dt1),
                 single_thread_value=n1 / dt1)
 
 
@@ -252,12 +253,12 @@ class Workload(object):
         world = self.world
         for i in range(warmup):
             self.step(i)
-        # the first tens of milliseconds after the device was idle run 5-8 % slower than the steady state (a 10 000-sample
-        # step is 2.7 ms: `warmup` steps are not the time the clocks take).  The K steps timed right behind the warm-up are
-        # kept as `cold_start`; the headline's W + K steps are run again behind the kernel split and the sustained loop below.
-        cold = self.timed(steps, warmup)
-        self.cold_start = {"ms_per_step": cold / steps * 1e3, "value": self.S * steps * world / cold, "unit": "samples/s",
-                           "what": "the same %d steps timed right behind the %d warm-up steps of a fresh process" % (steps, warmup)}
+        # THE HEADLINE: exactly `steps` steps timed right behind the `warmup` untimed ones of this process (barrier +
+        # synchronize on both sides, MAX over the ranks).  Everything below -- the per-kernel split, the sustained loop --
+        # runs BEHIND it and is reported beside it, never instead of it.  (On some boxes the first tens of milliseconds
+        # after the device was idle run 5-8 % slower than the steady state: `sustained` shows the difference.)
+        acc = dict((k, 0.0) for k in self.KEYS)
+        dt = self.timed(steps, warmup, acc)
         # the per-kernel split of the step (`kernels`, `sampler`): an event behind every kernel of the sampler costs a
         # call 50-60 us, so the library records them on request only -- here in a few steps of their own behind the timed
         # region (whose count kernel carries its two events always: `roofline`)
@@ -272,7 +273,7 @@ class Workload(object):
         # same number of steps: rank 0's estimate is broadcast)
         sustained = None
         if sustain_s > 0:
-            per = max(1, int(round(0.25 * sustain_s / max(cold / steps, 1e-6))))
+            per = max(1, int(round(0.25 * sustain_s / max(dt / steps, 1e-6))))
             if world > 1:
                 t = torch.tensor([per], dtype=torch.int64, device=self.dev)
                 dist.broadcast(t, src=0)
@@ -289,13 +290,7 @@ class Workload(object):
                     dist.broadcast(t, src=0)
                     total_t = float(t.item())
             sustained = {"value": self.S * total_n * world / total_t, "unit": "samples/s", "seconds": total_t, "steps": total_n,
-                         "repeats": len(rates), "min": min(rates), "max": max(rates)}
-        # the headline: W untimed steps, then exactly K timed ones (barrier + synchronize on both sides, MAX over the ranks)
-        nxt0 = warmup + steps + ksteps + (sustained["steps"] if sustained else 0)
-        for i in range(warmup):
-            self.step(nxt0 + i)
-        acc = dict((k, 0.0) for k in self.KEYS)
-        dt = self.timed(steps, nxt0 + warmup, acc)
+                         "ms_per_step": total_t / total_n * 1e3, "repeats": len(rates), "min": min(rates), "max": max(rates)}
         # the one collective of the path, timed by itself after the timed region (the split the report shows per N)
         allgather = None
         if world > 1:
@@ -312,7 +307,6 @@ class Workload(object):
         out = self.report(steps, warmup, dt, acc, allgather, acck, ksteps)
         if sustained is not None:
             out["sustained"] = sustained
-        out["cold_start"] = self.cold_start
         return out
 
     def report(self, steps, warmup, dt, acc, allgather, acck, ksteps):
@@ -394,8 +388,7 @@ class Workload(object):
             roof["fetch_factor"] = fx
             traffic = (fx * k["fetch_kib_per_launch"] + k["write_kib_per_launch"]) * 1024.0
             roof["traffic"] = traffic
-            roof["traffic_source"] = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; " \
-                                     "not re-measured in this run)" % src
+            roof["traffic_source"] = "%s (committed rocprofv3 --pmc passes of this command; not re-measured here)" % src
             if count_s > 0:
                 roof["hbm_measured_GBps"] = traffic / count_s / 1e9
                 roof["frac_of_achievable"] = traffic / count_s / 1e9 / HBM_ACHIEVABLE_GBPS
@@ -425,8 +418,7 @@ class Workload(object):
             "ms_per_step": dt / steps * 1e3,
             "steps": steps,
             "warmup": warmup,
-            "config": {"workload": "%s: %d segments x %d annotation tracks x %d intervals, %d units / %d contigs, "
-                                   "%d samples per GPU per step, %s" %
+            "config": {"workload": "%s: %d segments x %d tracks x %d intervals, %d units / %d contigs, %d samples/GPU/step, %s" %
                                    (self.name, len(flat["segs"]), A, len(flat["annos"]), flat["n_units"],
                                     flat["n_contigs"], S, self.counters[0]),
                        "samples_per_step_per_gpu": S,
@@ -478,7 +470,8 @@ def strong_scaling(args, dev_index, rank, world):
     STRONG_TOTAL / N samples + its read-back), which bounds the job from below: N GPUs finish no earlier than one shard's call
     (the all-gather comes on top).  world > 1: the job itself -- every rank its shard, one all-gather, read-back."""
     import torch
-    out = {"samples_total": STRONG_TOTAL, "scaling": "strong"}
+    out = {"samples_total": STRONG_TOTAL, "scaling": "strong",
+           "measured_on": "%d GPU(s)%s" % (world, "" if world > 1 else ": one GPU runs one shard of each N")}
     for name in ("config2", "config3"):
         rows = {}
         for n in ([world] if world > 1 else [1, 2, 4, 8]):
@@ -579,6 +572,80 @@ def api_block(args, repeats=5):
     return out
 
 
+LINE_LIMIT = 3000               # bytes of the one stdout line (the driver parses stdout; round 4's 21 KB line broke it)
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _r(x, nd=4):
+    """numbers of the line, rounded to what they are good for"""
+    if isinstance(x, float):
+        x = float("%.*g" % (nd + 3, x))
+        return int(x) if x == int(x) and abs(x) >= 1e6 else x
+    return x
+
+
+def _cut(x, n=120):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 3] + "..."
+
+
+def final_line(out, details_path=None):
+    """the ONE stdout line: the contract's keys (+ roofline, cpu_baseline) and a handful of small extras, every string at
+    most 120 characters, the whole line below LINE_LIMIT.  Everything else (`configs`, `strong_scaling`, `api`, `kernels`,
+    `sampler`, the long notes) lives in the details file only."""
+    line = dict((k, out.get(k)) for k in LINE_KEYS[:12])
+    for k in ("value", "ms_per_step"):
+        line[k] = _r(line[k])
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": _cut(cfg.get("workload", "")), "samples_per_step_per_gpu": cfg.get("samples_per_step_per_gpu"),
+                      "sharding": _cut(cfg.get("sharding", ""))}
+    roof = out.get("roofline") or {}
+    line["roofline"] = dict((k, _cut(_r(roof.get(k)))) for k in
+                            ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
+                             "algorithmic_bytes_per_launch", "traffic_source") if k in roof)
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = dict((k, _cut(_r(cb.get(k)))) for k in ("value", "unit", "cores", "kind", "sample",
+                                                                       "single_thread_value") if k in cb)
+    # small extras, dropped from the back if the line would not fit
+    extras = []
+    if out.get("sustained"):
+        extras.append(("sustained_value", _r(out["sustained"]["value"])))
+        if "ms_per_step" in out["sustained"]:
+            extras.append(("sustained_ms_per_step", _r(out["sustained"]["ms_per_step"])))
+    if out.get("step"):
+        extras.append(("step", {"hbm_bytes": out["step"]["hbm_bytes"], "hbm_frac": _r(out["step"]["hbm_frac"])}))
+    if out.get("distributed"):
+        d = out["distributed"]
+        extras.append(("distributed", {"backend": d["backend"], "world_size": d["world_size"], "one_gpu_per_rank": d["one_gpu_per_rank"]}))
+    if out.get("allgather"):
+        a = out["allgather"]
+        extras.append(("allgather", {"avg_ms": _r(a["avg_ms"]), "bytes_per_rank": a["bytes_per_rank"]}))
+    if out.get("strong_scaling"):
+        st = out["strong_scaling"]
+        extras.append(("strong_scaling", dict(
+            [("samples_total", st["samples_total"]), ("measured_on", st.get("measured_on"))] +
+            [(name, dict((n, _r(row["ms_per_job"])) for n, row in st[name].items())) for name in ("config2", "config3") if name in st])))
+    if out.get("configs"):
+        extras.append(("configs", dict((name, {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]),
+                                               "samples_per_step": r["config"]["samples_per_step_per_gpu"],
+                                               "roofline_bound": r["roofline"]["bound"], "roofline_frac": _r(r["roofline"]["frac"])})
+                                       for name, r in out["configs"].items())))
+    if out.get("api"):
+        extras.append(("api_ms_per_run", dict((name, _r(v["ms_per_run"])) for name, v in out["api"].items() if isinstance(v, dict))))
+    if details_path:
+        extras.append(("details", _cut(details_path)))
+    for k, v in extras:
+        line[k] = v
+    text = json.dumps(line)
+    while len(text) >= LINE_LIMIT and extras:
+        k, _ = extras.pop()
+        del line[k]
+        text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, "bench.py: the stdout line does not fit %d bytes" % LINE_LIMIT
+    return text
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -613,7 +680,7 @@ def main():
     out = {"metric": METRIC, "value": main_out["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u32", "data": "synthetic"}
-    for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained", "step", "cold_start"):
+    for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained", "step"):
         if k in main_out:
             out[k] = main_out[k]
     if "sustained" in main_out:
@@ -631,7 +698,8 @@ def main():
         torch.cuda.synchronize()
         np.savez(args.dump_counts, counts=W.host[W.last].numpy(), samples_per_rank=W.S, world=world, seed=args.seed,
                  first_sample=W.last_first)
-    if rank == 0 and not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
+    cpu_leg = rank == 0 and not args.no_cpu_baseline and world == 1      # reported on rank 0 at N=1 only
+    if cpu_leg:
         out["cpu_baseline"] = cpu_baseline(W.flat, W.counters, args.seed, args.cpu_seconds)
         if args.config in REFERENCE_CYTHON:
             out["cpu_baseline"]["reference_cython_engine"] = {
@@ -647,6 +715,8 @@ def main():
         # (a config-4 step is a rank's whole shard, about 0.1 s: a quarter of the steps)
         r = E.measure(max(1, args.extra_steps // 4 if name == "config4" else args.extra_steps), 2, args.sustain_seconds)
         r["n_gpus"] = world
+        if cpu_leg and name == "config3":                   # the north_star target shape: the port on the same workload
+            r["cpu_baseline"] = cpu_baseline(E.flat, E.counters, args.seed, args.cpu_seconds * 0.6)
         extras[name] = r
         E.close()
         del E
@@ -657,7 +727,17 @@ def main():
     if not args.no_api and world == 1 and args.scale == 1.0:
         out["api"] = api_block(args)
     if rank == 0:
-        print(json.dumps(out))
+        # the bulk goes to a file (and nowhere near stdout); stdout carries ONE small line, the last thing printed
+        details = args.details or os.path.join(ROOT, "bench_details.json")
+        try:
+            with open(details, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (details, e))
+            details = None
+        sys.stdout.flush()
+        print(final_line(out, os.path.relpath(details, ROOT) if details else None), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -160,8 +160,10 @@ thread_local int t_pool = 0;
 
 inline void cpu_relax() { __builtin_ia32_pause(); }
 
-void host_pool_worker(HostPool* P, int index) {
-  uint64_t seen = 0;
+// `seen` = the generation at the thread's creation (taken by the creator, which holds run_mutex: no job is out): a worker
+// born after earlier jobs must only react to jobs published after it exists -- starting from 0 it made a spurious pass over
+// the job fields while host_pool_run was writing them and acknowledged a job that had not been published
+void host_pool_worker(HostPool* P, int index, uint64_t seen) {
   t_in_pool_job = true;                       // (a parallel_for inside a job's body runs on the calling worker)
   for (;;) {
     uint64_t g;
@@ -211,7 +213,7 @@ void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg) {
   if (!P->run_mutex.try_lock()) { run_with_own_threads(n, fn, arg, nthreads); return; }
   while (P->threads.size() + 1 < nthreads) {                       // (grows to the largest team asked for; no job is out)
     const int index = (int)P->threads.size();
-    P->threads.emplace_back(host_pool_worker, P, index);
+    P->threads.emplace_back(host_pool_worker, P, index, P->gen.load(std::memory_order_acquire));
     P->threads.back().detach();
   }
   P->fn = fn; P->arg = arg; P->n = n;

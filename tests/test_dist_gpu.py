@@ -239,10 +239,12 @@ def test_bench_two_gpus_over_rccl(tmp_path):
                                                                     "GAT_BENCH_SHARE_GPU"))
     dump = str(tmp_path / "counts.npz")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "64",
-           "--extra", "", "--no-strong", "--sustain-seconds", "0", "--dump-counts", dump]
+           "--extra", "", "--no-strong", "--sustain-seconds", "0", "--dump-counts", dump, "--details", str(tmp_path / "d.json")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    assert len(last) < 4096 and json.loads(last)["distributed"]["backend"] == "nccl"
+    out = json.load(open(str(tmp_path / "d.json")))
     assert out["distributed"]["backend"] == "nccl" and out["distributed"]["world_size"] == 2
     assert out["distributed"]["one_gpu_per_rank"] and len(set(map(tuple, out["distributed"]["devices"]))) == 2
     z = np.load(dump)

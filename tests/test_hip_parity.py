@@ -764,7 +764,38 @@ def test_wave_only_sampler_mode(ctx, monkeypatch):
     P.close()
 
 
-def test_bench_two_ranks_on_one_gpu():
+def _bench_outputs(r, details):
+    """(the ONE stdout line of a bench.py run -- small, the last thing printed --, its details file)"""
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len([l for l in lines if l.startswith("{")]) == 1 and lines[-1].startswith("{")
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    return json.loads(lines[-1]), json.load(open(details))
+
+
+def test_bench_default_line_is_small_and_honest(tmp_path):
+    """one rank, the real run: the line the driver parses is below 4 KB, carries roofline + cpu_baseline, and its
+    value / ms_per_step are the K steps timed right behind the W warm-up steps (value = samples x K / that time)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    details = str(tmp_path / "details.json")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--extra", "config3", "--extra-steps", "2",
+           "--no-strong", "--no-api", "--sustain-seconds", "0.2", "--cpu-seconds", "2", "--details", details]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line, full = _bench_outputs(r, details)
+    assert line["steps"] == 4 and line["warmup"] == 2 and line["n_gpus"] == 1 and line["vs_baseline"] is None
+    assert line["value"] == pytest.approx(10000 * 1e3 / line["ms_per_step"], rel=1e-3)
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == pytest.approx(line["roofline"]["achieved"] / line["roofline"]["peak"], rel=1e-3)
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert full["configs"]["config3"]["cpu_baseline"]["value"] > 0       # the north_star target shape has its own
+    assert full["sustained"]["seconds"] >= 0.2 and "kernels" in full and "sampler" in full
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path (rank-disjoint sample ranges, all-gather of the count matrix, max-over-ranks timing,
     one JSON line from rank 0) with two ranks sharing this box's GPU: GAT_BENCH_SHARE_GPU=1 swaps RCCL, which
     refuses two ranks on one device, for gloo; everything else is the code the multi-GPU launch runs."""
@@ -774,16 +805,16 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--samples", "2000", "--extra", "", "--no-strong", "--sustain-seconds", "0.2"]
+           "--warmup", "1", "--samples", "2000", "--extra", "", "--no-strong", "--sustain-seconds", "0.2",
+           "--details", str(tmp_path / "d.json")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["allgather"]["bytes_per_rank"] == 2000 * 8
-    assert "cpu_baseline" not in out and "api" not in out # reported at N = 1 only
+    line, out = _bench_outputs(r, str(tmp_path / "d.json"))
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["allgather"]["bytes_per_rank"] == 2000 * 8 and out["allgather"]["bytes_per_rank"] == 2000 * 8
+    assert "cpu_baseline" not in line and "cpu_baseline" not in out and "api" not in out # reported at N = 1 only
     assert out["sustained"]["seconds"] >= 0.2 and out["sustained"]["min"] <= out["sustained_value"] <= out["sustained"]["max"]
+    assert line["sustained_value"] == pytest.approx(out["sustained_value"], rel=1e-5)
 
 
 def test_bench_eight_ranks_on_one_gpu(tmp_path):
@@ -797,11 +828,18 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     dump = str(tmp_path / "counts8.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
-           "--warmup", "1", "--samples", "64", "--extra", "", "--no-strong", "--sustain-seconds", "0", "--dump-counts", dump]
+           "--warmup", "1", "--samples", "64", "--extra", "", "--sustain-seconds", "0", "--dump-counts", dump,
+           "--details", str(tmp_path / "d8.json")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 8 and out["distributed"]["world_size"] == 8 and out["value"] > 0
+    line, out = _bench_outputs(r, str(tmp_path / "d8.json"))
+    assert line["n_gpus"] == 8 and line["distributed"]["world_size"] == 8 and line["value"] > 0
+    assert line["allgather"]["avg_ms"] > 0
+    # the metric's own job cut over the eight ranks: measured (every rank its 1 250 samples, the gather, the read-back)
+    st = out["strong_scaling"]
+    assert st["measured_on"].startswith("8 GPU") and st["config2"]["n8"]["samples_per_gpu"] == 1250
+    assert line["strong_scaling"]["config2"]["n8"] > 0 and line["strong_scaling"]["config3"]["n8"] > 0
+    assert len(out["distributed"]["devices"]) == 8
     z = np.load(dump)
     cfg = synthetic.config("config2")
     flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
@@ -811,7 +849,7 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
         assert np.array_equal(z["counts"][rk], want[0][:, rk * S:(rk + 1) * S]), rk
 
 
-def test_bench_starts_its_own_ranks():
+def test_bench_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment starts its two ranks itself (a child
     torch.distributed.run, before the parent touches a GPU) and relays their one JSON line; one extra shape rides along."""
     import subprocess
@@ -820,12 +858,11 @@ def test_bench_starts_its_own_ranks():
     env = dict((k, v) for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"))
     env["GAT_BENCH_SHARE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples",
-           "1000", "--extra", "config1", "--extra-steps", "1", "--sustain-seconds", "0"]
+           "1000", "--extra", "config1", "--extra-steps", "1", "--sustain-seconds", "0", "--details", str(tmp_path / "d2.json")]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    line, out = _bench_outputs(r, str(tmp_path / "d2.json"))
+    assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and line["value"] > 0
     assert out["n_gpus"] == 2 and out["distributed"]["world_size"] == 2 and out["value"] > 0
     assert out["configs"]["config1"]["value"] > 0 and out["configs"]["config1"]["n_gpus"] == 2
     # the metric's own job (10 000 samples in all) cut over the two ranks

@@ -14,13 +14,12 @@ for SH in $SHAPES; do
   CFG=${SH%%:*}; S=${SH##*:}
   OUT=$R/gpurun_out/prof_${TAG}/${CFG}; rm -rf $OUT; mkdir -p $OUT
   ARGS="--no-cpu-baseline --no-api --no-strong --sustain-seconds 0 --extra= --config $CFG --samples $S --steps 3 --warmup 1"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.log 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1 -- python3 bench.py $ARGS > $OUT/bench_sq1.log 2>&1
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/sq2 -- python3 bench.py $ARGS > $OUT/bench_sq2.log 2>&1
-  rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS > $OUT/bench_tcc.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS --details $OUT/bench.json > $OUT/bench_trace.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1 -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_sq1.log 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/sq2 -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_sq2.log 2>&1
+  rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_tcc.log 2>&1
   cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
-  grep -h "^{" $OUT/bench_trace.log | tail -1 > $OUT/bench.json
 done
 python3 tools/summarize_profiles.py $R/gpurun_out/prof_${TAG} $TAG

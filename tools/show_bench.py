@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""one line per configuration of a bench.py JSON line: value, ms/step, per-kernel ms; usage: tools/show_bench.py FILE..."""
+"""one line per configuration of a bench.py details file (bench_details.json): value, ms/step, per-kernel ms;
+usage: tools/show_bench.py FILE..."""
 import json
 import sys
 
@@ -14,10 +15,14 @@ def show(name, r):
 
 
 for fn in sys.argv[1:]:
-    for line in open(fn):
-        if not line.startswith("{"):
+    text = open(fn).read()
+    try:
+        docs = [json.loads(text)]
+    except ValueError:                                     # (a log with the report as one of its lines: earlier rounds)
+        docs = [json.loads(line) for line in text.splitlines() if line.startswith("{")]
+    for d in docs:
+        if "kernels" not in d:
             continue
-        d = json.loads(line)
         show(d["config"]["workload"].split(":")[0], d)
         for k, v in d.get("configs", {}).items():
             show(k, v)
