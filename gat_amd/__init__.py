@@ -419,6 +419,24 @@ def _run(segments, annotations, workspace, sampler, counters, workspace_generato
     output_samples_pattern = kwargs.get("output_samples_pattern", None)
     seed = kwargs.get("random_seed", None)
     reference_stream = bool(kwargs.get("reference_stream", False))
+    sample_files = kwargs.get("sample_files", None) or []
+    if sample_files:
+        # gat/__init__.py:952-961 + Engine.pyx:3215-3233 (SamplesFile): the files are read (every parse error of the bed
+        # reader surfaces), each one's track name is what the samples pattern's "%s" matches in its file name, a run that
+        # loads samples writes none (:977) -- and the samplers never look at what was loaded (UnconditionalSampler /
+        # ConditionalSampler keep `samples` and sample afresh): the table is the table of a plain run.  (The reference
+        # builds the regex with re.sub("%s", "(\S+)", pattern), an escape Python >= 3.7 refuses in a replacement string:
+        # under a current Python it dies there with re.error; this is the regex that line meant.)
+        if not output_samples_pattern:
+            raise ValueError("require output_samples_pattern if loading samples from files")
+        regex = re.compile(output_samples_pattern.replace("%s", "(\\S+)"))
+        loaded = {}
+        for filename in sample_files:
+            track = regex.search(filename).groups()[0]       # (no match: AttributeError, as in the reference)
+            coll = IntervalCollection(track)
+            coll.load(filename)
+            loaded[track] = coll
+        output_samples_pattern = None
     rank, world, _ = _dist_state()
     if seed is None:
         seed = int(np.random.randint(0, 2 ** 32))
@@ -632,6 +650,8 @@ def buildParser(usage=None):
     g.add_option("--annotations-label", dest="annotations_label", type="string")
     g.add_option("--annotations-to-points", dest="annotations_to_points", type="choice", choices=("midpoint", "start", "end"),
                  help="convert annotations from segments to positions (counters annotation-overlap / annotation-midoverlap)")
+    g.add_option("-l", "--sample-file", dest="sample_files", type="string", action="append",
+                 help="files with samples written by --output-samples-pattern (needs that pattern; see gat_amd.run)")
     g.add_option("--input-counts-file", dest="input_filename_counts", type="string",
                  help="start from a counts table written by --output-counts-pattern (statistics re-computed)")
     g.add_option("--input-results-file", dest="input_filename_results", type="string",
@@ -705,7 +725,7 @@ def buildParser(usage=None):
                         output_order="fold", output_samples_pattern=None, output_tables_pattern="%s.tsv.gz",
                         overlapping_annotations=False, pseudo_count=1.0, pvalue_method="empirical", qvalue_method="BH",
                         qvalue_lambda=None, qvalue_pi0_method="smoother",
-                        random_seed=None, reference_stream=False, restrict_workspace=False, sampler="annotator", segment_files=[],
+                        random_seed=None, reference_stream=False, restrict_workspace=False, sample_files=[], sampler="annotator", segment_files=[],
                         truncate_segments_to_workspace=False, truncate_workspace_to_annotations=False,
                         conditional="unconditional", conditional_extension=None, conditional_expansion=None,
                         workspace_files=[], device=0, loglevel=1, stdout=None, stdlog=None)
@@ -747,4 +767,5 @@ def fromSegments(options, args=None):
                num_samples=options.num_samples, output_counts_pattern=options.output_counts_pattern,
                output_samples_pattern=options.output_samples_pattern, pseudo_count=options.pseudo_count,
                num_threads=options.num_threads, random_seed=options.random_seed,
-               reference_stream=getattr(options, "reference_stream", False))
+               reference_stream=getattr(options, "reference_stream", False),
+               sample_files=getattr(options, "sample_files", []))

@@ -745,6 +745,12 @@ class IntervalCollection(object):
     def add(self, track, contig, segmentlist):
         self.intervals[track][contig] = segmentlist
 
+    def load(self, filenames, allow_multiple=False, ignore_tracks=False):
+        """load segments from bed file(s) (gat/Engine.pyx:2918-2922)."""
+        from . import io as _io
+        self.intervals = _io.readFromBed(filenames, allow_multiple=allow_multiple, ignore_tracks=ignore_tracks)
+        self._flat_cache = None
+
     def sum(self):  # noqa: A003
         return sum(v.sum() for v in self.intervals.values())
 

@@ -250,6 +250,7 @@ def buildSegments(options):
         setattr(options, attr, expandGlobs(getattr(options, attr)))
         if not getattr(options, attr):
             raise ValueError("please specify at least one %s file" % what)
+    options.sample_files = expandGlobs(getattr(options, "sample_files", None) or [])      # gat/IO.py:100
 
     segments = readSegmentList("segments", options.segment_files, ignore_tracks=options.ignore_segment_tracks)
     segments.normalize()

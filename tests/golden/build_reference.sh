@@ -18,6 +18,10 @@ sed -i 's/numpy\.float\b/float/g; s/numpy\.int\b/int/g' gat/Stats.py gat/IOTools
 # ConditionalSampler.sample (gat/__init__.py:832) joins the track name with an int and dies with a TypeError before
 # sampling anything; the one-token fix below lets the conditional workspaces run so that they can be pinned too
 sed -i "s/'_'.join((track, annoid))/'_'.join((track, str(annoid)))/" gat/__init__.py
+# --sample-file (gat/__init__.py:957) builds its regex with re.sub("%s", "(\S+)", pattern): Python >= 3.7 rejects the
+# unknown escape \S in a replacement string (re.error: bad escape), so the option cannot run at all under this image's
+# Python; a raw, doubled backslash gives the regex the line was written for (Python 2) and lets the option be pinned
+sed -i 's/re.sub("%s", "(\\S+)", output_samples_pattern)/re.sub("%s", r"(\\\\S+)", output_samples_pattern)/' gat/__init__.py
 cat > setup_probe.py <<'PY'
 import numpy
 from setuptools import setup, Extension

@@ -579,16 +579,10 @@ def write_bed(path, tracks, with_track_lines=True):
                     f.write("%s\t%i\t%i\n" % (contig, s, e))
 
 
-def g5_cli():
+def reference_cli():
+    """the reference's scripts/gat-run.py as a module, and gat.computeSample wrapped so that every work unit re-seeds the
+    global stream (the per-unit contract; segment tracks take disjoint ranges of unit streams)"""
     import importlib.util
-    cli_dir = os.path.join(HERE, "cli")
-    os.makedirs(cli_dir, exist_ok=True)
-    contigs, cfg = synthetic.small_genome()
-    seg2 = synthetic.random_segments(contigs, 120, 200, 77)
-    write_bed(os.path.join(cli_dir, "segments.bed"), [("segA", cfg["segments"]), ("segB", seg2)])
-    write_bed(os.path.join(cli_dir, "annotations.bed"), cfg["annotations"])
-    write_bed(os.path.join(cli_dir, "workspace.bed"), [("ws", cfg["workspace"])], with_track_lines=False)
-    write_bed(os.path.join(cli_dir, "isochores.bed"), list(cfg["isochores"].items()))
     spec = importlib.util.spec_from_file_location("gat_run_ref", os.path.join(os.path.dirname(gat.__file__), "..", "scripts", "gat-run.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -608,6 +602,66 @@ def g5_cli():
         rs.sample_id = int(w.sample_id)
         rs.records = []
         return original((w._replace(sampler=rs),) + tuple(args[1:]))
+
+    return mod, state, patched, original
+
+
+def g5s_sample_file():
+    """--sample-file (gat/__init__.py:952-961): the reference loads the files into a SamplesFile (track name from the
+    pattern's regex), requires --output-samples-pattern, does NOT write sample files then (:977) -- and samples afresh all
+    the same (UnconditionalSampler never looks at self.samples).  Inputs: the sample files the patterns run of g5 wrote."""
+    cli_dir = os.path.join(HERE, "cli")
+    pat = os.path.join(cli_dir, "aux", "patterns")
+    mod, state, patched, original = reference_cli()
+    files = [os.path.join(pat, "samples_segA.bed"), os.path.join(pat, "samples_segB.bed")]
+    before = [open(f).read() for f in files]
+    base = ["gat-run.py", "--segments=%s" % os.path.join(cli_dir, "segments.bed"),
+            "--annotations=%s" % os.path.join(cli_dir, "annotations.bed"),
+            "--workspace=%s" % os.path.join(cli_dir, "workspace.bed"),
+            "--isochores=%s" % os.path.join(cli_dir, "isochores.bed"), "--with-segment-tracks",
+            "--num-samples=5", "--random-seed=21", "--counter=nucleotide-overlap",
+            "--log=%s" % os.path.join(cli_dir, "ref.log")]
+    gat.computeSample = patched
+    try:
+        out = os.path.join(cli_dir, "aux", "expected_sample_file.tsv")
+        state.update(track=None, base=21, n_units=0, sampler=None, num_samples=5)
+        mod.main(base + ["--stdout=%s" % out, "--output-samples-pattern=%s" % os.path.join(pat, "samples_%s.bed"),
+                         "--sample-file=%s" % os.path.join(pat, "samples_seg*.bed")])
+        lines = [l for l in open(out) if not l.startswith("#")]
+        with open(out, "w") as f:
+            f.writelines(lines)
+        assert [open(f).read() for f in files] == before, "the reference rewrote the sample files"
+        errors = {}
+        for name, extra in (("no_pattern", ["--sample-file=%s" % files[0]]),
+                            ("pattern_does_not_match", ["--sample-file=%s" % files[0],
+                                                        "--output-samples-pattern=%s" % os.path.join(pat, "other_%s.txt")])):
+            state.update(track=None, base=21, n_units=0, sampler=None, num_samples=5)
+            try:
+                mod.main(base + ["--stdout=%s" % os.path.join(cli_dir, "aux", "tmp.tsv")] + extra)
+                errors[name] = None
+            except Exception as e:                             # noqa: BLE001
+                errors[name] = type(e).__name__
+        if os.path.exists(os.path.join(cli_dir, "aux", "tmp.tsv")):
+            os.remove(os.path.join(cli_dir, "aux", "tmp.tsv"))
+        with open(os.path.join(cli_dir, "aux", "sample_file_errors.json"), "w") as f:
+            json.dump(errors, f, indent=1)
+        print("G5s --sample-file: %d rows; errors %s" % (len(lines) - 1, errors))
+    finally:
+        gat.computeSample = original
+    if os.path.exists(os.path.join(cli_dir, "ref.log")):
+        os.remove(os.path.join(cli_dir, "ref.log"))
+
+
+def g5_cli():
+    cli_dir = os.path.join(HERE, "cli")
+    os.makedirs(cli_dir, exist_ok=True)
+    contigs, cfg = synthetic.small_genome()
+    seg2 = synthetic.random_segments(contigs, 120, 200, 77)
+    write_bed(os.path.join(cli_dir, "segments.bed"), [("segA", cfg["segments"]), ("segB", seg2)])
+    write_bed(os.path.join(cli_dir, "annotations.bed"), cfg["annotations"])
+    write_bed(os.path.join(cli_dir, "workspace.bed"), [("ws", cfg["workspace"])], with_track_lines=False)
+    write_bed(os.path.join(cli_dir, "isochores.bed"), list(cfg["isochores"].items()))
+    mod, state, patched, original = reference_cli()
 
     cases = collections.OrderedDict([
         ("default", ["--num-samples=100", "--random-seed=5"]),
@@ -853,8 +907,99 @@ def g5u_cli_unpatched():
         json.dump(dict((k, [x.replace(cli_dir + os.sep, "") for x in v]) for k, v in cases.items()), f, indent=1)
 
 
+# ------------------------------------------------------------------------------------------
+# G9: the two shapes north_star singles out -- config 3 (100 tracks x isochores) and config 5 (density against a
+# 1M-interval annotation) -- at their FULL interval counts through the reference's own computeSample (mode 1) and gat.run
+# (mode 0), a few samples each (the reference needs tens of milliseconds per sample and track).  The inputs are not stored
+# (synthetic.config(name) regenerates them, pure numpy): the file carries the hash of every array of the flattened problem
+# as the REFERENCE's structures gave it, so a test first proves it works on the same problem, then compares.
+INPUT_KEYS = ("segs", "seg_off", "ws", "ws_off", "unit_contig", "annos", "anno_off", "cws_nseg")
+
+
+def input_hashes(flat):
+    out = {}
+    for k in INPUT_KEYS:
+        a = numpy.ascontiguousarray(flat[k])
+        if k in ("seg_off", "ws_off", "anno_off", "cws_nseg"):
+            a = a.astype(numpy.int64)
+        elif k == "unit_contig":
+            a = a.astype(numpy.int32)
+        out[k] = hashlib.sha256(a.tobytes()).hexdigest()
+    return out
+
+
+def config_case(name, num_samples, seed):
+    import time
+    cfg = synthetic.config(name)
+    counters = [cfg["counter"], "nucleotide-density" if cfg["counter"] == "nucleotide-overlap" else "nucleotide-overlap"]
+    segments, annotations, workspace = build_reference_inputs(cfg)
+    counter_objs = [COUNTERS[c]() for c in counters]
+    flat = flat_problem(segments["merged"], workspace, annotations, 1, 100000)
+    tracks = list(annotations.tracks)
+    # mode 0: the reference's gat.run on one global stream
+    numpy.random.seed(seed)
+    t0 = time.time()
+    results = gat.run(segments, annotations, workspace, Engine.SamplerAnnotator(bucket_size=1, nbuckets=100000), counter_objs,
+                      Engine.UnconditionalWorkspace(), num_samples=num_samples, pseudo_count=1.0)
+    t_run = time.time() - t0
+    counts0 = numpy.zeros((len(counters), len(tracks), num_samples), dtype=numpy.float64)
+    observed = numpy.zeros((len(counters), len(tracks)), dtype=numpy.float64)
+    for r in results:
+        k, a = counters.index(r.counter), tracks.index(r.annotation)
+        counts0[k, a] = r.samples
+        observed[k, a] = r.observed
+    # mode 1: computeSample with per-unit re-seeding; sampled lists per (sample, contig) hashed one by one and together
+    segs = segments["merged"]
+    contig_annotations = annotations.clone()
+    contig_annotations.fromIsochores()
+    contig_workspace = workspace.clone()
+    contig_workspace.fromIsochores()
+    rsampler = ReseedingSampler(Engine.SamplerAnnotator(bucket_size=1, nbuckets=100000), segs, seed)
+    counts1 = numpy.zeros((len(counters), len(tracks), num_samples), dtype=numpy.float64)
+    sha, lens, first_last = hashlib.sha256(), [], []
+    for x in range(num_samples):
+        rsampler.sample_id = x
+        rsampler.records = []
+        w = gat.WorkData("merged", x, rsampler, segs, annotations, contig_annotations, workspace, contig_workspace, counter_objs)
+        res = gat.computeSample((w, None, None, None))
+        for k in range(len(counters)):
+            for a, t in enumerate(tracks):
+                counts1[k, a, x] = res[k][t]
+        d = Engine.IntervalDictionary()
+        for key, r in rsampler.records:
+            d.add(key, r.clone())
+        d.fromIsochores()
+        for c in flat["contig_names"]:
+            a = arr(d[str(c)]) if str(c) in d else numpy.empty(0, dtype=SEG)
+            sha.update(a.tobytes())
+            lens.append(len(a))
+            first_last.append([int(a[0]["start"]), int(a[-1]["end"])] if len(a) else [0, 0])
+    h = input_hashes(flat)
+    numpy.savez_compressed(os.path.join(HERE, "run_%s_s%d.npz" % (name, num_samples)),
+                           config=name, seed=seed, num_samples=num_samples, counters=numpy.array(counters),
+                           counts_mode0=counts0, counts_mode1=counts1, observed=observed,
+                           samples_sha256_mode1=sha.hexdigest(), sample_list_lengths=numpy.array(lens, dtype=numpy.int64),
+                           sample_list_first_last=numpy.array(first_last, dtype=numpy.int64),
+                           input_keys=numpy.array(list(h.keys())), input_sha256=numpy.array(list(h.values())),
+                           n_units=flat["n_units"], n_contigs=flat["n_contigs"], n_tracks=flat["n_tracks"],
+                           unit_names=flat["unit_names"], contig_names=flat["contig_names"], track_names=flat["track_names"],
+                           reference_seconds_per_sample_gat_run=t_run / num_samples)
+    print("G9 run_%s_s%d: units=%d contigs=%d tracks=%d intervals=%d; the reference's gat.run: %.3f s per sample; mean counts %s"
+          % (name, num_samples, flat["n_units"], flat["n_contigs"], flat["n_tracks"], len(flat["annos"]), t_run / num_samples,
+             numpy.round(counts1.mean(axis=2).ravel()[:3], 3)))
+
+
+def g9_configs():
+    config_case("config3", 4, 303)
+    config_case("config5", 2, 505)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5u", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g5u", "g6", "g7", "g8", "g9", "g5s"]
+    if "g9" in which:
+        g9_configs()
+    if "g5s" in which:
+        g5s_sample_file()
     if "g5u" in which:
         g5u_cli_unpatched()
     if "g1" in which:

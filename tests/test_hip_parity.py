@@ -53,6 +53,36 @@ def test_golden_counts_and_samples(ctx, name):
     P.close()
 
 
+@pytest.mark.parametrize("name", ["config3_s4", "config5_s2"])
+def test_golden_config_shapes_against_the_reference(ctx, name):
+    """configs 3 and 5 at their full interval counts (100 tracks x 192 isochore units; density against a 1M-interval
+    annotation): count matrices and sampled lists == what the REFERENCE's computeSample produced for the same inputs
+    (tests/golden/make_goldens.py g9), and the one-stream mode == its gat.run."""
+    from test_oracle_golden import config_golden
+    z, flat = config_golden(name)
+    counters = [str(c) for c in z["counters"]]
+    S, seed = int(z["num_samples"]), int(z["seed"])
+    P = _lib.Problem(ctx, flat)
+    try:
+        counts = P.sample_and_count(counters, seed, 0, S)
+        for k, c in enumerate(counters):
+            got = counts[k] if c == "nucleotide-density" else counts[k].astype(np.float64)
+            assert np.array_equal(got, z["counts_mode1"][k]), (name, c)
+        seg, off = P.sample(seed, 0, S)
+        assert np.array_equal(np.diff(off), z["sample_list_lengths"])
+        h = hashlib.sha256()
+        for i in range(len(off) - 1):
+            h.update(seg[off[i]:off[i + 1]].tobytes())
+        assert h.hexdigest() == str(z["samples_sha256_mode1"])
+        # the reference's real gat.run (one global stream): k_serial
+        serial = P.sample_and_count_serial(counters, _lib.mt19937_seed(seed), S)
+        for k, c in enumerate(counters):
+            got = serial[k] if c == "nucleotide-density" else serial[k].astype(np.float64)
+            assert np.array_equal(got, z["counts_mode0"][k]), (name, c, "mode 0")
+    finally:
+        P.close()
+
+
 def _single_unit_flat(segments, workspace, bucket_size, nbuckets):
     s, w = O.segs(segments), O.segs(workspace)
     return dict(n_units=1, segs=s, seg_off=[0, len(s)], ws=w, ws_off=[0, len(w)], unit_contig=[0], n_contigs=1,
@@ -904,6 +934,39 @@ def test_cli_pattern_outputs_match_reference(ctx, tmp_path):
             continue
         got = [l for l in open(str(tmp_path / fn)) if not l.startswith("#")]
         assert got == open(os.path.join(want, fn)).readlines(), fn
+
+
+def test_cli_sample_file_matches_reference(ctx, tmp_path):
+    """--sample-file (gat/__init__.py:952-961, Engine.pyx:3215-3233): the files --output-samples-pattern wrote are read
+    back (track name = what the pattern's %s matches), no sample file is written by such a run, and the table is the one the
+    reference's gat-run.py printed for the same command (tests/golden/cli/aux/expected_sample_file.tsv, make_goldens.py g5s
+    -- with the one-token fix of its regex line, build_reference.sh); the reference's two errors are reproduced."""
+    import shutil
+    cli = os.path.join(G, "cli")
+    base = ["--segments=%s" % os.path.join(cli, "segments.bed"), "--annotations=%s" % os.path.join(cli, "annotations.bed"),
+            "--workspace=%s" % os.path.join(cli, "workspace.bed"), "--isochores=%s" % os.path.join(cli, "isochores.bed"),
+            "--with-segment-tracks", "--num-samples=5", "--random-seed=21", "--counter=nucleotide-overlap"]
+    # the sample files: this build's own (equal to the reference's, test_cli_pattern_outputs_match_reference)
+    _run_cli(tmp_path, "first", base + ["--output-samples-pattern=%s" % str(tmp_path / "samples_%s.bed")])
+    files = [str(tmp_path / "samples_segA.bed"), str(tmp_path / "samples_segB.bed")]
+    for f in files:
+        assert open(f).read() == open(os.path.join(cli, "aux", "patterns", os.path.basename(f))).read()
+    before = [(os.path.getmtime(f), open(f).read()) for f in files]
+    got = _run_cli(tmp_path, "second", base + ["--output-samples-pattern=%s" % str(tmp_path / "samples_%s.bed"),
+                                               "--sample-file=%s" % str(tmp_path / "samples_seg*.bed")])
+    assert got == open(os.path.join(cli, "aux", "expected_sample_file.tsv")).readlines()
+    assert [(os.path.getmtime(f), open(f).read()) for f in files] == before          # read, not rewritten
+    errors = json.load(open(os.path.join(cli, "aux", "sample_file_errors.json")))
+    assert errors == {"no_pattern": "ValueError", "pattern_does_not_match": "AttributeError"}
+    with pytest.raises(ValueError):
+        _run_cli(tmp_path, "e1", base + ["--sample-file=%s" % files[0]])
+    with pytest.raises(AttributeError):
+        _run_cli(tmp_path, "e2", base + ["--sample-file=%s" % files[0], "--output-samples-pattern=%s" % str(tmp_path / "other_%s.txt")])
+    # a file that is not a bed file raises the bed reader's error, as loading it in the reference does
+    shutil.copy(os.path.join(cli, "aux", "descriptions.tsv"), str(tmp_path / "samples_bad.bed"))
+    with pytest.raises(Exception):
+        _run_cli(tmp_path, "e3", base + ["--sample-file=%s" % str(tmp_path / "samples_bad.bed"),
+                                         "--output-samples-pattern=%s" % str(tmp_path / "samples_%s.bed")])
 
 
 def test_more_units_than_a_grid_dimension(ctx):
