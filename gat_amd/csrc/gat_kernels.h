@@ -2044,7 +2044,107 @@ __device__ __forceinline__ void seg_vs_anno(const AnnoView& Y, uint32_t xs, uint
   }
 }
 
-constexpr int kCountXR = 8;   // sample segments held per lane per pass (512 per wave)
+constexpr int kCountXR = 8;      // sample segments held per lane per pass (512 per wave)
+#ifndef GAT_COUNT_NR
+#define GAT_COUNT_NR 2
+#endif
+constexpr int kCountNR = GAT_COUNT_NR;   // ... of which segs_vs_pairs looks up this many side by side (4 pairs of registers each)
+// The same quantities against a list STAGED in LDS as {start, end} pairs (k_count_seg<true, ..>), NR sample segments per lane
+// side by side.  seg_vs_anno is a chain of four to five dependent LDS reads per segment (grid cell -> start -> [next start]
+// -> end), walked segment by segment: the counters of round 4 (profiles/r04_config2_pmc.txt) have the kernel's waves parked at
+// s_waitcnt for 78 % of their cycles with the vector unit 27 % and the LDS 15 % busy.  Here a segment's look-up is TWO
+// dependent steps, and all NR segments of a lane take each step together: (1) the grid cells, (2) four consecutive pairs
+// P[k-1 .. k+2] around the cell's first start (two ds_read2_b64).  With at most two starts between the cell's beginning and xs
+// -- the grid holds about one start per two to four cells -- they hold everything: k1 = k + (s0 < xs) + (s1 < xs), the first
+// start >= xs and the end of the interval in front of it.  What they do not cover (a third start in front of xs; an interval
+// that starts inside x: the general form F(xe) - F(xs) over the running lengths) is redone lane by lane behind a wave-uniform
+// test, as before.  Entry -1 of a list is {0, 0} (no interval in front of the first), three {~0, ~0} sentinels end it.
+struct PairView {
+  const uint2* P;             // P[-1] .. P[m + 2]
+  const uint32_t* cumx;       // cumx[i] = bases of the list's intervals before interval i
+  const uint32_t* grid;
+  int shift, cells;
+};
+template <bool WANT_HITS, int NR>
+__device__ __forceinline__ void segs_vs_pairs(const PairView& Y, const uint2* x, uint32_t& ov_sum, uint32_t& hit_sum,
+                                              uint32_t& mid_sum) {
+  int k[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    uint32_t g = x[r].x >> Y.shift;
+    g = g < (uint32_t)(Y.cells - 1) ? g : (uint32_t)(Y.cells - 1);
+    k[r] = (int)Y.grid[g];
+  }
+  uint2 pm[NR], p0[NR], p1[NR], p2[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint2* q = Y.P + k[r];
+    pm[r] = q[-1]; p0[r] = q[0]; p1[r] = q[1]; p2[r] = q[2];
+  }
+  bool any_slow = false;
+  uint32_t slow_mask = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint32_t xs = x[r].x, xe = x[r].y;
+    const bool c0 = p0[r].x < xs, c1 = p1[r].x < xs;                 // (sorted starts: c1 implies c0)
+    const uint32_t sk = c1 ? p2[r].x : (c0 ? p1[r].x : p0[r].x);     // the first start >= xs (if p2's is)
+    const uint32_t pe_raw = c1 ? p1[r].y : (c0 ? p0[r].y : pm[r].y); // end of the last interval that starts before xs
+    const bool reach = pe_raw > xs;
+    ov_sum += reach ? (xe < pe_raw ? xe : pe_raw) - xs : 0u;
+    if (WANT_HITS) {
+      const uint32_t mid = xs + (xe - xs) / 2u;
+      hit_sum += reach ? 1u : 0u;
+      mid_sum += (reach && mid < pe_raw) ? 1u : 0u;
+    }
+    // a third start in front of xs, or an interval starting inside x (padding -- xs = ~0 -- is neither: its xe is ~0 too)
+    const bool slow = xs != 0xffffffffu && (p2[r].x < xs || sk < xe);
+    slow_mask |= slow ? 1u << r : 0u;
+    any_slow |= slow;
+  }
+  if (__any(any_slow)) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if (!(slow_mask >> r & 1u)) continue;
+      const uint32_t xs = x[r].x, xe = x[r].y;
+      // what the fast form added for this segment comes off again, then the general form (seg_vs_anno's)
+      {
+        const bool c0 = p0[r].x < xs, c1 = p1[r].x < xs;
+        const uint32_t pe_raw = c1 ? p1[r].y : (c0 ? p0[r].y : pm[r].y);
+        const bool reach = pe_raw > xs;
+        ov_sum -= reach ? (xe < pe_raw ? xe : pe_raw) - xs : 0u;
+        if (WANT_HITS) {
+          const uint32_t mid = xs + (xe - xs) / 2u;
+          hit_sum -= reach ? 1u : 0u;
+          mid_sum -= (reach && mid < pe_raw) ? 1u : 0u;
+        }
+      }
+      int k1 = k[r];
+      uint32_t sk = Y.P[k1].x;
+      while (sk < xs) { ++k1; sk = Y.P[k1].x; }
+      const uint32_t pe_raw = Y.P[k1 - 1].y;                         // (P[-1] = {0, 0})
+      const bool reach = pe_raw > xs;
+      uint32_t ov = reach ? (xe < pe_raw ? xe : pe_raw) - xs : 0u, hit = reach ? 1u : 0u, midhit = 0;
+      const uint32_t mid = xs + (xe - xs) / 2u;
+      if (WANT_HITS) midhit = (reach && mid < pe_raw) ? 1u : 0u;
+      if (sk < xe) {
+        int k2 = k1 + 1;
+        while (Y.P[k2].x < xe) ++k2;
+        uint32_t f1 = 0;
+        if (k1 > 0) f1 = Y.cumx[k1 - 1] + (xs < pe_raw ? xs : pe_raw) - Y.P[k1 - 1].x;
+        const uint2 l2 = Y.P[k2 - 1];
+        ov = Y.cumx[k2 - 1] + (xe < l2.y ? xe : l2.y) - l2.x - f1;
+        if (WANT_HITS) {
+          hit = 1;
+          if (pe_raw > xs) midhit = mid < pe_raw ? 1u : 0u;
+          else midhit = (sk <= mid && mid < Y.P[k1].y) ? 1u : 0u;
+        }
+      }
+      ov_sum += ov;
+      if (WANT_HITS) { hit_sum += hit; mid_sum += midhit; }
+    }
+  }
+}
+
 
 // One block per (sample chunk, track tile, contig): the tile's annotation slices of that contig
 // (starts / ends / cumulated lengths + position grid) are staged into LDS once and every wave
@@ -2068,34 +2168,41 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
   uint32_t* stage = reinterpret_cast<uint32_t*>(tile_off + ((TT + 1 + 3) & ~3));
   const int E = A.lds_entries;
   uint32_t* st_grid = stage + 3 * E;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;      // (the wave index as a scalar -- readfirstlane -- changes nothing: 0.218 ms either way)
   // (track tile, contig) = the linear index over grid y and z, tiles fastest: neither count is bound by a grid dimension
   const int n_tiles = (A.n_tracks + TT - 1) / TT;
+  // (measured and dropped, round 5: the (tile, contig) pair as the fastest index of the launch, so that workgroups resident
+  //  together read neighbouring regions of the same samples' slab: 0.238 against 0.214 ms on config 2)
   const int64_t lin = (int64_t)blockIdx.y + (int64_t)blockIdx.z * gridDim.y;
+  const int chunk = (int)blockIdx.x;
   const int c = (int)(lin / n_tiles);
   if (c >= A.n_contigs) return;                                     // (whole workgroup, before any barrier)
-  const int s0 = blockIdx.x * SC, t0 = (int)(lin % n_tiles) * TT;
+  const int s0 = chunk * SC, t0 = (int)(lin % n_tiles) * TT;
   const int nt = min(TT, A.n_tracks - t0), ns = min(SC, A.n_samples - s0);
   const int shift = A.c_shift[c], cells = A.c_cells[c];
+  // STAGED: per track of the tile {start, end} pairs -- entry -1 = {0, 0}, three sentinels {~0, ~0} behind the last -- the
+  // running lengths and the position grid (segs_vs_pairs)
+  uint2* st_pairs = reinterpret_cast<uint2*>(stage);
+  uint32_t* st_cumx = stage + 2 * E;
   if (STAGED) {
     if (tid == 0) {
       int o = 0;
       for (int t = 0; t < nt; ++t) {
-        tile_off[t] = o;                                    // (+1: the sentinel behind every track's starts)
-        o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]) + 1;
+        tile_off[t] = o;                                    // (+4: the entry in front and the sentinels)
+        o += (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - A.a_off[(int64_t)(t0 + t) * A.n_contigs + c]) + 4;
       }
       tile_off[nt] = o;
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
       const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
-      const int o = tile_off[t], m = tile_off[t + 1] - o - 1;
+      const int o = tile_off[t], m = tile_off[t + 1] - o - 4;
       for (int i = tid; i < m; i += 256) {
-        stage[o + i] = A.a_start[g + i];
-        stage[E + o + i] = A.a_end[g + i];
-        stage[2 * E + o + i] = A.a_cumx[g + i];
+        st_pairs[o + 1 + i] = make_uint2(A.a_start[g + i], A.a_end[g + i]);
+        st_cumx[o + 1 + i] = A.a_cumx[g + i];
       }
-      if (tid == 0) stage[o + m] = 0xffffffffu;
+      if (tid == 0) st_pairs[o] = make_uint2(0u, 0u);
+      if (tid < 3) st_pairs[o + 1 + m + tid] = make_uint2(0xffffffffu, 0xffffffffu);
       const int64_t gg = A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
       for (int i = tid; i <= cells; i += 256) st_grid[t * (cells + 1) + i] = A.a_grid[gg + i];
     }
@@ -2138,14 +2245,23 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
     }
     return v;
   };
-  auto load = [&](const View& v, int i) -> uint2 {
-    if (i >= v.n) return kPad;
-    if (!PATCH) return v.X[i];                                // (non-temporal here: 0.288 -> 0.283 ms on config 2, not worth a second form)
-    const uint2 y = *(i < v.nU ? v.X + i : v.Rex + i);
-    return y.x == y.y ? kPad : y;                            // (emptied by the trim: merge(0) drops it)
+  // Every load is issued whatever the lane's index: an index beyond the list re-reads its last element (a line the wave
+  // fetches anyway) and is turned into padding afterwards.  The form `if (i >= n) return pad; y = *p; return y.x == y.y ? ..`
+  // put each load, its s_waitcnt vmcnt(0) and the test into a branch of its own: the eight loads of a list went out one
+  // after the other, seven exposed round trips per list (round 5: found in the assembly; the waves were parked 78 % of
+  // their cycles, profiles/r04_config2_pmc.txt)
+  auto load_raw = [&](const View& v, int i) -> uint2 {
+    const int ic = i < v.n ? i : (v.n > 0 ? v.n - 1 : 0);
+    if (!PATCH) return v.X[ic];                               // (non-temporal here: 0.288 -> 0.283 ms on config 2, not worth a second form)
+    return *(ic < v.nU ? v.X + ic : v.Rex + ic);
   };
-  // (measured and dropped: the next list's first 512 segments in registers while the current one is counted -- 16 more
-  //  registers per lane cost more occupancy than the overlap gains: 0.29 -> 0.33 ms on config 2)
+  auto load_fix = [&](const View& v, int i, uint2 y) -> uint2 {
+    if (i >= v.n) return kPad;
+    return (PATCH && y.x == y.y) ? kPad : y;                   // (emptied by the trim: merge(0) drops it)
+  };
+  // (measured and dropped, rounds 2 and 5: the next list's segments on their way while this one is counted -- 16 to 20 more
+  //  registers per lane cost more occupancy than the overlap gains: 0.29 -> 0.33 ms on config 2 in round 2; behind the batched
+  //  loads of round 5 0.218 -> 0.262)
   Meta next = fetch_meta(wave);
   for (int sl = wave; sl < ns; sl += 4) {
     const int s = s0 + sl;
@@ -2156,39 +2272,61 @@ __global__ __launch_bounds__(256) void k_count_seg(CountArgs A) {
     uint2 x[kCountXR];
     if (one_pass) {
 #pragma unroll
-      for (int r = 0; r < kCountXR; ++r) x[r] = load(V, r * kWave + lane);
+      for (int r = 0; r < kCountXR; ++r) x[r] = load_raw(V, r * kWave + lane);
+#pragma unroll
+      for (int r = 0; r < kCountXR; ++r) x[r] = load_fix(V, r * kWave + lane, x[r]);
     }
     for (int t = 0; t < nt; ++t) {
-      AnnoView Y;
-      Y.shift = shift; Y.cells = cells;
-      if (STAGED) {
+      uint32_t ov = 0, hit = 0, mid = 0;
+      if constexpr (STAGED) {
         const int o = tile_off[t];
-        Y.start = stage + o; Y.end = stage + E + o; Y.cumx = stage + 2 * E + o;
-        Y.grid = st_grid + t * (cells + 1);
-        Y.m = tile_off[t + 1] - o - 1;
+        PairView Y;
+        Y.shift = shift; Y.cells = cells;
+        Y.P = st_pairs + o + 1; Y.cumx = st_cumx + o + 1; Y.grid = st_grid + t * (cells + 1);
+        if (tile_off[t + 1] - o - 4 > 0) {
+          for (int base = 0; base < n; base += kWave * kCountXR) {
+            if (!one_pass) {
+#pragma unroll
+              for (int r = 0; r < kCountXR; ++r) x[r] = load_raw(V, base + r * kWave + lane);
+#pragma unroll
+              for (int r = 0; r < kCountXR; ++r) x[r] = load_fix(V, base + r * kWave + lane, x[r]);
+            }
+            // (wave-uniform: a list's last pass often fills half of the rounds -- config 2's lists are ~400 segments)
+#pragma unroll
+            for (int r0 = 0; r0 < kCountXR; r0 += kCountNR) {
+              if (base + r0 * kWave >= n) break;
+              segs_vs_pairs<WANT_HITS, kCountNR>(Y, x + r0, ov, hit, mid);
+            }
+          }
+          ov = wave_total_u32(ov);                          // uint32 accumulate within the contig (:1034)
+          if (WANT_HITS) { hit = wave_total_u32(hit); mid = wave_total_u32(mid); }
+        }
       } else {
+        AnnoView Y;
+        Y.shift = shift; Y.cells = cells;
         const int64_t g = A.a_off[(int64_t)(t0 + t) * A.n_contigs + c];
         Y.start = A.a_start + g; Y.end = A.a_end + g; Y.cumx = A.a_cumx + g;
         Y.grid = A.a_grid + A.g_off[(int64_t)(t0 + t) * A.n_contigs + c];
         Y.m = (int)(A.a_off[(int64_t)(t0 + t) * A.n_contigs + c + 1] - g);
-      }
-      uint32_t ov = 0, hit = 0, mid = 0;
-      if (Y.m > 0) {
-        for (int base = 0; base < n; base += kWave * kCountXR) {
-          if (!one_pass) {
+        if (Y.m > 0) {
+          for (int base = 0; base < n; base += kWave * kCountXR) {
+            if (!one_pass) {
 #pragma unroll
-            for (int r = 0; r < kCountXR; ++r) x[r] = load(V, base + r * kWave + lane);
-          }
+              for (int r = 0; r < kCountXR; ++r) x[r] = load_raw(V, base + r * kWave + lane);
 #pragma unroll
-          for (int r = 0; r < kCountXR; ++r) {
-            if (base + r * kWave >= n) break;              // (wave-uniform: whole rounds beyond the list are skipped)
-            uint32_t o1, h1, m1;
-            seg_vs_anno<WANT_HITS, STAGED>(Y, x[r].x, x[r].y, o1, h1, m1);
-            ov += o1; hit += h1; mid += m1;
+              for (int r = 0; r < kCountXR; ++r) x[r] = load_fix(V, base + r * kWave + lane, x[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < kCountXR; ++r) {
+              if (base + r * kWave >= n) break;              // (wave-uniform: whole rounds beyond the list are skipped)
+              uint32_t o1, h1, m1;
+              seg_vs_anno<WANT_HITS, false>(Y, x[r].x, x[r].y, o1, h1, m1);
+              ov += o1; hit += h1; mid += m1;
+            }
           }
+          ov = wave_total_u32(ov);                          // uint32 accumulate within the contig (:1034)
+          if (WANT_HITS) { hit = wave_total_u32(hit); mid = wave_total_u32(mid); }
         }
-        ov = wave_total_u32(ov);                            // uint32 accumulate within the contig (:1034)
-        if (WANT_HITS) { hit = wave_total_u32(hit); mid = wave_total_u32(mid); }
       }
       if (lane == 0) {
         // part[((c*3 + q)*n_tracks + t)*n_samples + s]

@@ -287,13 +287,14 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     const int TT_max = env_tt ? atoi(env_tt) : 16;
     int TT;
     const char* env_st = getenv("GAT_COUNT_STAGED");
-    bool staged = annos.max_m > 0 && annos.max_m + 1 <= E_max && !(env_st && atoi(env_st) == 0);   // (+1: sentinel)
-    if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, TT_max), E_max / (annos.max_m + 1));
+    // (+4: a staged list has an entry in front of its first interval and three sentinels behind the last: segs_vs_pairs)
+    bool staged = annos.max_m > 0 && annos.max_m + 4 <= E_max && !(env_st && atoi(env_st) == 0);
+    if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, TT_max), E_max / (annos.max_m + 4));
     else TT = (int)std::min<int64_t>(A.n_tracks, TT_max);
     TT = std::max(1, TT);
     A.tracks_per_block = TT;
     A.samples_per_block = SC;
-    A.lds_entries = staged ? (int)std::min<int64_t>((int64_t)E_max, (annos.max_m + 1) * TT) : 0;
+    A.lds_entries = staged ? (int)std::min<int64_t>((int64_t)E_max, (annos.max_m + 4) * TT) : 0;
     A.lds_grid = staged ? (int)((annos.max_cells + 1) * TT) : 0;
     const size_t lds = (size_t)((TT + 1 + 3) & ~3) * 4 + (size_t)3 * A.lds_entries * 4 + (size_t)A.lds_grid * 4;
     const size_t need = (size_t)A.n_contigs * 3 * (size_t)A.n_tracks * (size_t)A.n_samples;
