@@ -333,10 +333,12 @@ def _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples,
     memory (the collation of the reference's pool, gat/__init__.py:694-700, :770-774), the statistics taken where the
     gathered matrix is, ONE read-back -- on rank 0; the other ranks read theirs when their rows' samples are asked for.
 
-    Every rank computes the same number of samples, ceil(num_samples / world) from rank * that on: the last ranks' surplus
-    samples (ids at or beyond num_samples: streams like any other) fall off the end of the gathered matrix, no rank has an
-    empty shard, and the blocks need no padding.  The library's stream is ordered against torch's with events (no
-    device-wide synchronisation): torch.cuda.ExternalStream around the context's stream."""
+    Every rank owns ceil(num_samples / world) columns of the gathered matrix, from rank * that on, and samples the ids of
+    its range that exist -- [rank * per, min((rank + 1) * per, num_samples)), the range distributed.shard_range gives the gloo
+    path: a sample id at or beyond num_samples is never drawn (a device-side assertion or a slab overflow in a surplus
+    sample must not fail a run that one process completes); the columns behind a short shard stay zero and fall off
+    the end of the gathered matrix.  The library's stream is ordered against torch's with events (no device-wide
+    synchronisation): torch.cuda.ExternalStream around the context's stream."""
     import torch
     import torch.distributed as dist
     from . import distributed
@@ -346,11 +348,19 @@ def _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples,
     K, A = len(names), len(tracks)
     lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
     cur = torch.cuda.current_stream(dev)
-    shard = torch.empty((K, A, per), dtype=torch.int64, device=dev)
+    lo, hi = min(rank * per, num_samples), min((rank + 1) * per, num_samples)
+    full = hi - lo == per
+    shard = (torch.empty if full else torch.zeros)((K, A, per), dtype=torch.int64, device=dev)
     gathered = torch.empty((world * K, A, per), dtype=torch.int64, device=dev)
-    lib_stream.wait_stream(cur)                               # (whatever torch still runs on memory it hands out here)
-    P.sample_and_count_device(names, seed, rank * per, (rank + 1) * per, shard.data_ptr())
-    cur.wait_stream(lib_stream)
+    if hi > lo:
+        # (a short shard -- the last one that holds samples -- is sampled into a block of its own width and copied in)
+        block = shard if full else torch.empty((K, A, hi - lo), dtype=torch.int64, device=dev)
+        lib_stream.wait_stream(cur)                           # (whatever torch still runs on memory it hands out here)
+        P.sample_and_count_device(names, seed, lo, hi, block.data_ptr())
+        cur.wait_stream(lib_stream)
+        if not full:
+            shard[..., :hi - lo].copy_(block)
+            block.record_stream(lib_stream)
     dist.all_gather_into_tensor(gathered, shard)
     # [G, K, A, per] -> [K, A, G * per], the surplus of the last ranks cut off: the one device copy of the path
     full_t = gathered.view(world, K, A, per).permute(1, 2, 0, 3).reshape(K, A, world * per)[..., :num_samples].contiguous()

@@ -76,6 +76,9 @@ struct gat_ctx {
   hipEvent_t ev_t[2] = {nullptr, nullptr};      // split path: behind k_tail, k_finalize
   bool t_recorded = false;
   hipEvent_t ev_cnt[2] = {nullptr, nullptr};    // around the count phase
+  const void* timed_owner = nullptr;            // the problem whose call in flight owns the per-kernel events above (they exist once
+                                                // per context: a second call enqueued meanwhile -- run() keeps two problems' calls
+                                                // in flight -- runs untimed instead of re-recording them under the first: ADVICE r4)
   // status word and statistics of a sampler batch, copied behind its kernels and read after the batch's ONE synchronisation
   std::vector<std::pair<void*, size_t>> user_allocs;   // gat_dev_alloc'ed blocks and their sizes (back to the pool at gat_dev_free)
   void* h_stage = nullptr;                      // pinned staging buffer of gat_memcpy_d2h (grows; pageable targets are filled from it)

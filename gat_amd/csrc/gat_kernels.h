@@ -511,9 +511,6 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // stores with nothing to overlap them (the row loads' asm statements fence the schedule)
   int nF = 0;                  // segments already written to the slab (multiple of 8)
   auto flush = [&]() __attribute__((always_inline)) {
-#ifdef GAT_EXP_NOFLUSH
-    if (nS - nF >= 8) { nF += 8; return; }
-#endif
     if (nS - nF >= 8 && nF + 8 <= cap) {                  // (beyond the capacity: GAT_STEP_SIMPLE_ASM's lanes run on, flagged below)
       uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + nF);
       const int w0 = nF & 15;

@@ -915,25 +915,18 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       st->n_full_units += (int64_t)stat[4];
       st->n_resumed_units += (int64_t)stat[5];
       if (timed) {
-        float ms = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-        st->ms_sampler += ms;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-        st->ms_contig += ms;
+        // (a timing query that fails leaves its figure at 0: it must not turn a call that computed its counts into an error)
+        auto lap = [](hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); ms = 0; } return ms; };
+        st->ms_sampler += lap(ctx->ev[0], ctx->ev[1]);
+        st->ms_contig += lap(ctx->ev[1], ctx->ev[2]);
         if (ctx->k_recorded && !P->h_order.empty()) {
-          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev_k[0]));
-          st->ms_rng += ms;
-          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[0], ctx->ev_k[1]));
-          st->ms_place += ms;
-          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[1], ctx->ev_k[2]));
-          st->ms_merge += ms;
-          HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[2], ctx->ev_k[3]));
-          st->ms_tail += ms;
+          st->ms_rng += lap(ctx->ev[0], ctx->ev_k[0]);
+          st->ms_place += lap(ctx->ev_k[0], ctx->ev_k[1]);
+          st->ms_merge += lap(ctx->ev_k[1], ctx->ev_k[2]);
+          st->ms_tail += lap(ctx->ev_k[2], ctx->ev_k[3]);
           if (ctx->t_recorded) {
-            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_k[2], ctx->ev_t[0]));
-            st->ms_ktail += ms;
-            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_t[0], ctx->ev_t[1]));
-            st->ms_finalize += ms;
+            st->ms_ktail += lap(ctx->ev_k[2], ctx->ev_t[0]);
+            st->ms_finalize += lap(ctx->ev_t[0], ctx->ev_t[1]);
           }
         }
       }
@@ -1091,6 +1084,7 @@ static void call_end(gat_ctx* ctx, gat_problem* P) {
   if (K.blk) ctx->call_blocks.push_back(K.blk);
   K.blk = nullptr;
   K.active = false;
+  if (ctx->timed_owner == (const void*)P) ctx->timed_owner = nullptr;
 }
 
 static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, int n_counters, uint32_t seed,
@@ -1117,7 +1111,8 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   K.done = K.enq = 0; K.n_flight = 0;
   memset(&K.local, 0, sizeof(K.local));
   // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
-  K.timed = ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr;
+  K.timed = (ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr) && ctx->timed_owner == nullptr;
+  if (K.timed) ctx->timed_owner = (const void*)P;
   K.mstat_on = false;                              // (set with the first count kernels: it takes the tables)
   K.count_pending = false;
   auto fail = [&](int code) { call_end(ctx, P); return code; };
@@ -1254,7 +1249,8 @@ static int sample_lists(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t sam
   while (done < S) {
     if ((rc = ensure_scratch(ctx, P, S - done))) return rc;
     const int64_t nb = std::min<int64_t>(P->batch, S - done);
-    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, true, unit_level)) == kRelayout) continue;
+    // (timed unless another problem's call in flight owns the context's per-kernel events)
+    if ((rc = run_sampler_batch(ctx, P, seed, sample_begin + done, nb, &local, ctx->timed_owner == nullptr, unit_level)) == kRelayout) continue;
     if (rc) return rc;
     const bool from_contigs = P->merge_contigs && !unit_level;
     const uint2* src = from_contigs ? P->d_cslab.p : P->final_slab();
@@ -1306,20 +1302,43 @@ static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_coun
   gat_ctx* x = ctx->aux_ctx;
   const int rc = count_lists_on(x, counter_ids, n_counters, lists, list_off, n_lists, annos, anno_begin, anno_end, n_tracks, ws_nseg,
                                 n_groups, counts_host);
-  (void)hipStreamSynchronize(x->stream);            // (its buffers have gone back to the pool: nothing may still be using them)
-  x->stage_used = 0;
+  x->stage_used = 0;                                // (count_lists_on has drained the stream before its buffers went back to the pool)
   if (rc) return set_err(ctx, rc, "%s", x->err.c_str());
   return GAT_OK;
 }
 
+// The device buffers of a gat_count_lists call.  They go back to the process-wide pool when they are destroyed, and the pool
+// hands an idle block to any context or stream: on EVERY path out of the call -- an error in the middle of its launches
+// too -- the stream is drained before that (count_lists_on owns them and synchronises behind count_lists_body: ADVICE r4)
+struct CountListBufs {
+  AnnoDev A;
+  DevBuf<uint2> d_seg;
+  DevBuf<int32_t> d_c_off, d_n, d_index;
+  DevBuf<int64_t> d_nseg, d_out;
+  DevBuf<uint32_t> d_part;
+};
+static int count_lists_body(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                            const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                            const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                            const int64_t* ws_nseg, int32_t n_groups, void* counts_host, CountListBufs& B);
 static int count_lists_on(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
                           const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
                           const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
                           const int64_t* ws_nseg, int32_t n_groups, void* counts_host) {
+  CountListBufs B;
+  const int rc = count_lists_body(ctx, counter_ids, n_counters, lists, list_off, n_lists, annos, anno_begin, anno_end, n_tracks,
+                                  ws_nseg, n_groups, counts_host, B);
+  (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+static int count_lists_body(gat_ctx* ctx, const int32_t* counter_ids, int n_counters,
+                            const gat_segment* lists, const int64_t* list_off, int64_t n_lists,
+                            const gat_segment* annos, const int64_t* anno_begin, const int64_t* anno_end, int32_t n_tracks,
+                            const int64_t* ws_nseg, int32_t n_groups, void* counts_host, CountListBufs& B) {
   Counters C;
   int rc = parse_counters(ctx, counter_ids, n_counters, C);
   if (rc) return rc;
-  AnnoDev A;
+  AnnoDev& A = B.A;
   // (the merged index pays when many lists are counted against it; for a handful -- the observed counts of a run's
   //  segment tracks -- building it costs more than the per-track kernel's extra look-ups)
   const bool want_merged = n_lists >= 16 || getenv("GAT_COUNT_LISTS_MERGED") != nullptr;
@@ -1329,10 +1348,10 @@ static int count_lists_on(gat_ctx* ctx, const int32_t* counter_ids, int n_counte
   const int64_t total = list_off[n_lists * n_groups];
   std::vector<uint2> h_seg((size_t)total);
   for (int64_t i = 0; i < total; ++i) h_seg[(size_t)i] = make_uint2(lists[i].start, lists[i].end);
-  DevBuf<uint2> d_seg;
-  DevBuf<int32_t> d_c_off, d_n, d_index;
-  DevBuf<int64_t> d_nseg, d_out;
-  DevBuf<uint32_t> d_part;
+  DevBuf<uint2>& d_seg = B.d_seg;
+  DevBuf<int32_t>&d_c_off = B.d_c_off, &d_n = B.d_n, &d_index = B.d_index;
+  DevBuf<int64_t>&d_nseg = B.d_nseg, &d_out = B.d_out;
+  DevBuf<uint32_t>& d_part = B.d_part;
   HIPCHK(ctx, d_seg.upload(h_seg, ctx));
   std::vector<int64_t> h_nseg(ws_nseg, ws_nseg + n_groups);
   HIPCHK(ctx, d_nseg.upload(h_nseg, ctx));

@@ -55,14 +55,19 @@ def contig_list_lengths(dictionary):
     before the running end joins it, gat/SegmentList.pyx:756-816) from the dictionary's flat form, all contigs in one pass:
     only the LENGTHS are wanted (len(workspace[contig]): the density counter's divisor, gat/Engine.pyx:1437)."""
     f = dictionary._flat()
-    contigs, index, cid, dotted_any = [], {}, [], False
+    contigs, index, cid, dotted_any, plain_any = [], {}, [], False, False
     for k in f.keys:
         contig, dotted = split_key(k)
         dotted_any |= dotted
+        plain_any |= not dotted
         if contig not in index:
             index[contig] = len(contigs)
             contigs.append(contig)
         cid.append(index[contig])
+    if dotted_any and plain_any:
+        # keys with and without a dot in one dictionary: a plain key REPLACES what its contig has gathered so far
+        # (new[isochore] = segmentlist, gat/Engine.pyx:2857-2876) -- rare enough for the list-by-list form (ADVICE r4)
+        return collections.OrderedDict((c, len(a)) for c, a in from_isochores(dictionary.asArrays()).items())
     if not dotted_any:
         # a key IS its contig (a later list of the same contig replaces an earlier one: dictionary assignment)
         out = collections.OrderedDict()

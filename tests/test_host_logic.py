@@ -1,5 +1,6 @@
 """Host-side logic (numpy interval algebra, problem flattening, statistics) against the
 reference-generated goldens and the oracle.  CPU only."""
+import collections
 import json
 import os
 
@@ -745,6 +746,20 @@ def test_contig_list_lengths_equal_from_isochores():
         else:
             assert dict(got) == dict((c, len(a)) for c, a in d.asArrays().items()), case
         assert list(got.keys()) == list(want.keys())
+
+
+def test_contig_list_lengths_with_dotted_and_plain_keys_of_one_contig():
+    """a plain key replaces what the dotted keys of its contig have gathered (gat/Engine.pyx:2857-2876: new[isochore] =
+    segmentlist); dotted keys behind it extend the plain list"""
+    import gat_amd
+    d = gat_amd.IntervalDictionary()
+    d.add("chr1.a", gat_amd.SegmentList(array=iv.make([0, 10, 20], [5, 15, 25])))
+    d.add("chr1", gat_amd.SegmentList(array=iv.make([100, 200], [150, 250])))
+    d.add("chr1.c", gat_amd.SegmentList(array=iv.make([300, 400, 500], [350, 450, 550])))
+    d.add("chr2.a", gat_amd.SegmentList(array=iv.make([1], [2])))
+    want = collections.OrderedDict((c, len(a)) for c, a in problem.from_isochores(d.asArrays()).items())
+    assert want == collections.OrderedDict([("chr1", 5), ("chr2", 1)])
+    assert problem.contig_list_lengths(d) == want
 
 
 def test_collection_ranges_equal_the_dictionaries_ranges():
