@@ -32,6 +32,7 @@ SYMBOLS = [
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
     "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums", "gat_problem_rng_rows",
+    "gat_isochore_split",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -192,6 +193,8 @@ def lib():
     L.gat_problem_rng_rows.argtypes = [vp]
     L.gat_list_sums.restype = C.c_int
     L.gat_list_sums.argtypes = [vp, vp, vp, i64, vp]
+    L.gat_isochore_split.restype = C.c_int
+    L.gat_isochore_split.argtypes = [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.gat_problem_info.restype = C.c_int
     L.gat_problem_info.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.gat_null_stats.restype = C.c_int
@@ -334,6 +337,34 @@ def list_sums(a, begin, end):
     out = np.zeros(len(begin), dtype=np.int64)
     _check(lib().gat_list_sums(_p(a), _p(begin), _p(end), len(begin), _p(out)))
     return out
+
+
+def isochore_split(arrays, contig_ids, cls_start, cls_end, cls_label, n_classes, truncate):
+    """toIsochores of many lists at once (gat_isochore_split, host threads): arrays -- the lists' SEG arrays (contiguous,
+    kept alive by the caller), contig_ids[l] -- the contig of list l in the numbering of the class segments' coordinates.
+    Returns (out, out_off): list (l, k) = out[out_off[l * n_classes + k]:out_off[l * n_classes + k + 1]]; None if a list is
+    not normalized (the caller's list-by-list form raises what the reference raises)."""
+    n = len(arrays)
+    # (the address of a list's data: the buffer protocol is the cheapest way to it -- 1 us; __array_interface__ of a structured
+    #  array builds its descriptor every time, 7 us; an empty list has no buffer to speak of and is never read)
+    addr, from_buffer = C.addressof, C.c_char.from_buffer
+    ptr = np.fromiter((addr(from_buffer(a)) if len(a) and a.flags["WRITEABLE"] else a.ctypes.data for a in arrays),
+                      dtype=np.uint64, count=n)
+    lens = np.fromiter((len(a) for a in arrays), dtype=np.int64, count=n)
+    cid = np.ascontiguousarray(contig_ids, dtype=np.int64)
+    cls_start = np.ascontiguousarray(cls_start, dtype=np.int64)
+    cls_end = np.ascontiguousarray(cls_end, dtype=np.int64)
+    cls_label = np.ascontiguousarray(cls_label, dtype=np.int64)
+    off = np.zeros(n * n_classes + 1, dtype=np.int64)
+    total = C.c_int64(0)
+    args = (_p(ptr), _p(lens), _p(cid), n, _p(cls_start), _p(cls_end), _p(cls_label), len(cls_start), int(n_classes), 1 if truncate else 0)
+    rc = lib().gat_isochore_split(*args, None, _p(off), C.byref(total))
+    if rc == 1:
+        return None
+    _check(rc)
+    out = np.empty(max(1, total.value), dtype=SEG)
+    _check(lib().gat_isochore_split(*args, _p(out), _p(off), C.byref(total)))
+    return out[:total.value], off
 
 
 COMM_ID_BYTES = 128

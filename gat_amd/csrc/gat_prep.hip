@@ -1379,6 +1379,69 @@ extern "C" int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off
   return GAT_OK;
 }
 
+// IntervalDictionary.toIsochores (gat/Engine.pyx:2837-2855) for every list of a collection at once: list l (normalized: sorted,
+// disjoint, no empty segment) of contig list_contig[l] against the isochore classes' segments -- cls_start / cls_end in
+// coordinates (contig << 32) + position, sorted, disjoint (the classes partition the contigs), cls_label = the class --,
+// truncate: one piece per (segment, class segment) that overlap (SegmentList.intersect, gat/SegmentList.pyx:1469-1549),
+// else the whole segment once per class it touches (SegmentList.filter, :1401-1467).  Output list (l, k) =
+// out[out_off[l * n_classes + k] .. out_off[l * n_classes + k + 1]), in position order.  Two calls: out == NULL counts
+// (fills out_off, returns the total in *n_out), the second fills.  Returns 1 (nothing written) if a list is not normalized:
+// the caller then splits list by list, which raises what the reference raises.  Host threads over the lists; input
+// pipeline of a run (gat/IO.py:188-293), nothing of a sample passes here.
+extern "C" int gat_isochore_split(const uint64_t* list_ptr, const int64_t* list_len, const int64_t* list_contig, int64_t n_lists,
+                                  const int64_t* cls_start, const int64_t* cls_end, const int64_t* cls_label, int64_t n_cls,
+                                  int32_t n_classes, int32_t truncate, gat_segment* out, int64_t* out_off, int64_t* n_out) {
+  if (n_lists < 0 || n_cls < 0 || n_classes < 1 || !out_off || !n_out || (n_lists > 0 && (!list_ptr || !list_len || !list_contig)) ||
+      (n_cls > 0 && (!cls_start || !cls_end || !cls_label)))
+    return set_err(nullptr, GAT_ERR_ARG, "gat_isochore_split: bad argument");
+  const int64_t K = n_classes;
+  std::atomic<int> bad(0);
+  const bool fill = out != nullptr;
+  constexpr int64_t kBlock = 16;
+  parallel_for((n_lists + kBlock - 1) / kBlock, [&](int64_t blk) {
+    std::vector<int64_t> cur((size_t)K);
+    std::vector<int64_t> last((size_t)K);
+    for (int64_t l = blk * kBlock; l < std::min(n_lists, (blk + 1) * kBlock); ++l) {
+      const gat_segment* a = reinterpret_cast<const gat_segment*>((uintptr_t)list_ptr[l]);
+      const int64_t n = list_len[l], hi = list_contig[l] << 32;
+      int64_t j = std::lower_bound(cls_start, cls_start + n_cls, hi) - cls_start;
+      // (a class segment that begins in an earlier contig cannot reach into this one: ends stay below the next contig's base)
+      const int64_t jend = std::lower_bound(cls_start, cls_start + n_cls, hi + ((int64_t)1 << 32)) - cls_start;
+      if (fill) for (int64_t k = 0; k < K; ++k) cur[(size_t)k] = out_off[l * K + k];
+      else for (int64_t k = 0; k < K; ++k) cur[(size_t)k] = 0;
+      for (int64_t k = 0; k < K; ++k) last[(size_t)k] = -1;
+      for (int64_t i = 0; i < n; ++i) {
+        if (!fill && (a[i].start >= a[i].end || (i > 0 && a[i - 1].end > a[i].start))) { bad.store(1); break; }
+        const int64_t as = hi + a[i].start, ae = hi + a[i].end;
+        while (j < jend && cls_end[j] <= as) ++j;
+        for (int64_t jj = j; jj < jend && cls_start[jj] < ae; ++jj) {
+          const int64_t k = cls_label[jj];
+          if (truncate) {
+            if (fill) {
+              gat_segment& o = out[cur[(size_t)k]];
+              o.start = (uint32_t)(std::max(as, cls_start[jj]) & 0xffffffff);
+              o.end = (uint32_t)(std::min(ae, cls_end[jj]) & 0xffffffff);
+            }
+            ++cur[(size_t)k];
+          } else if (last[(size_t)k] != i) {                 // (a segment touching two pieces of one class is kept once)
+            last[(size_t)k] = i;
+            if (fill) out[cur[(size_t)k]] = a[i];
+            ++cur[(size_t)k];
+          }
+        }
+      }
+      if (!fill) for (int64_t k = 0; k < K; ++k) out_off[l * K + k + 1] = cur[(size_t)k];   // (counts; the prefix sum follows)
+    }
+  });
+  if (bad.load()) return 1;
+  if (!fill) {
+    out_off[0] = 0;
+    for (int64_t g = 0; g < n_lists * K; ++g) out_off[g + 1] += out_off[g];
+  }
+  *n_out = out_off[n_lists * K];
+  return GAT_OK;
+}
+
 // SegmentList.sum() of many lists at once (gat/SegmentList.pyx:1607: a Position accumulator per list)
 extern "C" int gat_list_sums(const gat_segment* a, const int64_t* begin, const int64_t* end, int64_t n_lists, int64_t* sums_out) {
   if ((n_lists > 0 && (!begin || !end || !sums_out)) || n_lists < 0) return set_err(nullptr, GAT_ERR_ARG, "gat_list_sums: bad argument");

@@ -416,6 +416,121 @@ def _new_list(array, like):
     return s
 
 
+_MISSING = object()
+
+
+class _LazyLists(collections.defaultdict):
+    """key -> SegmentList whose lists are slices of ONE array (data[off[i]:off[i + 1]] for key i) and are only made when
+    somebody asks for them: toIsochores of config 3's annotations leaves 19 200 lists, and making 19 200 Python objects costs
+    more than splitting a million intervals (the run itself works on the array: IntervalDictionary._flat).  Until it is made a
+    key holds None in the underlying dict; every way to a value goes through here.  `protos[i // per]` is the list key i was
+    split from: the new list takes its class and its isNormalized."""
+
+    def __init__(self, keys, data, off, protos, per):
+        super().__init__(SegmentList)
+        dict.update(self, dict.fromkeys(keys))
+        self._keys, self._data, self._off, self._protos, self._per = keys, data, off, protos, per
+        self._index = None
+        self._made = []                 # (key, the view it was given): how _flat() finds out whether a list was replaced since
+        self._touched = False           # a key was set or deleted: the flat form has to be looked at again
+
+    def _make(self, key):
+        if self._index is None:
+            self._index = dict(zip(self._keys, range(len(self._keys))))
+        i = self._index[key]
+        w = self._data[self._off[i]:self._off[i + 1]]
+        s = _new_list(w, self._protos[i // self._per])
+        dict.__setitem__(self, key, s)
+        self._made.append((key, w))
+        return s
+
+    def _make_all(self):
+        if len(self._made) < len(self._keys):
+            get = dict.get
+            for k in self._keys:
+                if get(self, k, _MISSING) is None:
+                    self._make(k)
+
+    def pristine(self):
+        """nothing set or deleted, and every list that was made still holds the view it was given"""
+        if self._touched:
+            return False
+        get = dict.__getitem__
+        return all(get(self, k)._a is w for k, w in self._made)
+
+    def all_normalized(self):
+        return all(p.isNormalized for p in self._protos) and all(dict.__getitem__(self, k).isNormalized for k, _ in self._made)
+
+    def __getitem__(self, key):
+        v = dict.get(self, key, _MISSING)
+        if v is None:
+            return self._make(key)
+        if v is _MISSING:
+            self._touched = True
+            return self.__missing__(key)
+        return v
+
+    def get(self, key, default=None):
+        v = dict.get(self, key, _MISSING)
+        if v is None:
+            return self._make(key)
+        return default if v is _MISSING else v
+
+    def __setitem__(self, key, value):
+        self._touched = True
+        dict.__setitem__(self, key, value)
+
+    def __delitem__(self, key):
+        self._touched = True
+        dict.__delitem__(self, key)
+
+    def values(self):
+        self._make_all()
+        return dict.values(self)
+
+    def items(self):
+        self._make_all()
+        return dict.items(self)
+
+    def pop(self, *args):
+        self._make_all()
+        self._touched = True
+        return dict.pop(self, *args)
+
+    def popitem(self):
+        self._make_all()
+        self._touched = True
+        return dict.popitem(self)
+
+    def setdefault(self, key, default=None):
+        self._make_all()
+        self._touched = True
+        return dict.setdefault(self, key, default)
+
+    def update(self, *args, **kwargs):
+        self._touched = True
+        dict.update(self, *args, **kwargs)
+
+    def clear(self):
+        self._touched = True
+        self._made = []
+        self._keys = []
+        dict.clear(self)
+
+    def copy(self):
+        self._make_all()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._make_all()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+
 class IntervalDictionary(object):
     """key (contig or contig.isochore) -> SegmentList (gat/Engine.pyx:2741)."""
 
@@ -428,6 +543,11 @@ class IntervalDictionary(object):
         """the lists as one array (_DictFlat); built once and found again as long as no list was replaced, added or removed"""
         f = self._flat_cache
         d = self.intervals
+        if f is not None and f.arrays is None:
+            # (the lists of a toIsochores pass, most of them not made yet: _LazyLists)
+            if isinstance(d, _LazyLists) and d.pristine() and len(d) == len(f.keys):
+                return f
+            f = None
         if f is not None and len(f.arrays) == len(d) and all(map(operator.is_, map(_GET_A, d.values()), f.arrays)) \
                 and list(d.keys()) == f.keys:
             return f
@@ -445,10 +565,16 @@ class IntervalDictionary(object):
         return f
 
     def _all_normalized(self):
-        return all(map(_GET_NORMALIZED, self.intervals.values()))
+        d = self.intervals
+        if isinstance(d, _LazyLists) and not d._touched:
+            return d.all_normalized()
+        return all(map(_GET_NORMALIZED, d.values()))
 
     def _has_points(self):
-        return any(map(_GET_POINTS, self.intervals.values()))
+        d = self.intervals
+        if isinstance(d, _LazyLists) and not d._touched:
+            return False                                   # (toIsochores' one-pass form does not take points)
+        return any(map(_GET_POINTS, d.values()))
 
     def __len__(self):
         return len(self.intervals)
@@ -664,6 +790,16 @@ class IntervalDictionary(object):
             self._flat_cache = _DictFlat(out, off, keys, views)
         return True
 
+    def _install_split(self, keys, out, off, protos, per):
+        """the lists of a toIsochores pass made elsewhere (IntervalCollection.toIsochores: one native call for the whole
+        collection): `out` / `off` -- this dictionary's own array and offsets, keys -- contig.class in (contig, class) order"""
+        lazy = _LazyLists(keys, out, off.tolist(), protos, per)
+        if len(lazy) != len(keys):                       # two (contig, class) pairs share a key: the plain form
+            return False
+        self.intervals = lazy
+        self._flat_cache = _DictFlat(out, off, keys, None)
+        return True
+
     def fromIsochores(self):
         """gat/Engine.pyx:2857-2876."""
         new = collections.defaultdict(SegmentList)
@@ -863,15 +999,73 @@ class IntervalCollection(object):
             vv.filter(other)
 
     def toIsochores(self, isochores, truncate=False):
-        prep = None
-        for vv in self.intervals.values():
-            if prep is None:
-                # (the classes are the same for every track; a look-up of a contig they lack only adds an empty list)
-                for _, other_vv in isochores.items():
-                    for contig in list(vv.keys()):
+        dicts = list(self.intervals.values())
+        if not dicts:
+            return
+        tracks = list(isochores.items())
+        # a look-up of a contig an isochore track lacks adds an empty list to it (gat/Engine.pyx:2846: other_vv[contig] on a
+        # defaultdict), in the order the reference meets them: dictionary by dictionary, contig by contig
+        seen = set()
+        for vv in dicts:
+            for contig in vv.keys():
+                if contig not in seen:
+                    seen.add(contig)
+                    for _, other_vv in tracks:
                         other_vv[contig]
-                prep = _IsochorePrep(list(isochores.items()))
+        prep = _IsochorePrep(tracks)
+        if self._to_isochores_native(dicts, tracks, truncate, prep):
+            return
+        for vv in dicts:
             vv.toIsochores(isochores, truncate, _prep=prep)
+
+    def _to_isochores_native(self, dicts, tracks, truncate, prep):
+        """every list of every dictionary split in ONE call of the library (gat_isochore_split: host threads over the lists,
+        two passes -- count, fill -- into one array) where IntervalDictionary._to_isochores_flat's conditions hold for all of
+        them: the classes partition the contigs, no points, normalized lists.  The dictionaries receive their lists as slices
+        of that array, made on demand (_LazyLists).  False: nothing was done, the dictionaries split themselves."""
+        if not prep.valid or len(tracks) < 1:
+            return False
+        arrays, cids, protos_of = [], [], []
+        for vv in dicts:
+            if not isinstance(vv, IntervalDictionary) or not vv.intervals or vv._has_points():
+                return False
+            lists = list(vv.intervals.values())
+            for x in lists:
+                a = x._a
+                if a.dtype != iv.SEG or not a.flags["C_CONTIGUOUS"]:
+                    return False
+            if truncate and not all(map(_GET_NORMALIZED, lists)):
+                return False
+            arrays.extend(map(_GET_A, lists))
+            cids.extend(prep.contig_id(c) for c in vv.intervals.keys())
+            protos_of.append(lists)
+        K = len(tracks)
+        res = _lib.isochore_split(arrays, cids, prep.b_start, prep.b_end, prep.label, K, truncate)
+        if res is None:
+            return False
+        out, off = res
+        names = [t for t, _ in tracks]
+        key_cache = {}
+        l0 = 0
+        plans = []
+        for vv, protos in zip(dicts, protos_of):
+            contigs = tuple(vv.intervals.keys())
+            keys = key_cache.get(contigs)
+            if keys is None:
+                keys = key_cache[contigs] = ["%s.%s" % (c, t) for c in contigs for t in names]
+                if len(set(keys)) != len(keys):
+                    return False                              # (two (contig, class) pairs share a key: the plain form)
+            n = len(contigs)
+            o = off[l0 * K:(l0 + n) * K + 1]
+            plans.append((vv, keys, out[o[0]:o[-1]], o - o[0], protos))
+            l0 += n
+        for vv, keys, data, o, protos in plans:
+            vv._install_split(keys, data, o, protos, K)
+        if len(plans) == len(self.intervals):
+            bases = np.zeros(len(plans) + 1, dtype=np.int64)
+            np.cumsum([len(p[2]) for p in plans], out=bases[1:])
+            self._flat_cache = (out, bases, [vv._flat_cache for vv, _, _, _, _ in plans])
+        return True
 
     def fromIsochores(self):
         for vv in self.intervals.values():

@@ -283,6 +283,20 @@ int gat_intersection_sizes(const gat_segment* a, const int64_t* a_off, int32_t n
  * gat/Engine.pyx:1911-1928) of a run over 10^4 lists.  Host arithmetic on the inputs, like gat_intersection_sizes. */
 int gat_list_sums(const gat_segment* a, const int64_t* begin, const int64_t* end, int64_t n_lists, int64_t* sums_out);
 
+/* IntervalDictionary.toIsochores (gat/Engine.pyx:2837-2855; what IO.applyIsochores, gat/IO.py:188-293, does to the segments,
+ * annotations and workspace of a run) for every list of a collection in one call, on host threads.  list l: list_len[l]
+ * segments at address list_ptr[l] (HOST; normalized: sorted, disjoint, none empty) of contig list_contig[l]; the isochore
+ * classes' segments in coordinates (contig << 32) + position, sorted by start and disjoint (the classes partition the
+ * contigs), cls_label[j] = class of segment j in [0, n_classes).  truncate != 0: a segment is cut at the class boundaries
+ * (SegmentList.intersect, gat/SegmentList.pyx:1469-1549), else every class a segment touches receives it whole
+ * (SegmentList.filter, :1401-1467).  Result list (l, k) = out[out_off[l * n_classes + k] .. out_off[l * n_classes + k + 1]).
+ * Two calls: with out == NULL the lists are counted (out_off[0 .. n_lists * n_classes] filled, total in *n_out), with out
+ * and the same out_off they are written.  Returns GAT_OK, GAT_ERR_ARG, or 1 when a list is not normalized (nothing is
+ * written: the host then splits list by list and raises what the reference raises).  Input pipeline; no sample passes here. */
+int gat_isochore_split(const uint64_t* list_ptr, const int64_t* list_len, const int64_t* list_contig, int64_t n_lists,
+                       const int64_t* cls_start, const int64_t* cls_end, const int64_t* cls_label, int64_t n_cls,
+                       int32_t n_classes, int32_t truncate, gat_segment* out, int64_t* out_off, int64_t* n_out);
+
 /* ---- the reference's own random stream ---------------------------------------------------
  * scripts/gat-run.py:267-271 seeds numpy's global generator ONCE and every (sample, unit) of the run -- in the order of
  * gat/__init__.py:531-541, segment track after segment track -- draws from that one MT19937.  gat_sample_and_count's

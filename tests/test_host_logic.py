@@ -482,27 +482,79 @@ def test_to_isochores_one_pass_equals_list_by_list():
                 per[c] = rand_list(rs.randint(0, 40), 3200)
             tr.append(("t%d" % t, per))
         for truncate in (True, False):
-            A, B = _coll(tr), _coll(tr)
-            A.toIsochores(_coll(iso), truncate)
+            # A: the whole collection in one call of the library (gat_isochore_split; lists made on demand), C: one vectorised
+            # numpy pass per dictionary, B: list by list as the reference does
+            A, B, Cc = _coll(tr), _coll(tr), _coll(tr)
+            isoA, isoB = _coll(iso), _coll(iso)
+            A.toIsochores(isoA, truncate)
+            assert all(isinstance(A[t].intervals, engine._LazyLists) for t in A.tracks) or not any(len(A[t]) for t in A.tracks)
             orig = engine.IntervalDictionary._to_isochores_flat
-            engine.IntervalDictionary._to_isochores_flat = lambda *a, **k: False
+            orig_native = engine.IntervalCollection._to_isochores_native
+            engine.IntervalCollection._to_isochores_native = lambda *a, **k: False
             try:
-                B.toIsochores(_coll(iso), truncate)
+                Cc.toIsochores(_coll(iso), truncate)
+                engine.IntervalDictionary._to_isochores_flat = lambda *a, **k: False
+                B.toIsochores(isoB, truncate)
             finally:
                 engine.IntervalDictionary._to_isochores_flat = orig
+                engine.IntervalCollection._to_isochores_native = orig_native
+            # (the keys a look-up added to the isochore tracks, in the reference's order)
+            assert [list(isoA[t].keys()) for t in isoA.tracks] == [list(isoB[t].keys()) for t in isoB.tracks]
             for t in A.tracks:
-                assert list(A[t].keys()) == list(B[t].keys())
+                assert list(A[t].keys()) == list(B[t].keys()) == list(Cc[t].keys())
+                assert A[t].sum() == B[t].sum() and A[t].counts() == B[t].counts()        # (from the flat form: no list is made)
+                f = A[t]._flat()
+                assert f is A[t]._flat()
                 for k in A[t].keys():
                     assert np.array_equal(A[t][k].asArray(), B[t][k].asArray()), (trial, truncate, t, k)
-                    assert A[t][k].isNormalized == B[t][k].isNormalized
-                assert A[t].sum() == B[t].sum() and A[t].counts() == B[t].counts()
-                assert A[t]._flat() is A[t]._flat()
+                    assert np.array_equal(Cc[t][k].asArray(), B[t][k].asArray()), (trial, truncate, t, k)
+                    assert A[t][k].isNormalized == B[t][k].isNormalized and type(A[t][k]) is type(B[t][k])
+                assert A[t]._flat() is f                                                   # the lists made meanwhile are its views
+                assert [np.array_equal(x.asArray(), y.asArray()) for x, y in zip(A[t].intervals.values(), B[t].intervals.values())] \
+                    == [True] * len(B[t])
+            cf = A._flat()
+            assert cf is A._flat() and len(cf[0]) == sum(len(A[t]._flat().data) for t in A.tracks)
     # overlapping classes are not a partition: the shortcut steps aside and the result is still the reference's
     seg = [("t", collections.OrderedDict([("c0", iv.make([10, 100], [60, 180]))]))]
     iso2 = [("a", collections.OrderedDict([("c0", iv.make([0], [120]))])), ("b", collections.OrderedDict([("c0", iv.make([50], [200]))]))]
     A = _coll(seg)
     A.toIsochores(_coll(iso2), True)
     assert A["t"]["c0.a"].asList() == [(10, 60), (100, 120)] and A["t"]["c0.b"].asList() == [(50, 60), (100, 180)]
+
+
+def test_lists_made_on_demand_behave_like_a_dictionary():
+    """engine._LazyLists (what IntervalCollection.toIsochores leaves in a dictionary): reading, replacing, adding and deleting
+    keys, iteration, clone / fromIsochores on top of it; the flat form is kept while nothing was replaced and rebuilt after."""
+    import collections
+    from gat_amd import engine, intervals as iv
+    import gat_amd
+    seg = [("t", collections.OrderedDict([("c0", iv.make([10, 100, 300], [60, 180, 320])), ("c1", iv.make([5], [500]))]))]
+    iso = [("a", collections.OrderedDict([("c0", iv.make([0], [120])), ("c1", iv.make([0], [100]))])),
+           ("b", collections.OrderedDict([("c0", iv.make([120], [400])), ("c1", iv.make([100], [600]))]))]
+    A = _coll(seg)
+    A.toIsochores(_coll(iso), True)
+    d = A["t"]
+    assert isinstance(d.intervals, engine._LazyLists) and list(d.keys()) == ["c0.a", "c0.b", "c1.a", "c1.b"]
+    assert "c0.a" in d and "c9.a" not in d and len(d) == 4
+    assert dict.__getitem__(d.intervals, "c0.b") is None                      # not made yet
+    f = d._flat()
+    assert d.sum() == 50 + 20 + 60 + 20 + 95 + 400 and d.counts() == 6
+    assert d["c0.b"].asList() == [(120, 180), (300, 320)] and d["c0.b"] is d["c0.b"]
+    assert d.intervals.get("c1.a").asList() == [(5, 100)] and d.intervals.get("nope") is None
+    assert d._flat() is f
+    c = d.clone()                                                             # (goes through items(): everything is made)
+    assert [k for k, _ in c.items()] == list(d.keys()) and c["c1.b"].asList() == [(100, 500)]
+    assert d._flat() is f
+    d["c0.a"].normalize()                                                     # (in place, the view stays: still the same form)
+    d["c0.a"] = gat_amd.SegmentList(array=iv.make([1], [2]))                  # replaced: the flat form follows
+    f2 = d._flat()
+    assert f2 is not f and d.sum() == 1 + 20 + 60 + 95 + 400 and d._flat() is f2
+    del d["c1.a"]
+    assert list(d.keys()) == ["c0.a", "c0.b", "c1.b"] and d.counts() == 4
+    d["c7.a"]                                                                 # a look-up adds an empty list (defaultdict)
+    assert list(d.keys())[-1] == "c7.a" and len(d["c7.a"]) == 0
+    d.fromIsochores()
+    assert list(d.keys()) == ["c0", "c1", "c7"] and d["c0"].asList() == [(1, 2), (120, 180), (300, 320)]
 
 
 def test_flat_form_follows_the_lists():
