@@ -366,6 +366,7 @@ struct gat_problem {
   uint32_t max_hist = 0;                 // longest length-rank table of an active unit
   bool long_lists = false;               // units beyond the wave's bucket sorts (k_merge_big, k_tail_big)
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
+  bool all_cm_ok = false;                // ... and the offset draw's mask does not depend on the length drawn (k_place_scan's units)
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
   bool all_one_ws = false;               // every active unit: one workspace segment, bucket 1, and most of the working segments in units

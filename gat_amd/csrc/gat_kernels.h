@@ -973,6 +973,223 @@ __global__ __launch_bounds__(kPlaceWide * 64) void k_place_wide(SamplerArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_place_scan: the same placement loop with ONE STREAM WALKED BY THE 64 LANES OF A WAVE, for small calls of problems of
+// simple units (one workspace segment, bucket size 1, rank table within LDS, the offset draw's mask independent of the
+// length: cm_ok above).  k_place gives every stream a lane, so a call cannot end before one lane has walked the longest
+// unit's ~3 000 rows one by one (0.37 ms on config 2 whatever the sample count); a call of a few hundred samples leaves most
+// of the chip idle meanwhile.  Here lane j of a wave takes row j of a chunk of 64 rows of one stream:
+//   * whether a row is accepted as a rank / position / offset draw is a function of the row alone (but for the band
+//     c_r3 + 1 < y & maskP <= c_r3 + longest length, one row in ~10^5: a chunk with such a row is scanned twice),
+//     so a row is a function on the three states L -> P -> O -> L (advance if accepted, else stay) and the state in front of
+//     every row is a PREFIX SCAN of function composition -- a function is three bytes holding the images of L, P, O, and a
+//     composition is ONE v_perm_b32 with the earlier function as the byte selector (the DPP scan of gat_device.h does seven);
+//   * the length in force at an offset draw is the one of the last accepted rank draw in front of it (a ballot, a
+//     count-leading-zeros and one ds_bpermute), `remaining` in front of a row the chunk's entry value less the prefix sum of
+//     the overlaps placed before it, the trigger (gat/Engine.pyx:582) the first accepted rank draw whose length reaches it;
+//   * the placed segments go to the slab compacted by a ballot's population count.
+// Rows reach the wave transposed through LDS: a workgroup is a QUARTER TILE -- 16 streams, four waves with four streams
+// each -- that loads blocks of 64 rows x 16 lanes (64 contiguous bytes of every row; the other quarters of the tile read
+// their shares of the same lines out of the same XCD's L2: blockIdx -> tile is dealt so that a tile's four workgroups have
+// one residue mod 8, the stride with which workgroups go round the XCDs) and stores them column-major, a stream's 64 rows
+// one conflict-free LDS read.  The next block's loads are in flight while a block is worked on; one barrier per block.
+// Hand-over (st, raw segments in the slab, flags) exactly k_place's.
+#ifndef GAT_SCAN_WAVES
+#define GAT_SCAN_WAVES 8      /* config 2, k_place_scan at 625 / 1 250 / 2 500 samples: 4 waves 0.142 / 0.205 / 0.360 ms, 8 waves 0.123 / 0.209 / 0.393, 16: 0.24 / 0.45 / 0.86 */
+#endif
+constexpr int kScanStreams = 16, kScanWaves = GAT_SCAN_WAVES, kScanPer = kScanStreams / kScanWaves, kScanPitch = kWave + 1;
+constexpr int kScanRankTab = kPlaceRankLds;
+constexpr int kFnIdentity = 0x03020100;      // byte s = the image of state s (0 L, 1 P, 2 O; byte 3 is never looked at)
+
+// h = a after b: byte s of h = byte b(s) of a -- v_perm_b32 with b as the selector (selector values 0..3 pick bytes of the
+// second source)
+__device__ __forceinline__ int scan_fn_compose(int a, int b) {
+  return (int)__builtin_amdgcn_perm(0u, (uint32_t)a, (uint32_t)b);
+}
+
+struct ScanStream {
+  uint32_t state8;       // 8 x the state in front of the next row (the bit offset of its byte in a function): 0 L, 8 P, 16 O
+  uint32_t len;          // the length in force (drawn by the last accepted rank draw)
+  int32_t rem;           // `remaining`
+  int32_t nS;            // segments placed
+  uint32_t used;         // raw outputs consumed up to the last placement / the trigger
+  int32_t pend;          // > 0: triggered with this length pending; -1 not (yet)
+  int32_t flag;
+  bool done;             // halted (trigger, overflow) or not a stream of the batch
+};
+
+struct ScanUnit {
+  uint32_t maskL, rangeL, maskP, rangeP, c_r3;
+  int32_t c_ss, ws_start, ws_end, cap;
+};
+
+// one chunk of up to 64 rows of one stream, lane j = row j (rows at and beyond nrows do nothing).
+// The offset draw's range is c_r3 + length: a row is accepted for certain up to c_r3 + 1 (every length is at least 1) and
+// in the band above it -- one row in ~10^5 -- only for lengths that reach it.  The scan starts from "accepted for certain";
+// once the states and the lengths in force are known, every row IN STATE O is tested exactly, and if one of them was guessed
+// wrong the scan is repeated with the exact answers.  (The first row whose state differs from the truth is preceded by a
+// wrongly guessed row in state O whose length in force is already the true one, so a pass without a wrong guess is the
+// truth; every pass extends the correct prefix.)  pessimist (GAT_PLACE_SCAN_SEQ, tests): start from "none accepted".
+__device__ __forceinline__ void place_scan_chunk(ScanStream& T, const ScanUnit& U, uint32_t y, uint32_t lr, int nrows, uint32_t row0,
+                                                 uint2* __restrict__ out, int lane, bool pessimist) {
+  const bool in = lane < nrows;
+  const uint32_t vO = y & U.maskP;
+  const bool aL = in && (y & U.maskL) <= U.rangeL, aP = in && vO <= U.rangeP;
+  bool aO = in && !pessimist && vO <= U.c_r3 + 1u;
+  const uint64_t lt = lanemask_lt(lane), le = lt | (1ull << lane);
+  const int fLP = 0x03000000 | (aL ? 1 : 0) | ((aP ? 2 : 1) << 8);
+  int Fi;
+  uint32_t len;
+  bool isL, isO;
+  uint64_t bL;
+  for (;;) {
+    const int f = fLP | ((aO ? 0 : 2) << 16);
+    Fi = wave_incl_scan_dpp(f, kFnIdentity, [](int a, int b) { return scan_fn_compose(a, b); });
+    const int Fe = __builtin_amdgcn_update_dpp(kFnIdentity, Fi, 0x138, 0xf, 0xf, false);        // wave_shr:1: the rows in front
+    const uint32_t st = __builtin_amdgcn_ubfe((uint32_t)Fe, T.state8, 8);                         // the state in front of row j
+    isL = aL && st == 0u;
+    bL = __ballot(isL);
+    // the length in force: the last accepted rank draw in front of (or at) this row, else the chunk's entry value
+    const uint64_t mL = bL & le;
+    const int src = mL ? 63 - __builtin_clzll(mL) : lane;
+    const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)lr);
+    len = mL ? got : T.len;
+    const bool exact = in && vO <= U.c_r3 + len;
+    isO = aO && st == 2u;
+    if (!__any(st == 2u && exact != aO)) break;
+    aO = st == 2u ? exact : aO;
+  }
+  const int32_t q = U.c_ss - (int32_t)len + (int32_t)vO;
+  const uint32_t start = (uint32_t)(q > 0 ? q : 0), end = (uint32_t)(q + (int32_t)len);
+  const int32_t omin = U.ws_end < (int32_t)end ? U.ws_end : (int32_t)end, omax = U.ws_start > (int32_t)start ? U.ws_start : (int32_t)start;
+  const uint32_t ov = isO ? (uint32_t)(omin - omax > 0 ? omin - omax : 0) : 0u;
+  const uint32_t incl = wave_incl_sum_u32(ov, lane);
+  const int32_t rem_before = T.rem - (int32_t)(incl - ov);
+  const bool trig = isL && rem_before <= (int32_t)lr;                       // gat/Engine.pyx:582
+  const uint64_t bT = __ballot(trig);
+  const int jt = bT ? __builtin_ctzll(bT) : kWave - 1;                      // rows behind the first trigger do not happen
+  const uint64_t keep = bT ? ((1ull << jt) - 1ull) : ~0ull;
+  const uint64_t bO = __ballot(isO) & keep;
+  const int idx = T.nS + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bO >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bO, 0u));
+  const int nput = __popcll(bO);
+  const bool over = T.nS + nput > U.cap;                                    // (k_place: the unit is run in full with a larger slab)
+  if (!over && ((bO >> lane) & 1ull)) out[idx] = make_uint2(start, end);
+  // the stream behind the chunk: at the trigger (row jt) / at the chunk's last row
+  const int32_t rem_t = __builtin_amdgcn_readlane(rem_before, jt), lr_t = __builtin_amdgcn_readlane((int)lr, jt);
+  const int32_t tot = __builtin_amdgcn_readlane((int)incl, kWave - 1);
+  const uint32_t len_end = bL ? (uint32_t)__builtin_amdgcn_readlane((int)lr, 63 - __builtin_clzll(bL)) : T.len;
+  const uint32_t st_end = 8u * __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(Fi, kWave - 1), T.state8, 8);
+  const uint32_t used_put = bO ? row0 + (uint32_t)(63 - __builtin_clzll(bO)) + 1u : T.used;
+  T.flag |= over ? kStatusOverflow : 0;
+  T.done = over || bT != 0;
+  if (!over) {
+    T.nS += nput;
+    T.used = bT ? row0 + (uint32_t)jt + 1u : used_put;
+    T.pend = bT ? lr_t : T.pend;
+    T.rem = bT ? rem_t : T.rem - tot;
+    T.len = len_end;
+    T.state8 = st_end;
+  }
+}
+
+__global__ __launch_bounds__(kScanWaves * 64) void k_place_scan(SamplerArgs A, int n_sb, int pessimist) {
+  __shared__ uint32_t l_rows[2][kScanStreams * kScanPitch];
+  __shared__ uint32_t l_rank[kScanRankTab];
+  __shared__ int32_t l_live[2][kScanWaves];
+  const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // tile = (launch position a, sample block sb), largest units first; the four quarters of a tile on one XCD
+  const int64_t n_tiles = (int64_t)n_sb * A.n_active;
+  const int64_t b = blockIdx.x, slot = b >> 3;
+  const int64_t tile = (slot >> 2) * 8 + (b & 7);
+  const int quarter = (int)(slot & 3);
+  if (tile >= n_tiles) return;
+  const int a = (int)(tile / n_sb), sb = (int)(tile % n_sb);
+  const UnitDev* __restrict__ Up = A.units_o + a;
+  const uint32_t hist_total = Up->hist_total, ws_total = Up->ws_total;
+  const int rows = A.rng_rows[a];
+  const uint2 ws0 = A.ws[Up->ws_off];
+  const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
+  const int col0 = quarter * kScanStreams;
+  ScanUnit U;
+  ScanStream T[kScanPer];
+  uint2* outp[kScanPer];
+  int64_t so[kScanPer];
+  bool live[kScanPer];
+  const bool degenerate = !(hist_total > 2 && ws_total > 1);              // k_sampler runs those from their seed (as k_place)
+#pragma unroll
+  for (int q = 0; q < kScanPer; ++q) {
+    const int sidx = sb * kWave + col0 + wv * kScanPer + q;
+    live[q] = sidx < A.batch;
+    so[q] = GAT_REC(A, live[q] ? sidx : 0, a);
+    outp[q] = A.slab + (int64_t)(live[q] ? sidx : 0) * A.slab_stride + Up->slab_off;
+    T[q].state8 = 0u; T[q].len = 0u; T[q].rem = Up->ltotal; T[q].nS = 0; T[q].used = 0u; T[q].pend = -1; T[q].flag = 0;
+    T[q].done = !live[q];
+  }
+  if (degenerate) {
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q)
+      if (live[q] && lane == 0) A.st[so[q]] = make_int4(0, Up->ltotal, -1, 0);
+    return;
+  }
+  U.rangeL = hist_total - 2u; U.maskL = 0xffffffffu >> __builtin_clz(U.rangeL);
+  U.rangeP = ws_total - 1u; U.maskP = 0xffffffffu >> __builtin_clz(U.rangeP);
+  U.c_ss = (int32_t)ws0.x + 1; U.c_r3 = ws0.y - ws0.x - 2u;
+  U.ws_start = (int32_t)ws0.x; U.ws_end = (int32_t)ws0.y; U.cap = Up->slab_cap;
+  for (int i = (int)threadIdx.x; i <= (int)U.maskL && i < kScanRankTab; i += kScanWaves * kWave)
+    l_rank[i] = (uint32_t)i <= U.rangeL ? rank_len[i + 1] : 0u;
+  // rows of the tile: rp[j * 64 + lane of the stream]; a load instruction takes 4 rows x this quarter's 16 lanes
+  const uint32_t* __restrict__ rp = A.rng_out + A.rng_off[a] + (int64_t)sb * rows * kWave + col0;
+  const int lrow = lane >> 4, lcol = lane & 15;
+  const int nblk = (rows + kWave - 1) / kWave;
+  // (a block is 16 groups of 4 rows x 16 lanes; a wave loads kScanPer of them)
+  uint32_t ld[kScanPer];
+  auto load_block = [&](int blk) {
+#pragma unroll
+    for (int i = 0; i < kScanPer; ++i) {
+      int r = blk * kWave + (wv * kScanPer + i) * 4 + lrow;
+      r = r < rows ? r : rows - 1;
+      ld[i] = rp[(int64_t)r * kWave + lcol];
+    }
+  };
+  auto store_block = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kScanPer; ++i) l_rows[buf][lcol * kScanPitch + (wv * kScanPer + i) * 4 + lrow] = ld[i];
+  };
+  load_block(0);
+  store_block(0);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int buf = blk & 1;
+    if (blk + 1 < nblk) load_block(blk + 1);
+    const int nrows = rows - blk * kWave < kWave ? rows - blk * kWave : kWave;
+    int nlive = 0;
+#pragma unroll
+    for (int q = 0; q < kScanPer; ++q) {
+      if (!T[q].done) {
+        const uint32_t y = l_rows[buf][(wv * kScanPer + q) * kScanPitch + lane];
+        const uint32_t lr = l_rank[y & U.maskL];
+        place_scan_chunk(T[q], U, y, lr, nrows, (uint32_t)(blk * kWave), outp[q], lane, pessimist != 0);
+      }
+      nlive += T[q].done ? 0 : 1;
+    }
+    if (lane == 0) l_live[buf][wv] = nlive;
+    if (blk + 1 < nblk) store_block(buf ^ 1);
+    __syncthreads();
+    int all_live = 0;
+#pragma unroll
+    for (int w = 0; w < kScanWaves; ++w) all_live += l_live[buf][w];
+    if (all_live == 0) break;
+  }
+#pragma unroll
+  for (int q = 0; q < kScanPer; ++q) {
+    if (!live[q]) continue;
+    // halted at the trigger: the pending length; rows ran out with the stream still placing: -3, k_sampler goes on behind the
+    // last placement; overflow: -1, the unit is run in full (k_place's record)
+    if (lane == 0) A.st[so[q]] = make_int4(T[q].nS, T[q].rem, T[q].flag != 0 ? -1 : (T[q].pend > 0 ? T[q].pend : -3), (int)T[q].used);
+    if (T[q].flag != 0 && lane == 0) atomicOr(A.flags, T[q].flag);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_merge_big: the FIRST consolidation (sort + merge(0) + workspace coverage, gat/Engine.pyx:582-606) of the long
 // lists, one workgroup of 256 threads per (sample, unit).  A single wave needs dozens of rounds per pass over a list of
 // thousands of segments and, with the list in LDS, only two or three such waves fit a CU; here four waves share the list

@@ -511,6 +511,19 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // (k_place_wide: kPlaceWide tiles per workgroup, the largest unit's rank table beside their rings)
         const dim3 gw((nsb + gat::kPlaceWide - 1) / gat::kPlaceWide, gy, gz);
         const size_t lds_wide = (size_t)P->max_hist * 4;
+        // calls of a few hundred tiles of a problem of simple units: one stream walked by the 64 lanes of a wave (k_place_scan:
+        // a stream's states as a prefix scan over its rows) instead of one lane walking it row by row -- the chain of the longest
+        // unit's tile, 0.37 ms on config 2 whatever the sample count, is what such a call waited for
+        const char* env_scan = getenv("GAT_PLACE_SCAN_TILES");
+        const int64_t scan_tiles = env_scan ? atoll(env_scan) : 768;      // (config 2: faster up to ~2 300 samples x 24 units per call)
+        const bool scan = P->sampler == GAT_SAMPLER_ANNOTATOR && P->all_simple && P->all_cm_ok && A.place_plain_step == 0 &&
+                          (int64_t)nsb * (int64_t)n_act <= scan_tiles;
+        if (scan) {
+          const int64_t n_tiles = (int64_t)nsb * n_act;
+          const unsigned nblocks = (unsigned)(((n_tiles + 7) / 8) * 8 * 4);
+          hipLaunchKernelGGL(gat::k_place_scan, dim3(nblocks), dim3(gat::kScanWaves * 64), 0, ctx->stream, A, (int)nsb,
+                             getenv("GAT_PLACE_SCAN_SEQ") ? 1 : 0);
+        } else
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
           if (mode == 3) {
             HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_wide<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
@@ -646,9 +659,13 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         const dim3 gu((unsigned)nb, gy, gz), gt((unsigned)((nb + 63) / 64), gy, gz);
         if (tree) HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         else HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        // (a call of a few hundred tiles does not fill the chip whatever the LDS of a workgroup: one launch for all classes,
+        //  each launch less is a tail less -- config 2 at 1 250 samples: k_consolidate 0.121 -> 0.101 ms)
+        const bool one_class = (int64_t)((nb + 63) / 64) * (int64_t)n_act <= 1024 && !getenv("GAT_SIZE_CLASSES");
         for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
           // one launch per size class, its LDS sized for the class's longest list
-          const int a0 = P->h_class_start[c], a1 = P->h_class_start[c + 1];
+          if (one_class && c > 0) break;
+          const int a0 = P->h_class_start[c], a1 = one_class ? P->h_class_start.back() : P->h_class_start[c + 1];
           // (as for k_merge_big: LDS for what the class's longest unit is expected to have placed -- its segments +- a renewal
           //  count's spread -- not for its slab region; the rare list beyond it is k_sampler's.  GAT_CONSOLIDATE_SLAB_LDS: the old size)
           const int n0 = (int)P->h_units[(size_t)P->h_order[(size_t)a0]].hist_total;

@@ -1169,11 +1169,21 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   uint32_t max_hist = 0;
   uint64_t work_simple = 0, work_all = 0, work_big_rank = 0;
   P->all_one_ws = !P->h_order.empty();
+  P->all_cm_ok = true;
   for (int32_t u : P->h_order) {
     const UnitDev& U = P->h_units[(size_t)u];
     const bool degenerate = !(U.hist_total > 2 && U.ws_total > 1);          // k_place leaves those to k_sampler
     const bool simple = U.n_ws == 1 && U.bucket <= 1 && U.hist_total < (uint32_t)gat::kPlaceRankLds && U.ws_total > 1;
     if (!degenerate && !simple) P->all_simple = false;
+    if (!degenerate && simple) {
+      // k_place's cm_ok: the offset draw's mask (of the range workspace length - 2 + length) is the position draw's (of the range
+      // workspace length - 1) for every length the unit can draw -- no power of two between them (k_place_scan runs only such units)
+      const uint2 w0v = h_ws[(size_t)U.ws_off];
+      const gat_segment w0 = {w0v.x, w0v.y};
+      const uint32_t range_p = U.ws_total - 1u, mask_p = 0xffffffffu >> __builtin_clz(range_p);
+      const uint32_t lmax = h_rank_len[(size_t)U.rank_off + U.hist_total - 1u];     // (rank_len[1 + rangeL], rangeL = hist_total - 2)
+      if ((uint64_t)(w0.end - w0.start - 2u) + (uint64_t)lmax > (uint64_t)mask_p) P->all_cm_ok = false;
+    }
     if (!degenerate) { work_all += U.hist_total; if (simple) work_simple += U.hist_total; }
     if (!degenerate && !(U.n_ws == 1 && U.bucket <= 1)) P->all_one_ws = false;
     if (!degenerate && U.hist_total >= (uint32_t)gat::kPlaceRankLds) work_big_rank += U.hist_total;

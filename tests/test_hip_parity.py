@@ -506,6 +506,54 @@ def test_contig_lists_longer_than_expected(ctx, monkeypatch):
     P.close()
 
 
+def _scan_case(ctx, seed, setenv):
+    """one random problem of SIMPLE units (one workspace segment per contig, bucket size 1, fewer than 1 024 working segments:
+    what k_place_scan takes): counts of all six counters and the sampled lists against the oracle.  Workspaces from a few
+    thousand bases -- where every tenth row falls into the band in which the offset draw's acceptance depends on the length,
+    and the scan has to be repeated -- to just below a power of two; odd seeds start every chunk from "no offset draw
+    accepted" (GAT_PLACE_SCAN_SEQ: the fixed-point loop runs dozens of times per chunk), every third seed keeps the
+    lane-per-stream kernels (GAT_PLACE_SCAN_TILES=0) as the cross-check of the cross-check."""
+    import collections
+    from gat_amd import problem
+    rs = np.random.RandomState(seed)
+    if seed % 2 == 1:
+        setenv("GAT_PLACE_SCAN_SEQ", "1")
+    setenv("GAT_PLACE_SCAN_TILES", "0" if seed % 3 == 0 else "100000")
+    n_contigs = int(rs.randint(1, 5))
+    sizes = [3000, 5000, 40000, (1 << 16) - 3, (1 << 16) + 700, (1 << 20) - 50, 3000000, 150000000]
+    contigs = collections.OrderedDict(("g%d" % i, int(rs.choice(sizes)) + int(rs.randint(0, 40))) for i in range(n_contigs))
+    mean_len = int(rs.choice([15, 60, 300]))
+    total = sum(contigs.values())
+    # (at most a tenth of the smallest workspace covered, a unit below 1 024 segments)
+    n_segs = int(max(6, min(rs.choice([40, 300, 1500, 3000]), min(contigs.values()) * n_contigs // (10 * mean_len), 900 * n_contigs)))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    annos = [("t%d" % t, synthetic.random_segments(contigs, int(rs.randint(5, 300)), int(rs.randint(20, 2000)),
+                                                   int(rs.randint(1 << 30)))) for t in range(int(rs.randint(1, 3)))]
+    ws = synthetic.workspace_contigs(contigs)
+    flat = problem.flatten_arrays(segs, annos, ws, None, bucket_size=1, nbuckets=100000)
+    counters = list(_lib.COUNTER_IDS.keys())
+    S = int(rs.choice([5, 70, 130]))                         # (a ragged last tile; more than one sample block)
+    first = int(rs.randint(0, 1000))
+    want, wsamples = O.run_samples(flat, counters, 9000 + seed, 1, first, first + S, want_samples=True)
+    P = _lib.Problem(ctx, flat)
+    try:
+        got = P.sample_and_count(counters, 9000 + seed, first, first + S)
+        for k, c in enumerate(counters):
+            assert np.array_equal(got[k], want[k]), (c, n_segs, dict(contigs))
+        seg, off = P.sample(9000 + seed, first, first + S)
+        assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
+    finally:
+        P.close()
+    return total
+
+
+@pytest.mark.parametrize("seed", list(range(400, 436)))
+def test_place_scan_vs_oracle(ctx, seed, monkeypatch):
+    """k_place_scan (one stream walked by the 64 lanes of a wave, the states as a prefix scan) on random problems of simple
+    units: bit-exact with the oracle, with the scan's fixed-point loop forced on odd seeds"""
+    _scan_case(ctx, seed, monkeypatch.setenv)
+
+
 @pytest.mark.parametrize("seed", list(range(100, 164)))
 def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
     """random combinations of the knobs that select code paths -- segments per unit (register / bucket / counting

@@ -1,5 +1,5 @@
 """one-off sweep of the fuzz generator of tests/test_hip_parity.py over many seeds (GPU vs oracle, bit-exact);
-usage: tools/fuzz_sweep.py first_seed n_seeds [edge|merged|long]"""
+usage: tools/fuzz_sweep.py first_seed n_seeds [edge|merged|long|scan]"""
 import importlib.util, os, sys, time
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, root)
@@ -22,17 +22,20 @@ first, n = int(sys.argv[1]), int(sys.argv[2])
 edge = len(sys.argv) > 3 and sys.argv[3] == "edge"
 merged = len(sys.argv) > 3 and sys.argv[3] == "merged"
 long_lists = len(sys.argv) > 3 and sys.argv[3] == "long"
+scan = len(sys.argv) > 3 and sys.argv[3] == "scan"
 handed = 0
 bad = 0
 outcomes = {}
 t0 = time.time()
 for seed in range(first, first + n):
-    for k in ("GAT_TEST_HUGE", "GAT_PLACE_NO_WIDE", "GAT_PLACE_NO_CM"):       # (what a seed's test sets stays set here: MP does not undo)
+    for k in ("GAT_TEST_HUGE", "GAT_PLACE_NO_WIDE", "GAT_PLACE_NO_CM", "GAT_PLACE_SCAN_SEQ", "GAT_PLACE_SCAN_TILES"):       # (what a seed's test sets stays set here: MP does not undo)
         os.environ.pop(k, None)
     if (merged or long_lists or edge) and seed % 4 >= 2:
         os.environ["GAT_PLACE_NO_CM"] = "1"           # k_place's steps as the compiler writes them (the shapes test picks by itself)
     try:
-        if merged:
+        if scan:
+            m._scan_case(ctx, seed, MP().setenv)
+        elif merged:
             for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED", "GAT_MERGED_BLOCK"):
                 os.environ.pop(k, None)
             m.test_merged_track_index_vs_oracle(ctx, seed, MP())
