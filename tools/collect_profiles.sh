@@ -19,6 +19,7 @@ for SH in $SHAPES; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq1 -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_sq1.log 2>&1
   rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/sq2 -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_sq2.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/sq3 -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_sq3.log 2>&1
   rocprofv3 --kernel-trace --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS --details /dev/null > $OUT/bench_tcc.log 2>&1
   cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 done
