@@ -340,8 +340,8 @@ struct gat_problem {
   DevBuf<int32_t> d_rng_rows;
   DevBuf<int4> d_st;
   DevBuf<int4> d_st2;                    // k_merge_big -> k_sampler hand-off (first consolidation of the long lists)
-#ifdef GAT_DIAG
-  DevBuf<unsigned long long> d_diag;     // diagnostic build: per work unit, cycles per phase of k_sampler
+#if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
+  DevBuf<unsigned long long> d_diag;     // diagnostic build: per work unit, cycles per phase of k_sampler (GAT_DIAG_CONS: of k_consolidate)
   DevBuf<unsigned long long> d_diag_place;   // ... per launch position, cycles per phase of k_place's loop
   DevBuf<unsigned long long> d_diag_tiles;   // ... per tile of k_place, begin and end (s_memrealtime)
 #endif

@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_place_scan(SamplerArgs A, i
 // written back to the slab, coverage and total length reduced over the block.  k_sampler resumes behind it with a
 // clean merged list (st2) and goes straight to the tail.  Lists the counting sort declines (clustered keys) are left
 // to k_sampler's own sort.
-constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 words, padded to 16 bytes)
+constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave: 513 prefix words, the pads' counter at 520, a dummy segment slot behind it
 #ifndef GAT_MERGE_THREADS
 #define GAT_MERGE_THREADS 512
 #endif
@@ -1901,7 +1901,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     GAT_PHASE(7)                                     // final merge (after a trim), workspace filter, list to the slab
     break;
   }
-#ifdef GAT_DIAG
+#if defined(GAT_DIAG) && !defined(GAT_DIAG_CONS)
   if (lane == 0 && A.diag != nullptr)
     for (int k = 0; k < 8; ++k) A.diag[so * 8 + k] = dg[k];
 #endif
@@ -2033,14 +2033,14 @@ struct ContigArgs {
 template <bool HUGE>
 __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  uint32_t* scratch = lds;                               // 513 words for the bucket sort
+  uint32_t* scratch = lds;                               // kSortScratchWords for the bucket sort
   const int lane = threadIdx.x;
   const int sidx = blockIdx.x;
   const int cp = (int)(blockIdx.y + blockIdx.z * gridDim.y);     // (contigs beyond one grid dimension)
   if (cp >= A.count) return;
   const int c = A.order[A.base + cp];
   uint2* out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
-  uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + 520);
+  uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + kSortScratchWords);
   int n = 0;
   const int u0 = A.contig_unit_off[c], u1 = A.contig_unit_off[c + 1];
   // Units are taken 64 at a time: lane k looks up unit k's list (count, place in the slab) -- one round trip for all of

@@ -460,12 +460,16 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.place_plain_step = getenv("GAT_PLACE_NO_CM") ? 1 : 0;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->flags_dev(); A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
-#ifdef GAT_DIAG
+#if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
       {
         const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
         if (P->d_diag.n < nd) HIPCHK(ctx, P->d_diag.alloc(nd));
         HIPCHK(ctx, hipMemsetAsync(P->d_diag.p, 0, nd * 8, ctx->stream));
         A.diag = P->d_diag.p;
+      }
+#endif
+#ifdef GAT_DIAG
+      {
         const size_t np = std::max<size_t>(1, P->h_order.size()) * 8;
         if (P->d_diag_place.n < np) HIPCHK(ctx, P->d_diag_place.alloc(np));
         HIPCHK(ctx, hipMemsetAsync(P->d_diag_place.p, 0, np * 8, ctx->stream));
@@ -787,9 +791,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         B.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
       }
       const int need_max = P->h_contig_order.empty() ? 64 : P->h_contig_need[(size_t)P->h_contig_order[0]];
-      size_t lds = (size_t)std::max(64, need_max) * 8 + 520 * 4;
+      size_t lds = (size_t)std::max(64, need_max) * 8 + gat::kSortScratchWords * 4;
       const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
-      if (huge_c) lds = 520 * 4;
+      if (huge_c) lds = gat::kSortScratchWords * 4;
       const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
       HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       B.order = P->d_contig_order.p;
@@ -801,7 +805,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         B.base = huge_c ? 0 : c0;
         B.count = huge_c ? P->n_contigs : c1 - c0;
         B.lds_cap = huge_c ? 0 : std::max(64, P->h_contig_need[(size_t)P->h_contig_order[(size_t)c0]]);
-        const size_t lds_k = huge_c ? lds : (size_t)B.lds_cap * 8 + 520 * 4;
+        const size_t lds_k = huge_c ? lds : (size_t)B.lds_cap * 8 + gat::kSortScratchWords * 4;
         const unsigned gcy = (unsigned)std::min(B.count, 32768), gcz = ((unsigned)B.count + gcy - 1) / gcy;
         if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
         else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
@@ -848,7 +852,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       if (st) st->n_retried += nb * (int64_t)P->h_order.size();
       return kRelayout;
     }
-#ifdef GAT_DIAG
+#if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
     if (const char* fn = getenv("GAT_DIAG_OUT")) {
       // shares of a k_sampler work unit's life per phase, summed over the batch (tools/diag_sampler.sh)
       const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;

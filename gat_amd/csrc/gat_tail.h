@@ -80,6 +80,17 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   else if (lane == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
   const int n = pre.x;
   if (pre.z < 0 || n <= 0 || n > A.lds_cap) return;               // not handed over by k_place / beyond this kernel's LDS: k_sampler's
+#ifdef GAT_DIAG_CONS
+  // (tools/diag_consolidate.sh: cycles of a unit per phase -- 0 record + workspace, 1 list in registers, 2 sort, 3 merge(0),
+  //  4 coverage + write-back; the stamps fence the schedule: shares, not a timing)
+  // (a build of its own, without GAT_DIAG: k_place's stamps push its hand-pipelined loops over their registers)
+  unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_t;
+#define GAT_CSTAMP(T) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); }
+  GAT_CSTAMP(dg_t);
+#define GAT_CPHASE(K) { unsigned long long t__; GAT_CSTAMP(t__); dg[K] += t__ - dg_t; dg_t = t__; }
+#else
+#define GAT_CPHASE(K)
+#endif
   uint32_t* scratch = lds;                                          // bucket-sort scratch
   uint2* seg = reinterpret_cast<uint2*>(lds + kSortScratchWords);
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
@@ -89,12 +100,14 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const uint32_t* __restrict__ ws_cdf = A.ws_cdf + Up->ws_off;
   constexpr int kWsRegMax = 64, kWsLoopMax = 32;
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
+  GAT_CPHASE(0)
   if (n <= kWave) {
     // A list within one round (the units of an isochore problem: ~50 segments) never touches LDS: one load, the sorting
     // network on registers, merge(0) as one scan -- heads by the running maximum of the ends, a head's merged end = the
     // running maximum in front of the next head --, coverage and running lengths on the head lanes, one store.
     const uint2 x = lane < n ? out[lane] : make_uint2(0xffffffffu, 0xffffffffu);
     uint32_t ks[1] = {x.x}, ke[1] = {x.y};
+    GAT_CPHASE(1)
 #ifdef GAT_SORT64_BPERMUTE
     for (int lk = 1; lk <= 6; ++lk) {
       sort_stage_lanes<1>(ks, ke, (1 << lk) - 1, lk - 1, lane);   // flip
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
 #else
     sort64_by_start(ks[0], ke[0], lane);                          // (partners within a row of 16 lanes by DPP modifiers)
 #endif
+    GAT_CPHASE(2)
     const bool valid = ks[0] != ke[0];                            // (empty segments are dropped; the padding is empty)
     const int32_t m = wave_incl_max_i32(valid ? (int32_t)ke[0] : INT32_MIN, lane);
     const int32_t excl = __builtin_amdgcn_update_dpp(INT32_MIN, m, 0x138, 0xf, 0xf, false);   // wave_shr:1
@@ -115,6 +129,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     const int last = later ? lane + __builtin_ctzll(later) : kWave - 1;                        // the lane in front of the next head
     const uint32_t mend = (uint32_t)__builtin_amdgcn_ds_bpermute(last << 2, m);
     const uint32_t s1 = head ? ks[0] : 0u, e1 = head ? mend : 0u;
+    GAT_CPHASE(3)
     uint32_t cov1 = 0;
     const uint32_t* __restrict__ tree_start1 = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
     if (nws <= 8) cov1 = ws_overlap_regs(W, s1, e1);
@@ -128,6 +143,10 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     cov1 = wave_total_u32(cov1);
     const uint32_t run1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, kWave - 1);
     if (lane == 0) A.st2[sa] = make_int4(nU1, (int)cov1, (int)run1, 1);
+    GAT_CPHASE(4)
+#ifdef GAT_DIAG_CONS
+    if (lane == 0 && A.diag != nullptr) for (int k = 0; k < 8; ++k) A.diag[((int64_t)sidx * A.n_units + Up->pad) * 8 + k] = dg[k];
+#endif
     return;
   }
   if (n > 1024) {
@@ -147,15 +166,31 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
       wave_sort_auto(seg, n, lane);
     }
   } else {
-    // (all loads of the list in flight together: nothing else hides their latency)
-    uint2 v[8];
+    // (all loads of the list in flight together: nothing else hides their latency; the bucket sort takes the list from these
+    //  registers -- it used to be stored to LDS and read back first -- and only a list it declines goes there unsorted)
+    uint32_t ks[8], ke[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; v[r] = i < n ? out[i] : make_uint2(0u, 0u); }
+    for (int r = 0; r < 8; ++r) {
+      const int i = r * kWave + lane;
+      const uint2 x = out[i < n ? i : 0];
+      ks[r] = i < n ? x.x : 0u; ke[r] = i < n ? x.y : 0u;
+    }
+    GAT_CPHASE(1)
+    bool done = false;
+    if (n > 256) done = wave_sort_bucket_core<8>(seg, ks, ke, n, scratch, lane);
+    else {
+      const uint32_t ks4[4] = {ks[0], ks[1], ks[2], ks[3]}, ke4[4] = {ke[0], ke[1], ke[2], ke[3]};
+      done = wave_sort_bucket_core<4>(seg, ks4, ke4, n, scratch, lane);
+    }
+    if (!done) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = v[r]; }
-    wave_sort_fast<8>(seg, n, scratch, lane);
+      for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = make_uint2(ks[r], ke[r]); }
+      wave_sort_auto(seg, n, lane);
+    }
   }
+  GAT_CPHASE(2)
   const int nU = wave_merge0(seg, n, lane);
+  GAT_CPHASE(3)
   // coverage (intersect(workspace).sum()), total length, running lengths; the merged list goes back to the slab
   uint32_t cov = 0, run = 0;
   const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
@@ -178,6 +213,12 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   }
   cov = wave_total_u32(cov);
   if (lane == 0) A.st2[sa] = make_int4(nU, (int)cov, (int)run, 1);
+  GAT_CPHASE(4)
+#ifdef GAT_DIAG_CONS
+  if (lane == 0 && A.diag != nullptr) for (int k = 0; k < 8; ++k) A.diag[((int64_t)sidx * A.n_units + Up->pad) * 8 + k] = dg[k];
+#endif
+#undef GAT_CPHASE
+#undef GAT_CSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------
