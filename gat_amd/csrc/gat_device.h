@@ -438,45 +438,36 @@ __device__ __forceinline__ void wave_sort_auto(uint2* seg, int n, int lane) {
 // prefix sum the bucket offsets, and a rank among the few members of its own bucket the final
 // index.  ~10x fewer instructions than the sorting network.  Returns false (nothing written) when
 // the keys are too clustered (a bucket with more than 16 members, or all starts equal); the caller
-// then uses the network.  scratch: 528 words of LDS (kSortScratchWords).
-// (the list in registers: element r * 64 + lane in ks[r] / ke[r]; seg only receives the sorted list)
-// Round 5: STRAIGHT-LINE.  The phase stamps of tools/diag_consolidate.sh put 58 % of a config-2 unit's cycles into this sort --
-// ~1 500 instructions for 400 elements, most of them the price of `if (i < n) { ... }` around every LDS operation of every
-// round (mask, branch, restore; a scalar branch on `direct` per element) in a kernel that is bound by instruction issue (4
-// waves per SIMD, 0.4 instructions per cycle).  Now every lane runs every round: an index beyond the list is a PAD -- its
-// atomic goes to a counter behind the buckets, its stores to a dummy slot behind the scratch words, its count is 0 -- and
-// what used to be branches are selects.  The bucket scale comes from one v_rcp_f32 (rounded down far enough that no key
-// lands beyond the last bucket) instead of a 64-bit division: any monotone map of the keys gives the same sorted list.
+// then uses the network.  scratch: 513 words of LDS.
 template <int E, bool MEM = false>
-__device__ __forceinline__ bool wave_sort_bucket_core(uint2* seg, const uint32_t (&ks)[E], const uint32_t (&ke)[E], int n, uint32_t* scratch,
-                                                      int lane) {
-  constexpr int NB = 512, PER = NB / kWave, PAD = NB + 8;
-  static_assert(NB + 16 <= 528, "scratch: NB + 1 prefix words, the pads' counter at NB + 8, a dummy segment slot at 522");
-  uint2* const dummy = reinterpret_cast<uint2*>(scratch + 522);
+__device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* scratch, int lane) {
+  constexpr int NB = 512, PER = NB / kWave;
+  uint32_t ks[E], ke[E];
+  wave_sync<MEM>();
   uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
   for (int r = 0; r < E; ++r) {
-    const bool valid = r * kWave + lane < n;
-    const uint32_t a = valid ? ks[r] : 0xffffffffu, b = valid ? ks[r] : 0u;
-    lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    const int i = r * kWave + lane;
+    ks[r] = 0; ke[r] = 0;
+    if (i < n) { const uint2 x = seg[i]; ks[r] = x.x; ke[r] = x.y; lo = x.x < lo ? x.x : lo; hi = x.x > hi ? x.x : hi; }
   }
   lo = wave_min_u32(lo); hi = wave_max_u32(hi);
   const uint32_t span = hi - lo;
   if (span == 0) return false;
   const bool direct = span < (uint32_t)NB;                       // fewer positions than buckets
-  // floor(NB * 2^32 / (span + 1)) or a little less: d * scale < NB * 2^32 for every d <= span
-  const float scale_f = 2199023255552.0f * __builtin_amdgcn_rcpf((float)span + 1.0f) * 0.99999905f;      // NB * 2^32 = 2^41
-  const uint32_t scale = direct ? 0u : (uint32_t)scale_f;
-#pragma unroll
-  for (int q = 0; q < (PAD + kWave) / kWave; ++q) { const int i = q * kWave + lane; if (i <= PAD) scratch[i] = 0; }
+  const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)NB << 32) / ((uint64_t)span + 1u));
+  for (int i = lane; i <= NB; i += kWave) scratch[i] = 0;
   wave_sync<MEM>();
   uint32_t bk[E], slot[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) {
-    const bool valid = r * kWave + lane < n;
-    const uint32_t d = ks[r] - lo, b = direct ? d : __umulhi(d, scale);
-    bk[r] = valid ? b : (uint32_t)PAD;
-    slot[r] = atomicAdd(&scratch[bk[r]], 1u);
+    const int i = r * kWave + lane;
+    bk[r] = 0; slot[r] = 0;
+    if (i < n) {
+      const uint32_t d = ks[r] - lo;
+      bk[r] = direct ? d : __umulhi(d, scale);
+      slot[r] = atomicAdd(&scratch[bk[r]], 1u);
+    }
   }
   wave_sync<MEM>();
   // exclusive prefix over the bucket counts: lane owns PER consecutive buckets
@@ -493,48 +484,32 @@ __device__ __forceinline__ bool wave_sort_bucket_core(uint2* seg, const uint32_t
   wave_sync<MEM>();
   uint32_t base[E], cnt[E];
 #pragma unroll
-  for (int r = 0; r < E; ++r) { base[r] = scratch[bk[r]]; cnt[r] = scratch[bk[r] + 1]; }
-#pragma unroll
   for (int r = 0; r < E; ++r) {
-    const bool valid = r * kWave + lane < n;
-    cnt[r] = valid ? cnt[r] - base[r] : 0u;
-    base[r] = valid ? base[r] : 0u;
-    if constexpr (MEM) { if (valid) seg[base[r] + slot[r]] = make_uint2(ks[r], ke[r]); }   // (the list in global memory: no dummy there)
-    else { uint2* const dst = valid ? seg + (base[r] + slot[r]) : dummy; *dst = make_uint2(ks[r], ke[r]); }
+    const int i = r * kWave + lane;
+    base[r] = 0; cnt[r] = 0;
+    if (i < n) { base[r] = scratch[bk[r]]; cnt[r] = scratch[bk[r] + 1] - base[r]; seg[base[r] + slot[r]] = make_uint2(ks[r], ke[r]); }
   }
   wave_sync<MEM>();
   uint32_t rank[E];
 #pragma unroll
   for (int r = 0; r < E; ++r) rank[r] = 0;
   for (uint32_t m = 0; m < maxc; ++m) {
-    uint32_t s2[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) s2[r] = seg[base[r] + (m < cnt[r] ? m : 0u)].x;      // (a pad: base 0, count 0)
-#pragma unroll
-    for (int r = 0; r < E; ++r)
-      rank[r] += (m < cnt[r] && (s2[r] < ks[r] || (s2[r] == ks[r] && m < slot[r]))) ? 1u : 0u;
+    for (int r = 0; r < E; ++r) {
+      if (m < cnt[r]) {
+        const uint32_t s2 = seg[base[r] + m].x;
+        rank[r] += (s2 < ks[r] || (s2 == ks[r] && m < slot[r])) ? 1u : 0u;
+      }
+    }
   }
-  wave_sync<MEM>();
-#pragma unroll
-  for (int r = 0; r < E; ++r) {
-    const bool valid = r * kWave + lane < n;
-    if constexpr (MEM) { if (valid) seg[base[r] + rank[r]] = make_uint2(ks[r], ke[r]); }
-    else { uint2* const dst = valid ? seg + (base[r] + rank[r]) : dummy; *dst = make_uint2(ks[r], ke[r]); }
-  }
-  wave_sync<MEM>();
-  return true;
-}
-template <int E, bool MEM = false>
-__device__ __forceinline__ bool wave_sort_bucket(uint2* seg, int n, uint32_t* scratch, int lane) {
-  uint32_t ks[E], ke[E];
   wave_sync<MEM>();
 #pragma unroll
   for (int r = 0; r < E; ++r) {
     const int i = r * kWave + lane;
-    const uint2 x = seg[i < n ? i : 0];
-    ks[r] = i < n ? x.x : 0u; ke[r] = i < n ? x.y : 0u;
+    if (i < n) seg[base[r] + rank[r]] = make_uint2(ks[r], ke[r]);
   }
-  return wave_sort_bucket_core<E, MEM>(seg, ks, ke, n, scratch, lane);
+  wave_sync<MEM>();
+  return true;
 }
 // Counting sort by position bucket for long lists whose unsorted source is still in global memory
 // (the slab k_place wrote): histogram pass, exclusive prefix, scatter pass into the LDS list

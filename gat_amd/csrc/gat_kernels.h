@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(kScanWaves * 64) void k_place_scan(SamplerArgs A, i
 // written back to the slab, coverage and total length reduced over the block.  k_sampler resumes behind it with a
 // clean merged list (st2) and goes straight to the tail.  Lists the counting sort declines (clustered keys) are left
 // to k_sampler's own sort.
-constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave: 513 prefix words, the pads' counter at 520, a dummy segment slot behind it
+constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 words, padded to 16 bytes)
 #ifndef GAT_MERGE_THREADS
 #define GAT_MERGE_THREADS 512
 #endif

@@ -166,27 +166,19 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
       wave_sort_auto(seg, n, lane);
     }
   } else {
-    // (all loads of the list in flight together: nothing else hides their latency; the bucket sort takes the list from these
-    //  registers -- it used to be stored to LDS and read back first -- and only a list it declines goes there unsorted)
-    uint32_t ks[8], ke[8];
+    // (all loads of the list in flight together: nothing else hides their latency)
+    uint2 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int i = r * kWave + lane;
-      const uint2 x = out[i < n ? i : 0];
-      ks[r] = i < n ? x.x : 0u; ke[r] = i < n ? x.y : 0u;
-    }
+    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; v[r] = i < n ? out[i] : make_uint2(0u, 0u); }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = v[r]; }
     GAT_CPHASE(1)
-    bool done = false;
-    if (n > 256) done = wave_sort_bucket_core<8>(seg, ks, ke, n, scratch, lane);
-    else {
-      const uint32_t ks4[4] = {ks[0], ks[1], ks[2], ks[3]}, ke4[4] = {ke[0], ke[1], ke[2], ke[3]};
-      done = wave_sort_bucket_core<4>(seg, ks4, ke4, n, scratch, lane);
-    }
-    if (!done) {
-#pragma unroll
-      for (int r = 0; r < 8; ++r) { const int i = r * kWave + lane; if (i < n) seg[i] = make_uint2(ks[r], ke[r]); }
-      wave_sort_auto(seg, n, lane);
-    }
+    // (round 5, measured and dropped: the bucket sort taking the list from these registers instead of from LDS, and in
+    //  straight-line form -- pads instead of `if (i < n)` around every LDS operation, selects instead of branches: the dynamic
+    //  instruction count did not fall (selects for branches, one for one), config 2 0.69 -> 0.68 ms, and the arrays that
+    //  form keeps alive took the kernel from 54 to 80 registers and k_contig from 99 to 132: config 3 1.52 -> 1.87 and
+    //  0.99 -> 1.13 ms)
+    wave_sort_fast<8>(seg, n, scratch, lane);
   }
   GAT_CPHASE(2)
   const int nU = wave_merge0(seg, n, lane);
