@@ -1234,6 +1234,17 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   const int n = pre.x;
   if (tid == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
   if (pre.z < 0 || n <= 1024 || n > A.lds_cap) return;          // not handed over by k_place / short list: k_sampler does it
+#ifdef GAT_DIAG_CONS
+  // (tools/diag_consolidate.sh: a workgroup's cycles per phase -- 0 record + workspace, 1 histogram pass over the slab, 2 prefix,
+  //  3 scatter pass over the slab into LDS, 4 buckets sorted thread by thread, 5 merge(0), 6 coverage, 7 running lengths; a
+  //  barrier and a drained wave in front of every stamp)
+  unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dg_t;
+#define GAT_MSTAMP(T) { __syncthreads(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); }
+  GAT_MSTAMP(dg_t);
+#define GAT_MPHASE(K) { unsigned long long t__; GAT_MSTAMP(t__); dg[K] += t__ - dg_t; dg_t = t__; }
+#else
+#define GAT_MPHASE(K)
+#endif
   uint2* seg = reinterpret_cast<uint2*>(lds);                     // lds_cap entries
   uint32_t* hist = lds + 2 * (size_t)A.lds_cap;                  // big_buckets + 1
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
@@ -1263,6 +1274,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)nb << 32) / ((uint64_t)span + 1u));
   for (int i = tid; i <= nb; i += kMergeThreads) hist[i] = 0;
   __syncthreads();
+  GAT_MPHASE(0)
   for (int base = 0; base < n; base += kB * kMergeThreads) {
     uint32_t x[kB];
 #pragma unroll
@@ -1272,6 +1284,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       if (base + q * kMergeThreads + tid < n) { const uint32_t d = x[q] - lo; atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u); }
   }
   __syncthreads();
+  GAT_MPHASE(1)
   {
     // exclusive prefix over the buckets: thread owns nb/256 consecutive ones
     const int per = nb / kMergeThreads;
@@ -1288,6 +1301,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
     for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
   }
   __syncthreads();
+  GAT_MPHASE(2)
   for (int base = 0; base < n; base += kB * kMergeThreads) {
     uint2 v[kB];
 #pragma unroll
@@ -1300,6 +1314,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       }
   }
   __syncthreads();
+  GAT_MPHASE(3)
   for (int b = tid; b < nb; b += kMergeThreads) {                // hist[b] is now the END of bucket b
     const int e = (int)hist[b], s0 = b ? (int)hist[b - 1] : 0;
     for (int i = s0 + 1; i < e; ++i) {
@@ -1310,6 +1325,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
     }
   }
   __syncthreads();
+  GAT_MPHASE(4)
 
   // ---- merge(0) (gat/SegmentList.pyx:756-816): head = first non-empty, or int32(start) > running max end
   int count = 0;
@@ -1353,6 +1369,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   }
   if (count > 0 && tid == 0) out[count - 1].y = (uint32_t)carry;
   __syncthreads();                                                // the merged list in the slab, visible to the block
+  GAT_MPHASE(5)
 
   // ---- coverage of the merged list inside the workspace, and its total length
   uint32_t cov = 0, tot = 0;
@@ -1381,6 +1398,7 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   }
   cov = block_reduce_u32(cov, red, tid, false, false);
   tot = block_reduce_u32(tot, red, tid, false, false);
+  GAT_MPHASE(6)
   if (A.cum != nullptr) {
     // split path: the running lengths k_tail's position draw searches (block-wide inclusive scan, 256 elements a round)
     uint32_t* __restrict__ cum = A.cum + (((int64_t)sidx * A.slab_stride + Up->slab_off) >> 3);
@@ -1400,6 +1418,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
     }
   }
   if (tid == 0) A.st2[sa] = make_int4(count, (int)cov, (int)tot, 1);
+  GAT_MPHASE(7)
+#ifdef GAT_DIAG_CONS
+  if (tid == 0 && A.diag != nullptr) for (int k = 0; k < 8; ++k) A.diag[((int64_t)sidx * A.n_units + Up->pad) * 8 + k] = dg[k];
+#undef GAT_MSTAMP
+#endif
+#undef GAT_MPHASE
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic build (-DGAT_DIAG_CONS): where a k_consolidate work unit spends its cycles -- unit record + workspace,
+# Diagnostic build (-DGAT_DIAG_CONS): where a k_consolidate work unit (config4: a k_merge_big workgroup) spends its cycles -- unit record + workspace,
 # the list into registers, the sort, merge(0), coverage + write-back.  Every stamp drains the wave's memory queues (the shares
 # are of a unit walked phase by phase: bounds, not the product kernel's timing).
 # usage (GPU box): bash tools/diag_consolidate.sh <tag> [config:samples ...]   (the library is built beforehand where hipcc is:
@@ -20,6 +20,12 @@ for SH in $SHAPES; do
 import json, sys
 names = [("prologue", "unit record + workspace"), ("sort", "list into registers"), ("merge", "sort"), ("coverage", "merge(0)"),
          ("fast_paths", "coverage + write-back")]
+kernel = "k_consolidate"
+if sys.argv[2] == "config4":       # long lists: k_merge_big's stamps land in the same slots (a workgroup per unit)
+    kernel = "k_merge_big"
+    names = [("prologue", "record + workspace + zeroed histogram"), ("sort", "histogram pass over the slab"), ("merge", "prefix over the buckets"),
+             ("coverage", "scatter pass over the slab into LDS"), ("fast_paths", "buckets sorted thread by thread"), ("trim", "merge(0)"),
+             ("draws_placement", "coverage"), ("final_filter_write", "running lengths + record")]
 tot, wu = {}, 0
 for l in open(sys.argv[1]):
     d = json.loads(l)
@@ -27,7 +33,7 @@ for l in open(sys.argv[1]):
     wu += d["work_units"]
     for k, v in d["cycles"].items(): tot[k] = tot.get(k, 0) + v
 s = sum(tot.get(k, 0) for k, _ in names)
-print("k_consolidate, %s at %s samples per call: %.0f cycles per work unit" % (sys.argv[2], sys.argv[3], s / max(1, wu)))
+print("%s, %s at %s samples per call: %.0f cycles per work unit" % (kernel, sys.argv[2], sys.argv[3], s / max(1, wu)))
 for k, what in names: print("  %-26s %5.1f %%  %8.0f cycles/unit" % (what, 100 * tot.get(k, 0) / max(1, s), tot.get(k, 0) / max(1, wu)))
 PY
 done
