@@ -14,19 +14,23 @@ running `python -m torch.distributed.run ... bench.py`, before anything here tou
 JSON line.  With N > 1 every rank takes its own contiguous range of sample ids (weak scaling), the step ends with
 ONE RCCL all-gather of the per-sample count matrix, and rank 0 reads the gathered matrix back.
 
-Prints one JSON line (rank 0): metric/value per the driver contract plus
+Prints ONE JSON line on stdout (rank 0), below 3 KB (final_line; the driver parses stdout, and round 4's 21 KB line was cut
+by its reader): metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline / dtype /
+data / config per the driver contract -- value and ms_per_step are the K steps timed right behind the W warm-up steps of this
+process -- plus
   roofline       : the overlap-count kernel: algorithmic bytes / kernel time measured with HIP events in this run.  For
                    k_count_seg the bytes are SURVEY.md 8d's contract; k_count_merged never moves those (it looks a sample
-                   segment up once in an index of all tracks), so its bytes are what it does move, counted by the kernel
-                   itself: segments once + index entries read + grid look-ups + partials (contract number kept beside)
+                   segment up once in an index of all tracks): bound "l2", its L2 requests against the L2s' peak
+  cpu_baseline   : the CPU oracle (oracle/gat_oracle.c, a port of the reference) timed on this host (N = 1 only)
+and a few small extras (sustained_value, the step's HBM bytes, strong-scaling ms per job, the extra shapes' values, under N > 1
+the collective's figures).  Everything else goes to the details file (--details, default bench_details.json beside this script):
   kernels        : per-kernel time of the step (HIP events on the launch stream)
   sustained      : the same step repeated for at least a second behind the driver's K steps (mean, min, max over repeats)
-  configs        : the same for config3 / config5 / config4 shapes
+  configs        : the same for config3 / config5 / config4 shapes (config3 with its own cpu_baseline)
   strong_scaling : the metric's own job -- 10 000 samples in all -- cut into N shards: at N = 1 the time of one shard's
                    call for N = 1, 2, 4, 8 (what each of N GPUs would run; no collective), under --gpus N the job itself
   api            : gat_amd.run() end to end (the drop-in seam: observed counts, problem creation, sampling + counting,
-                   statistics, result rows) on config2 and config3, 10 000 samples
-  cpu_baseline   : the CPU oracle (oracle/gat_oracle.c, a port of the reference) timed on this host
+                   statistics, result rows) on config2 and config3, 10 000 samples; ms_with_inputs adds building the collections
 """
 import argparse
 import json
