@@ -196,8 +196,10 @@ def _sample_start(segs, annotations, workspace, sampler, counters, num_samples, 
         if shared_annos is None and flat.get("annos") is not None:
             total = float(len(flat["segs"]))
             mean = float((flat["segs"]["end"].astype(np.int64) - flat["segs"]["start"]).sum()) / total if total else 0.0
-            # (built by a thread of the library while this one goes on: the sampler's kernels do not wait for the tables)
-            shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean, asynchronous=True)
+            # (built by a thread of the library while this one goes on: the sampler's kernels do not wait for the tables; a run
+            #  that only asks for the nucleotide counters -- the default -- says so: no per-track tables beside the merged index)
+            shared_annos = share[akey] = _lib.Annotations(ctx, flat, mean_segment_length=mean, asynchronous=True,
+                                                         nucleotide_only=all(n in ("nucleotide-overlap", "nucleotide-density") for n in names))
     job.P = _lib.Problem(ctx, flat, annotations=shared_annos)
     rank, world, _ = _dist_state()
     if world == 1 and mt_state is None and num_samples > 0 and not _force_collective_path():

@@ -400,9 +400,10 @@ class Annotations(object):
     """the annotation side of a problem as a device-resident object of its own (gat_annotations): made once per run(),
     shared by the problems of every segment track whose contigs are `flat`'s (same names, same order)."""
 
-    def __init__(self, ctx, flat, mean_segment_length=0.0, asynchronous=False):
+    def __init__(self, ctx, flat, mean_segment_length=0.0, asynchronous=False, nucleotide_only=False):
         """asynchronous: the tables are built by a thread of the library while the caller goes on (GAT_ANNOTATIONS_ASYNC);
-        the arrays handed over stay referenced by this object."""
+        the arrays handed over stay referenced by this object.  nucleotide_only: only the nucleotide counters will be asked
+        for (GAT_ANNOTATIONS_NUCLEOTIDE_ONLY: where the merged index is built the per-track tables are left out)."""
         self.ctx = ctx
         keep = self._keep = {}
 
@@ -422,7 +423,7 @@ class Annotations(object):
         else:
             assert len(keep["anno_off"]) == d.n_tracks * d.n_contigs + 1
         d.mean_segment_length = float(mean_segment_length)
-        d.flags = 1 if asynchronous else 0
+        d.flags = (1 if asynchronous else 0) | (2 if nucleotide_only else 0)
         self.n_tracks, self.n_contigs, self.merge_contigs = d.n_tracks, d.n_contigs, d.merge_contigs
         self._h = C.c_void_p()
         _check(lib().gat_annotations_create(ctx._h, C.byref(d), C.byref(self._h)), ctx._h)

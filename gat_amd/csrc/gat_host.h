@@ -225,7 +225,9 @@ struct DevBuf {
 };
 
 // annotations on the device: SoA starts / ends / exclusive cumulated lengths + CSR offsets
+constexpr int kMergedWavesHost = 4;   // waves of a k_count_merged workgroup (gat_kernels.h: kMergedThreads / 64; asserted in gat_mi355.hip)
 struct AnnoDev {
+  bool per_track = true;       // the per-track tables (SoA, grids) exist; false: merged index only (GAT_ANNOTATIONS_NUCLEOTIDE_ONLY)
   DevBuf<uint32_t> start, end, cumx, grid;
   DevBuf<int64_t> off, goff;
   DevBuf<int32_t> shift, cells;
@@ -379,6 +381,6 @@ struct gat_problem {
 
 // gat_prep.hip
 int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
-                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len = 0.0);
+                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len = 0.0, bool nucleotide_only = false);
 int layout_slab(gat_problem* P);
 int upload_layout(gat_ctx* ctx, gat_problem* P);

@@ -246,6 +246,7 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
   return GAT_OK;
 }
 
+static_assert(gat::kMergedThreads / gat::kWave == kMergedWavesHost, "gat_host.h: kMergedWavesHost");
 // which kernel serves the segment-side counters (the choice launch_count makes)
 static int count_route(const gat_ctx* ctx, bool has_merged, const Counters& C, int n_contigs, int n_tracks, int swap_capx) {
   if (!C.any_seg || n_contigs <= 0) return GAT_COUNT_KERNEL_NONE;
@@ -272,6 +273,9 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
   A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
   if (A.n_samples <= 0 || A.n_tracks <= 0) return GAT_OK;
+  if (!annos.per_track && (C.any_anno || (C.any_seg && count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx) != GAT_COUNT_KERNEL_MERGED)))
+    return set_err(ctx, GAT_ERR_ARG, "the annotation tables were made for the nucleotide counters only (GAT_ANNOTATIONS_NUCLEOTIDE_ONLY): "
+                                     "no per-track tables for the counters asked for");
   if (C.any_seg) {
     const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
     const int E_max = env_e ? atoi(env_e) : 1024;

@@ -454,7 +454,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
 // (a CSR array passes off and off + 1); checked: whether the lists have to be verified normalized (the ones the library
 // merged itself are).  want_merged: build the merged index when the problem's shape asks for it (see below).
 int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_t* lbeg, const int64_t* lend, int64_t n_lists,
-                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len) {
+                int32_t n_groups, bool want_merged, bool checked, double mean_seg_len, bool nucleotide_only) {
   PrepTimer tm;
   A.h_off.assign((size_t)n_lists + 1, 0);
   A.max_m = 0;
@@ -486,6 +486,20 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
         return check_list(ctx, annos + lbeg[l], lend[l] - lbeg[l], "annotation", l);
       }
   }
+  // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
+  // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
+  // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
+  const int64_t n_tracks = n_groups > 0 ? n_lists / n_groups : 0;
+  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
+  const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+  const bool do_merged = want_merged && n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged);
+  // GAT_ANNOTATIONS_NUCLEOTIDE_ONLY: the per-track tables are k_count_seg's / k_count_anno's; a caller that will only ask for the
+  // nucleotide counters never reaches them once the merged index exists (config 3: 2.0 of the build's 5.3 ms)
+  // (... and the count launch would take it: count_route's conditions, gat_mi355.hip)
+  A.per_track = !(nucleotide_only && do_merged && n_tracks * 4 * kMergedWavesHost + 1024 <= (int64_t)ctx->max_lds &&
+                  !getenv("GAT_COUNT_NO_MERGED"));
+  if (A.per_track) {
   {
     // starts / ends / running lengths: one pass over the lists, written straight into the pinned staging buffer (three
     // arrays side by side) when they fit one piece of it, and sent from there
@@ -529,7 +543,6 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   }
   // per group (contig) a uniform grid over the start coordinates, about one start per cell:
   // grid[g] = #starts < (g << shift); the count kernels look a position up instead of bisecting
-  const int64_t n_tracks = n_groups > 0 ? n_lists / n_groups : 0;
   std::vector<int32_t> h_shift((size_t)std::max(1, n_groups), 0), h_cells((size_t)std::max(1, n_groups), 1);
   std::vector<int64_t> h_goff((size_t)n_lists + 1, 0);
   A.max_cells = 1;
@@ -575,15 +588,10 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   HIPCHK(ctx, A.goff.upload(h_goff, ctx));
   HIPCHK(ctx, A.shift.upload(h_shift, ctx));
   HIPCHK(ctx, A.cells.upload(h_cells, ctx));
+  }
   HIPCHK(ctx, A.off.upload(A.h_off, ctx));
   tm.lap("  annotation tables: offsets sent");
-  // the merged index: from four tracks up -- and for fewer when their lists do not fit the LDS tile of k_count_seg (it
-  // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
-  // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
-  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
-  const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
-  const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
-  if (want_merged && n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged)) {
+  if (do_merged) {
     int rc = build_merged(ctx, A, annos, lbeg, lend, n_tracks, n_groups, mean_seg_len);
     if (rc) return rc;
   }
@@ -840,14 +848,14 @@ static int annotations_build(gat_ctx* ctx, gat_annotations* A, const gat_annotat
     if ((rc = group_annotations(ctx, &pd, buf, gbeg, gend))) return rc;
     tm.lap("annotations grouped by contig");
     rc = build_annos(ctx, A->dev, buf.data(), gbeg.data(), gend.data(), (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true,
-                     d->merge_contigs != 0, d->mean_segment_length);
+                     d->merge_contigs != 0, d->mean_segment_length, (d->flags & GAT_ANNOTATIONS_NUCLEOTIDE_ONLY) != 0);
   } else {
     if ((int64_t)d->n_tracks * d->n_contigs > 0 && (!d->anno_off || (!d->annos && d->anno_off[(int64_t)d->n_tracks * d->n_contigs] > 0)))
       return set_err(ctx, GAT_ERR_ARG, "gat_annotations_create: NULL lists");
     static const int64_t kZero[2] = {0, 0};
     const int64_t* off = d->anno_off ? d->anno_off : kZero;
     rc = build_annos(ctx, A->dev, d->annos, off, off + 1, (int64_t)d->n_tracks * d->n_contigs, d->n_contigs, true, false,
-                     d->mean_segment_length);
+                     d->mean_segment_length, (d->flags & GAT_ANNOTATIONS_NUCLEOTIDE_ONLY) != 0);
   }
   if (rc) return rc;
   HIPCHK(ctx, stage_flush(ctx));

@@ -105,7 +105,7 @@ typedef struct {
   const int32_t* anno_group;
   double mean_segment_length;   /* of the segments that will be counted against them, 0 if unknown: picks the form of  */
                                 /* the merged index (speed only, never a result)                                       */
-  int32_t flags;                /* GAT_ANNOTATIONS_ASYNC or 0                                                           */
+  int32_t flags;                /* 0 or an OR of GAT_ANNOTATIONS_ASYNC, GAT_ANNOTATIONS_NUCLEOTIDE_ONLY                 */
 } gat_annotations_desc;
 
 /* gat_annotations_create returns at once and a thread of the library builds the tables (its own stream and staging
@@ -115,6 +115,12 @@ typedef struct {
  * gat_wait).  Errors of the build are reported by the call that first needs the tables.  Honoured where the shape alone
  * tells which count kernel will run (four tracks or more); otherwise the build is synchronous. */
 #define GAT_ANNOTATIONS_ASYNC 1
+/* The object will only be counted against with the nucleotide counters (GAT_COUNTER_NUCLEOTIDE_OVERLAP / _DENSITY: what
+ * gat.run() does unless the caller asked for segment or annotation counters).  Where the merged index of all tracks is built
+ * (four tracks or more, or lists beyond the per-track kernel's LDS tile) the per-track tables -- starts / ends / running
+ * lengths and the position grids, a third of the build -- are left out; gat_sample_and_count with any other counter on a
+ * problem made against such an object fails with GAT_ERR_ARG.  Ignored where no merged index is built. */
+#define GAT_ANNOTATIONS_NUCLEOTIDE_ONLY 2
 
 /* per-call statistics of gat_sample_and_count / gat_sample (device time from HIP events on the
  * ctx stream; counts summed over all (sample, unit) work units of the call).  ms_total and ms_count_main are always

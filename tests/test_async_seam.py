@@ -177,6 +177,37 @@ def test_annotation_tables_built_while_the_device_samples(ctx, n_tracks, isochor
     P2.close()
 
 
+@pytest.mark.parametrize("n_tracks,isochores", [(6, True), (5, False), (2, False)])
+def test_annotation_tables_for_the_nucleotide_counters_only(ctx, n_tracks, isochores):
+    """GAT_ANNOTATIONS_NUCLEOTIDE_ONLY: with four tracks or more only the merged index is built -- the nucleotide counters
+    equal the oracle, any other counter is refused (GAT_ERR_ARG -> ValueError); with fewer tracks (no merged index for lists
+    that fit the per-track kernel) the flag changes nothing."""
+    rs = np.random.RandomState(300 + n_tracks)
+    flat = _random_problem(rs, 4, 400, n_tracks, isochores)
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    S = 48
+    want, _ = O.run_samples(flat, counters + ["segment-overlap"], 23, 1, 0, S)
+    A = _lib.Annotations(ctx, flat, mean_segment_length=60.0, asynchronous=True, nucleotide_only=True)
+    units = dict(flat)
+    for k in ("annos", "anno_off", "anno_end", "anno_group"):
+        units[k] = None
+    P = _lib.Problem(ctx, units, annotations=A)
+    try:
+        got = P.sample_and_count(counters, 23, 0, S)
+        for k, c in enumerate(counters):
+            assert np.array_equal(got[k], want[k]), c
+        if n_tracks >= 4:
+            with pytest.raises(ValueError):
+                P.sample_and_count(counters + ["segment-overlap"], 23, 0, S)
+            assert np.array_equal(P.sample_and_count(counters, 23, 0, S)[0], want[0])      # (and the object is still good)
+        else:
+            got = P.sample_and_count(counters + ["segment-overlap"], 23, 0, S)
+            assert np.array_equal(got[2], want[2])
+    finally:
+        P.close()
+        A.close()
+
+
 def test_an_error_of_the_asynchronous_build_is_reported_by_the_call_that_needs_the_tables(ctx):
     rs = np.random.RandomState(3)
     flat = dict(_random_problem(rs, 3, 200, 5, False))
