@@ -519,7 +519,9 @@ class _LazyLists(collections.defaultdict):
 
     def copy(self):
         self._make_all()
-        return dict(self)
+        return collections.defaultdict(SegmentList, dict.items(self))
+
+    __copy__ = copy
 
     def __eq__(self, other):
         self._make_all()
@@ -527,6 +529,11 @@ class _LazyLists(collections.defaultdict):
 
     def __ne__(self, other):
         return not self.__eq__(other)
+
+    def __reduce__(self):
+        """pickled / copied as the plain dictionary it stands for"""
+        self._make_all()
+        return (collections.defaultdict, (SegmentList,), None, None, iter(list(dict.items(self))))
 
     __hash__ = None
 

@@ -542,6 +542,11 @@ def test_lists_made_on_demand_behave_like_a_dictionary():
     assert d["c0.b"].asList() == [(120, 180), (300, 320)] and d["c0.b"] is d["c0.b"]
     assert d.intervals.get("c1.a").asList() == [(5, 100)] and d.intervals.get("nope") is None
     assert d._flat() is f
+    import copy
+    import pickle
+    e = pickle.loads(pickle.dumps(d.intervals))                               # (travels as the plain dictionary it stands for)
+    assert type(e) is collections.defaultdict and list(e.keys()) == list(d.keys()) and e["c1.b"].asList() == [(100, 500)]
+    assert copy.copy(d.intervals)["c0.b"].asList() == [(120, 180), (300, 320)] and d._flat() is f
     c = d.clone()                                                             # (goes through items(): everything is made)
     assert [k for k, _ in c.items()] == list(d.keys()) and c["c1.b"].asList() == [(100, 500)]
     assert d._flat() is f
