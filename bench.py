@@ -7,7 +7,10 @@ read-back of the count matrix to the host ("seed -> count matrix o
 BASELINE.json's config2 (10k segments x 1 annotation track x 10k intervals, hg19 workspace, 10 000 samples,
 CounterNucleotideOverlap); the same run then measures the other single-GPU shapes of BASELINE.json (config3, the
 north_star target shape; one call's worth of config5 and config4) and reports them under "configs".  Inputs are
-resident in HBM before the timed region.
+resident in HBM before the timed region.  The headline shape's steps are software-pipelined one deep (--pipeline 2, the
+default; config.steps_in_flight): step i+1's kernels are enqueued before the host waits for step i, as gat_amd.run() does
+with consecutive segment tracks; all K steps' kernels AND read-backs complete inside the timed region.  --pipeline 1:
+enqueue, wait, read back, one step at a time (what rounds 1-4 measured; ~1 % slower).
 
 `python bench.py --gpus N` without torch.distributed.run in the environment starts its own N ranks (a child process
 running `python -m torch.distributed.run ... bench.py`, before anything here touches a GPU) and relays their one
@@ -67,6 +70,9 @@ def parse():
                     help="further BASELINE shapes measured in the same run and reported under 'configs' ('' = none)")
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of the extra shapes (config4: a quarter of it)")
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the sustained loop per shape (0 = none)")
+    ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
+                    help="steps in flight: 2 = step i+1 is enqueued before the host waits for step i (as gat_amd.run() does "
+                         "with its segment tracks), 1 = enqueue, wait, read back, one step at a time")
     ap.add_argument("--no-api", action="store_true", help="skip the gat_amd.run() block")
     ap.add_argument("--dump-counts", default=None, help="rank 0 saves the gathered count matrix of the last step (tests)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling block")
@@ -162,10 +168,11 @@ def counters_profile(config, S):
 class Workload(object):
     """one BASELINE shape resident on this rank's GPU."""
 
-    def __init__(self, name, S, args, dev_index, rank, world):
+    def __init__(self, name, S, args, dev_index, rank, world, depth=1):
         import torch
         from gat_amd import _lib, problem, synthetic
         self.name, self.S, self.args, self.rank, self.world = name, S, args, rank, world
+        self.depth = max(1, min(2, int(depth)))
         cfg = synthetic.config(name, args.scale)
         self.counters = [args.counter or cfg["counter"]]
         self.flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], cfg["isochores"])
@@ -175,7 +182,23 @@ class Workload(object):
         self.stream = torch.cuda.Stream(device=self.dev)
         torch.cuda.set_stream(self.stream)               # ... and torch's current stream from here on (one workload at a time)
         self.ctx = _lib.Context(dev_index, stream=self.stream.cuda_stream)
-        self.P = _lib.Problem(self.ctx, self.flat)
+        # depth 2: the steps are software-pipelined one deep, the way gat_amd.run() keeps two segment tracks' calls in flight
+        # (gat_amd/__init__.py, _start_job): step i+1's kernels are put on the stream BEFORE the host waits for step i, so the
+        # device does not idle while the host wakes up, reads step i's status word, issues its read-back and launches again
+        # (~60 us of a 2.5 ms step).  A call in flight belongs to a problem, so there are two problems over the same inputs --
+        # one set of annotation tables shared, the sampler's scratch twice -- on ONE stream: their kernels run one behind
+        # the other, never side by side.
+        if self.depth > 1:
+            segs = self.flat["segs"]
+            mean = float((segs["end"].astype("int64") - segs["start"]).sum()) / max(1, len(segs))
+            self.anno = _lib.Annotations(self.ctx, self.flat, mean_segment_length=mean)
+            self.Ps = [_lib.Problem(self.ctx, self.flat, annotations=self.anno) for _ in range(self.depth)]
+        else:
+            self.anno = None
+            self.Ps = [_lib.Problem(self.ctx, self.flat)]
+        self.P = self.Ps[0]
+        self.pending = None                              # (buffer, problem) of the step whose wait() is still to come
+        self.pipelined = self.depth > 1
         self.info = self.P.info()
         K, A = len(self.counters), self.flat["n_tracks"]
         # The step's tail -- the ONE all-gather of the count matrix (N > 1) and its read-back -- runs on a second stream while
@@ -203,9 +226,26 @@ class Workload(object):
         self.n_step += 1
         if self.tail_done[b] is not None:
             self.stream.wait_event(self.tail_done[b])           # (the tail of two steps ago has read this buffer)
-        # the batch seam in its two halves: the host is free between them (here it has nothing else to do)
-        self.P.enqueue(self.counters, self.args.seed, begin, begin + self.S, self.counts_ptr[b])
-        st = self.P.wait()
+        # the batch seam in its two halves: the host is free between them -- it finishes the step before (pipelined), or has
+        # nothing else to do
+        P = self.Ps[b] if self.pipelined else self.P
+        P.enqueue(self.counters, self.args.seed, begin, begin + self.S, self.counts_ptr[b])
+        if self.pipelined:
+            st = self.finish() if self.pending is not None else {}
+            self.pending = (b, P)
+            return st
+        self.pending = (b, P)
+        return self.finish()
+
+    def finish(self):
+        """second half of the step in flight: wait for its kernels, start its tail (all-gather, read-back); its statistics"""
+        import torch
+        import torch.distributed as dist
+        if self.pending is None:
+            return {}
+        b, P = self.pending
+        self.pending = None
+        st = P.wait()
         # (wait() returns when the step's kernels have completed: the tail needs no event of theirs)
         with torch.cuda.stream(self.tail_stream):
             src = self.counts[b]
@@ -233,13 +273,15 @@ class Workload(object):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(steps):
-            st = self.step(first_step + i)
-            if acc is not None:
+        def add(st):
+            if acc is not None and st:
                 for k in self.KEYS:
                     acc[k] += st.get(k, 0.0)
                 acc["count_kernel"] = st.get("count_kernel", 1)
                 acc["merged_form"] = st.get("merged_form", 0)
+        for i in range(steps):
+            add(self.step(first_step + i))
+        add(self.finish())                               # (pipelined: the last step's second half -- inside the timed region)
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
@@ -257,6 +299,7 @@ class Workload(object):
         world = self.world
         for i in range(warmup):
             self.step(i)
+        self.finish()
         # THE HEADLINE: exactly `steps` steps timed right behind the `warmup` untimed ones of this process (barrier +
         # synchronize on both sides, MAX over the ranks).  Everything below -- the per-kernel split, the sustained loop --
         # runs BEHIND it and is reported beside it, never instead of it.  (On some boxes the first tens of milliseconds
@@ -269,9 +312,12 @@ class Workload(object):
         ksteps = max(1, min(steps, 10))
         acck = dict((k, 0.0) for k in self.KEYS)
         self.ctx.set_kernel_times(True)
+        was = self.pipelined
+        self.pipelined = False                           # (the events behind every kernel exist once per context: one call in flight)
         try:
             self.timed(ksteps, warmup + steps, acck)
         finally:
+            self.pipelined = was
             self.ctx.set_kernel_times(False)
         # the same step for at least `sustain_s` seconds more, in repeats of about a quarter of that (every rank runs the
         # same number of steps: rank 0's estimate is broadcast)
@@ -427,6 +473,7 @@ class Workload(object):
                                     flat["n_contigs"], S, self.counters[0]),
                        "samples_per_step_per_gpu": S,
                        "sharding": "samples, contiguous ranges per rank; one RCCL all-gather",
+                       "steps_in_flight": self.depth,
                        "timed_region": "sampling + counting + all-gather (N > 1) + D2H of the count matrix (%d bytes); a step's "
                                        "all-gather and D2H run on a second stream beside the next step's kernels"
                                        % (self.host[0].numel() * 8 if self.host is not None else 0)},
@@ -461,7 +508,11 @@ class Workload(object):
         return out
 
     def close(self):
-        self.P.close()
+        self.finish()
+        for P in self.Ps:
+            P.close()
+        if self.anno is not None:
+            self.anno.close()
         self.ctx.close()
 
 
@@ -611,7 +662,7 @@ def final_line(out, details_path=None):
         line[k] = _r(line[k])
     cfg = out.get("config") or {}
     line["config"] = {"workload": _cut(cfg.get("workload", "")), "samples_per_step_per_gpu": cfg.get("samples_per_step_per_gpu"),
-                      "sharding": _cut(cfg.get("sharding", ""))}
+                      "sharding": _cut(cfg.get("sharding", "")), "steps_in_flight": cfg.get("steps_in_flight", 1)}
     roof = out.get("roofline") or {}
     line["roofline"] = dict((k, _cut(_r(roof.get(k)))) for k in
                             ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms",
@@ -688,7 +739,7 @@ def main():
         assert dist.get_world_size() == args.gpus
 
     cfg_samples = synthetic.CONFIG_SAMPLES[args.config]
-    W = Workload(args.config, args.samples or cfg_samples, args, dev_index, rank, world)
+    W = Workload(args.config, args.samples or cfg_samples, args, dev_index, rank, world, depth=args.pipeline)
     main_out = W.measure(args.steps, args.warmup, args.sustain_seconds)
     out = {"metric": METRIC, "value": main_out["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": main_out["ms_per_step"], "higher_is_better": True, "scaling": "weak",
@@ -724,6 +775,8 @@ def main():
     extras = {}
     for name in [x for x in args.extra.split(",") if x and x != args.config]:
         torch.cuda.empty_cache()
+        # (one step in flight: these steps are 6-70 ms, the host's share of them is nothing, and two problems' scratch taking
+        #  turns cost config 3 about 1 % when it was tried)
         E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world)
         # (a config-4 step is a rank's whole shard, about 0.1 s: a quarter of the steps)
         r = E.measure(max(1, args.extra_steps // 4 if name == "config4" else args.extra_steps), 2, args.sustain_seconds)

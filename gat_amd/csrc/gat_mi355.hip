@@ -1052,8 +1052,9 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
       if (K.enq == K.S) {
         // (the call's end rides on the last batch's synchronisation -- one round trip to the device less per call; a batch
         //  that has to be repeated enqueues it again)
-        HIPCHK(ctx, hipEventRecord(K.blk->ev_end, ctx->stream));
         if (K.mstat_on) HIPCHK(ctx, hipMemcpyAsync(K.blk->h_mstat, P->d_mstat.p, 512 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(K.blk->ev_end, ctx->stream));
+        K.end_recorded = true;
       }
     }
     if (!(K.enq < K.S && K.n_flight < max_flight)) break;
@@ -1140,6 +1141,7 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   if (K.timed) ctx->timed_owner = (const void*)P;
   K.mstat_on = false;                              // (set with the first count kernels: it takes the tables)
   K.count_pending = false;
+  K.end_recorded = false;
   auto fail = [&](int code) { call_end(ctx, P); return code; };
   if (hipEventRecord(K.blk->ev_begin, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
   if (state_host != nullptr) {
@@ -1150,6 +1152,7 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   }
   if (K.S == 0) {                                                  // (no batch will run: nothing to ride on)
     if (hipEventRecord(K.blk->ev_end, ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipEventRecord failed"));
+    K.end_recorded = true;
     return GAT_OK;
   }
   if ((rc = call_enqueue_more(ctx, P, false))) return fail(rc);
@@ -1173,7 +1176,12 @@ static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
     // upload_layout) sets P->batch = 0, so the scratch is sized and zeroed again before the next kernel runs, and no length
     // written under another layout survives into this one.  The counts of such a batch, and of the batches enqueued behind
     // it, are thrown away (they are redone)
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "hipStreamSynchronize failed: %s", hipGetErrorString(hipGetLastError())));
+    // (the call's own end where it is on the stream -- its last batch enqueued --, not the stream's: another problem's call
+    //  enqueued behind this one -- run() keeps two segment tracks in flight, bench.py two steps -- goes on running while the
+    //  host reads this one's status words and enqueues the next)
+    const hipError_t se = K.end_recorded ? hipEventSynchronize(K.blk->ev_end) : hipStreamSynchronize(ctx->stream);
+    if (se != hipSuccess) return fail(set_err(ctx, GAT_ERR_DEVICE, "synchronising with the call's batches failed: %s", hipGetErrorString(hipGetLastError())));
+    K.end_recorded = false;
     tm.lap("batches synchronised");
     for (int slot = 0; slot < K.n_flight; ++slot) {
       rc = finish_sampler_batch(ctx, P, K.nb[slot], &K.local, K.timed, K.blk->h_stat + (size_t)slot * 16);

@@ -232,8 +232,9 @@ int gat_sample_and_count(gat_ctx* ctx, gat_problem* p,
  * completed, checks their status words -- a batch that has to be repeated (a unit's region of the slab overflowed) is
  * repeated in here, with everything that was enqueued behind it -- and reports what gat_sample_and_count would have
  * (GAT_ERR_ASSERT where the reference's sampler asserts, :645).  One call in flight per problem; several problems of one
- * context may each have one (they run one behind the other on the context's stream).  gat_problem_destroy drops a call in
- * flight.  gat_sample_and_count(...) == enqueue + wait. */
+ * context may each have one (they run one behind the other on the context's stream; gat_wait waits for the end of ITS call
+ * -- an event behind its last batch --, not for the stream: what another problem has enqueued behind it keeps running
+ * while the host reads the results and enqueues the next call).  gat_problem_destroy drops a call in flight.  gat_sample_and_count(...) == enqueue + wait. */
 int gat_sample_and_count_enqueue(gat_ctx* ctx, gat_problem* p,
                                  const int32_t* counter_ids, int n_counters,
                                  uint32_t seed, int64_t sample_begin, int64_t sample_end, void* counts_dev);

@@ -114,6 +114,61 @@ def test_two_problems_in_flight_on_one_context(ctx):
         P.close()
 
 
+def test_steps_taking_turns_on_two_problems_over_the_same_inputs(ctx, monkeypatch):
+    """bench.py's pipeline (and run()'s tracks): step i+1 is enqueued before step i is waited for.  gat_wait returns at the
+    call's OWN end (its event), with the other problem's kernels still running behind it -- the statistics, the status words
+    and the counts it hands out are the finished call's; one of the steps overflows its slab on the way and is redone"""
+    import time
+    rs = np.random.RandomState(91)
+    flat = _big_problem(rs, 700, 3)
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S, steps = 64, 6
+    wants = [O.run_samples(flat, counters, 77, 1, i * S, (i + 1) * S)[0] for i in range(steps)]
+    A = _lib.Annotations(ctx, flat)
+    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+    monkeypatch.setenv("GAT_SLAB_BYTES", "300000")            # (tiny slabs: a call is several batches, some overflow)
+    Ps = [_lib.Problem(ctx, flat, annotations=A) for _ in range(2)]
+    small = _lib.Problem(ctx, flat, annotations=A)
+    devs = [ctx.alloc(len(counters) * flat["n_tracks"] * S * 8) for _ in range(2)]
+
+    def check(i):
+        host = np.empty((len(counters), flat["n_tracks"], S), dtype=np.int64)
+        ctx.d2h(host, devs[i & 1])
+        for k, c in enumerate(counters):
+            assert np.array_equal(host[k], wants[i][k]), (i, c)
+
+    order = [Ps[0], Ps[1], small, Ps[1], Ps[0], small]         # (a problem's next call only after its last one was waited for)
+    retried = 0
+    for i in range(steps):
+        order[i].enqueue(counters, 77, i * S, (i + 1) * S, devs[i & 1])
+        if i > 0:
+            retried += order[i - 1].wait()["n_retried"]
+            check(i - 1)
+    retried += order[steps - 1].wait()["n_retried"]
+    check(steps - 1)
+    assert retried > 0
+    monkeypatch.delenv("GAT_TEST_SMALL_CAPS")
+    monkeypatch.delenv("GAT_SLAB_BYTES")
+    for P in Ps:
+        P.close()
+    Ps = [_lib.Problem(ctx, flat, annotations=A) for _ in range(2)]
+    # the wait is for the call, not for the stream: a short call's wait returns while a long one enqueued behind it runs
+    big = ctx.alloc(len(counters) * flat["n_tracks"] * 6000 * 8)
+    Ps[0].enqueue(counters, 5, 0, 8, devs[0])
+    Ps[1].enqueue(counters, 5, 0, 6000, big)
+    t0 = time.perf_counter()
+    Ps[0].wait()
+    t1 = time.perf_counter()
+    Ps[1].wait()
+    t2 = time.perf_counter()
+    assert (t1 - t0) < 0.5 * (t2 - t0), (t1 - t0, t2 - t0)
+    for d in devs + [big]:
+        ctx.free(d)
+    for P in Ps + [small]:
+        P.close()
+    A.close()
+
+
 def test_seam_errors(ctx):
     rs = np.random.RandomState(6)
     flat = _random_problem(rs, 2, 100, 2, False)

@@ -46,7 +46,7 @@ def test_final_line_of_a_full_report_is_small(name):
         assert k in line["cpu_baseline"], k
     assert line["value"] == pytest.approx(out["value"], rel=1e-6) and line["steps"] == out["steps"] and line["warmup"] == out["warmup"]
     assert all(len(s) <= 120 for s in _strings(line))
-    assert set(line["config"]) == {"workload", "samples_per_step_per_gpu", "sharding"}          # no model keys
+    assert set(line["config"]) == {"workload", "samples_per_step_per_gpu", "sharding", "steps_in_flight"}   # no model keys
 
 
 def test_final_line_drops_extras_before_it_grows():
