@@ -48,5 +48,7 @@ for seed in range(first, first + n):
             m.test_fuzz_shapes_vs_oracle(ctx, seed, MP())
     except Exception as e:             # noqa: BLE001
         bad += 1
-        print("seed %d: %s: %s" % (seed, type(e).__name__, str(e)[:300]))
+        print("seed %d: %s: %s" % (seed, type(e).__name__, str(e)[:300]), flush=True)
+    if (seed - first + 1) % 2000 == 0:  # (a sweep cut short by `timeout` still says how far it came)
+        print("... %d seeds, %d failures, %.0f s" % (seed - first + 1, bad, time.time() - t0), flush=True)
 print("%d seeds, %d failures, %.1f s %s" % (n, bad, time.time() - t0, outcomes if edge else ("units through k_tail_big: %d" % handed if long_lists else "")))
