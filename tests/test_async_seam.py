@@ -153,9 +153,9 @@ def test_steps_taking_turns_on_two_problems_over_the_same_inputs(ctx, monkeypatc
         P.close()
     Ps = [_lib.Problem(ctx, flat, annotations=A) for _ in range(2)]
     # the wait is for the call, not for the stream: a short call's wait returns while a long one enqueued behind it runs
-    big = ctx.alloc(len(counters) * flat["n_tracks"] * 6000 * 8)
+    big = ctx.alloc(len(counters) * flat["n_tracks"] * 40000 * 8)
     Ps[0].enqueue(counters, 5, 0, 8, devs[0])
-    Ps[1].enqueue(counters, 5, 0, 6000, big)
+    Ps[1].enqueue(counters, 5, 0, 40000, big)      # (tens of milliseconds: a stalled host thread does not decide the test)
     t0 = time.perf_counter()
     Ps[0].wait()
     t1 = time.perf_counter()
