@@ -775,9 +775,9 @@ def main():
     extras = {}
     for name in [x for x in args.extra.split(",") if x and x != args.config]:
         torch.cuda.empty_cache()
-        # (one step in flight: these steps are 6-70 ms, the host's share of them is nothing, and two problems' scratch taking
-        #  turns cost config 3 about 1 % when it was tried)
-        E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world)
+        # (measured like the headline shape: these steps are 6-70 ms and gain 0-1 % from the second step in flight)
+        E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world,
+                     depth=args.pipeline)
         # (a config-4 step is a rank's whole shard, about 0.1 s: a quarter of the steps)
         r = E.measure(max(1, args.extra_steps // 4 if name == "config4" else args.extra_steps), 2, args.sustain_seconds)
         r["n_gpus"] = world
