@@ -928,10 +928,13 @@ def input_hashes(flat):
     return out
 
 
-def config_case(name, num_samples, seed):
+def config_case(name, num_samples, seed, counters=None, tag=None):
+    """counters: the counters run side by side (default: the configuration's own and the other nucleotide counter);
+    tag: the golden's name where it is not the configuration's (run_<tag>_s<n>.npz)"""
     import time
     cfg = synthetic.config(name)
-    counters = [cfg["counter"], "nucleotide-density" if cfg["counter"] == "nucleotide-overlap" else "nucleotide-overlap"]
+    if counters is None:
+        counters = [cfg["counter"], "nucleotide-density" if cfg["counter"] == "nucleotide-overlap" else "nucleotide-overlap"]
     segments, annotations, workspace = build_reference_inputs(cfg)
     counter_objs = [COUNTERS[c]() for c in counters]
     flat = flat_problem(segments["merged"], workspace, annotations, 1, 100000)
@@ -975,7 +978,7 @@ def config_case(name, num_samples, seed):
             lens.append(len(a))
             first_last.append([int(a[0]["start"]), int(a[-1]["end"])] if len(a) else [0, 0])
     h = input_hashes(flat)
-    numpy.savez_compressed(os.path.join(HERE, "run_%s_s%d.npz" % (name, num_samples)),
+    numpy.savez_compressed(os.path.join(HERE, "run_%s_s%d.npz" % (tag or name, num_samples)),
                            config=name, seed=seed, num_samples=num_samples, counters=numpy.array(counters),
                            counts_mode0=counts0, counts_mode1=counts1, observed=observed,
                            samples_sha256_mode1=sha.hexdigest(), sample_list_lengths=numpy.array(lens, dtype=numpy.int64),
@@ -984,8 +987,8 @@ def config_case(name, num_samples, seed):
                            n_units=flat["n_units"], n_contigs=flat["n_contigs"], n_tracks=flat["n_tracks"],
                            unit_names=flat["unit_names"], contig_names=flat["contig_names"], track_names=flat["track_names"],
                            reference_seconds_per_sample_gat_run=t_run / num_samples)
-    print("G9 run_%s_s%d: units=%d contigs=%d tracks=%d intervals=%d; the reference's gat.run: %.3f s per sample; mean counts %s"
-          % (name, num_samples, flat["n_units"], flat["n_contigs"], flat["n_tracks"], len(flat["annos"]), t_run / num_samples,
+    print("G9 run_%s_s%d (%s): units=%d contigs=%d tracks=%d intervals=%d; the reference's gat.run: %.3f s per sample; mean counts %s"
+          % (tag or name, num_samples, ", ".join(counters), flat["n_units"], flat["n_contigs"], flat["n_tracks"], len(flat["annos"]), t_run / num_samples,
              numpy.round(counts1.mean(axis=2).ravel()[:3], 3)))
 
 
@@ -993,6 +996,9 @@ def g9_configs():
     config_case("config3", 4, 303)
     config_case("config5", 2, 505)
     config_case("config4", 2, 404)          # 100 k segments x 1 000 tracks: 2.3 s per sample of the reference's gat.run
+    # every counter of the reference side by side on config 3's inputs (100 tracks x 192 isochore units): the segment- and
+    # annotation-side counters at full interval counts, not only the two nucleotide counters of the metric
+    config_case("config3", 3, 313, counters=list(COUNTERS), tag="config3all")
 
 
 if __name__ == "__main__":
