@@ -999,6 +999,8 @@ def g9_configs():
     # every counter of the reference side by side on config 3's inputs (100 tracks x 192 isochore units): the segment- and
     # annotation-side counters at full interval counts, not only the two nucleotide counters of the metric
     config_case("config3", 3, 313, counters=list(COUNTERS), tag="config3all")
+    # ... and on the headline shape (config 2: 10 k segments x 1 track x 10 k intervals, 24 contigs, no isochores)
+    config_case("config2", 4, 202, counters=list(COUNTERS), tag="config2all")
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@ def test_golden_counts_and_samples(ctx, name):
     P.close()
 
 
-@pytest.mark.parametrize("name", ["config3_s4", "config5_s2", "config4_s2", "config3all_s3"])
+@pytest.mark.parametrize("name", ["config3_s4", "config5_s2", "config4_s2", "config3all_s3", "config2all_s4"])
 def test_golden_config_shapes_against_the_reference(ctx, name):
     """configs 3, 5 and 4 at their full interval counts (100 tracks x 192 isochore units; density against a 1M-interval
     annotation; 100 k segments x 1 000 tracks; config 3 again with all six counters side by side): count matrices and sampled
