@@ -6,6 +6,7 @@ tests/golden/make_goldens.py.  Shapes follow the reference tutorial data
 tracks, ungapped-contig workspaces) but contain no reference data.
 """
 import collections
+import os
 
 import numpy as np
 
@@ -108,7 +109,34 @@ def isochores_blocks(contigs, nclasses=8, block=1000000):
 
 
 # Monte-Carlo samples of each BASELINE.json configuration (config4 / config5 are 8-GPU jobs: 12 500 / 125 000 per GPU)
-CONFIG_SAMPLES = {"config1": 1000, "config2": 10000, "config3": 10000, "config4": 100000, "config5": 1000000}
+CONFIG_SAMPLES = {"config1": 1000, "config2": 10000, "config3": 10000, "config4": 100000, "config5": 1000000,
+                  "refdata": 10000}
+
+# the reference's own integration-test data (test/data/*.bed.gz of the reference, kept as data fixtures under
+# tests/golden/refdata: mouse ChIP-seq peaks, a workspace of 279 844 segments -- 6 600 to 21 000 per contig --, 7 annotation
+# tracks; test/check_run.py, test/data/output_single.tsv:66-125 are its only published timings)
+REFDATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "refdata")
+REFDATA_TRACK = "Rela-120m"        # the 8 549-segment track: 30 samples/s in the reference's 2013 log
+
+
+def refdata(track=REFDATA_TRACK):
+    """the reference's test data set as a configuration: one segment track against the seven annotation tracks inside the
+    fragmented workspace, read and prepared as gat-run.py does (IO.buildSegments / IO.applyIsochores, gat/IO.py:88-248)."""
+    import gat_amd
+    from gat_amd import IO
+    d = REFDATA_DIR
+    opts, _ = gat_amd.buildParser().parse_args(["--segments=%s" % os.path.join(d, "segments_single.bed.gz"),
+                                               "--annotations=%s" % os.path.join(d, "annotations.bed.gz"),
+                                               "--workspace=%s" % os.path.join(d, "workspace.bed.gz"), "--with-segment-tracks"])
+    segments, annotations, workspaces, isochores = IO.buildSegments(opts)
+    workspace = IO.applyIsochores(segments, annotations, workspaces, opts, isochores)
+    tracks = [t for t in segments.tracks if track in t]
+    if len(tracks) != 1:
+        raise ValueError("refdata: segment track %r not found among %r" % (track, list(segments.tracks)))
+    return dict(segments=segments[tracks[0]].asArrays(),
+                annotations=[(t, annotations[t].asArrays()) for t in annotations.tracks],
+                workspace=workspace.asArrays(), isochores=None, num_samples=10000, counter="nucleotide-overlap",
+                segment_track=tracks[0])
 
 
 def config(name, scale=1.0):
@@ -144,6 +172,8 @@ def config(name, scale=1.0):
                     annotations=[("anno0", random_segments(HG19, n(1000000), 300, 100))],
                     workspace=workspace_ungapped(HG19), isochores=None,
                     num_samples=1000000, counter="nucleotide-density")
+    if name == "refdata":      # the reference's own test data: a workspace of 13 000 segments per contig
+        return refdata()
     raise ValueError("unknown config %r" % name)
 
 

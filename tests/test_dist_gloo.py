@@ -2,7 +2,6 @@
 stands in for the GPU here -- tests may use it) and one all-gather reassembles the count matrix;
 it must equal the single-process matrix column for column."""
 import os
-import socket
 
 import numpy as np
 import torch.multiprocessing as mp
@@ -10,21 +9,18 @@ import torch.multiprocessing as mp
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _init(backend, rank, world, path, **kw):
+    """rendezvous over a file in the test's own directory: no TCP port to find free (a port handed out by bind(0) and closed
+    again was taken by the time the store wanted it: EADDRINUSE in the GPU suite, round 6)"""
+    import torch.distributed as dist
+    dist.init_process_group(backend, init_method="file://" + os.path.join(path, "rendezvous"), rank=rank, world_size=world, **kw)
 
 
-def _worker(rank, world, port, S, path):
+def _worker(rank, world, S, path):
     import torch.distributed as dist
     from gat_amd import distributed
     from oracle import oracle as O
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init("gloo", rank, world, path)
     z = np.load(os.path.join(G, "run_small_isochores.npz"))
     flat = {k: z[k] for k in z.files}
     counters = ["nucleotide-overlap", "nucleotide-density"]
@@ -43,8 +39,7 @@ def _worker(rank, world, port, S, path):
 def test_two_rank_sharding_and_allgather(tmp_path):
     from oracle import oracle as O
     S = 37                       # odd on purpose: ragged last shard
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, S, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, S, str(tmp_path)), nprocs=2, join=True)
     z = np.load(os.path.join(G, "run_small_isochores.npz"))
     flat = {k: z[k] for k in z.files}
     want, _ = O.run_samples(flat, ["nucleotide-overlap", "nucleotide-density"], 11, 1, 0, S)
@@ -66,12 +61,10 @@ def test_shard_ranges_cover_everything():
             assert all(e - b <= distributed.padded_shard(n, w) for b, e in r)
 
 
-def _worker_ragged(rank, world, port, S, path):
+def _worker_ragged(rank, world, S, path):
     import torch.distributed as dist
     from gat_amd import distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init("gloo", rank, world, path)
     begin, end = distributed.shard_range(S, rank, world)
     per = distributed.padded_shard(S, world)
     # slot (k, a, s) of the whole matrix holds a number that names it; a rank fills its own columns
@@ -89,7 +82,7 @@ def test_eight_ranks_ragged_shards(tmp_path):
     """the node's shape -- eight ranks -- with 37 samples: shards of 5, the last of 2, ranks past the end of nothing; every rank
     must end up with every column in sample order."""
     S, world = 37, 8
-    mp.spawn(_worker_ragged, args=(world, _free_port(), S, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_ragged, args=(world, S, str(tmp_path)), nprocs=world, join=True)
     want = np.zeros((2, 3, S), dtype=np.int64)
     for k in range(2):
         for a in range(3):

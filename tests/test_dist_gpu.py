@@ -2,7 +2,6 @@
 samples, all-gather the count matrix and must print the rows a single process prints; the seed is agreed on by
 broadcast when none is given; pattern files have one writer."""
 import os
-import socket
 
 import numpy as np
 import pytest
@@ -11,12 +10,11 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _init(backend, rank, world, path, **kw):
+    """rendezvous over a file in the test's own directory: no TCP port to find free (a port handed out by bind(0) and closed
+    again was taken by the time the store wanted it: EADDRINUSE in the GPU suite, round 6)"""
+    import torch.distributed as dist
+    dist.init_process_group(backend, init_method="file://" + os.path.join(path, "rendezvous"), rank=rank, world_size=world, **kw)
 
 
 def _collections():
@@ -57,12 +55,10 @@ def _run(num_samples, seed, counts_pattern=None):
                                         gat_amd.UnconditionalWorkspace(), **kw)]
 
 
-def _worker(rank, world, port, path, seed):
+def _worker(rank, world, path, seed):
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_RANK"] = "0"                     # one GPU on this box: both ranks drive device 0
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init("gloo", rank, world, path)
     np.random.seed(100 + rank)                         # different global RNG states: the base seed must be rank 0's
     rows = _run(37, seed, os.path.join(path, "counts_%s.tsv"))
     with open(os.path.join(path, "rows%d.txt" % rank), "w") as f:
@@ -73,7 +69,7 @@ def _worker(rank, world, port, path, seed):
 
 @pytest.mark.parametrize("seed", [5, None])
 def test_run_two_ranks_equals_single_process(tmp_path, seed):
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), seed), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, str(tmp_path), seed), nprocs=2, join=True)
     r0 = open(str(tmp_path / "rows0.txt")).read().split("\n")
     r1 = open(str(tmp_path / "rows1.txt")).read().split("\n")
     assert r0 == r1 and len(r0) == 9                    # 3 counters x 3 annotation tracks
@@ -108,16 +104,14 @@ def test_c_abi_allgather_counts_single_rank():
         ctx.close()
 
 
-def _worker_nccl_one_rank(rank, world, port, path, device_stats):
+def _worker_nccl_one_rank(rank, world, path, device_stats):
     import torch
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_RANK"] = "0"
     os.environ["GAT_DEVICE_STATS"] = "1" if device_stats else "0"
     os.environ["GAT_FORCE_COLLECTIVE_PATH"] = "1"
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    _init("nccl", 0, 1, path, device_id=torch.device("cuda", 0))
     import gat_amd
     segments, annotations, workspace = _collections()
     counters = [gat_amd.CounterNucleotideOverlap(), gat_amd.CounterNucleotideDensity(), gat_amd.CounterSegmentOverlap()]
@@ -136,7 +130,7 @@ def test_the_collective_path_over_rccl_with_one_rank(tmp_path, device_stats):
     """the code run() takes under the nccl backend -- the library's stream ordered against torch's by events, equal shards,
     the all-gather of device memory over RCCL, statistics from the gathered matrix, rows that read it back on demand -- with a
     process group of ONE rank (RCCL refuses two ranks on this box's one GPU): same rows, same samples, same count files."""
-    mp.spawn(_worker_nccl_one_rank, args=(1, _free_port(), str(tmp_path), device_stats), nprocs=1, join=True)
+    mp.spawn(_worker_nccl_one_rank, args=(1, str(tmp_path), device_stats), nprocs=1, join=True)
     rows = open(str(tmp_path / "forced_rows.txt")).read().split("\n")
     os.environ["GAT_DEVICE_STATS"] = "0"
     try:
@@ -192,15 +186,13 @@ def test_c_abi_allgather_counts_two_ranks(tmp_path):
         assert np.array_equal(np.load(str(tmp_path / ("abi%d.npy" % r))), want), r
 
 
-def _worker_nccl(rank, world, port, path, seed, device_stats, num_samples=37):
+def _worker_nccl(rank, world, path, seed, device_stats, num_samples=37):
     import torch
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
     os.environ["LOCAL_RANK"] = str(rank)
     os.environ["GAT_DEVICE_STATS"] = "1" if device_stats else "0"
     torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    _init("nccl", rank, world, path, device_id=torch.device("cuda", rank))
     rows = _run(num_samples, seed)
     with open(os.path.join(path, "nccl_rows%d.txt" % rank), "w") as f:
         f.write("\n".join(rows))
@@ -214,7 +206,7 @@ def test_run_under_nccl_equals_single_process(tmp_path, device_stats, num_sample
     """gat_amd.run() under the nccl backend (= RCCL): two ranks, one GPU each, shard the samples, all-gather the device
     matrix, take the statistics from it (on the device, or with numpy) and print the rows one process prints.  One sample
     over two ranks: the second rank's shard lies beyond the job (every rank computes a full shard; the surplus is cut off)."""
-    mp.spawn(_worker_nccl, args=(2, _free_port(), str(tmp_path), 5, device_stats, num_samples), nprocs=2, join=True)
+    mp.spawn(_worker_nccl, args=(2, str(tmp_path), 5, device_stats, num_samples), nprocs=2, join=True)
     r0 = open(str(tmp_path / "nccl_rows0.txt")).read().split("\n")
     r1 = open(str(tmp_path / "nccl_rows1.txt")).read().split("\n")
     assert r0 == r1 and len(r0) == 9

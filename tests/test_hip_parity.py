@@ -843,6 +843,25 @@ def test_wave_only_sampler_mode(ctx, monkeypatch):
     P.close()
 
 
+def _torchrun(nproc, script_args, env, root, timeout):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py ...` the way the driver launches it, on a port found free
+    -- and once more on another one should somebody have taken it in between (EADDRINUSE)"""
+    import socket
+    import subprocess
+    import sys
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + script_args
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
+    return r
+
+
 def _bench_outputs(r, details):
     """(the ONE stdout line of a bench.py run -- small, the last thing printed --, its details file)"""
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -878,15 +897,11 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py's N > 1 path (rank-disjoint sample ranges, all-gather of the count matrix, max-over-ranks timing,
     one JSON line from rank 0) with two ranks sharing this box's GPU: GAT_BENCH_SHARE_GPU=1 swaps RCCL, which
     refuses two ranks on one device, for gloo; everything else is the code the multi-GPU launch runs."""
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--samples", "2000", "--extra", "", "--no-strong", "--sustain-seconds", "0.2",
-           "--details", str(tmp_path / "d.json")]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                      "--warmup", "1", "--samples", "2000", "--extra", "", "--no-strong", "--sustain-seconds", "0.2",
+                      "--details", str(tmp_path / "d.json")], env, root, 600)
     assert r.returncode == 0, r.stderr[-2000:]
     line, out = _bench_outputs(r, str(tmp_path / "d.json"))
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak" and line["value"] > 0
@@ -899,17 +914,13 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
 def test_bench_eight_ranks_on_one_gpu(tmp_path):
     """the launch the driver's scaling run makes -- eight ranks under torch.distributed.run -- on this box's one GPU (gloo
     instead of RCCL): every rank its own sample range, the gathered matrix of the last step against the oracle's columns"""
-    import subprocess
-    import sys
     from gat_amd import problem
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, GAT_BENCH_SHARE_GPU="1")
     dump = str(tmp_path / "counts8.npz")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
-           "--warmup", "1", "--samples", "64", "--extra", "", "--sustain-seconds", "0", "--dump-counts", dump,
-           "--details", str(tmp_path / "d8.json")]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    r = _torchrun(8, [os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2",
+                      "--warmup", "1", "--samples", "64", "--extra", "", "--sustain-seconds", "0", "--dump-counts", dump,
+                      "--details", str(tmp_path / "d8.json")], env, root, 900)
     assert r.returncode == 0, r.stderr[-2000:]
     line, out = _bench_outputs(r, str(tmp_path / "d8.json"))
     assert line["n_gpus"] == 8 and line["distributed"]["world_size"] == 8 and line["value"] > 0
