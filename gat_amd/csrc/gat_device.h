@@ -854,6 +854,28 @@ __device__ __forceinline__ uint32_t seg_overlap_tree1(const uint2* __restrict__ 
   return ov[0];
 }
 
+// Overlap of [s, e) with a long normalized list W through its position grid (gat_prep.hip; UnitDev::pgrid_off): entry c = the
+// first segment whose end lies beyond c << shift, so no segment in front of entry s >> shift reaches s, and the segments that
+// can overlap [s, e) are walked from there -- one or two where the pieces of W are longer than [s, e).  One 4-byte and one or two
+// 8-byte accesses, dependent, where the trees read 2 x (four 64-byte nodes + a segment + a running length).
+// pg: the grid's entries (behind its header), shift / cells: header words 0 / 1.
+__device__ __forceinline__ uint32_t ws_overlap_pgrid(const uint2* __restrict__ w, int n, const uint32_t* __restrict__ pg,
+                                                     uint32_t shift, uint32_t cells, uint32_t s, uint32_t e) {
+  uint32_t c = s >> shift;
+  c = c < cells ? c : cells;
+  int j = (int)pg[c];
+  uint32_t ov = 0;
+  while (j < n) {
+    const uint2 x = w[j];
+    if (x.x >= e) break;
+    const uint32_t lo = s > x.x ? s : x.x, hi = e < x.y ? e : x.y;
+    ov += hi > lo ? hi - lo : 0u;
+    if (x.y >= e) break;
+    ++j;
+  }
+  return ov;
+}
+
 // A unit's workspace held in registers (lane i = workspace segment i), for units with <= 64
 // workspace segments: SegmentListSampler's CDF lookup becomes one v_cmp + ballot and the chosen
 // segment is fetched with v_readlane -- no memory access in the placement loop.

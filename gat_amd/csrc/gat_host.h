@@ -324,7 +324,10 @@ struct gat_problem {
   DevBuf<int32_t> d_order, d_contig_unit_off, d_contig_units, d_contig_slab_off, d_count_c_off, d_count_n_index;
   DevBuf<uint2> d_ws;
   DevBuf<uint32_t> d_ws_cdf, d_rank_len;
-  DevBuf<uint32_t> d_ws_tree;            // 16-ary search trees over the starts and the cumulated lengths of long workspaces
+  DevBuf<uint32_t> d_ws_tree;            // 16-ary search trees over the starts and the cumulated lengths of long workspaces,
+                                         // and their grids (UnitDev::pgrid_off / cgrid_off)
+  DevBuf<uint4> d_ws_rec;                // per workspace segment {start, end, previous segment's end (INT32_MIN: none), cdf}: what a
+                                         // position draw needs of its segment in ONE 16-byte access (k_place_grid)
   DevBuf<int64_t> d_cws_nseg;
   gat_annotations* anno = nullptr;       // the annotation tables: its own (made from the lists of its desc) or a shared object
   // per-batch scratch
@@ -371,6 +374,10 @@ struct gat_problem {
   bool all_simple = false;               // every active unit: one workspace segment (> 1 base), bucket 1, rank table in LDS
   bool all_cm_ok = false;                // ... and the offset draw's mask does not depend on the length drawn (k_place_scan's units)
   int32_t max_nws = 0;                   // longest workspace among the active units (selects the kernel variants)
+  bool grid_place = false;               // some unit's workspace is beyond k_place's LDS table and every such unit has its cdf grid
+                                         // (k_place_grid, MODE 4); false: k_place<., 2> searches the trees in global memory
+  int32_t grid_lds_words = 0;            // ... the largest grid image: the launch's dynamic LDS
+  bool tail_long_ws = false;             // k_tail takes units of more than kTailMaxWs workspace segments (their grids / trees exist)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
   bool all_one_ws = false;               // every active unit: one workspace segment, bucket 1, and most of the working segments in units
                                          // whose rank table is beyond k_place's LDS table but within k_place_wide's (k_place MODE 3)

@@ -26,7 +26,8 @@ struct SamplerArgs {
   const uint2* ws;
   const uint32_t* ws_cdf;
   const uint32_t* rank_len;
-  const uint32_t* ws_tree;    // 16-ary search trees of the long workspaces (UnitDev::tree_*_off)
+  const uint32_t* ws_tree;    // 16-ary search trees of the long workspaces (UnitDev::tree_*_off) and their grids (pgrid_off, cgrid_off)
+  const uint4* ws_rec;        // per workspace segment {start, end, previous end, cdf} (k_place_grid)
   int4* st2;                  // [launch position][rec_stride]: first consolidation done by k_merge_big
                               // {merged segments, workspace bases covered, sum of lengths, 1}, .w == 0 otherwise
   int32_t n_long;             // launch positions [0, n_long) were given to k_merge_big
@@ -272,12 +273,14 @@ template <int KIND, int MODE, int SMALL, bool PIPE>
 __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   constexpr bool ALL_SIMPLE = MODE == 1 || MODE == 3;
   constexpr bool TREES = MODE == 2;
+  constexpr bool GRID = MODE == 4 || MODE == 5;                            // k_place_grid: see GAT_PRE_WS3
   constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = MODE == 3 ? 1 : (SMALL == 1 ? 256 : kPlaceRankLds);
-  constexpr int WIDE = MODE == 3 ? kPlaceWide : 1;                         // tiles (waves) of a workgroup
+  constexpr int WIDE = MODE == 3 ? kPlaceWide : (MODE == 4 ? kPlaceGridTiles : (MODE == 5 ? kPlaceGridTiles / 2 : 1));   // tiles (waves) of a workgroup
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank_tab[kRankTab];
   __shared__ __attribute__((aligned(8192))) uint2 l_out_all[WIDE][16][kWave];   // (8 KB-aligned: GAT_STEP_SIMPLE_ASM) ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
   extern __shared__ __attribute__((aligned(16))) uint32_t l_rank_wide[];   // MODE 3: the unit's rank table, entry v = length of rank 1 + v
+                                                                           // MODE 4 / 5: the image of the unit's cdf grid (UnitDev::cgrid_off)
   uint32_t* const l_rank = MODE == 3 ? l_rank_wide : l_rank_tab;
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint2 (*const l_out)[kWave] = l_out_all[wv];
@@ -342,6 +345,27 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     for (int i = lane; i <= (int)maskL && i < kRankTab; i += kWave) l_rank[i] = (uint32_t)i <= rangeL ? rank_len[i + 1] : 0u;
   } else if (rank_lds)
     for (int i = lane; i <= (int)hist_total; i += kWave) l_rank[i] = rank_len[i];
+  // k_place_grid: a workspace beyond the LDS table is looked up through the grid over its cumulated lengths (gat_prep.hip;
+  // UnitDev::cgrid_off): g[c] = #{i : cdf[i] < c << cshift} and 16-bit keys cdf[i] & cmask, copied into LDS by the workgroup's
+  // waves -- kPlaceGridTiles tiles of ONE unit --, and the segment's {start, end, previous end} as one 16-byte record
+  int cshift = 0, cspan = 0;
+  uint32_t cmask = 0u;
+  const uint16_t* l_g16 = nullptr;
+  const uint16_t* l_k16 = nullptr;
+  const uint4* __restrict__ wrec = A.ws_rec + Up->ws_off;
+  if constexpr (GRID) {
+    if (!ws_lds) {
+      const uint32_t* __restrict__ cg = A.ws_tree + Up->cgrid_off;
+      cshift = (int)cg[0]; cspan = (int)cg[2];
+      const int ccells = (int)cg[1], nwords = (int)cg[3];
+      cmask = (1u << cshift) - 1u;
+      const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(cg + kGridHeader);
+      uint4* dst4 = reinterpret_cast<uint4*>(l_rank_wide);
+      for (int i = (int)threadIdx.x; i < (nwords + 3) / 4; i += WIDE * kWave) dst4[i] = src4[i];
+      l_g16 = reinterpret_cast<const uint16_t*>(l_rank_wide);
+      l_k16 = reinterpret_cast<const uint16_t*>(l_rank_wide + (ccells + 2) / 2);
+    }
+  }
   __syncthreads();
   // The workspace segment of a position draw from a grid over the cumulated lengths instead of a halving search over the
   // whole table (five dependent LDS reads per raw output for an isochore unit's 31 blocks, looked up for EVERY output of a
@@ -688,6 +712,34 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       const uint2 w2 = ws[lo[c]];                                                                              \
       pcs[c] = w2.x; pce[c] = w2.y; ppe[c] = lo[c] > 0 ? ws[lo[c] - 1].y : 0x80000000u; }                      \
   }
+  // the same for a workspace beyond the LDS table where its grid is in LDS (k_place_grid): the cell's two entries, a halving
+  // search over the widest cell's span among the cell's 16-bit keys (entries behind the cell's end count as above every p),
+  // and ONE 16-byte record of the chosen segment from global memory -- where the tree took four dependent 64-byte nodes
+#define GAT_PRE_WS3(Y)                                                                                         \
+  {                                                                                                            \
+    uint32_t tk[kPlaceChunk]; int lo[kPlaceChunk], hi[kPlaceChunk];                                            \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const uint32_t v = (Y)[c] & maskP; const uint32_t pv = v <= rangeP ? v : rangeP;                         \
+      const uint32_t cell = pv >> cshift; tk[c] = pv & cmask;                                                  \
+      lo[c] = (int)l_g16[cell]; hi[c] = (int)l_g16[cell + 1u]; }                                               \
+    for (int n = cspan; n > 1;) {                                                                              \
+      const int half = n >> 1;                                                                                 \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        const int pr = lo[c] + half - 1;                                                                       \
+        const bool in = pr < hi[c];                                                                            \
+        const uint32_t key = (uint32_t)l_k16[in ? pr : lo[c]];                                                 \
+        lo[c] = (in && key < tk[c]) ? lo[c] + half : lo[c];                                                    \
+      }                                                                                                        \
+      n -= half;                                                                                               \
+    }                                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const bool in = lo[c] < hi[c];                                                                           \
+      const uint32_t key = (uint32_t)l_k16[lo[c] < nws ? lo[c] : nws - 1];                                     \
+      lo[c] += (in && key < tk[c]) ? 1 : 0; }                                                                  \
+    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
+      const uint4 w4 = wrec[lo[c]];                                                                            \
+      pcs[c] = w4.x; pce[c] = w4.y; ppe[c] = w4.z; }                                                           \
+  }
 #define GAT_PRE_SIMPLE_L(Y)                                                                                    \
   _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lr[c] = l_rank[(Y)[c] & maskL];
 #define GAT_PRE_SIMPLE_W(Y)                    /* (k_place_wide's table ends at rangeL) */                    \
@@ -698,6 +750,8 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_PRE_TABLE_GL(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS(Y)
 #define GAT_PRE_TABLE_LG(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS2(Y)
 #define GAT_PRE_TABLE_GG(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS2(Y)
+#define GAT_PRE_TABLE_L3(Y) GAT_PRE_RANK_L(Y) GAT_PRE_WS3(Y)
+#define GAT_PRE_TABLE_G3(Y) GAT_PRE_RANK_G(Y) GAT_PRE_WS3(Y)
 #define GAT_ONE_SIMPLE_B(Y, C, JJ) GAT_STEP_SIMPLE_B((Y)[C], lr[C], JJ)
 #define GAT_ALIVE_B (sL || sP || sO)
 #define GAT_ONE_TABLE(Y, C, JJ) GAT_STEP_TABLE_B((Y)[C], lr[C], pcs[C], pce[C], ppe[C], JJ)
@@ -890,6 +944,11 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
         } else GAT_PLACE_LOOP(GAT_PRE_TABLE_GL, GAT_ONE_TABLE, GAT_ALIVE_TB)
       } else if constexpr (TREES) {
         if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_TB)
+      } else if constexpr (GRID) {
+        if (rank_lds) {
+          if (!kind1 && !drawB && A.place_plain_step == 0) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_TABLE_L3, GAT_ONE_TABLE_ASM) }
+          else GAT_PLACE_LOOP(GAT_PRE_TABLE_L3, GAT_ONE_TABLE, GAT_ALIVE_TB)
+        } else GAT_PLACE_LOOP(GAT_PRE_TABLE_G3, GAT_ONE_TABLE, GAT_ALIVE_TB)
       }
     }
   }
@@ -924,6 +983,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PLACE_CHUNK_ASM
 #undef GAT_FOLD_USED
 #undef GAT_PRE_TABLE_GG
+#undef GAT_PRE_TABLE_L3
+#undef GAT_PRE_TABLE_G3
+#undef GAT_PRE_WS3
 #undef GAT_PRE_TABLE_LG
 #undef GAT_PRE_TABLE_GL
 #undef GAT_PRE_TABLE_LL
@@ -970,6 +1032,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(96), amdgpu_wave
 template <int KIND>
 __global__ __launch_bounds__(kPlaceWide * 64) void k_place_wide(SamplerArgs A) {
   place_body<KIND, 3, 0, true>(A);
+}
+
+// MODE 4 / 5 (round 6): problems with workspaces beyond the LDS table (fragmented workspaces: the reference's own test data has
+// 6 600 - 21 000 workspace segments per contig).  kPlaceGridTiles (MODE 5: half as many) tiles of one unit per workgroup around
+// the image of the unit's cdf grid in dynamic LDS (2 bytes per workspace segment + 2 per cell): the position draw's
+// searchsorted is a handful of LDS reads and one 16-byte record from global memory, and the table step runs written out on
+// the hand-pipelined rows -- k_place<., 2> walked a 16-ary tree in global memory for every random number of a chunk, on the
+// compiler's step and loads (refdata, 8 549 segments, 10 000 samples: 7.0 ms)
+template <int TILES>
+__global__ __launch_bounds__(TILES * 64) void k_place_grid(SamplerArgs A) {
+  static_assert(TILES == kPlaceGridTiles || TILES == kPlaceGridTiles / 2, "MODE 4 / 5");
+  place_body<0, TILES == kPlaceGridTiles ? 4 : 5, 0, true>(A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1388,12 +1462,12 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       }
     }
   } else if constexpr (TREE) {
-    const uint32_t* __restrict__ tree_start = A.ws_tree + Up->tree_start_off;
-    const WsTreeGeom G = ws_tree_geom(nws);
+    const uint32_t* __restrict__ pg = A.ws_tree + Up->pgrid_off;          // (round 6: the position grid, not two tree searches)
+    const uint32_t pshift = pg[0], pcells = pg[1];
     for (int i = tid; i < count; i += kMergeThreads) {
       const uint2 v = out[i];
       tot += v.y - v.x;
-      cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y);
+      cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y);
     }
   }
   cov = block_reduce_u32(cov, red, tid, false, false);
@@ -1468,8 +1542,13 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
     }
     return bisect_u32(ws_cdf, nws, p);
   };
+  // (round 6: overlaps with a long workspace through its position grid -- a cell and the one or two pieces a segment can
+  //  reach -- where the tree over the starts was searched twice per segment)
+  const uint32_t* __restrict__ pgrid = A.ws_tree + (Up->pgrid_off >= 0 ? Up->pgrid_off : 0);
+  const uint32_t pshift = TREE && Up->pgrid_off >= 0 ? pgrid[0] : 0u, pcells = TREE && Up->pgrid_off >= 0 ? pgrid[1] : 0u;
+  (void)tree_start;
   auto ws_overlap1 = [&](uint32_t s, uint32_t e) -> uint32_t {   // one segment, a workspace beyond the register loop
-    if constexpr (TREE) return seg_overlap_tree1(ws, ws_cdf, tree_start, G, s, e);
+    if constexpr (TREE) return ws_overlap_pgrid(ws, nws, pgrid + kGridHeader, pshift, pcells, s, e);
     else return 0u;                                              // (no such unit in this instantiation)
   };
   const WsRegs W = ws_load(ws, ws_cdf, nws < kWsRegMax ? nws : kWsRegMax, lane);
@@ -1733,7 +1812,8 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
                 v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
                 tot += v[r].y - v[r].x;
               }
-              seg_overlap_tree<R>(ws, ws_cdf, tree_start, G, v, ov);
+#pragma unroll
+              for (int r = 0; r < R; ++r) ov[r] = ws_overlap_pgrid(ws, nws, pgrid + kGridHeader, pshift, pcells, v[r].x, v[r].y);
 #pragma unroll
               for (int r = 0; r < R; ++r) cov += ov[r];
             }
@@ -1909,7 +1989,8 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
             const int i = base + r * kWave + lane;
             v[r] = i < nU ? seg[i] : make_uint2(0u, 0u);
           }
-          seg_overlap_tree<R>(ws, ws_cdf, tree_start, G, v, ov);
+#pragma unroll
+          for (int r = 0; r < R; ++r) ov[r] = ws_overlap_pgrid(ws, nws, pgrid + kGridHeader, pshift, pcells, v[r].x, v[r].y);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const bool keep = ov[r] > 0;                     // (0,0) fillers overlap nothing

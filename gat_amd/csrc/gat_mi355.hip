@@ -460,6 +460,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.units = P->d_units.p; A.units_o = P->d_units_o.p; A.order = P->d_order.p; A.n_units = P->n_units; A.batch = (int32_t)nb;
       A.rec_stride = (int32_t)P->batch;                  // (the scratch's size in samples: the records' row length in every batch)
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
+      A.ws_rec = P->d_ws_rec.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
       A.place_plain_step = getenv("GAT_PLACE_NO_CM") ? 1 : 0;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
@@ -543,6 +544,25 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           // (k_place_pipe: the rows of the single-workspace-segment units prefetched by hand, see GAT_PLACE_LOOP_PIPE)
           const bool pipe = P->pipe_pays && !getenv("GAT_PLACE_NO_PIPE");
           const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
+          // fragmented workspaces: the cdf grids of the long workspaces in LDS, eight (or four, where the largest image leaves
+          // no room for eight rings) tiles of a unit per workgroup (k_place_grid); static LDS: the workspace and rank tables
+          // (4 KB each) and an 8 KB ring per tile
+          const size_t lds_grid = (size_t)P->grid_lds_words * 4 + 16;
+          const int64_t lds_static8 = 8192 + 1024 + (int64_t)gat::kPlaceGridTiles * 8192;
+          const int64_t lds_static4 = 8192 + 1024 + (int64_t)(gat::kPlaceGridTiles / 2) * 8192;
+          const int grid_tiles = mode == 2 && P->grid_place
+                                     ? ((int64_t)lds_grid + lds_static8 <= ctx->max_lds && !getenv("GAT_PLACE_GRID_HALF") ? gat::kPlaceGridTiles
+                                        : ((int64_t)lds_grid + lds_static4 <= ctx->max_lds ? gat::kPlaceGridTiles / 2 : 0))
+                                     : 0;
+          if (grid_tiles == gat::kPlaceGridTiles) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_grid<gat::kPlaceGridTiles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grid));
+            hipLaunchKernelGGL((gat::k_place_grid<gat::kPlaceGridTiles>), dim3((nsb + grid_tiles - 1) / grid_tiles, gy, gz),
+                               dim3(grid_tiles * 64), lds_grid, ctx->stream, A);
+          } else if (grid_tiles > 0) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_grid<gat::kPlaceGridTiles / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grid));
+            hipLaunchKernelGGL((gat::k_place_grid<gat::kPlaceGridTiles / 2>), dim3((nsb + grid_tiles - 1) / grid_tiles, gy, gz),
+                               dim3(grid_tiles * 64), lds_grid, ctx->stream, A);
+          } else
           if (mode == 3) {
             HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_wide<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));
             hipLaunchKernelGGL((gat::k_place_wide<0>), gw, dim3(gat::kPlaceWide * 64), lds_wide, ctx->stream, A);
@@ -689,7 +709,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           HIPCHK(ctx, hipGetLastError());
         }
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_k[2], ctx->stream));
-        hipLaunchKernelGGL(gat::k_tail, gt, dim3(64), 0, ctx->stream, T);
+        if (P->tail_long_ws && P->max_nws > gat::kTailMaxWs) hipLaunchKernelGGL(gat::k_tail<true>, gt, dim3(64), 0, ctx->stream, T);
+        else hipLaunchKernelGGL(gat::k_tail<false>, gt, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream));
         // isochore problems: k_contig re-sorts the units of a contig anyway and takes (merged list, k_tail's record) as

@@ -1015,6 +1015,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     std::vector<uint32_t> rank;          // rank 0 (never drawn) + the bucket indices in ascending order
     std::vector<uint2> ws;
     std::vector<uint32_t> cdf, tree_start, tree_cdf;
+    std::vector<uint32_t> pgrid, cgrid;  // the grids of a fragmented workspace, header included (UnitDev::pgrid_off / cgrid_off)
     int64_t nwork = 0;
     double cv2 = 0.0;
   };
@@ -1127,6 +1128,69 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       };
       build(R.tree_start, [&](int64_t i) { return uw[i].start; }, 0xffffffffu);
       build(R.tree_cdf, [&](int64_t i) { return R.cdf[(size_t)i]; }, 0x7fffffffu);
+      // Round 6, fragmented workspaces (the reference's own test data: 6 600 - 21 000 workspace segments per contig).  A tree
+      // search is four dependent 64-byte node reads; the two questions asked of a workspace have cheaper answers:
+      // (a) "how many bases of [s, e) lie inside?" (SegmentList.intersect(workspace).sum(), gat/Engine.pyx:596-598): a grid over
+      //     the POSITIONS, entry c = the first segment whose end lies beyond c << shift -- the segments that can overlap [s, e)
+      //     are walked from entry s >> shift (one or two for segments shorter than the workspace's pieces).  About two cells
+      //     per segment, at most 2^16.
+      {
+        const uint32_t top = uw[nuw - 1].end;                      // (coordinates are below 2^31)
+        int shift = 0;
+        int64_t want = 2 * nuw;
+        if (want > 65536) want = 65536;
+        while (((int64_t)top >> shift) + 1 > want) ++shift;
+        const int64_t cells = ((int64_t)top >> shift) + 1;
+        R.pgrid.assign((size_t)gat::kGridHeader + (size_t)cells + 1, 0u);
+        R.pgrid[0] = (uint32_t)shift; R.pgrid[1] = (uint32_t)cells;
+        int64_t j = 0;
+        uint32_t span = 0, prev = 0;
+        for (int64_t c = 0; c <= cells; ++c) {
+          const uint64_t x = (uint64_t)c << shift;
+          while (j < nuw && (uint64_t)uw[j].end <= x) ++j;
+          R.pgrid[(size_t)gat::kGridHeader + (size_t)c] = (uint32_t)j;
+          if (c > 0) span = std::max(span, (uint32_t)j - prev);
+          prev = (uint32_t)j;
+        }
+        R.pgrid[(size_t)gat::kGridHeader + (size_t)cells] = (uint32_t)nuw;       // (a position beyond the last cell: nothing to walk)
+        R.pgrid[2] = span;
+      }
+      // (b) "which segment holds base p of the workspace?" (SegmentListSampler.sample, gat/Engine.pyx:299-305: searchsorted over
+      //     cdf[i] = cumulated length - 1 with cmpPosition): a grid over the CUMULATED lengths, g[c] = #{i : cdf[i] < c << shift},
+      //     and 16-bit keys cdf[i] & mask -- within a cell the high bits agree, so #{cdf < p} = g[c] + #{i in [g[c], g[c + 1]) :
+      //     key[i] < (p & mask)}.  2 bytes per segment + 2 per cell: k_place_grid keeps the image in LDS, where the trees (64 bytes
+      //     per node and level, in global memory) were four dependent L2 round trips for EVERY random number of a chunk.  shift
+      //     <= 16 (the keys), at most 65 535 segments (the entries), the widest cell at most 8 segments where the cells allow it.
+      if (nuw > gat::kPlaceWsLds && nuw <= 65535 && tot > 1u && tot <= 0x80000000u) {
+        const uint32_t topc = tot - 1u;                             // the largest p
+        int shift = 16;
+        while (shift > 0 && ((int64_t)topc >> shift) + 1 < nuw / 2) --shift;       // about half a cell per segment to begin with
+        for (;;) {
+          const int64_t cells = ((int64_t)topc >> shift) + 1;
+          std::vector<uint32_t> g((size_t)cells + 1);
+          int64_t j = 0;
+          uint32_t span = 0;
+          for (int64_t c = 0; c <= cells; ++c) {
+            const uint64_t x = (uint64_t)c << shift;
+            while (j < nuw && (uint64_t)R.cdf[(size_t)j] < x) ++j;
+            g[(size_t)c] = (uint32_t)j;
+            if (c > 0) span = std::max(span, g[(size_t)c] - g[(size_t)c - 1]);
+          }
+          // finer while a cell holds more than 8 segments and the image stays below 96 KB (24 K words)
+          const int64_t cells_next = shift > 0 ? ((int64_t)topc >> (shift - 1)) + 1 : cells;
+          const int64_t words_next = (cells_next + 2) / 2 + (nuw + 1) / 2;
+          if (span > 8 && shift > 0 && words_next <= 24576) { --shift; continue; }
+          const size_t gw = ((size_t)cells + 2) / 2, kw = ((size_t)nuw + 1) / 2;
+          R.cgrid.assign((size_t)gat::kGridHeader + gw + kw, 0u);
+          R.cgrid[0] = (uint32_t)shift; R.cgrid[1] = (uint32_t)cells; R.cgrid[2] = span; R.cgrid[3] = (uint32_t)(gw + kw);
+          uint16_t* g16 = reinterpret_cast<uint16_t*>(R.cgrid.data() + gat::kGridHeader);
+          for (int64_t c = 0; c <= cells; ++c) g16[c] = (uint16_t)g[(size_t)c];
+          uint16_t* k16 = reinterpret_cast<uint16_t*>(R.cgrid.data() + gat::kGridHeader + gw);
+          const uint32_t mask = shift >= 32 ? 0xffffffffu : ((1u << shift) - 1u);
+          for (int64_t i = 0; i < nuw; ++i) k16[i] = (uint16_t)(R.cdf[(size_t)i] & mask);
+          break;
+        }
+      }
     }
     U.ltotal = (int32_t)ltotal;
     U.n_target = (int32_t)nus;                       // SamplerSegments places len(segments) segments
@@ -1155,6 +1219,16 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       U.tree_cdf_off = (int32_t)h_ws_tree.size();
       h_ws_tree.insert(h_ws_tree.end(), R.tree_cdf.begin(), R.tree_cdf.end());
     }
+    U.pgrid_off = -1;
+    U.cgrid_off = -1;
+    auto append16 = [&](const std::vector<uint32_t>& v) {          // (16-byte aligned: the images are copied in 16-byte pieces)
+      while (h_ws_tree.size() & 3u) h_ws_tree.push_back(0u);
+      const int32_t off = (int32_t)h_ws_tree.size();
+      h_ws_tree.insert(h_ws_tree.end(), v.begin(), v.end());
+      return off;
+    };
+    if (!R.pgrid.empty()) U.pgrid_off = append16(R.pgrid);
+    if (!R.cgrid.empty()) U.cgrid_off = append16(R.cgrid);
     len_cv2[(size_t)u] = R.cv2;
     P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(R.nwork, d->seg_off[u + 1] - d->seg_off[u]) : R.nwork);
     work.push_back(std::make_pair(R.nwork, (int32_t)u));
@@ -1199,6 +1273,21 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     max_hist = std::max(max_hist, U.hist_total);
   }
   P->small_tables = !P->h_order.empty() && P->max_nws <= 64 && max_hist < 256;
+  {
+    // k_place_grid (MODE 4): some workspace is beyond k_place's LDS table and every such unit has the grid over its cumulated
+    // lengths (UnitDev::cgrid_off), the largest image within the LDS the rings leave
+    bool any = false, all = true;
+    int32_t words = 0;
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[(size_t)u];
+      if (U.n_ws <= gat::kPlaceWsLds) continue;
+      any = true;
+      if (U.cgrid_off < 0) { all = false; break; }
+      words = std::max(words, (int32_t)h_ws_tree[(size_t)U.cgrid_off + 3]);
+    }
+    P->grid_place = any && all && !getenv("GAT_PLACE_NO_GRID");
+    P->grid_lds_words = words;
+  }
   P->pipe_pays = 2 * work_simple >= work_all;
   P->all_one_ws = P->all_one_ws && !P->all_simple && 2 * work_big_rank >= work_all && max_hist <= (uint32_t)gat::kPlaceWideMaxRank;
   P->long_lists = max_hist + max_hist / 8 > 1024;
@@ -1207,7 +1296,10 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     // the split path pays when k_tail can take most units: SamplerAnnotator, lists the wave bucket sorts hold, workspaces
     // of up to kTailMaxWs segments
     size_t small_ws = 0;
-    for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs) ++small_ws;
+    // (round 6: k_tail takes the longer workspaces too -- their position draw through the tree over the cumulated lengths, their
+    //  overlaps through the position grid; GAT_TAIL_NO_LONG_WS: as before, such units are k_sampler's)
+    P->tail_long_ws = !getenv("GAT_TAIL_NO_LONG_WS");
+    for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs || P->tail_long_ws) ++small_ws;
     // (long lists: their tail places dozens of segments, not the handful k_tail keeps aside -- 0.2 % finished there on the
     //  config-4 shape -- so those problems stay with k_merge_big + k_sampler)
     P->split_path = P->sampler == GAT_SAMPLER_ANNOTATOR && !P->h_order.empty() && 2 * small_ws >= P->h_order.size() &&
@@ -1292,6 +1384,18 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
   HIPCHK(ctx, P->d_contig_units.upload(P->h_contig_units, ctx));
   HIPCHK(ctx, P->d_ws.upload(h_ws, ctx));
   HIPCHK(ctx, P->d_ws_cdf.upload(h_ws_cdf, ctx));
+  {
+    // what a position draw needs of its workspace segment (gat/Engine.pyx:318-325) as one record
+    std::vector<uint4> rec(std::max<size_t>(1, h_ws.size()));
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[(size_t)u];
+      for (int32_t i = 0; i < U.n_ws; ++i) {
+        const size_t k = (size_t)U.ws_off + (size_t)i;
+        rec[k] = make_uint4(h_ws[k].x, h_ws[k].y, i > 0 ? h_ws[k - 1].y : 0x80000000u, h_ws_cdf[k]);
+      }
+    }
+    HIPCHK(ctx, P->d_ws_rec.upload(rec, ctx));
+  }
   if (h_ws_tree.empty()) h_ws_tree.assign(16, 0u);
   HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx));
   HIPCHK(ctx, P->d_rank_len.upload(h_rank_len, ctx));

@@ -33,6 +33,12 @@ namespace gat {
 constexpr int kTailMaxExtra = 4;      // new segments k_tail keeps aside per unit
 // (kTailMaxWs = 64 workspace segments k_tail scans linearly: gat_types.h)
 constexpr int kTailMaxWalk = 6;       // segments an overshoot trim may touch
+#ifndef GAT_TAIL_LONG_WALK
+#define GAT_TAIL_LONG_WALK 96
+#endif
+constexpr int kTailMaxWalkLong = GAT_TAIL_LONG_WALK;   // ... in a fragmented workspace (k_tail<true>): the placement loop books a segment's overlap with
+                                      // the CHOSEN workspace segment only (gat/Engine.pyx:331-343), what it covers of the neighbouring pieces
+                                      // shows at the consolidation -- the overshoot, and with it the trim's walk, is dozens of segments there
 constexpr int kTailRows = 8;          // random rows fetched at a time
 
 // what k_tail hands on, per (sample, unit) by launch position.  A finished unit (state 1) is: its merged list in the
@@ -131,10 +137,13 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     const uint32_t s1 = head ? ks[0] : 0u, e1 = head ? mend : 0u;
     GAT_CPHASE(3)
     uint32_t cov1 = 0;
-    const uint32_t* __restrict__ tree_start1 = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
     if (nws <= 8) cov1 = ws_overlap_regs(W, s1, e1);
     else if (nws <= kWsLoopMax) cov1 = ws_overlap_search(W, s1, e1);
-    else if constexpr (TREE) { if (head) cov1 = seg_overlap_tree1(ws, ws_cdf, tree_start1, ws_tree_geom(nws), s1, e1); }
+    else if constexpr (TREE) {
+      // (round 6: the position grid instead of two tree searches per segment)
+      const uint32_t* __restrict__ pg1 = A.ws_tree + Up->pgrid_off;
+      if (head) cov1 = ws_overlap_pgrid(ws, nws, pg1 + kGridHeader, pg1[0], pg1[1], s1, e1);
+    }
     const uint32_t incl1 = wave_incl_sum_u32(e1 - s1, lane);
     if (head) {
       out[pos] = make_uint2(s1, e1);
@@ -185,8 +194,8 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   GAT_CPHASE(3)
   // coverage (intersect(workspace).sum()), total length, running lengths; the merged list goes back to the slab
   uint32_t cov = 0, run = 0;
-  const uint32_t* __restrict__ tree_start = A.ws_tree + (Up->tree_start_off >= 0 ? Up->tree_start_off : 0);
-  const WsTreeGeom G = ws_tree_geom(nws);
+  const uint32_t* __restrict__ pg = A.ws_tree + (Up->pgrid_off >= 0 ? Up->pgrid_off : 0);
+  const uint32_t pshift = TREE ? pg[0] : 0u, pcells = TREE ? pg[1] : 0u;
   for (int base = 0; base < nU; base += kWave) {
     const int i = base + lane;
     uint2 v = make_uint2(0u, 0u);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     //  cheaper by the loop)
     if (nws <= 8) cov += ws_overlap_regs(W, v.x, v.y);
     else if (nws <= kWsLoopMax) cov += ws_overlap_search(W, v.x, v.y);
-    else if constexpr (TREE) { if (i < nU) cov += seg_overlap_tree1(ws, ws_cdf, tree_start, G, v.x, v.y); }
+    else if constexpr (TREE) { if (i < nU) cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y); }
     const uint32_t incl = run + wave_incl_sum_u32(v.y - v.x, lane);
     if (i < nU) {
       out[i] = v;
@@ -286,6 +295,10 @@ __device__ __forceinline__ uint32_t tail_range(TailRng& r, uint32_t range) {
   return v;
 }
 
+// LONGWS (round 6): units of more than kTailMaxWs workspace segments are taken too -- the position draw's segment through the
+// tree over the cumulated lengths (a handful of draws per unit), the overlaps through the position grid (ws_overlap_pgrid); the
+// instantiation without it is what problems of short workspaces run (such units are k_sampler's there)
+template <bool LONGWS>
 __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   __shared__ uint32_t l_ws[3 * kTailMaxWs];         // starts, ends, cdf of the unit's workspace
   const SamplerArgs& A = T.S;
@@ -294,19 +307,26 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
-  if (nws > kTailMaxWs) {                            // long workspace: left to k_sampler (search trees)
+  const bool longws = LONGWS && nws > kTailMaxWs;    // (wave-uniform)
+  if (nws > kTailMaxWs && !longws) {                 // long workspace: left to k_sampler (search trees)
     const int sx = sb * kWave + lane;
     if (sx < A.batch) T.todo[atomicAdd(T.todo_count, 1u)] = (uint32_t)sx * (uint32_t)A.n_active + (uint32_t)a;
     return;
   }
+  const uint2* __restrict__ wsg = A.ws + Up->ws_off;
+  const uint32_t* __restrict__ pgh = A.ws_tree + (longws ? Up->pgrid_off : 0);
+  const uint32_t pshift = longws ? pgh[0] : 0u, pcells = longws ? pgh[1] : 0u;
+  const uint32_t* __restrict__ tree_cdf = A.ws_tree + (longws ? Up->tree_cdf_off : 0);
+  const WsTreeGeom G = ws_tree_geom(nws);
   const uint32_t hist_total = Up->hist_total, bucket = Up->bucket, ws_total = Up->ws_total;
   const int32_t ltotal = Up->ltotal;
   const int cap = Up->slab_cap;
   const uint32_t* __restrict__ rank_len = A.rank_len + Up->rank_off;
-  for (int i = lane; i < nws; i += kWave) {
-    const uint2 w = A.ws[Up->ws_off + i];
-    l_ws[i] = w.x; l_ws[kTailMaxWs + i] = w.y; l_ws[2 * kTailMaxWs + i] = A.ws_cdf[Up->ws_off + i];
-  }
+  if (!longws)
+    for (int i = lane; i < nws; i += kWave) {
+      const uint2 w = A.ws[Up->ws_off + i];
+      l_ws[i] = w.x; l_ws[kTailMaxWs + i] = w.y; l_ws[2 * kTailMaxWs + i] = A.ws_cdf[Up->ws_off + i];
+    }
   __syncthreads();
   const int sidx = sb * kWave + lane;
   if (sidx >= A.batch) return;
@@ -330,6 +350,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 
   // bases of [s, e) inside the workspace (SegmentList.intersect(workspace).sum() of one segment)
   auto ws_overlap = [&](uint32_t s, uint32_t e) -> uint32_t {
+    if constexpr (LONGWS) { if (longws) return ws_overlap_pgrid(wsg, nws, pgh + kGridHeader, pshift, pcells, s, e); }
     uint32_t ov = 0;
     for (int j = 0; j < nws; ++j) {
       const uint32_t ws0 = l_ws[j], we0 = l_ws[kTailMaxWs + j];
@@ -439,7 +460,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       int idx = v, full = 0;
       uint32_t part = 0;
       for (int w = 0; s > 0; ++w) {
-        if (w >= kTailMaxWalk) { bail = true; break; }
+        if (w >= (longws ? kTailMaxWalkLong : kTailMaxWalk)) { bail = true; break; }
         const uint2 x = vget(idx);
         const int32_t l = (int32_t)x.y - (int32_t)x.x;
         uint32_t ra, rb;
@@ -472,11 +493,25 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       // ---- sls.sample(length) (:279-343)
       const uint32_t p = tail_range(rng, ws_total - 1u);
       int k = 0;
-      for (int j = 0; j < nws; ++j) k += ((int32_t)(l_ws[2 * kTailMaxWs + j] - p) < 0) ? 1 : 0;   // searchsorted + cmpPosition
-      k = k < nws ? k : nws - 1;
-      const uint32_t cs = l_ws[k], ce = l_ws[kTailMaxWs + k];
+      uint32_t cs, ce;
+      int32_t pe = INT32_MIN;
+      bool lw = false;
+      if constexpr (LONGWS) lw = longws;
+      if (lw) {
+        const uint32_t tp[1] = {p};
+        int kk[1];
+        ws_tree_count<true, 1>(tree_cdf, G, tp, kk);                                  // searchsorted + cmpPosition
+        k = kk[0] < nws ? kk[0] : nws - 1;
+        const uint4 w4 = A.ws_rec[Up->ws_off + k];
+        cs = w4.x; ce = w4.y; pe = (int32_t)w4.z;
+      } else {
+        for (int j = 0; j < nws; ++j) k += ((int32_t)(l_ws[2 * kTailMaxWs + j] - p) < 0) ? 1 : 0;   // searchsorted + cmpPosition
+        k = k < nws ? k : nws - 1;
+        cs = l_ws[k]; ce = l_ws[kTailMaxWs + k];
+        if (k > 0) pe = (int32_t)l_ws[kTailMaxWs + k - 1];
+      }
       int32_t sampling_start = (int32_t)cs - length + 1;
-      if (k > 0) { const int32_t pe = (int32_t)l_ws[kTailMaxWs + k - 1]; sampling_start = pe > sampling_start ? pe : sampling_start; }
+      sampling_start = pe > sampling_start ? pe : sampling_start;
       const uint32_t range = ce - 1u - (uint32_t)sampling_start;
       const int32_t q = sampling_start + (int32_t)tail_range(rng, range);
       if (rng.out_of_rows) break;

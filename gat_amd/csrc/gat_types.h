@@ -13,6 +13,11 @@ constexpr int kWsTreeMin = 32;      // workspaces with more segments get trees (
 constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so that the geometry stays in scalar registers
 
 constexpr int kPlaceWsLds = 256;      // k_place: workspace segments kept in LDS (16 B each)
+#ifndef GAT_PLACE_GRID_TILES
+#define GAT_PLACE_GRID_TILES 8
+#endif
+constexpr int kPlaceGridTiles = GAT_PLACE_GRID_TILES;   // k_place_grid (MODE 4): tiles (waves) of a workgroup around one unit's cdf grid in LDS
+constexpr int kGridHeader = 4;        // words in front of a grid in ws_tree: {shift, cells, widest cell's span, words of the LDS image}
 constexpr int kPlaceRankLds = 1024;   // k_place: length-rank table entries kept in LDS
 #ifndef GAT_PLACE_WIDE_TILES
 #define GAT_PLACE_WIDE_TILES 4         // (tuning builds: -DGAT_PLACE_WIDE_TILES=2 / 8; tools/exp_wide_tiles*.sh: config-4 shape k_place_wide
@@ -40,7 +45,15 @@ struct UnitDev {
   int32_t rank_off;     // offset into rank_len: rank_len[r] = bucket index searchsorted(cdf, r) returns
   int32_t n_target;     // SamplerSegments: len(segments) placements (gat/Engine.pyx:726)
   int32_t pad;          // units_o: the unit id
+  // fragmented workspaces (round 6; both -1 for a short workspace), offsets into ws_tree, kGridHeader words in front of each:
+  int32_t pgrid_off;    // position grid: entry c = the first workspace segment whose END lies beyond c << shift (u32 entries;
+                        //   cells + 1 of them, the last = n_ws): the overlap of [s, e) with the workspace is a walk from entry s >> shift
+  int32_t cgrid_off;    // grid over the cumulated lengths (the position draw's searchsorted, gat/Engine.pyx:299-305): u16 entries
+                        //   g[c] = #{i : cdf[i] < c << shift} (cells + 1, padded to a word), then u16 keys cdf[i] & ((1 << shift) - 1):
+                        //   #{cdf < p} = g[c] + #{i in [g[c], g[c + 1]) : key[i] < (p & mask)} for c = p >> shift -- the image k_place_grid
+                        //   copies into LDS (2 bytes per workspace segment + 2 per cell)
 };
+static_assert(sizeof(UnitDev) == 64, "UnitDev: sixteen words");
 
 enum : int32_t {
   kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab

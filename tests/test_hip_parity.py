@@ -398,6 +398,88 @@ def _long_list_case(ctx, seed):
     return handed
 
 
+def _frag_ws_case(ctx, seed, setenv=None):
+    """fragmented workspaces (the reference's own test data: 6 600 - 21 000 workspace segments per contig): units of 300 to
+    30 000 workspace segments of mixed lengths -- one-base pieces, pieces longer than everything else together, adjacent pieces,
+    pieces shorter than the segments placed (a placed segment then reaches over several) -- through k_place_grid (the cdf grid in
+    LDS), k_consolidate / k_tail with the position grid, or (knobs by seed) the trees those replaced"""
+    import collections
+    from gat_amd import problem
+    rs = np.random.RandomState(seed)
+    n_contigs = int(rs.randint(1, 4))
+    style = int(rs.randint(0, 4))
+    contigs = collections.OrderedDict()
+    ws = collections.OrderedDict()
+    for i in range(n_contigs):
+        n = int(rs.choice([300, 700, 2000, 6000, 13000, 30000]) * (0.7 + 0.6 * rs.rand())) if i == 0 else int(rs.randint(2, 2000))
+        if style == 0:        # kilobase pieces with kilobase gaps (the mouse workspace's shape)
+            lens = 1000 + rs.geometric(1.0 / 6000, size=n)
+            gaps = rs.geometric(1.0 / 3000, size=n)
+        elif style == 1:      # short pieces, many of them shorter than the segments placed; adjacent pieces
+            lens = rs.geometric(1.0 / 40, size=n)
+            gaps = rs.geometric(1.0 / 30, size=n) - 1
+        elif style == 2:      # a few giants among crumbs
+            lens = np.where(rs.rand(n) < 0.01, rs.randint(100000, 3000000, size=n), rs.geometric(1.0 / 8, size=n))
+            gaps = rs.geometric(1.0 / 200, size=n)
+        else:                 # equal pieces
+            lens = np.full(n, int(rs.randint(1, 5000)))
+            gaps = np.full(n, int(rs.randint(0, 3000)))
+        gaps = np.asarray(gaps, dtype=np.int64)
+        lens = np.asarray(lens, dtype=np.int64)
+        starts = int(rs.randint(0, 5000)) + np.cumsum(gaps + np.concatenate([[0], lens[:-1]]))
+        keep = starts + lens < (1 << 31) - 10
+        a = np.empty(int(keep.sum()), dtype=synthetic.SEG)
+        a["start"], a["end"] = starts[keep], (starts + lens)[keep]
+        name = "f%d" % i
+        ws[name] = a
+        contigs[name] = int(a["end"][-1]) + int(rs.randint(1, 5000))
+    total = sum(int((a["end"].astype(np.int64) - a["start"]).sum()) for a in ws.values())
+    n_segs = int(rs.choice([40, 150, 400, 900]))
+    mean_len = max(1, int(min(total * float(rs.choice([0.002, 0.02, 0.1])) / n_segs, 20000)))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    annos = [("t0", synthetic.random_segments(contigs, 200, 1500, int(rs.randint(1 << 30))))]
+    flat = problem.flatten_arrays(segs, annos, ws, None, bucket_size=int(rs.choice([0, 1, 1, 1])), nbuckets=100000)
+    if flat["n_contigs"] == 0:
+        return 0
+    knobs = {}
+    if seed % 2 == 1:
+        knobs["GAT_PLACE_NO_CM"] = "1"                 # the compiler's step behind the grid look-ups
+    if seed % 8 == 2:
+        knobs["GAT_PLACE_GRID_HALF"] = "1"             # four tiles per workgroup
+    if seed % 8 == 4:
+        knobs["GAT_PLACE_NO_GRID"] = "1"               # the trees in global memory (k_place<., 2>)
+    if seed % 8 == 6:
+        knobs["GAT_TAIL_NO_LONG_WS"] = "1"             # k_sampler alone behind k_place, as before round 6
+    counters = ["nucleotide-overlap", "segment-overlap"]
+    S = 70 if seed % 3 == 0 else 5                      # (more than a tile of samples now and then)
+    try:
+        want, wsamples = O.run_samples(flat, counters, seed, 1, 0, S, want_samples=True)
+    except ValueError:                                  # (a segment longer than nbuckets x bucket_size: gat/SegmentList.pyx:1170)
+        with pytest.raises(ValueError):
+            _lib.Problem(ctx, flat)
+        return 0
+    for k, v in knobs.items():
+        os.environ[k] = v
+    try:
+        P = _lib.Problem(ctx, flat)
+        got = P.sample_and_count(counters, seed, 0, S)
+        st = P.last_stats
+        for k, c in enumerate(counters):
+            assert np.array_equal(got[k], want[k]), (seed, c, style, n_segs, mean_len, knobs)
+        seg, off = P.sample(seed, 0, S)
+        assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0]), (seed, style, knobs)
+        P.close()
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+    return st["n_tail_units"]
+
+
+@pytest.mark.parametrize("seed", list(range(700, 732)))
+def test_fragmented_workspaces_vs_oracle(ctx, seed):
+    _frag_ws_case(ctx, seed)
+
+
 @pytest.mark.parametrize("sampler", [0, 1])
 def test_wide_placement_tiles_vs_oracle(ctx, sampler):
     """k_place_wide (units of thousands of segments on one workspace segment: eight tiles of a unit per workgroup around
