@@ -6,7 +6,8 @@ per contig, count every annotation track) over `--samples` Monte-Carlo samples p
 read-back of the count matrix to the host ("seed -> count matrix on host").  The headline line is
 BASELINE.json's config2 (10k segments x 1 annotation track x 10k intervals, hg19 workspace, 10 000 samples,
 CounterNucleotideOverlap); the same run then measures the other single-GPU shapes of BASELINE.json (config3, the
-north_star target shape; one call's worth of config5 and config4) and reports them under "configs".  Inputs are
+north_star target shape; one call's worth of config5 and config4; refdata, the reference's own test data with its
+fragmented workspace) and reports them under "configs".  Inputs are
 resident in HBM before the timed region.  The headline shape's steps are software-pipelined one deep (--pipeline 2, the
 default; config.steps_in_flight): step i+1's kernels are enqueued before the host waits for step i, as gat_amd.run() does
 with consecutive segment tracks; all K steps' kernels AND read-backs complete inside the timed region.  --pipeline 1:
@@ -53,7 +54,7 @@ L2_PEAK_GBPS = 34500.0          # ... 34.5 TB/s aggregate L2 bandwidth (128-byte
 # samples per GPU per step of the extra shapes: config3 = its own 10 000; config4 is an 8-GPU job of 12 500 samples per
 # GPU, config5 one of 125 000 per GPU: a rank's whole shard per step (the library cuts it into batches that fit its
 # scratch budget)
-EXTRA_SAMPLES = {"config3": 10000, "config5": 125000, "config4": 12500}
+EXTRA_SAMPLES = {"config3": 10000, "config5": 125000, "config4": 12500, "refdata": 10000}
 # the reference itself (Cython engine, one core, build container) -- it cannot travel
 REFERENCE_CYTHON = {"config2": 19.1}
 
@@ -66,8 +67,10 @@ def parse():
     ap.add_argument("--config", default="config2")
     ap.add_argument("--samples", type=int, default=0, help="samples per GPU per step (default: the config's)")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--extra", default="config3,config5,config4",
-                    help="further BASELINE shapes measured in the same run and reported under 'configs' ('' = none)")
+    ap.add_argument("--extra", default="config3,config5,config4,refdata",
+                    help="further shapes measured in the same run and reported under 'configs' ('' = none): BASELINE's config3 / 5 / 4 and "
+                         "refdata, the reference's own test data set (tests/golden/refdata: 8 549 segments, a workspace of 279 057 "
+                         "segments, 7 annotation tracks; test/data/output_single.tsv:66-77 has the reference at 30 samples/s on it)")
     ap.add_argument("--extra-steps", type=int, default=20, help="timed steps of the extra shapes (config4: a quarter of it)")
     ap.add_argument("--sustain-seconds", type=float, default=1.0, help="length of the sustained loop per shape (0 = none)")
     ap.add_argument("--pipeline", type=int, default=2, choices=(1, 2),
@@ -783,6 +786,13 @@ def main():
         r["n_gpus"] = world
         if cpu_leg and name == "config3":                   # the north_star target shape: the port on the same workload
             r["cpu_baseline"] = cpu_baseline(E.flat, E.counters, args.seed, args.cpu_seconds * 0.6)
+        if name == "refdata":
+            # the one workload the reference publishes a timing for: its own log of this data set
+            r["reference_published"] = {"value": 30.3, "unit": "samples/s", "cores": 1,
+                                        "source": "test/data/output_single.tsv:66-77 of the reference: 1000 samples of this track in 33.0 s "
+                                                  "(cgat150, Linux 2.6.32, Python 2.7.1, 2013); BASELINE.md"}
+            if cpu_leg:
+                r["cpu_baseline"] = cpu_baseline(E.flat, E.counters, args.seed, args.cpu_seconds * 0.4)
         extras[name] = r
         E.close()
         del E

@@ -273,9 +273,9 @@ template <int KIND, int MODE, int SMALL, bool PIPE>
 __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   constexpr bool ALL_SIMPLE = MODE == 1 || MODE == 3;
   constexpr bool TREES = MODE == 2;
-  constexpr bool GRID = MODE == 4 || MODE == 5;                            // k_place_grid: see GAT_PRE_WS3
+  constexpr bool GRID = MODE == 5;                                         // k_place_grid: see GAT_PRE_WS3
   constexpr int kWsTab = SMALL ? 64 : kPlaceWsLds, kRankTab = MODE == 3 ? 1 : (SMALL == 1 ? 256 : kPlaceRankLds);
-  constexpr int WIDE = MODE == 3 ? kPlaceWide : (MODE == 4 ? kPlaceGridTiles : (MODE == 5 ? kPlaceGridTiles / 2 : 1));   // tiles (waves) of a workgroup
+  constexpr int WIDE = MODE == 3 ? kPlaceWide : (MODE == 5 ? kPlaceGridTiles : 1);   // tiles (waves) of a workgroup
   __shared__ uint4 l_ws[kWsTab];          // {cdf, start, end, previous segment's end (INT32_MIN for the first)}
   __shared__ uint32_t l_rank_tab[kRankTab];
   __shared__ __attribute__((aligned(8192))) uint2 l_out_all[WIDE][16][kWave];   // (8 KB-aligned: GAT_STEP_SIMPLE_ASM) ring of 16 placed segments per lane, flushed 8 at a time as one 64-byte burst
@@ -285,9 +285,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   const int lane = threadIdx.x & (kWave - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   uint2 (*const l_out)[kWave] = l_out_all[wv];
   const int n_tiles = (A.batch + kWave - 1) / kWave;
-  const int sb_own = (int)blockIdx.x * WIDE + wv;          // (a wide workgroup's last waves may be beyond the batch: they idle
-  const int sb = sb_own < n_tiles ? sb_own : n_tiles - 1;  //  through the loop on the last tile's rows and write nothing)
   const int a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
+  const int sb_own = (int)blockIdx.x * WIDE + wv;                       // (a wide workgroup's last waves may be beyond the batch: they idle
+  const int sb = sb_own < n_tiles ? sb_own : n_tiles - 1;  //  through the loop on the last tile's rows and write nothing)
   if (a >= A.n_active) return;
   const UnitDev* __restrict__ Up = A.units_o + a;
   const int nws = Up->n_ws;
@@ -553,6 +553,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // whether an output would be accepted is worked out for every kind of draw, the lane's state picks; the offset draw's
   // mask and range (they follow from the chosen workspace segment and the length) are kept from the position draw on.
   bool sB = false;
+  bool alive_c = true;         // the lane is in some state at the head of the chunk (GAT_PRE_WS3 asks for no record otherwise)
   uint32_t omask = 0u, orange = 0u;
 #define GAT_STEP_TABLE_B(Y, LR, PCS, PCE, PPE, JJ)                                                             \
   {                                                                                                            \
@@ -715,30 +716,60 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
   // the same for a workspace beyond the LDS table where its grid is in LDS (k_place_grid): the cell's two entries, a halving
   // search over the widest cell's span among the cell's 16-bit keys (entries behind the cell's end count as above every p),
   // and ONE 16-byte record of the chosen segment from global memory -- where the tree took four dependent 64-byte nodes
-#define GAT_PRE_WS3(Y)                                                                                         \
+#ifdef GAT_EXP_NOGATHER                 /* timing-only builds (results are wrong): every look-up reads record 0 */
+#define GAT_EXP_REC(I) ((I) & 0)
+#else
+#define GAT_EXP_REC(I) (I)
+#endif
+#ifdef GAT_EXP_NOSEARCH                 /* ... / the LDS search left out: the cell's first segment it is */
+#define GAT_EXP_SPAN(N) 0
+#else
+#define GAT_EXP_SPAN(N) (N)
+#endif
+#define GAT_PRE_WS3(Y) GAT_PRE_WS3X(Y, pcs, pce, ppe)
+#define GAT_PRE_WS3X(Y, PCS, PCE, PPE)                                                                         \
   {                                                                                                            \
     uint32_t tk[kPlaceChunk]; int lo[kPlaceChunk], hi[kPlaceChunk];                                            \
+    bool need[kPlaceChunk];                                                                                    \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
       const uint32_t v = (Y)[c] & maskP; const uint32_t pv = v <= rangeP ? v : rangeP;                         \
+      /* a lane that has halted, or a value numpy's rejection would not take as a position: no record is wanted -- all   \
+         such lanes read record 0, one request per instruction instead of one per lane (the look-ups run at the rate    \
+         the L2s serve 16-byte gathers: a fifth of the values are rejected, a sixth of a tile's lane-rows are idle) */ \
+      need[c] = alive_c && v <= rangeP;                                                                        \
       const uint32_t cell = pv >> cshift; tk[c] = pv & cmask;                                                  \
       lo[c] = (int)l_g16[cell]; hi[c] = (int)l_g16[cell + 1u]; }                                               \
-    for (int n = cspan; n > 1;) {                                                                              \
+    /* (the eight reads of a step issued together, every one of them: written as `in && key < t` the compiler sank each read   \
+        into a branch of its own behind the bound test, with its s_waitcnt -- 32 LDS round trips one after the other per    \
+        chunk, most of k_place_grid's time; the empty asm pins the value outside any branch) */                               \
+    for (int n = GAT_EXP_SPAN(cspan); n > 1;) {                                                                \
       const int half = n >> 1;                                                                                 \
+      uint32_t key[kPlaceChunk];                                                                               \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
         const int pr = lo[c] + half - 1;                                                                       \
-        const bool in = pr < hi[c];                                                                            \
-        const uint32_t key = (uint32_t)l_k16[in ? pr : lo[c]];                                                 \
-        lo[c] = (in && key < tk[c]) ? lo[c] + half : lo[c];                                                    \
+        key[c] = (uint32_t)l_k16[pr < nws ? pr : nws - 1];                                                     \
+        asm volatile("" : "+v"(key[c]));                                                                       \
+      }                                                                                                        \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        const int pr = lo[c] + half - 1;                                                                       \
+        const uint32_t kx = pr < hi[c] ? key[c] : 0xffffffffu;      /* (behind the cell's end: above every p) */  \
+        lo[c] = kx < tk[c] ? lo[c] + half : lo[c];                                                             \
       }                                                                                                        \
       n -= half;                                                                                               \
     }                                                                                                          \
+    {                                                                                                          \
+      uint32_t key[kPlaceChunk];                                                                               \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        key[c] = (uint32_t)l_k16[lo[c] < nws ? lo[c] : nws - 1];                                               \
+        asm volatile("" : "+v"(key[c]));                                                                       \
+      }                                                                                                        \
+      _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                \
+        const uint32_t kx = lo[c] < hi[c] ? key[c] : 0xffffffffu;                                              \
+        lo[c] += kx < tk[c] ? 1 : 0; }                                                                         \
+    }                                                                                                          \
     _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
-      const bool in = lo[c] < hi[c];                                                                           \
-      const uint32_t key = (uint32_t)l_k16[lo[c] < nws ? lo[c] : nws - 1];                                     \
-      lo[c] += (in && key < tk[c]) ? 1 : 0; }                                                                  \
-    _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) {                                                  \
-      const uint4 w4 = wrec[lo[c]];                                                                            \
-      pcs[c] = w4.x; pce[c] = w4.y; ppe[c] = w4.z; }                                                           \
+      const uint4 w4 = wrec[GAT_EXP_REC(need[c] ? lo[c] : 0)];                                                 \
+      PCS[c] = w4.x; PCE[c] = w4.y; PPE[c] = w4.z; }                                                           \
   }
 #define GAT_PRE_SIMPLE_L(Y)                                                                                    \
   _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) lr[c] = l_rank[(Y)[c] & maskL];
@@ -843,6 +874,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #define GAT_ONE_TABLE_ASM(C, JJ1, YREG) GAT_STEP_TABLE_ASM(YREG, lr[C], pcs[C], pce[C], ppe[C], JJ1)
 #define GAT_PLACE_CHUNK_ASM(PRE, ONE, K, R0, R1, R2, R3, R4, R5, R6, R7)                                     \
   GAT_PSTAMP(0)                                                                                              \
+  if constexpr (GRID) alive_c = (((mL | mP | mO) >> lane) & 1ull) != 0ull;                                   \
   PRE(ya)                                                                                                    \
   GAT_PSTAMP(1)                                                                                              \
   ONE(0, (K) * 8 + 1, R0) ONE(1, (K) * 8 + 2, R1) ONE(2, (K) * 8 + 3, R2) ONE(3, (K) * 8 + 4, R3)            \
@@ -890,6 +922,69 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
     nS = (int)(nS9 >> 9);                                                                                    \
     sL = (mL >> lane) & 1; sP = (mP >> lane) & 1; sO = (mO >> lane) & 1;                                     \
   }
+  // k_place_grid with eight tiles (MODE 5): the same loop with the look-ups of a chunk ONE CHUNK AHEAD of its steps.  A
+  // look-up ends in a 16-byte record from global memory; with the record asked for and used in the same trip every chunk of
+  // eight rows exposed a round trip to the L2, and at the two waves per SIMD the LDS image leaves the kernel nothing hides it
+  // (refdata: 2.2 ms, 1.1 with the records left out).  Here the rows of chunk k + 1 are taken, searched and their records asked
+  // for BEFORE the steps of chunk k run -- two sets of records (A / B, by the chunk's parity) and of taken rows, a register
+  // budget only this variant has (two waves per SIMD: 256 registers each), which is why its rows are pinned at v192..v223.
+  // Order of a sub-trip: take k + 1 (vmcnt(24): younger than its loads are the two chunks behind it and the eight records of
+  // chunk k), search + gathers k + 1, rank lengths k, steps k (the compiler waits for k's records: everything but the eight
+  // youngest loads), flush, loads of chunk k + 4 into the buffer chunk k has just left.
+#define GAT_PIN_TAKE2(Y, R0, R1, R2, R3, R4, R5, R6, R7)                                                       \
+  asm volatile("s_waitcnt vmcnt(24)\n\tv_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R2 "\n\t" \
+               "v_mov_b32 %3, v" #R3 "\n\tv_mov_b32 %4, v" #R4 "\n\tv_mov_b32 %5, v" #R5 "\n\tv_mov_b32 %6, v" #R6 "\n\t" \
+               "v_mov_b32 %7, v" #R7                                                                            \
+               : "=v"(Y[0]), "=v"(Y[1]), "=v"(Y[2]), "=v"(Y[3]), "=v"(Y[4]), "=v"(Y[5]), "=v"(Y[6]), "=v"(Y[7]) \
+               :: "memory");
+#define GAT_ONE_TABLE_ASM2(C, JJ1, YREG, PCS, PCE, PPE) GAT_STEP_TABLE_ASM(YREG, lr[C], PCS[C], PCE[C], PPE[C], JJ1)
+#define GAT_DEEP_SUB(K, YK, PCSK, PCEK, PPEK, YN, PCSN, PCEN, PPEN, N0, N1, N2, N3, N4, N5, N6, N7,              \
+                     R0, R1, R2, R3, R4, R5, R6, R7, NEXTROW)                                                    \
+  GAT_PIN_TAKE2(YN, N0, N1, N2, N3, N4, N5, N6, N7)                                                             \
+  alive_c = (((mL | mP | mO) >> lane) & 1ull) != 0ull;                                                         \
+  GAT_PRE_WS3X(YN, PCSN, PCEN, PPEN)                                                                            \
+  GAT_PRE_RANK_L(YK)                                                                                           \
+  GAT_ONE_TABLE_ASM2(0, (K) * 8 + 1, R0, PCSK, PCEK, PPEK) GAT_ONE_TABLE_ASM2(1, (K) * 8 + 2, R1, PCSK, PCEK, PPEK) \
+  GAT_ONE_TABLE_ASM2(2, (K) * 8 + 3, R2, PCSK, PCEK, PPEK) GAT_ONE_TABLE_ASM2(3, (K) * 8 + 4, R3, PCSK, PCEK, PPEK) \
+  GAT_ONE_TABLE_ASM2(4, (K) * 8 + 5, R4, PCSK, PCEK, PPEK) GAT_ONE_TABLE_ASM2(5, (K) * 8 + 6, R5, PCSK, PCEK, PPEK) \
+  GAT_ONE_TABLE_ASM2(6, (K) * 8 + 7, R6, PCSK, PCEK, PPEK) GAT_ONE_TABLE_ASM2(7, (K) * 8 + 8, R7, PCSK, PCEK, PPEK) \
+  if ((K) & 1) { nS = (int)(nS9 >> 9); flush(); }                                                              \
+  GAT_PIN_LOAD(R0, R1, R2, R3, R4, R5, R6, R7, NEXTROW)
+#define GAT_PLACE_LOOP_DEEP_ASM                                                                              \
+  {                                                                                                          \
+    static_assert(kPlaceChunk == 8, "the loads above are written out for chunks of 8");                      \
+    mL = __ballot(sL); mP = 0; mO = 0;                                                                       \
+    int jbase = 0;                                                                                           \
+    uint32_t pcsB[kPlaceChunk], pceB[kPlaceChunk], ppeB[kPlaceChunk];                                        \
+    asm volatile("; GAT_PINNED_BEGIN BASE=192" ::: "memory");                                                \
+    GAT_PIN_LOAD(192, 193, 194, 195, 196, 197, 198, 199, 0)                                                  \
+    GAT_PIN_LOAD(200, 201, 202, 203, 204, 205, 206, 207, kPlaceChunk)                                        \
+    GAT_PIN_LOAD(208, 209, 210, 211, 212, 213, 214, 215, 2 * kPlaceChunk)                                    \
+    GAT_PIN_LOAD(216, 217, 218, 219, 220, 221, 222, 223, 3 * kPlaceChunk)                                    \
+    GAT_PIN_TAKE2(ya, 192, 193, 194, 195, 196, 197, 198, 199)                                                \
+    alive_c = sL;                                                                                            \
+    GAT_PRE_WS3X(ya, pcs, pce, ppe)                                                                          \
+    for (int j = 0; j < rows; j += 4 * kPlaceChunk) {                                                        \
+      if ((mL | mP | mO) == 0) break;                                                                        \
+      GAT_FOLD_USED(jbase)                                                                                   \
+      jbase = j;                                                                                             \
+      GAT_DEEP_SUB(0, ya, pcs, pce, ppe, yb, pcsB, pceB, ppeB, 200, 201, 202, 203, 204, 205, 206, 207,        \
+                   192, 193, 194, 195, 196, 197, 198, 199, j + 4 * kPlaceChunk)                               \
+      if (j + 1 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_DEEP_SUB(1, yb, pcsB, pceB, ppeB, ya, pcs, pce, ppe, 208, 209, 210, 211, 212, 213, 214, 215,        \
+                   200, 201, 202, 203, 204, 205, 206, 207, j + 5 * kPlaceChunk)                               \
+      if (j + 2 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_DEEP_SUB(2, ya, pcs, pce, ppe, yb, pcsB, pceB, ppeB, 216, 217, 218, 219, 220, 221, 222, 223,        \
+                   208, 209, 210, 211, 212, 213, 214, 215, j + 6 * kPlaceChunk)                               \
+      if (j + 3 * kPlaceChunk >= rows || (mL | mP | mO) == 0) break;                                         \
+      GAT_DEEP_SUB(3, yb, pcsB, pceB, ppeB, ya, pcs, pce, ppe, 192, 193, 194, 195, 196, 197, 198, 199,        \
+                   216, 217, 218, 219, 220, 221, 222, 223, j + 7 * kPlaceChunk)                               \
+    }                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)\n\t; GAT_PINNED_END" ::: "memory");                                     \
+    GAT_FOLD_USED(jbase)                                                                                     \
+    nS = (int)(nS9 >> 9);                                                                                    \
+    sL = (mL >> lane) & 1; sP = (mP >> lane) & 1; sO = (mO >> lane) & 1;                                     \
+  }
 #define GAT_PLACE_LOOP(PRE, ONE, ALIVE)                                                                        \
   {                                                                                                            \
     const uint32_t* __restrict__ rq = rp;                                                                      \
@@ -902,6 +997,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
         _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) yb[c] = rq[(kPlaceChunk + c) * kWave];         \
       }                                                                                                        \
       GAT_PSTAMP(0)                                                                                            \
+      if constexpr (GRID) alive_c = (ALIVE);                                                                   \
       PRE(ya)                                                                                                  \
       GAT_PSTAMP(1)                                                                                            \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(ya, c, (uint32_t)(j + c))                    \
@@ -914,6 +1010,7 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
       }                                                                                                        \
       rq += 2 * kPlaceChunk * kWave;                                                                           \
       GAT_PSTAMP(0)                                                                                            \
+      if constexpr (GRID) alive_c = (ALIVE);                                                                   \
       PRE(yb)                                                                                                  \
       GAT_PSTAMP(1)                                                                                            \
       _Pragma("unroll") for (int c = 0; c < kPlaceChunk; ++c) ONE(yb, c, (uint32_t)(j + kPlaceChunk + c))      \
@@ -946,8 +1043,10 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
         if (rank_lds) GAT_PLACE_LOOP(GAT_PRE_TABLE_LG, GAT_ONE_TABLE, GAT_ALIVE_TB) else GAT_PLACE_LOOP(GAT_PRE_TABLE_GG, GAT_ONE_TABLE, GAT_ALIVE_TB)
       } else if constexpr (GRID) {
         if (rank_lds) {
-          if (!kind1 && !drawB && A.place_plain_step == 0) { plain_step = false; GAT_PLACE_LOOP_PIPE_ASM(GAT_PRE_TABLE_L3, GAT_ONE_TABLE_ASM) }
-          else GAT_PLACE_LOOP(GAT_PRE_TABLE_L3, GAT_ONE_TABLE, GAT_ALIVE_TB)
+          if (!kind1 && !drawB && A.place_plain_step == 0) {
+            plain_step = false;
+            GAT_PLACE_LOOP_DEEP_ASM
+          } else GAT_PLACE_LOOP(GAT_PRE_TABLE_L3, GAT_ONE_TABLE, GAT_ALIVE_TB)
         } else GAT_PLACE_LOOP(GAT_PRE_TABLE_G3, GAT_ONE_TABLE, GAT_ALIVE_TB)
       }
     }
@@ -986,6 +1085,11 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #undef GAT_PRE_TABLE_L3
 #undef GAT_PRE_TABLE_G3
 #undef GAT_PRE_WS3
+#undef GAT_PRE_WS3X
+#undef GAT_PLACE_LOOP_DEEP_ASM
+#undef GAT_DEEP_SUB
+#undef GAT_ONE_TABLE_ASM2
+#undef GAT_PIN_TAKE2
 #undef GAT_PRE_TABLE_LG
 #undef GAT_PRE_TABLE_GL
 #undef GAT_PRE_TABLE_LL
@@ -1034,16 +1138,14 @@ __global__ __launch_bounds__(kPlaceWide * 64) void k_place_wide(SamplerArgs A) {
   place_body<KIND, 3, 0, true>(A);
 }
 
-// MODE 4 / 5 (round 6): problems with workspaces beyond the LDS table (fragmented workspaces: the reference's own test data has
-// 6 600 - 21 000 workspace segments per contig).  kPlaceGridTiles (MODE 5: half as many) tiles of one unit per workgroup around
+// MODE 5 (round 6): problems with workspaces beyond the LDS table (fragmented workspaces: the reference's own test data has
+// 6 600 - 21 000 workspace segments per contig).  kPlaceGridTiles = 8 tiles of one unit per workgroup around
 // the image of the unit's cdf grid in dynamic LDS (2 bytes per workspace segment + 2 per cell): the position draw's
 // searchsorted is a handful of LDS reads and one 16-byte record from global memory, and the table step runs written out on
 // the hand-pipelined rows -- k_place<., 2> walked a 16-ary tree in global memory for every random number of a chunk, on the
 // compiler's step and loads (refdata, 8 549 segments, 10 000 samples: 7.0 ms)
-template <int TILES>
-__global__ __launch_bounds__(TILES * 64) void k_place_grid(SamplerArgs A) {
-  static_assert(TILES == kPlaceGridTiles || TILES == kPlaceGridTiles / 2, "MODE 4 / 5");
-  place_body<0, TILES == kPlaceGridTiles ? 4 : 5, 0, true>(A);
+__global__ __launch_bounds__(kPlaceGridTiles * 64) void k_place_grid(SamplerArgs A) {
+  place_body<0, 5, 0, true>(A);
 }
 
 // ------------------------------------------------------------------------------------------

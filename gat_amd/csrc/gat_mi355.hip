@@ -544,24 +544,14 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           // (k_place_pipe: the rows of the single-workspace-segment units prefetched by hand, see GAT_PLACE_LOOP_PIPE)
           const bool pipe = P->pipe_pays && !getenv("GAT_PLACE_NO_PIPE");
           const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
-          // fragmented workspaces: the cdf grids of the long workspaces in LDS, eight (or four, where the largest image leaves
-          // no room for eight rings) tiles of a unit per workgroup (k_place_grid); static LDS: the workspace and rank tables
-          // (4 KB each) and an 8 KB ring per tile
+          // fragmented workspaces: the cdf grids of the long workspaces in LDS, eight tiles of a unit per workgroup (k_place_grid);
+          // static LDS: the workspace and rank tables (4 KB each) and an 8 KB ring per tile
           const size_t lds_grid = (size_t)P->grid_lds_words * 4 + 16;
-          const int64_t lds_static8 = 8192 + 1024 + (int64_t)gat::kPlaceGridTiles * 8192;
-          const int64_t lds_static4 = 8192 + 1024 + (int64_t)(gat::kPlaceGridTiles / 2) * 8192;
-          const int grid_tiles = mode == 2 && P->grid_place
-                                     ? ((int64_t)lds_grid + lds_static8 <= ctx->max_lds && !getenv("GAT_PLACE_GRID_HALF") ? gat::kPlaceGridTiles
-                                        : ((int64_t)lds_grid + lds_static4 <= ctx->max_lds ? gat::kPlaceGridTiles / 2 : 0))
-                                     : 0;
-          if (grid_tiles == gat::kPlaceGridTiles) {
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_grid<gat::kPlaceGridTiles>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grid));
-            hipLaunchKernelGGL((gat::k_place_grid<gat::kPlaceGridTiles>), dim3((nsb + grid_tiles - 1) / grid_tiles, gy, gz),
-                               dim3(grid_tiles * 64), lds_grid, ctx->stream, A);
-          } else if (grid_tiles > 0) {
-            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_grid<gat::kPlaceGridTiles / 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grid));
-            hipLaunchKernelGGL((gat::k_place_grid<gat::kPlaceGridTiles / 2>), dim3((nsb + grid_tiles - 1) / grid_tiles, gy, gz),
-                               dim3(grid_tiles * 64), lds_grid, ctx->stream, A);
+          const bool grid_k = mode == 2 && P->grid_place && (int64_t)lds_grid + 8192 + 1024 + (int64_t)gat::kPlaceGridTiles * 8192 <= ctx->max_lds;
+          if (grid_k) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_grid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_grid));
+            hipLaunchKernelGGL(gat::k_place_grid, dim3((nsb + gat::kPlaceGridTiles - 1) / gat::kPlaceGridTiles, gy, gz),
+                               dim3(gat::kPlaceGridTiles * 64), lds_grid, ctx->stream, A);
           } else
           if (mode == 3) {
             HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_place_wide<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide));

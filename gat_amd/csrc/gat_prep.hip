@@ -1163,8 +1163,12 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       //     <= 16 (the keys), at most 65 535 segments (the entries), the widest cell at most 8 segments where the cells allow it.
       if (nuw > gat::kPlaceWsLds && nuw <= 65535 && tot > 1u && tot <= 0x80000000u) {
         const uint32_t topc = tot - 1u;                             // the largest p
+        // (one cell per two segments -- GAT_GRID_CELL_SEGS -- to begin with; refdata, k_place_grid with eight tiles: 2.2 ms at
+        //  two, 2.6 at eight: the halving search over a cell's span is LDS round trips on the lane's chain)
+        const char* env_cs = getenv("GAT_GRID_CELL_SEGS");
+        const int64_t cell_segs = env_cs ? std::max<int64_t>(1, atoll(env_cs)) : 2;
         int shift = 16;
-        while (shift > 0 && ((int64_t)topc >> shift) + 1 < nuw / 2) --shift;       // about half a cell per segment to begin with
+        while (shift > 0 && ((int64_t)topc >> shift) + 1 < nuw / cell_segs) --shift;
         for (;;) {
           const int64_t cells = ((int64_t)topc >> shift) + 1;
           std::vector<uint32_t> g((size_t)cells + 1);
@@ -1176,7 +1180,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
             g[(size_t)c] = (uint32_t)j;
             if (c > 0) span = std::max(span, g[(size_t)c] - g[(size_t)c - 1]);
           }
-          // finer while a cell holds more than 8 segments and the image stays below 96 KB (24 K words)
+          // finer while some cell holds more than 8 segments and the image stays below 96 KB (24 K words)
           const int64_t cells_next = shift > 0 ? ((int64_t)topc >> (shift - 1)) + 1 : cells;
           const int64_t words_next = (cells_next + 2) / 2 + (nuw + 1) / 2;
           if (span > 8 && shift > 0 && words_next <= 24576) { --shift; continue; }

@@ -13,10 +13,8 @@ constexpr int kWsTreeMin = 32;      // workspaces with more segments get trees (
 constexpr int kWsTreeLevels = 6;   // 16^6 keys; the level loops are unrolled so that the geometry stays in scalar registers
 
 constexpr int kPlaceWsLds = 256;      // k_place: workspace segments kept in LDS (16 B each)
-#ifndef GAT_PLACE_GRID_TILES
-#define GAT_PLACE_GRID_TILES 8
-#endif
-constexpr int kPlaceGridTiles = GAT_PLACE_GRID_TILES;   // k_place_grid (MODE 4): tiles (waves) of a workgroup around one unit's cdf grid in LDS
+constexpr int kPlaceGridTiles = 8;    // k_place_grid (MODE 5): tiles (waves) of a workgroup around one unit's cdf grid in LDS: two waves per SIMD, each with
+                                      // the registers for its look-ups one chunk ahead (rows pinned at v192..v223)
 constexpr int kGridHeader = 4;        // words in front of a grid in ws_tree: {shift, cells, widest cell's span, words of the LDS image}
 constexpr int kPlaceRankLds = 1024;   // k_place: length-rank table entries kept in LDS
 #ifndef GAT_PLACE_WIDE_TILES

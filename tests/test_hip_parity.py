@@ -445,7 +445,7 @@ def _frag_ws_case(ctx, seed, setenv=None):
     if seed % 2 == 1:
         knobs["GAT_PLACE_NO_CM"] = "1"                 # the compiler's step behind the grid look-ups
     if seed % 8 == 2:
-        knobs["GAT_PLACE_GRID_HALF"] = "1"             # four tiles per workgroup
+        knobs["GAT_GRID_CELL_SEGS"] = "16"             # coarse grids: long halving searches
     if seed % 8 == 4:
         knobs["GAT_PLACE_NO_GRID"] = "1"               # the trees in global memory (k_place<., 2>)
     if seed % 8 == 6:

@@ -10,22 +10,31 @@ usage: tools/check_pinned_regs.py <device .s>"""
 import re
 import sys
 
-PINNED = re.compile(r"\bv(9[6-9]|1[01][0-9]|12[0-7])\b|\bv\[(\d+):(\d+)\]")
-LOAD = re.compile(r"^\s*global_load_dword v(9[6-9]|1[01][0-9]|12[0-7]), v\[\d+:\d+\], off( offset:\d+)?( nt)?\s*$")
-TAKE = re.compile(r"^\s*v_mov_b32(_e32)? v(\d+), v(9[6-9]|1[01][0-9]|12[0-7])\s*$")
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+LOAD = re.compile(r"^\s*global_load_dword v(\d+), v\[\d+:\d+\], off( offset:\d+)?( nt)?\s*$")
+TAKE = re.compile(r"^\s*v_mov_b32(_e32)? v(\d+), v(\d+)\s*$")
+FIRST = re.compile(r"^\s*\S+\s+v(\d+)\b")
+BASE = 96          # the pinned rows of the region at hand: v[BASE, BASE + 32) -- 96 unless the marker says "BASE=n" (k_place_grid<8>: 192)
+
+
+def pinned(n):
+    return BASE <= n < BASE + 32
 
 
 def touches(line):
-    for m in PINNED.finditer(line):
+    for m in REG.finditer(line):
         if m.group(1):
-            return True
+            if pinned(int(m.group(1))):
+                return True
+            continue
         lo, hi = int(m.group(2)), int(m.group(3))
-        if lo <= 127 and hi >= 96:
+        if lo <= BASE + 31 and hi >= BASE:
             return True
     return False
 
 
 def main(path):
+    global BASE
     kernel, inside, regions, bad, nloads, in_asm = None, False, 0, [], {}, False
     for no, line in enumerate(open(path, errors="replace"), 1):
         code = line.split("//")[0]
@@ -37,6 +46,8 @@ def main(path):
             continue
         if "GAT_PINNED_BEGIN" in line:
             inside, regions = True, regions + 1
+            m = re.search(r"BASE=(\d+)", line)
+            BASE = int(m.group(1)) if m else 96
             continue
         if "GAT_PINNED_END" in line:
             inside = False
@@ -49,14 +60,16 @@ def main(path):
         if re.match(r"^\s*(scratch_|buffer_)", code):
             bad.append((kernel, no, code.strip() + "   <- scratch / buffer access inside a pinned loop"))
             continue
-        if LOAD.match(code):
+        ld = LOAD.match(code)
+        if ld and pinned(int(ld.group(1))):
             nloads[regions] = nloads.get(regions, 0) + 1
         if touches(code):
             t = TAKE.match(code)
-            if LOAD.match(code) or (t and int(t.group(2)) < 96):
+            if (ld and pinned(int(ld.group(1)))) or (t and pinned(int(t.group(3))) and not pinned(int(t.group(2)))):
                 continue
+            f = FIRST.match(code)
             if in_asm and not re.match(r"^\s*(global_|flat_|buffer_|scratch_|ds_read|ds_load)", code) and \
-                    not re.match(r"^\s*\S+\s+v(9[6-9]|1[01][0-9]|12[0-7])\b", code):
+                    not (f and pinned(int(f.group(1)))):
                 continue                  # a hand-written instruction READING a row register (never a load into one, never its destination)
             bad.append((kernel, no, code.strip()))
     if regions == 0:
@@ -64,8 +77,8 @@ def main(path):
     if bad:
         for k, no, code in bad[:20]:
             sys.stderr.write("%s:%d: %s  [%s]\n" % (path, no, code, k))
-        sys.exit("check_pinned_regs: %d instruction(s) inside a pinned-register loop use v96..v127: the loop's values no "
-                 "longer fit below v96 -- lower the pressure or take the loop off the pipe" % len(bad))
+        sys.exit("check_pinned_regs: %d instruction(s) inside a pinned-register loop use its pinned rows (v96..v127, or the 32 from "
+                 "the marker's BASE): the loop's values no longer fit below them -- lower the pressure or take the loop off the pipe" % len(bad))
     odd = [r for r, n in nloads.items() if n % 8 != 0 or n == 0]
     if odd or len(nloads) != regions:
         sys.exit("check_pinned_regs: pinned loops with a number of row loads that is not a multiple of the chunk (8): %r" % (nloads,))

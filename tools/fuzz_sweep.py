@@ -29,7 +29,7 @@ bad = 0
 outcomes = {}
 t0 = time.time()
 for seed in range(first, first + n):
-    for k in ("GAT_TEST_HUGE", "GAT_PLACE_NO_WIDE", "GAT_PLACE_NO_CM", "GAT_PLACE_SCAN_SEQ", "GAT_PLACE_SCAN_TILES", "GAT_PLACE_GRID_HALF",
+    for k in ("GAT_TEST_HUGE", "GAT_PLACE_NO_WIDE", "GAT_PLACE_NO_CM", "GAT_PLACE_SCAN_SEQ", "GAT_PLACE_SCAN_TILES", "GAT_GRID_CELL_SEGS",
               "GAT_PLACE_NO_GRID", "GAT_TAIL_NO_LONG_WS"):       # (what a seed's test sets stays set here: MP does not undo)
         os.environ.pop(k, None)
     if (merged or long_lists or edge) and seed % 4 >= 2:
