@@ -118,6 +118,8 @@ class Stats(C.Structure):
         ("n_batches", C.c_int64),
         ("merged_form", C.c_int64),
         ("n_resumed_units", C.c_int64),
+        ("n_straddle_candidates", C.c_int64),
+        ("n_unit_overlaps", C.c_int64),
     ]
 
     def asdict(self):

@@ -378,6 +378,14 @@ struct gat_problem {
                                          // (k_place_grid, MODE 4); false: k_place<., 2> searches the trees in global memory
   int32_t grid_lds_words = 0;            // ... the largest grid image: the launch's dynamic LDS
   bool tail_long_ws = false;             // k_tail takes units of more than kTailMaxWs workspace segments (their grids / trees exist)
+  // isochore problems counted from the units' lists (k_count_merged<2, .> + k_units_overlap: no k_contig for the nucleotide counters)
+  bool units_direct_ok = false;          // merge_contigs, the split path; false for good once a batch had to be repeated through k_contig
+  bool units_direct = false;             // ... and the batch in flight took it
+  DevBuf<uint32_t> d_bmap;               // per contig one bit per 2^bshift bases: a workspace boundary lies in the cell or the next
+  DevBuf<int64_t> d_bmap_off;
+  int32_t bshift = 12;
+  DevBuf<uint4> d_cand;                  // the candidates k_count_merged notes for k_units_overlap (kCandSlots regions)
+  DevBuf<uint32_t> d_cand_count;         // ... their numbers per region, and k_units_overlap's words behind them
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
   bool all_one_ws = false;               // every active unit: one workspace segment, bucket 1, and most of the working segments in units
                                          // whose rank table is beyond k_place's LDS table but within k_place_wide's (k_place MODE 3)

@@ -1736,6 +1736,7 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
       int4 pre2 = make_int4(0, 0, 0, 0);
       if (!HUGE && A.st2 != nullptr && a < A.n_long) pre2 = A.st2[GAT_REC(A, sidx, a)];
       const int32_t* __restrict__ R = nullptr;
+      pre2.w &= 1;                                             // (bit 1: k_consolidate's "a segment reaches out of the unit's workspace")
       if (BIG && !HUGE && A.tb != nullptr && pre2.w == 1) {
         R = A.tb + GAT_REC(A, sidx, a) * A.skip_stride;
         if (R[kPatchState] == 1) return;                       // k_resume_big has finished the unit
@@ -2207,6 +2208,7 @@ __global__ __launch_bounds__(256) void k_reduce_stats(const uint32_t* __restrict
 
 // ------------------------------------------------------------------------------------------
 // fromIsochores (gat/Engine.pyx:2857-2876): new[contig].extend(unit lists) then merge(0).
+constexpr int kCandSlots = 256;    // regions of the candidate buffer (CountArgs::cand), each with a counter of its own
 struct ContigArgs {
   const int32_t* contig_unit_off;  // n_contigs+1: range into contig_units
   const int32_t* contig_units;     // unit ids grouped by contig, reference order
@@ -2234,10 +2236,21 @@ struct ContigArgs {
   int32_t base, count;
   int32_t lds_cap;                 // segments the launch's LDS holds (not HUGE)
   int32_t* flags;
+  // k_contig<., true> (NOSORT): the lists only concatenated, the candidates for k_units_overlap noted (CountArgs::cand)
+  const uint32_t* bmap;            // per contig, bmap_off[c] words in: one bit per 2^bshift bases, a workspace boundary lies in the cell
+  const int64_t* bmap_off;
+  int32_t bshift;
+  uint4* cand;
+  uint32_t* cand_count;
+  uint32_t cand_cap;
 };
 
 // HUGE: a contig's list does not fit LDS; it is gathered, sorted and merged in its output region in global memory.
-template <bool HUGE>
+// NOSORT (round 6): counts alone through the merged index, whose look-ups do not care for the order -- the units' lists are only
+// concatenated (no bucket sort, no merge(0): 40 % of the kernel), and the segments of the units whose record says that one of
+// theirs reaches out of the unit's workspace (st2.w bit 1, TailPatch::nuns bit 16; a unit k_sampler finished: always) are tested against the
+// contig's boundary map: a segment whose cells hold a boundary is a candidate for k_units_overlap.
+template <bool HUGE, bool NOSORT = false>
 __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* scratch = lds;                               // kSortScratchWords for the bucket sort
@@ -2247,7 +2260,8 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   if (cp >= A.count) return;
   const int c = A.order[A.base + cp];
   uint2* out = A.slab_out + (int64_t)sidx * A.slab_stride + A.contig_slab_off[c];
-  uint2* seg = HUGE ? out : reinterpret_cast<uint2*>(lds + kSortScratchWords);
+  constexpr bool INPLACE = HUGE || NOSORT;                // the list is put together where it goes (NOSORT: nothing is sorted in LDS)
+  uint2* seg = INPLACE ? out : reinterpret_cast<uint2*>(lds + kSortScratchWords);
   int n = 0;
   const int u0 = A.contig_unit_off[c], u1 = A.contig_unit_off[c + 1];
   // Units are taken 64 at a time: lane k looks up unit k's list (count, place in the slab) -- one round trip for all of
@@ -2255,7 +2269,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
   for (int ub = u0; ub < u1; ub += kWave) {
     const int nu = u1 - ub < kWave ? u1 - ub : kWave;
     int my_cnt = 0, my_off = 0, my_copy = 0;
-    bool my_patched = false;
+    bool my_patched = false, my_flag = false;
     const int32_t* my_patch = nullptr;
     int my_u = 0;
     uint4 pw[4] = {make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u), make_uint4(0u, 0u, 0u, 0u)};
@@ -2283,9 +2297,11 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
       my_patched = have_patch && (int32_t)pw[0].x == 1;
       if (my_patched) { my_copy = c2.x; my_cnt = my_copy + (int32_t)pw[0].y; }
       else my_cnt = my_copy = final_n;
+      // (a segment of the unit reaches out of its workspace: st2.w bit 1 for the merged list, the record's nuns bit 16 for k_tail's extras)
+      my_flag = my_cnt > 0 && (!my_patched || (c2.w & 2) != 0 || (pw[1].x >> 16) != 0u);
     }
     const int my_dst = n + (int)(wave_incl_sum_u32((uint32_t)my_cnt, lane) - (uint32_t)my_cnt);
-    if (!HUGE && n + (int)wave_total_u32((uint32_t)my_cnt) > A.lds_cap) {      // (wave-uniform; nothing of this batch is kept)
+    if (!INPLACE && n + (int)wave_total_u32((uint32_t)my_cnt) > A.lds_cap) {      // (wave-uniform; nothing of this batch is kept)
       if (lane == 0) atomicOr(A.flags, kStatusContigLds);
       return;
     }
@@ -2316,7 +2332,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
     if (patched_mask != 0) {
       // one lane per finished unit: its extras behind the merged list (k_tail has applied the trim to both; the order
       // inside the contig's list does not matter: it is sorted below, and merge(0) drops the emptied segments)
-      wave_sync<HUGE>();
+      wave_sync<INPLACE>();
       if (my_patched) {
         // (record words: 0 state, 1 n_extra, 2 placed, 3 ndraws, 4 nuns, 5 pad, 6.. extras)
         const int nU = my_copy, nE = (int32_t)pw[0].y;
@@ -2324,15 +2340,55 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (j < nE) seg[my_dst + nU + j] = ex[j];
-        *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, my_u) * 4) = make_uint4(pw[0].z, pw[0].w, pw[1].x, 0u);
+        *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, my_u) * 4) = make_uint4(pw[0].z, pw[0].w, pw[1].x & 0xffffu, 0u);
       }
-      wave_sync<HUGE>();
+      wave_sync<INPLACE>();
+    }
+    if constexpr (NOSORT) {
+      uint64_t fm = __ballot(my_flag);
+      if (fm != 0ull) {                                              // (one unit in forty on config 3)
+        wave_sync<INPLACE>();
+        const uint32_t* __restrict__ BM = A.bmap + A.bmap_off[c];
+        const uint32_t slot_c = ((uint32_t)sidx + (uint32_t)cp) % (uint32_t)kCandSlots;
+        while (fm != 0ull) {
+          const int k = __builtin_ctzll(fm);
+          fm &= fm - 1ull;
+          const int cnt_k = __builtin_amdgcn_readlane(my_cnt, k), dst_k = __builtin_amdgcn_readlane(my_dst, k);
+          for (int j0 = 0; j0 < cnt_k; j0 += kWave) {
+            const int j = j0 + lane;
+            const uint2 xv = j < cnt_k ? seg[dst_k + j] : make_uint2(0u, 0u);
+            bool cand = false;
+            if (xv.x != xv.y) {
+              // the bits from the first base's cell to the last base's (a boundary strictly inside the segment lies in one of them)
+              const uint32_t c0 = xv.x >> A.bshift, c1 = (xv.y - 1u) >> A.bshift, nb = c1 - c0 + 1u;
+              const uint32_t* __restrict__ wp = BM + (c0 >> 5);
+              const uint64_t win = ((uint64_t)wp[0] | ((uint64_t)wp[1] << 32)) >> (c0 & 31u);
+              cand = nb > 32u || (win & ((1ull << nb) - 1ull)) != 0ull;
+            }
+            const uint64_t m = __ballot(cand);
+            if (m == 0ull) continue;
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.cand_count[slot_c], (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (cand) {
+              const uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt(lane));
+              if (at < A.cand_cap) A.cand[(size_t)slot_c * A.cand_cap + at] = make_uint4((uint32_t)sidx, (uint32_t)(ub + k), xv.x, xv.y);
+              else A.cand_count[kCandSlots] = 1u;
+            }
+          }
+        }
+      }
     }
     n += (int)wave_total_u32((uint32_t)my_cnt);
   }
-  wave_sort_fast<16, HUGE>(seg, n, scratch, lane);
-  n = wave_merge0<HUGE>(seg, n, lane);
-  if (!HUGE)
+  if constexpr (!NOSORT) {
+    wave_sort_fast<16, HUGE>(seg, n, scratch, lane);
+    n = wave_merge0<HUGE>(seg, n, lane);
+  } else {
+    (void)scratch;
+    wave_sync<INPLACE>();
+  }
+  if (!INPLACE)
     for (int i = lane; i < n; i += kWave) out[i] = seg[i];
   if (lane == 0) {
     A.contig_n[(int64_t)sidx * A.n_contigs + c] = n;
@@ -2398,6 +2454,24 @@ struct CountArgs {
   const int32_t* patch;       // TailPatch records as words (kPatch*), patch_stride words each
   int32_t patch_stride, n_units;
   int32_t rec_stride;         // (GAT_REC: st2 / patch are [launch position][rec_stride])
+  // Isochore problems counted from contig lists that k_contig<., true> only CONCATENATED (nucleotide counters through the merged
+  // index; round 6): no sort, no merge(0) -- the index look-ups do not care for the order, and what fromIsochores' merge(0)
+  // (gat/Engine.pyx:2857-2876) would have united -- a segment of one unit reaching over the end of its workspace piece into a
+  // neighbouring unit's segment -- is found by k_units_overlap among the CANDIDATES k_contig notes (segments of units flagged in
+  // their record's `pad` whose cells of the boundary map hold a workspace boundary) and taken off the partial sums again.  For
+  // that kernel: the contig's units = units[contig_unit_off[c] ..), cu_rec = {unit id, its place in a sample's slab, its launch
+  // position (-1: inactive), 0}; a unit k_tail finished = (merged list in seg_units_merged, its record), any other its final list
+  // in seg_units with unit_n segments.
+  const int32_t* contig_unit_off;
+  const int4* cu_rec;
+  const int32_t* unit_n;      // [sample][n_units]
+  const uint2* seg_units;
+  const uint2* seg_units_merged;
+  uint4* cand;                // {sample, entry of cu_rec, start, end}: kCandSlots regions of cand_cap entries, a workgroup appends to
+                              // region blockIdx % kCandSlots (one counter for the chip's appends would be most of the time)
+  uint32_t* cand_count;       // [0, kCandSlots) candidates appended per region; [kCandSlots] set when a region was too small / the overlaps
+                              // were not pairwise, [kCandSlots + 1] overlaps taken off, [kCandSlots + 2] candidates in all (k_units_overlap adds them up)
+  uint32_t cand_cap;
 };
 
 struct AnnoView {
@@ -3002,6 +3076,140 @@ __global__ __launch_bounds__(kMergedThreads) void k_count_merged(CountArgs A) {
     for (int t = lane; t < T; t += kWave) { dst[t] = acc[t]; acc[t] = 0u; }
 #endif
     wave_fence();
+  }
+}
+
+// k_units_overlap (round 6): what IntervalDictionary.fromIsochores' merge(0) (gat/Engine.pyx:2857-2876) unites when the units'
+// lists are counted as they are (k_contig<., true> only concatenates them).  The lists of ONE unit are disjoint, so a base is counted twice only
+// where a segment of one unit overlaps a segment of another -- the first reaches over the end of its workspace piece (the
+// sampler's last step is filter, not intersect: gat/Engine.pyx:639-646).  One lane per candidate k_contig noted (a segment
+// with a workspace boundary in its cells): is it a straddler at all (its overlap with its own unit's workspace is
+// short of its length); which segments of the contig's other units does it overlap (a bisection per unit; a list k_tail trimmed
+// in place has empty elements -- a probe that meets one scans the list instead); every overlap [max starts, min ends) is taken
+// off the tracks' partial sums by the same walk through the merged index that added it twice.  Two straddlers that overlap each
+// other both see the pair: the one of the lower unit takes it.  Overlaps of one segment that overlap EACH OTHER (a base under
+// three units' segments: workspace pieces shorter than the segments) are not pairwise any more: word 1 of cand_count is set
+// and the host repeats the batch through k_contig (and keeps to it for the problem).
+struct UnitsOverlapArgs {
+  CountArgs C;
+  const UnitDev* units;
+  const uint2* ws;
+  const uint32_t* ws_tree;
+};
+__device__ __forceinline__ uint32_t unit_ws_overlap(const UnitsOverlapArgs& A, const UnitDev& U, uint32_t s, uint32_t e) {
+  const uint2* __restrict__ w = A.ws + U.ws_off;
+  if (U.pgrid_off >= 0) {
+    const uint32_t* __restrict__ pg = A.ws_tree + U.pgrid_off;
+    return ws_overlap_pgrid(w, U.n_ws, pg + kGridHeader, pg[0], pg[1], s, e);
+  }
+  uint32_t ov = 0;
+  for (int j = 0; j < U.n_ws; ++j) {
+    const uint2 x = w[j];
+    if (x.x >= e) break;
+    const uint32_t lo = s > x.x ? s : x.x, hi = e < x.y ? e : x.y;
+    ov += hi > lo ? hi - lo : 0u;
+  }
+  return ov;
+}
+// the segments of unit entry k (of cu_rec) in sample s that overlap [xs, xe): f(segment) for each
+template <typename F>
+__device__ __forceinline__ void unit_overlapping(const CountArgs& A, const int s, const int k, const uint32_t xs, const uint32_t xe, F f) {
+  const int4 r2 = A.cu_rec[k];
+  const uint2* L = A.seg_units + (int64_t)s * A.seg_stride + r2.y;
+  int nL = 0;
+  bool patched = false;
+  if (r2.z >= 0) {
+    const int64_t sa = GAT_REC(A, s, r2.z);
+    const int32_t* __restrict__ R = A.patch + sa * A.patch_stride;
+    const uint2 r01 = *reinterpret_cast<const uint2*>(R);
+    if ((int32_t)r01.x == 1) {
+      patched = true;
+      L = A.seg_units_merged + (int64_t)s * A.seg_stride + r2.y;
+      nL = A.st2[sa].x;
+      const uint2* __restrict__ ex = reinterpret_cast<const uint2*>(R + kPatchExtra);
+      for (int j = 0; j < (int32_t)r01.y; ++j) { const uint2 y = ex[j]; if (y.x != y.y && y.x < xe && y.y > xs) f(y); }
+    }
+  }
+  if (!patched) nL = A.unit_n[(int64_t)s * A.n_units + r2.x];
+  // the first element that starts at or behind xs, by bisection (the list ascends but for what a trim emptied)
+  int lo = 0, hi = nL;
+  bool holes = false;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    const uint2 y = L[mid];
+    if (y.x == y.y) { holes = true; break; }
+    if (y.x < xs) lo = mid + 1; else hi = mid;
+  }
+  if (holes) {
+    for (int j = 0; j < nL; ++j) { const uint2 y = L[j]; if (y.x != y.y && y.x < xe && y.y > xs) f(y); }
+  } else {
+    int j = lo - 1;
+    while (j >= 0) { const uint2 y = L[j]; if (y.x != y.y) { if (y.y > xs) f(y); break; } --j; }   // the one in front may reach over xs
+    for (j = lo; j < nL; ++j) {
+      const uint2 y = L[j];
+      if (y.x == y.y) continue;
+      if (y.x >= xe) break;
+      f(y);
+    }
+  }
+}
+// One lane per (candidate, OTHER unit of its contig): a lane that walked the contig's units one after the other was a chain of
+// a hundred dependent reads, and the kernel as long as its chains (0.34 ms for config 3's 107 000 candidates and 230 overlaps).
+__global__ __launch_bounds__(256) void k_units_overlap(UnitsOverlapArgs B, int max_units) {
+  const CountArgs& A = B.C;
+  // (blockIdx.y: the region; a region's workgroups beyond its candidates leave at once)
+  const uint32_t item = blockIdx.x * 256u + threadIdx.x, region = blockIdx.y;
+  const uint32_t total = A.cand_count[region] < A.cand_cap ? A.cand_count[region] : A.cand_cap;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && total != 0u) atomicAdd(&A.cand_count[kCandSlots + 2], total);
+  const uint32_t idx = item / (uint32_t)max_units;
+  if (idx >= total) return;
+  const uint4 cd = A.cand[(size_t)region * A.cand_cap + idx];
+  const int s = (int)cd.x, cu = (int)cd.y;
+  const uint32_t xs = cd.z, xe = cd.w;
+  const int4 rec = A.cu_rec[cu];
+  const UnitDev U = B.units[rec.x];
+  const int c = U.contig;
+  const int k = A.contig_unit_off[c] + (int)(item - idx * (uint32_t)max_units);
+  if (k >= A.contig_unit_off[c + 1] || k == cu) return;
+  if (unit_ws_overlap(B, U, xs, xe) == xe - xs) return;            // inside its own workspace: overlaps nothing of another unit
+  const UnitDev U2 = B.units[A.cu_rec[k].x];
+  constexpr int kMaxPairs = 4;
+  uint32_t is_[kMaxPairs], ie_[kMaxPairs];
+  bool skip[kMaxPairs];
+  int np = 0;
+  bool bad = false;
+  unit_overlapping(A, s, k, xs, xe, [&](const uint2 y) {
+    if (np >= kMaxPairs) { bad = true; return; }
+    is_[np] = y.x > xs ? y.x : xs; ie_[np] = y.y < xe ? y.y : xe;
+    // both straddlers see this pair: the lower unit's takes it
+    skip[np] = k < cu && unit_ws_overlap(B, U2, y.x, y.y) != y.y - y.x;
+    ++np;
+  });
+  // an overlap that a THIRD unit's segment reaches into is not pairwise: the batch goes through the sorted lists
+  for (int a = 0; a < np && !bad; ++a)
+    for (int k3 = A.contig_unit_off[c]; k3 < A.contig_unit_off[c + 1] && !bad; ++k3) {
+      if (k3 == cu || k3 == k) continue;
+      unit_overlapping(A, s, k3, is_[a], ie_[a], [&](const uint2) { bad = true; });
+    }
+  if (bad) { A.cand_count[kCandSlots] = 1u; return; }
+  const uint2* __restrict__ Z = A.mz + A.mz_off[c];
+  const uint32_t* __restrict__ F = A.mfirst + A.mf_off[c];
+  const int shift = A.m_shift[c];
+  const uint32_t last = (uint32_t)(A.m_cells[c] - 1);
+  uint32_t* __restrict__ dst = A.part + ((int64_t)c * A.n_samples + s) * A.n_tracks;
+  for (int a = 0; a < np; ++a) {
+    if (skip[a]) continue;
+    atomicAdd(&A.cand_count[kCandSlots + 1], 1u);
+    const uint32_t g = is_[a] >> shift;
+    uint32_t kk = F[g < last ? g : last];
+    while (true) {
+      const uint2 e = Z[kk];
+      if (!(e.x < ie_[a])) break;                                      // (the contig's sentinel ends the walk)
+      const uint32_t ze = e.x + (e.y & 0xffffu);
+      const uint32_t lo = e.x > is_[a] ? e.x : is_[a], hi = ze < ie_[a] ? ze : ie_[a];
+      if (hi > lo) atomicSub(&dst[e.y >> 16], hi - lo);
+      ++kk;
+    }
   }
 }
 

@@ -73,6 +73,7 @@ extern "C" int gat_ctx_create(gat_ctx** out, int device_id, void* stream) {
   for (auto& ev : ctx->ev_cnt) HIPCHK(ctx, hipEventCreate(&ev));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_flags, 64, hipHostMallocDefault));
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_stat, 128, hipHostMallocDefault));
+  memset(ctx->h_stat, 0, 128);
   *out = ctx;
   return GAT_OK;
 }
@@ -264,6 +265,11 @@ struct CountLaunch {
   hipEvent_t* ev_main = nullptr;
   bool main_recorded = false;
   int count_kernel = GAT_COUNT_KERNEL_NONE;
+  // k_units_overlap (CountArgs::cu_rec set): the units and their workspaces
+  const gat::UnitDev* units = nullptr;
+  const uint2* ws = nullptr;
+  const uint32_t* ws_tree = nullptr;
+  int max_units = 1;          // ... the most units a contig has
 };
 static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, gat::CountArgs A, DevBuf<uint32_t>& part,
                         int swap_capx, int list_cap, CountLaunch& L) {
@@ -346,6 +352,16 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       else if (blk == 1) hipLaunchKernelGGL((gat::k_count_merged<false, 1>), gm, bm, lds_merged, ctx->stream, A);
       else hipLaunchKernelGGL((gat::k_count_merged<false, 2>), gm, bm, lds_merged, ctx->stream, A);
       HIPCHK(ctx, hipGetLastError());
+      if (A.cu_rec != nullptr) {
+        // the contig lists were only concatenated (k_contig<., true>): what fromIsochores would have united -- the overlaps
+        // between different units' segments -- off the partial sums again
+        gat::UnitsOverlapArgs B;
+        B.C = A; B.units = L.units; B.ws = L.ws; B.ws_tree = L.ws_tree;
+        const int64_t items = (int64_t)A.cand_cap * std::max(1, L.max_units);
+        hipLaunchKernelGGL(gat::k_units_overlap, dim3((unsigned)((items + 255) / 256), gat::kCandSlots), dim3(256), 0, ctx->stream, B,
+                           std::max(1, L.max_units));
+        HIPCHK(ctx, hipGetLastError());
+      }
       HIPCHK(ctx, hipEventRecord(L.ev_main[1], ctx->stream));
       L.main_recorded = true;
       L.count_kernel = GAT_COUNT_KERNEL_MERGED;
@@ -439,10 +455,14 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
 // defer: only enqueue (the caller adds the count kernels behind, synchronises once and calls finish_sampler_batch)
 // records_ok: the consumer is k_count_seg alone, which reads (merged list, k_tail's record): no k_finalize
 // serial_state: the run's ONE MT19937 state on the device (k_serial: the reference's own stream) instead of the per-unit streams
+// units_direct: an isochore problem whose counters (the nucleotide counters, through the merged index) take the units' lists as
+// the sampler leaves them: no k_contig (k_count_merged<2, .> + k_units_overlap; P->units_direct says whether the batch took it)
 static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_t begin, int64_t nb,
                              gat_stats* st, bool timed, bool need_unit_lists = false, bool defer = false, bool records_ok = false,
-                             uint32_t* serial_state = nullptr, bool loose_ok = false, unsigned long long* h_stat = nullptr) {
+                             uint32_t* serial_state = nullptr, bool loose_ok = false, unsigned long long* h_stat = nullptr,
+                             bool units_direct = false) {
   if (h_stat == nullptr) h_stat = ctx->h_stat;
+  P->units_direct = false;
   {
     int rc = ensure_scratch(ctx, P, nb);
     if (rc) return rc;
@@ -450,6 +470,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     // (unit_n, contig_n and ws_stat are zeroed once when allocated: the kernels rewrite every entry of the active units
     //  in every batch and never touch the others)
     HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 10 * 8, ctx->stream));         // (statistics, status word, k_tail's queue length)
+    if (units_direct && P->d_cand_count.n) HIPCHK(ctx, hipMemsetAsync(P->d_cand_count.p, 0, P->d_cand_count.n * 4, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const int32_t* skip_ptr = nullptr;
     int skip_stride = 0;
@@ -706,6 +727,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // isochore problems: k_contig re-sorts the units of a contig anyway and takes (merged list, k_tail's record) as
         // it is -- no final unit lists unless somebody asked for them (gat_sample_units)
         P->patched_contigs = P->merge_contigs && P->n_contigs > 0 && !need_unit_lists && !getenv("GAT_CONTIG_FINAL_LISTS");
+        P->units_direct = units_direct && P->patched_contigs && P->units_direct_ok && serial_state == nullptr;
         P->patched_counts = !P->merge_contigs && records_ok && !need_unit_lists;
         if (!P->patched_contigs && !P->patched_counts) hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
         HIPCHK(ctx, hipGetLastError());
@@ -809,20 +831,29 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       size_t lds = (size_t)std::max(64, need_max) * 8 + gat::kSortScratchWords * 4;
       const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
       if (huge_c) lds = gat::kSortScratchWords * 4;
-      const void* kc = huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>;
+      // (units_direct: the lists only concatenated, the candidates for k_units_overlap noted: k_contig<., true>)
+      const bool nosort = P->units_direct;
+      B.bmap = P->d_bmap.p; B.bmap_off = P->d_bmap_off.p; B.bshift = P->bshift;
+      B.cand = P->d_cand.p; B.cand_cap = (uint32_t)(P->d_cand.n / gat::kCandSlots); B.cand_count = P->d_cand_count.p;
+      const void* kc = nosort ? (huge_c ? (const void*)gat::k_contig<true, true> : (const void*)gat::k_contig<false, true>)
+                              : (huge_c ? (const void*)gat::k_contig<true> : (const void*)gat::k_contig<false>);
       HIPCHK(ctx, hipFuncSetAttribute(kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       B.order = P->d_contig_order.p;
       B.flags = P->flags_dev();
       // one launch per size class: LDS for the class's longest expected list (more waves per CU for the short contigs)
       for (size_t k = 0; k + 1 < P->h_contig_class_start.size(); ++k) {
         const int c0 = P->h_contig_class_start[k], c1 = P->h_contig_class_start[k + 1];
-        if (huge_c && k > 0) break;
-        B.base = huge_c ? 0 : c0;
-        B.count = huge_c ? P->n_contigs : c1 - c0;
-        B.lds_cap = huge_c ? 0 : std::max(64, P->h_contig_need[(size_t)P->h_contig_order[(size_t)c0]]);
-        const size_t lds_k = huge_c ? lds : (size_t)B.lds_cap * 8 + gat::kSortScratchWords * 4;
+        // (one launch where the list is put together in place: beyond LDS, or only concatenated)
+        const bool one = huge_c || nosort;
+        if (one && k > 0) break;
+        B.base = one ? 0 : c0;
+        B.count = one ? P->n_contigs : c1 - c0;
+        B.lds_cap = one ? 0 : std::max(64, P->h_contig_need[(size_t)P->h_contig_order[(size_t)c0]]);
+        const size_t lds_k = nosort ? 64 : (huge_c ? lds : (size_t)B.lds_cap * 8 + gat::kSortScratchWords * 4);
         const unsigned gcy = (unsigned)std::min(B.count, 32768), gcz = ((unsigned)B.count + gcy - 1) / gcy;
-        if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
+        if (nosort && huge_c) hipLaunchKernelGGL((gat::k_contig<true, true>), dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
+        else if (nosort) hipLaunchKernelGGL((gat::k_contig<false, true>), dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
+        else if (huge_c) hipLaunchKernelGGL(gat::k_contig<true>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
         else hipLaunchKernelGGL(gat::k_contig<false>, dim3((unsigned)nb, gcy, gcz), dim3(64), lds_k, ctx->stream, B);
         HIPCHK(ctx, hipGetLastError());
       }
@@ -866,6 +897,17 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       if ((rc = upload_layout(ctx, P))) return rc;
       if (st) st->n_retried += nb * (int64_t)P->h_order.size();
       return kRelayout;
+    }
+    {
+      // k_units_overlap: overlaps between the units' lists that were not pairwise, or more candidates than the buffer holds --
+      // the batch is repeated through k_contig, and the problem keeps to that
+      const uint32_t* uw = reinterpret_cast<const uint32_t*>(h_stat + 10);
+      if (P->units_direct && P->units_direct_ok && uw[0] != 0u) {
+        P->units_direct_ok = false;
+        if (st) st->n_retried += nb * (int64_t)P->h_order.size();
+        return kRelayout;
+      }
+      if (st && P->units_direct) { st->n_straddle_candidates += (int64_t)uw[2]; st->n_unit_overlaps += (int64_t)uw[1]; }
     }
 #if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
     if (const char* fn = getenv("GAT_DIAG_OUT")) {
@@ -982,6 +1024,20 @@ static void fill_count_args(gat_problem* P, gat::CountArgs& A, int64_t nb) {
   A.n_contigs = P->n_contigs;
   A.n_tracks = P->n_tracks;
   A.n_samples = (int32_t)nb;
+  if (P->split_ran && P->units_direct) {       // k_contig only concatenated: k_units_overlap mends (it reads the units' lists themselves)
+    A.contig_unit_off = P->d_contig_unit_off.p;
+    A.cu_rec = P->d_cu_rec.p;
+    A.unit_n = P->d_unit_n.p;
+    A.seg_units = P->final_slab();
+    A.seg_units_merged = P->d_slab.p;
+    A.cand = P->d_cand.p; A.cand_cap = (uint32_t)(P->d_cand.n / gat::kCandSlots);
+    A.cand_count = P->d_cand_count.p;
+    A.st2 = P->d_st2.p;
+    A.patch = reinterpret_cast<const int32_t*>(P->d_patch.p);
+    A.patch_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+    A.n_units = P->n_units;
+    A.rec_stride = (int32_t)P->batch;
+  }
   if (P->split_ran && P->patched_counts) {     // no k_finalize ran: k_count_seg<.., PATCH> reads merged lists + records
     A.seg_merged = P->d_slab.p;
     A.unit_pos = P->d_unit_pos.p;
@@ -1054,8 +1110,13 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
       if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[0], ctx->stream));
       CountLaunch L;
       L.ev_main = K.blk->ev_main[slot];
+      L.units = P->d_units.p; L.ws = P->d_ws.p; L.ws_tree = P->d_ws_tree.p;
+      for (int c = 0; c < P->n_contigs; ++c) L.max_units = std::max(L.max_units, P->h_contig_unit_off[(size_t)c + 1] - P->h_contig_unit_off[(size_t)c]);
       if ((rc = launch_count(ctx, P->anno->dev, C, A, P->d_part, swap_capx,
                              P->merge_contigs ? P->max_contig_cap : P->max_unit_cap, L))) return rc;
+      if (A.cu_rec != nullptr)       // k_units_overlap's words (candidates, "not pairwise", overlaps taken off) into the batch's slot
+        HIPCHK(ctx, hipMemcpyAsync(K.blk->h_stat + (size_t)slot * 16 + 10, P->d_cand_count.p + gat::kCandSlots, 16, hipMemcpyDeviceToHost, ctx->stream));
+      else { K.blk->h_stat[(size_t)slot * 16 + 10] = 0; K.blk->h_stat[(size_t)slot * 16 + 11] = 0; }
       if (K.timed) HIPCHK(ctx, hipEventRecord(ctx->ev_cnt[1], ctx->stream));
       K.main_rec[slot] = L.main_recorded;
       K.count_kernel[slot] = L.count_kernel;
@@ -1103,8 +1164,19 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
+    // isochore problems: the merged index takes the units' lists as they are, no k_contig (round 6)
+    const bool units_direct = loose_ok && P->merge_contigs && P->units_direct_ok && !getenv("GAT_COUNT_VIA_CONTIGS");
+    if (units_direct && P->d_cand.n == 0) {
+      // candidates: segments with a workspace boundary in their cells, of units that have a segment reaching out of their workspace
+      // -- a fraction of a per cent of a batch's segments on isochore blocks much longer than the segments --, dealt to kCandSlots
+      // regions by (sample, contig); a region that overflows sends the batch through the sorted contig lists
+      const double est = 0.006 * (double)nb * (double)std::max<int64_t>(1, P->n_seg_total) / gat::kCandSlots + 512.0;
+      HIPCHK(ctx, P->d_cand.alloc((size_t)std::min(est, 64.0 * 1024) * gat::kCandSlots));
+      HIPCHK(ctx, P->d_cand_count.alloc(gat::kCandSlots + 4));
+      HIPCHK(ctx, hipMemsetAsync(P->d_cand_count.p, 0, (gat::kCandSlots + 4) * 4, ctx->stream));
+    }
     if ((rc = run_sampler_batch(ctx, P, K.seed, K.begin + K.enq, nb, &K.local, K.timed, false, true, records_ok, d_state, loose_ok,
-                                K.blk->h_stat + (size_t)slot * 16))) return rc;   // (enqueued only)
+                                K.blk->h_stat + (size_t)slot * 16, units_direct))) return rc;   // (enqueued only)
     K.nb[slot] = nb;
     K.main_rec[slot] = false;
     K.count_kernel[slot] = GAT_COUNT_KERNEL_NONE;

@@ -1112,22 +1112,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       fail_unit(R, GAT_ERR_CAPACITY, "unit %d: %lld workspace segments (> %lld)", u, (long long)nuw, (long long)((int64_t)1 << (4 * gat::kWsTreeLevels)));
       continue;
     }
-    if (nuw > gat::kWsTreeMin) {
-      auto build = [&](std::vector<uint32_t>& tree, auto key, uint32_t pad) {
-        std::vector<uint32_t> level((size_t)nuw);
-        for (int64_t i = 0; i < nuw; ++i) level[(size_t)i] = key(i);
-        for (;;) {
-          const size_t n = level.size(), nodes = (n + 15) / 16;
-          tree.insert(tree.end(), level.begin(), level.end());
-          tree.insert(tree.end(), nodes * 16 - n, pad);
-          if (n <= 16) break;
-          std::vector<uint32_t> up(nodes);
-          for (size_t j = 0; j < nodes; ++j) up[j] = level[std::min(16 * j + 15, n - 1)];   // largest key of node j
-          level.swap(up);
-        }
-      };
-      build(R.tree_start, [&](int64_t i) { return uw[i].start; }, 0xffffffffu);
-      build(R.tree_cdf, [&](int64_t i) { return R.cdf[(size_t)i]; }, 0x7fffffffu);
+    if (nuw > gat::kWsTreeMin || (d->merge_contigs && nuw > 2)) {   // (isochore problems: k_units_overlap asks every candidate's unit)
       // Round 6, fragmented workspaces (the reference's own test data: 6 600 - 21 000 workspace segments per contig).  A tree
       // search is four dependent 64-byte node reads; the two questions asked of a workspace have cheaper answers:
       // (a) "how many bases of [s, e) lie inside?" (SegmentList.intersect(workspace).sum(), gat/Engine.pyx:596-598): a grid over
@@ -1155,6 +1140,23 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
         R.pgrid[(size_t)gat::kGridHeader + (size_t)cells] = (uint32_t)nuw;       // (a position beyond the last cell: nothing to walk)
         R.pgrid[2] = span;
       }
+    }
+    if (nuw > gat::kWsTreeMin) {
+      auto build = [&](std::vector<uint32_t>& tree, auto key, uint32_t pad) {
+        std::vector<uint32_t> level((size_t)nuw);
+        for (int64_t i = 0; i < nuw; ++i) level[(size_t)i] = key(i);
+        for (;;) {
+          const size_t n = level.size(), nodes = (n + 15) / 16;
+          tree.insert(tree.end(), level.begin(), level.end());
+          tree.insert(tree.end(), nodes * 16 - n, pad);
+          if (n <= 16) break;
+          std::vector<uint32_t> up(nodes);
+          for (size_t j = 0; j < nodes; ++j) up[j] = level[std::min(16 * j + 15, n - 1)];   // largest key of node j
+          level.swap(up);
+        }
+      };
+      build(R.tree_start, [&](int64_t i) { return uw[i].start; }, 0xffffffffu);
+      build(R.tree_cdf, [&](int64_t i) { return R.cdf[(size_t)i]; }, 0x7fffffffu);
       // (b) "which segment holds base p of the workspace?" (SegmentListSampler.sample, gat/Engine.pyx:299-305: searchsorted over
       //     cdf[i] = cumulated length - 1 with cmpPosition): a grid over the CUMULATED lengths, g[c] = #{i : cdf[i] < c << shift},
       //     and 16-bit keys cdf[i] & mask -- within a cell the high bits agree, so #{cdf < p} = g[c] + #{i in [g[c], g[c + 1]) :
@@ -1399,6 +1401,36 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       }
     }
     HIPCHK(ctx, P->d_ws_rec.upload(rec, ctx));
+  }
+  P->units_direct_ok = false;
+  if (P->merge_contigs && P->n_contigs > 0 && P->split_path && !getenv("GAT_COUNT_VIA_CONTIGS")) {
+    // counting an isochore problem from the units' lists: where a segment could reach over the end of its workspace piece.
+    // One bit per cell of 2^bshift bases (about two mean segment lengths): a boundary of some unit's workspace piece lies in the
+    // cell -- a segment whose cells hold no boundary lies inside one piece (k_count_merged<2, .> tests the bits from its first
+    // base's cell to its last's: a 64-bit window of the map)
+    double bases = 0, segs = 0;
+    for (int32_t u : P->h_order) { bases += (double)(uint32_t)P->h_units[(size_t)u].ltotal; segs += (double)P->h_units[(size_t)u].hist_total; }
+    const double mean_len = segs > 0 ? bases / segs : 1.0;
+    int bshift = 8;
+    while (bshift < 24 && (double)(1u << bshift) < 2.0 * mean_len) ++bshift;
+    P->bshift = bshift;
+    std::vector<int64_t> boff((size_t)P->n_contigs + 1, 0);
+    std::vector<uint32_t> extent((size_t)P->n_contigs, 0u);
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[(size_t)u];
+      extent[(size_t)U.contig] = std::max(extent[(size_t)U.contig], h_ws[(size_t)U.ws_off + (size_t)U.n_ws - 1].y);
+    }
+    for (int c = 0; c < P->n_contigs; ++c) boff[(size_t)c + 1] = boff[(size_t)c] + (((int64_t)(extent[(size_t)c] >> bshift) + 2) + 31) / 32 + 2;
+    std::vector<uint32_t> bm((size_t)boff.back() + 2, 0u);
+    for (int32_t u : P->h_order) {
+      const UnitDev& U = P->h_units[(size_t)u];
+      uint32_t* b = bm.data() + boff[(size_t)U.contig];
+      auto mark = [&](uint32_t pos) { const int64_t j = (int64_t)(pos >> bshift); b[j >> 5] |= 1u << (j & 31); };
+      for (int32_t i = 0; i < U.n_ws; ++i) { mark(h_ws[(size_t)U.ws_off + (size_t)i].x); mark(h_ws[(size_t)U.ws_off + (size_t)i].y); }
+    }
+    HIPCHK(ctx, P->d_bmap.upload(bm, ctx));
+    HIPCHK(ctx, P->d_bmap_off.upload(boff, ctx));
+    P->units_direct_ok = true;
   }
   if (h_ws_tree.empty()) h_ws_tree.assign(16, 0u);
   HIPCHK(ctx, P->d_ws_tree.upload(h_ws_tree, ctx));

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   const int4 pre = A.st[sa];
   if (lane == 0) T.patch[sa].state = 0;
   // (launched behind k_merge_big when the problem has long lists: launch positions below n_long carry its verdict)
-  if (a < A.n_long) { if (A.st2[sa].w == 1) return; }
+  if (a < A.n_long) { if ((A.st2[sa].w & 1) == 1) return; }
   else if (lane == 0) A.st2[sa] = make_int4(0, 0, 0, 0);
   const int n = pre.x;
   if (pre.z < 0 || n <= 0 || n > A.lds_cap) return;               // not handed over by k_place / beyond this kernel's LDS: k_sampler's
@@ -149,9 +149,12 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
       out[pos] = make_uint2(s1, e1);
       if ((pos & 7) == 7 || pos == nU1 - 1) cum[pos >> 3] = incl1;                     // (running lengths per block of eight: GAT_CUM8)
     }
+    // (a merged segment that is not wholly inside the unit's workspace may reach into another unit's segment: bit 1 of st2.w,
+    //  beside bit 16 of the record's `nuns` (k_tail's, for the segments it added) what k_contig<., true> asks before it looks closer)
+    const bool strad1 = __ballot(head && cov1 != e1 - s1) != 0ull;
     cov1 = wave_total_u32(cov1);
     const uint32_t run1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, kWave - 1);
-    if (lane == 0) A.st2[sa] = make_int4(nU1, (int)cov1, (int)run1, 1);
+    if (lane == 0) A.st2[sa] = make_int4(nU1, (int)cov1, (int)run1, strad1 ? 3 : 1);
     GAT_CPHASE(4)
 #ifdef GAT_DIAG_CONS
     if (lane == 0 && A.diag != nullptr) for (int k = 0; k < 8; ++k) A.diag[((int64_t)sidx * A.n_units + Up->pad) * 8 + k] = dg[k];
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
   GAT_CPHASE(3)
   // coverage (intersect(workspace).sum()), total length, running lengths; the merged list goes back to the slab
   uint32_t cov = 0, run = 0;
+  bool strad = false;
   const uint32_t* __restrict__ pg = A.ws_tree + (Up->pgrid_off >= 0 ? Up->pgrid_off : 0);
   const uint32_t pshift = TREE ? pg[0] : 0u, pcells = TREE ? pg[1] : 0u;
   for (int base = 0; base < nU; base += kWave) {
@@ -202,9 +206,12 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     if (i < nU) v = seg[i];
     // (all lanes are here: the search's cross-lane reads see every lane's workspace segment; a short workspace is
     //  cheaper by the loop)
-    if (nws <= 8) cov += ws_overlap_regs(W, v.x, v.y);
-    else if (nws <= kWsLoopMax) cov += ws_overlap_search(W, v.x, v.y);
-    else if constexpr (TREE) { if (i < nU) cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y); }
+    uint32_t cv = 0;
+    if (nws <= 8) cv = ws_overlap_regs(W, v.x, v.y);
+    else if (nws <= kWsLoopMax) cv = ws_overlap_search(W, v.x, v.y);
+    else if constexpr (TREE) { if (i < nU) cv = ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y); }
+    cov += cv;
+    strad |= i < nU && cv != v.y - v.x;
     const uint32_t incl = run + wave_incl_sum_u32(v.y - v.x, lane);
     if (i < nU) {
       out[i] = v;
@@ -213,7 +220,8 @@ __global__ __launch_bounds__(64) void k_consolidate(TailArgs T) {
     run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
   }
   cov = wave_total_u32(cov);
-  if (lane == 0) A.st2[sa] = make_int4(nU, (int)cov, (int)run, 1);
+  const bool strad_any = __ballot(strad) != 0ull;
+  if (lane == 0) A.st2[sa] = make_int4(nU, (int)cov, (int)run, strad_any ? 3 : 1);
   GAT_CPHASE(4)
 #ifdef GAT_DIAG_CONS
   if (lane == 0 && A.diag != nullptr) for (int k = 0; k < 8; ++k) A.diag[((int64_t)sidx * A.n_units + Up->pad) * 8 + k] = dg[k];
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   const int4 c2 = A.st2[sa];
   const uint32_t qe = (uint32_t)sidx * (uint32_t)A.n_active + (uint32_t)a;
   // (every unit that is not finished here goes to k_sampler's queue)
-  if (pre.z < 0 || c2.w != 1 || c2.x <= 0) { T.todo[atomicAdd(T.todo_count, 1u)] = qe; return; }   // not consolidated
+  if (pre.z < 0 || (c2.w & 1) != 1 || c2.x <= 0) { T.todo[atomicAdd(T.todo_count, 1u)] = qe; return; }   // not consolidated
   uint2* U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;     // (read; the trim is written into it at the very end)
   const uint32_t* __restrict__ cum = T.cum + (((int64_t)sidx * A.slab_stride + Up->slab_off) >> 3);
   const int nU = c2.x;
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   bool bail = false;
   uint32_t trim = 0, trim_part = 0, drop_len = 0;
   int trim_v0 = 0, trim_full = 0;
+  bool strad_extra = false;    // a new segment that is not wholly inside the unit's workspace (TailPatch::pad, bit 16)
 
   // element v of the list with the extras in place
   auto vget = [&](int v) -> uint2 {
@@ -567,7 +576,11 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 #pragma unroll
         for (int j = 0; j < kTailMaxExtra; ++j) if (j == at) { ex[j] = x; epos[j] = lo; }
         nE++;
-        cov += ws_overlap(x.x, x.y);
+        {
+          const uint32_t ovx = ws_overlap(x.x, x.y);
+          cov += ovx;
+          strad_extra |= ovx != x.y - x.x;
+        }
         total += x.y - x.x;
       }
       if (bail) break;
@@ -613,7 +626,9 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   }
   TailPatch* P = T.patch + sa;
   P->n_extra = nE;
-  P->placed = placed; P->ndraws = rng.used; P->nuns = (uint32_t)nuns;
+  // (bit 16 of nuns: a new segment reaches out of the unit's workspace -- beside bit 1 of st2.w, k_consolidate's for the merged list:
+  //  what k_contig<., true> asks before it looks at the unit's segments.  A store of its own for it cost the kernel 7 %)
+  P->placed = placed; P->ndraws = rng.used; P->nuns = (uint32_t)nuns | (strad_extra ? 0x10000u : 0u);
 #pragma unroll
   for (int j = 0; j < kTailMaxExtra; ++j) { P->extra[j] = ex[j]; P->pos[j] = epos[j]; }
   P->state = 1;
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
   if (sidx >= A.batch) return;
   const int4 pre = A.st[sa];
   const int4 c2 = A.st2[sa];
-  if (pre.z < 0 || c2.w != 1 || c2.x <= 0) return;     // not consolidated by k_merge_big: k_sampler's as before
+  if (pre.z < 0 || (c2.w & 1) != 1 || c2.x <= 0) return;     // not consolidated by k_merge_big: k_sampler's as before
   uint2* U = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   int nU = c2.x;
   uint32_t cov = (uint32_t)c2.y, total = (uint32_t)c2.z;
@@ -1093,7 +1108,7 @@ __global__ __launch_bounds__(64) void k_finalize(TailArgs T) {
     const int64_t so = (int64_t)sidx * A.n_units + u;
     A.unit_n[so] = nout;
     if (!(total > 0)) atomicOr(A.flags, kStatusAssert);
-    *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, u) * 4) = make_uint4(P->placed, P->ndraws, P->nuns, 0u);
+    *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, u) * 4) = make_uint4(P->placed, P->ndraws, P->nuns & 0xffffu, 0u);
   }
 }
 

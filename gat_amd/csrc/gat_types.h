@@ -57,6 +57,8 @@ enum : int32_t {
   kStatusOverflow = 1,   // LDS/slab capacity exceeded: host retries with a larger slab
   kStatusAssert = 2,     // reference assert would fire (gat/Engine.pyx:645 sum()>0)
   kStatusTrimAssert = 4, // gat/SegmentList.pyx:560 sum() > size
+  kStatusUnitsOverlap = 16, // k_units_overlap: overlaps between the units' lists that are not pairwise (or more candidates than the
+                         // buffer holds): host repeats the batch through k_contig and keeps to it for the problem
   kStatusContigLds = 8,  // k_contig: a contig's lists exceed the LDS the launch was given (sized for what is expected,
                          // not for every unit at its capacity): host repeats the batch with the full size
 };

@@ -156,6 +156,10 @@ typedef struct {
                                 /* 1 the grid cell's record (its first two entries) + pairs; 0: the kernel did not run     */
   int64_t n_resumed_units;      /* work units whose pre-generated random rows ran out and whose stream went on from the     */
                                 /* generator moved up to its position (instead of a run in full: n_full_units)              */
+  int64_t n_straddle_candidates; /* isochore problems counted from the units' lists (no k_contig): segments beginning within a  */
+                                /* cell of a workspace boundary, looked at by k_units_overlap; 0: the contig lists were made    */
+  int64_t n_unit_overlaps;      /* ... and the overlaps between different units' segments it took off the sums again -- what      */
+                                /* IntervalDictionary.fromIsochores' merge(0) unites (gat/Engine.pyx:2857-2876)                   */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0

@@ -475,6 +475,73 @@ def _frag_ws_case(ctx, seed, setenv=None):
     return st["n_tail_units"]
 
 
+def _units_direct_case(ctx, seed):
+    """isochore problems counted from the units' lists (k_count_merged<2, .> + k_units_overlap, no k_contig): isochore blocks from
+    one base to tens of kilobases against segments of tens to thousands of bases -- segments that reach over the end of their
+    block into a neighbouring unit's segment (fromIsochores' merge(0) unites them: gat/Engine.pyx:2857-2876), both of them
+    straddlers, a base under three units' segments (the batch is repeated through k_contig)"""
+    import collections
+    from gat_amd import problem
+    rs = np.random.RandomState(seed)
+    block = int(rs.choice([1, 7, 100, 1000, 5000, 30000]))
+    hi = 400000 if block >= 100 else 20000                         # (one-base blocks: tens of thousands of workspace pieces)
+    contigs = collections.OrderedDict(("u%d" % i, int(rs.randint(hi // 20, hi))) for i in range(int(rs.randint(1, 4))))
+    nclasses = int(rs.choice([2, 3, 8]))
+    size = sum(contigs.values())
+    n_segs = int(rs.choice([60, 300, 1200]))
+    mean_len = max(1, int(size * float(rs.choice([0.02, 0.1, 0.3])) / n_segs))
+    segs = synthetic.random_segments(contigs, n_segs, mean_len, int(rs.randint(1 << 30)))
+    n_tracks = int(rs.choice([1, 4, 9]))
+    annos = [("t%d" % i, synthetic.random_segments(contigs, 150, 800, int(rs.randint(1 << 30)))) for i in range(n_tracks)]
+    ws = synthetic.workspace_ungapped(contigs, pieces=int(rs.choice([1, 3])), gap=int(rs.choice([0, 50, 700])) + 2)
+    iso = synthetic.isochores_blocks(contigs, nclasses=nclasses, block=block)
+    flat = problem.flatten_arrays(segs, annos, ws, iso, bucket_size=1, nbuckets=100000)
+    if flat["n_contigs"] == 0:
+        return 0, 0, 0
+    counters = ["nucleotide-overlap", "nucleotide-density"]
+    S = 70 if seed % 4 == 0 else 6
+    try:
+        want, _ = O.run_samples(flat, counters, seed, 1, 0, S)
+    except ValueError:
+        return 0, 0, 0
+    os.environ["GAT_MERGED_MIN_TRACKS"] = "1"
+    try:
+        P = _lib.Problem(ctx, flat)
+        got = P.sample_and_count(counters, seed, 0, S)
+        st = P.last_stats
+        assert _lib.COUNT_KERNELS[st["count_kernel"]] == "k_count_merged"
+        for k, c in enumerate(counters):
+            assert np.array_equal(got[k], want[k]), (seed, c, block, nclasses, n_segs, mean_len)
+        # ... and once more through the contig lists (k_contig), which must agree
+        os.environ["GAT_COUNT_VIA_CONTIGS"] = "1"
+        try:
+            other = P.sample_and_count(counters, seed, 0, S)
+            assert P.last_stats["n_straddle_candidates"] == 0
+        finally:
+            os.environ.pop("GAT_COUNT_VIA_CONTIGS")
+        for k in range(len(counters)):
+            assert np.array_equal(other[k], want[k])
+        P.close()
+    finally:
+        os.environ.pop("GAT_MERGED_MIN_TRACKS", None)
+    return st["n_straddle_candidates"], st["n_unit_overlaps"], st["n_retried"]
+
+
+@pytest.mark.parametrize("seed", list(range(800, 840)))
+def test_isochore_units_counted_directly_vs_oracle(ctx, seed):
+    _units_direct_case(ctx, seed)
+
+
+def test_isochore_units_counted_directly_takes_overlaps_off(ctx):
+    """over a handful of seeds the path must have met what it is there for: overlaps between different units' segments
+    taken off the sums, and a batch that had to be repeated through k_contig"""
+    cands = ovl = retried = 0
+    for seed in range(840, 880):
+        c, o, r = _units_direct_case(ctx, seed)
+        cands, ovl, retried = cands + c, ovl + o, retried + (1 if r else 0)
+    assert cands > 0 and ovl > 0 and retried > 0, (cands, ovl, retried)
+
+
 @pytest.mark.parametrize("seed", list(range(700, 732)))
 def test_fragmented_workspaces_vs_oracle(ctx, seed):
     _frag_ws_case(ctx, seed)
