@@ -639,6 +639,25 @@ def api_block(args, repeats=5):
     return out
 
 
+def headline(main_out, steps):
+    """`value` / `ms_per_step` of the line: the K steps timed right behind the W warm-up steps -- unless they are a blink (the
+    driver's 20 steps of config 2 are 50 ms) AND the same step repeated for a second or more says something else by more than
+    2 %: then the longer measurement is the number to quote ("the number to quote is 3.8-4.0 M", not the 4.02 M of
+    50 ms).  The K steps' own figure stays in the line as k_steps_value, value_source says which it is."""
+    k_seconds = main_out["ms_per_step"] * steps / 1e3
+    out = {"value": main_out["value"], "ms_per_step": main_out["ms_per_step"],
+           "k_steps_value": main_out["value"], "k_steps_ms_per_step": main_out["ms_per_step"],
+           "value_source": "the %d timed steps (%.3f s)" % (steps, k_seconds)}
+    sus = main_out.get("sustained")
+    if sus:
+        out["sustained_value"] = sus["value"]
+        if k_seconds < 0.5 and sus["seconds"] >= 0.5 and abs(main_out["value"] - sus["value"]) > 0.02 * sus["value"]:
+            out["value"], out["ms_per_step"] = sus["value"], sus["ms_per_step"]
+            out["value_source"] = ("sustained: %d steps in %.2f s (the %d steps behind the warm-up took %.3f s and read %+.1f %%)"
+                                   % (sus["steps"], sus["seconds"], steps, k_seconds, 100.0 * (main_out["value"] / sus["value"] - 1.0)))
+    return out
+
+
 LINE_LIMIT = 3000               # bytes of the one stdout line (the driver parses stdout; round 4's 21 KB line broke it)
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "config", "roofline", "cpu_baseline")
@@ -676,6 +695,9 @@ def final_line(out, details_path=None):
                                                                        "single_thread_value") if k in cb)
     # small extras, dropped from the back if the line would not fit
     extras = []
+    if out.get("value_source"):
+        extras.append(("value_source", _cut(out["value_source"])))
+        extras.append(("k_steps_value", _r(out.get("k_steps_value"))))
     if out.get("sustained"):
         extras.append(("sustained_value", _r(out["sustained"]["value"])))
         if "ms_per_step" in out["sustained"]:
@@ -684,7 +706,8 @@ def final_line(out, details_path=None):
         extras.append(("step", {"hbm_bytes": out["step"]["hbm_bytes"], "hbm_frac": _r(out["step"]["hbm_frac"])}))
     if out.get("distributed"):
         d = out["distributed"]
-        extras.append(("distributed", {"backend": d["backend"], "world_size": d["world_size"], "one_gpu_per_rank": d["one_gpu_per_rank"]}))
+        extras.append(("distributed", {"backend": d["backend"], "world_size": d["world_size"], "one_gpu_per_rank": d["one_gpu_per_rank"],
+                                       "ranks_in_collective": d.get("ranks_in_collective")}))
     if out.get("allgather"):
         a = out["allgather"]
         extras.append(("allgather", {"avg_ms": _r(a["avg_ms"]), "bytes_per_rank": a["bytes_per_rank"]}))
@@ -694,10 +717,17 @@ def final_line(out, details_path=None):
             [("samples_total", st["samples_total"]), ("measured_on", st.get("measured_on"))] +
             [(name, dict((n, _r(row["ms_per_job"])) for n, row in st[name].items())) for name in ("config2", "config3") if name in st])))
     if out.get("configs"):
-        extras.append(("configs", dict((name, {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]),
-                                               "samples_per_step": r["config"]["samples_per_step_per_gpu"],
-                                               "roofline_bound": r["roofline"]["bound"], "roofline_frac": _r(r["roofline"]["frac"])})
-                                       for name, r in out["configs"].items())))
+        def small(name, r):
+            d = {"value": _r(r["value"]), "ms_per_step": _r(r["ms_per_step"]), "samples_per_step": r["config"]["samples_per_step_per_gpu"],
+                 "roofline_bound": r["roofline"]["bound"], "roofline_frac": _r(r["roofline"]["frac"])}
+            if name == "config3":                                # the north_star target shape: its kernel and the port beside it
+                d["kernel"] = _cut(r["roofline"].get("kernel", ""), 40)
+                if r.get("cpu_baseline"):
+                    d["cpu_baseline"] = {"value": _r(r["cpu_baseline"]["value"]), "cores": r["cpu_baseline"]["cores"], "kind": r["cpu_baseline"]["kind"]}
+            if r.get("reference_published"):
+                d["reference_published"] = r["reference_published"]["value"]
+            return d
+        extras.append(("configs", dict((name, small(name, r)) for name, r in out["configs"].items())))
     if out.get("api"):
         extras.append(("api_ms_per_run", dict((name, _r(v["ms_per_run"])) for name, v in out["api"].items() if isinstance(v, dict))))
     if details_path:
@@ -713,16 +743,74 @@ def final_line(out, details_path=None):
     return text
 
 
+class Guard(object):
+    """N > 1: whatever happens, rank 0 leaves ONE JSON line and the job ends -- never a hang, never a run without a line.  A rank
+    that fails takes the job down (the launcher terminates the others: SIGTERM; a collective that waits for a dead rank ends at
+    the process group's timeout); rank 0 then prints what it knows -- world size, backend, the devices the ranks reported,
+    RCCL's own count of the ranks -- with "error" and value null, and exits non-zero."""
+
+    def __init__(self, args, rank, world):
+        self.args, self.rank, self.world = args, rank, world
+        self.phase, self.dist, self.printed = "start", None, False
+
+    def line(self, reason):
+        return json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": self.world, "steps": self.args.steps,
+                           "warmup": self.args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                           "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": self.args.config},
+                           "error": _cut(str(reason), 300), "phase": self.phase, "distributed": self.dist})
+
+    def emergency(self, reason):
+        if self.rank == 0 and not self.printed:
+            self.printed = True
+            sys.stdout.flush()
+            print(self.line(reason), flush=True)
+
+    def arm(self, deadline_s):
+        import signal
+        import threading
+
+        def on_term(signum, frame):
+            self.emergency("signal %d in phase %r (another rank failed, or the launcher gave up)" % (signum, self.phase))
+            os._exit(128 + signum)
+        signal.signal(signal.SIGTERM, on_term)
+        self.done = threading.Event()
+
+        def watch():
+            if not self.done.wait(deadline_s):
+                self.emergency("deadline of %d s passed in phase %r" % (deadline_s, self.phase))
+                os._exit(3)
+        threading.Thread(target=watch, daemon=True).start()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    guard = Guard(args, rank, world)
+    if world > 1:
+        guard.arm(int(os.environ.get("GAT_BENCH_DEADLINE", "3000")))
+    try:
+        run(args, rank, world, guard)
+    except SystemExit as e:
+        if e.code not in (0, None):
+            guard.emergency(e.code)
+        raise
+    except BaseException as e:                                    # noqa: BLE001  (the line first, then the traceback)
+        guard.emergency("%s: %s" % (type(e).__name__, e))
+        raise
+    finally:
+        if world > 1 and hasattr(guard, "done"):
+            guard.done.set()
+
+
+def run(args, rank, world, guard):
+    import datetime
     import torch
     import torch.distributed as dist
     from gat_amd import synthetic
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -735,11 +823,29 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
+        guard.phase = "init_process_group"
+        # (a collective that waits for a rank that is gone ends here, not after the default half hour)
+        timeout = datetime.timedelta(seconds=int(os.environ.get("GAT_BENCH_DIST_TIMEOUT", "600")))
         if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
         assert dist.get_world_size() == args.gpus
+        # who is there, known from the start: the devices the ranks sit on, and the collective's own count of the ranks (an
+        # all-reduce of ones over the backend the run uses)
+        guard.phase = "roll call"
+        devs = [None] * world
+        dist.all_gather_object(devs, (socket.gethostname(), torch.cuda.current_device(),
+                                      str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", dev_index))))
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        guard.dist = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_in_collective": int(ones.item()),
+                      "devices": [list(d) for d in devs], "one_gpu_per_rank": len(set(devs)) == world}
+        if not share and not guard.dist["one_gpu_per_rank"]:
+            raise SystemExit("bench.py: %d ranks landed on %d devices: %r" % (world, len(set(devs)), devs))
+        if os.environ.get("GAT_BENCH_FAIL_RANK") == str(rank):        # (tests: a rank that dies behind the roll call)
+            raise RuntimeError("rank %d fails on purpose (GAT_BENCH_FAIL_RANK)" % rank)
+    guard.phase = "headline shape"
 
     cfg_samples = synthetic.CONFIG_SAMPLES[args.config]
     W = Workload(args.config, args.samples or cfg_samples, args, dev_index, rank, world, depth=args.pipeline)
@@ -750,16 +856,9 @@ def main():
     for k in ("config", "roofline", "kernels", "sampler", "allgather", "sustained", "step"):
         if k in main_out:
             out[k] = main_out[k]
-    if "sustained" in main_out:
-        out["sustained_value"] = main_out["sustained"]["value"]
+    out.update(headline(main_out, args.steps))
     if world > 1:
-        devs = [None] * world
-        dist.all_gather_object(devs, (socket.gethostname(), torch.cuda.current_device(),
-                                      str(getattr(torch.cuda.get_device_properties(dev_index), "uuid", dev_index))))
-        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                              "devices": [list(d) for d in devs], "one_gpu_per_rank": len(set(devs)) == world}
-        if not share and not out["distributed"]["one_gpu_per_rank"]:
-            raise SystemExit("bench.py: %d ranks landed on %d devices: %r" % (world, len(set(devs)), devs))
+        out["distributed"] = guard.dist
     if args.dump_counts and rank == 0:
         import numpy as np
         torch.cuda.synchronize()
@@ -777,6 +876,7 @@ def main():
     del W
     extras = {}
     for name in [x for x in args.extra.split(",") if x and x != args.config]:
+        guard.phase = "extra shape " + name
         torch.cuda.empty_cache()
         # (measured like the headline shape: these steps are 6-70 ms and gain 0-1 % from the second step in flight)
         E = Workload(name, EXTRA_SAMPLES.get(name, synthetic.CONFIG_SAMPLES[name]), args, dev_index, rank, world,
@@ -799,6 +899,7 @@ def main():
     if extras:
         out["configs"] = extras
     if not args.no_strong and args.scale == 1.0:
+        guard.phase = "strong scaling"
         out["strong_scaling"] = strong_scaling(args, dev_index, rank, world)
     if not args.no_api and world == 1 and args.scale == 1.0:
         out["api"] = api_block(args)
@@ -813,6 +914,7 @@ def main():
             sys.stderr.write("bench.py: could not write %s: %s\n" % (details, e))
             details = None
         sys.stdout.flush()
+        guard.printed = True
         print(final_line(out, os.path.relpath(details, ROOT) if details else None), flush=True)
     if world > 1:
         dist.barrier()

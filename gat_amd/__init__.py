@@ -345,27 +345,24 @@ def _nccl_shard_and_gather(ctx, P, names, tracks, seed, begin, end, num_samples,
     import torch.distributed as dist
     from . import distributed
     rank = dist.get_rank() if dist.is_initialized() else 0
-    per = distributed.padded_shard(num_samples, world)
     dev = torch.device("cuda", ctx.device)
     K, A = len(names), len(tracks)
     lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
     cur = torch.cuda.current_stream(dev)
-    lo, hi = min(rank * per, num_samples), min((rank + 1) * per, num_samples)
-    full = hi - lo == per
-    shard = (torch.empty if full else torch.zeros)((K, A, per), dtype=torch.int64, device=dev)
-    gathered = torch.empty((world * K, A, per), dtype=torch.int64, device=dev)
-    if hi > lo:
-        # (a short shard -- the last one that holds samples -- is sampled into a block of its own width and copied in)
-        block = shard if full else torch.empty((K, A, hi - lo), dtype=torch.int64, device=dev)
+
+    def fill(lo, hi, block):
         lib_stream.wait_stream(cur)                           # (whatever torch still runs on memory it hands out here)
         P.sample_and_count_device(names, seed, lo, hi, block.data_ptr())
-        cur.wait_stream(lib_stream)
-        if not full:
-            shard[..., :hi - lo].copy_(block)
-            block.record_stream(lib_stream)
-    dist.all_gather_into_tensor(gathered, shard)
+
+    def order(what):
+        if what is True:
+            cur.wait_stream(lib_stream)                       # the shard's columns are there before torch copies / gathers them
+        else:
+            what.record_stream(lib_stream)                    # (a short shard's block: the library's stream wrote it)
+
+    # the shards' arithmetic and the ONE all-gather: distributed.shard_and_gather (the same code the CPU tests run over gloo);
     # [G, K, A, per] -> [K, A, G * per], the surplus of the last ranks cut off: the one device copy of the path
-    full_t = gathered.view(world, K, A, per).permute(1, 2, 0, 3).reshape(K, A, world * per)[..., :num_samples].contiguous()
+    full_t = distributed.shard_and_gather(fill, K, A, num_samples, dev, order=order)
     stats = None
     if device_stats is not None:
         lib_stream.wait_stream(cur)                           # gathered and re-ordered before k_null_stats reads

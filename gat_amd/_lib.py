@@ -32,7 +32,7 @@ SYMBOLS = [
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
     "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums", "gat_problem_rng_rows",
-    "gat_isochore_split",
+    "gat_isochore_split", "gat_comm_library_preloaded",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -203,6 +203,8 @@ def lib():
     L.gat_null_stats.argtypes = [vp, vp, i64, i64, vp, vp, i64, i64, vp]
     L.gat_comm_unique_id.restype = C.c_int
     L.gat_comm_unique_id.argtypes = [vp]
+    L.gat_comm_library_preloaded.restype = C.c_int
+    L.gat_comm_library_preloaded.argtypes = []
     L.gat_comm_create.restype = C.c_int
     L.gat_comm_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, vp]
     L.gat_comm_destroy.restype = None

@@ -6,6 +6,7 @@
 // (gat_kernels.h); there is no CPU path for them in this library.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <link.h>            // dl_iterate_phdr: the RCCL a host process has mapped already
 #include <rccl/rccl.h>          // types only: the library is loaded with dlopen at the first collective
 
 #include <algorithm>
@@ -1529,6 +1530,7 @@ extern "C" int gat_count_list_ranges(gat_ctx* ctx, const int32_t* counter_ids, i
 // have it (and so that a process that already holds torch's copy does not get a second one by linking).
 struct RcclApi {
   void* handle = nullptr;
+  bool preloaded = false;      // the library was in the process already (torch's copy, or one the host linked)
   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
@@ -1540,11 +1542,36 @@ static RcclApi* rccl_api() {
   static bool tried = false;
   if (!tried) {
     tried = true;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.handle) break;
+    // A process must not hold two RCCLs (two sets of communicators' bootstrap state, two IPC caches): where one is mapped
+    // already -- torch brings its own copy, torch/lib/librccl.so, and resolves it by that name -- that one is taken:
+    // RTLD_NOLOAD returns a handle only for a library that is loaded, by soname or by the path it was loaded from.  Failing
+    // that, any object of the process that exports the entry points (RTLD_DEFAULT: a host that linked RCCL itself); only then
+    // is a library loaded afresh.  GAT_RCCL_LIB names one explicitly.
+    const char* env_lib = getenv("GAT_RCCL_LIB");
+    if (env_lib && *env_lib) api.handle = dlopen(env_lib, RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle)
+      for (const char* name : {"librccl.so", "librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (api.handle) break;
+      }
+    if (!api.handle) {
+      // (mapped under a path dlopen does not search -- torch/lib --: find it among the process's objects)
+      struct Find { std::string path; } f;
+      dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* data) -> int {
+        const char* nm = info->dlpi_name;
+        if (nm && strstr(nm, "librccl.so")) { static_cast<Find*>(data)->path = nm; return 1; }
+        return 0;
+      }, &f);
+      if (!f.path.empty()) api.handle = dlopen(f.path.c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     }
-    if (api.handle) {
+    api.preloaded = api.handle != nullptr;
+    if (!api.handle && dlsym(RTLD_DEFAULT, "ncclAllGather") != nullptr) { api.handle = RTLD_DEFAULT; api.preloaded = true; }
+    if (!api.handle)
+      for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+      }
+    if (api.handle || api.preloaded) {
       api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.handle, "ncclGetUniqueId");
       api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(api.handle, "ncclCommInitRank");
       api.comm_destroy = (decltype(api.comm_destroy))dlsym(api.handle, "ncclCommDestroy");
@@ -1552,8 +1579,14 @@ static RcclApi* rccl_api() {
       api.error_string = (decltype(api.error_string))dlsym(api.handle, "ncclGetErrorString");
     }
   }
-  const bool ok = api.handle && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather;
+  const bool ok = (api.handle || api.preloaded) && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_gather;
   return ok ? &api : nullptr;
+}
+
+// which RCCL gat_comm_* resolved: 1 one the process had mapped already (RTLD_NOLOAD / among its objects), 0 loaded afresh, -1 none
+extern "C" int gat_comm_library_preloaded(void) {
+  RcclApi* R = rccl_api();
+  return R ? (R->preloaded ? 1 : 0) : -1;
 }
 
 struct gat_comm {

@@ -349,6 +349,10 @@ void gat_comm_destroy(gat_comm* comm);
 /* send_dev: this rank's n_slots 8-byte slots (its [counter][track][shard] block); recv_dev: n_ranks * n_slots
  * slots, rank r's block at r * n_slots.  Enqueued on the ctx stream; returns after completion. */
 int gat_allgather_counts(gat_ctx* ctx, gat_comm* comm, const void* send_dev, void* recv_dev, int64_t n_slots);
+/* Which RCCL the calls above resolved: 1 = one the process had mapped already (a host with torch holds torch/lib/librccl.so: it
+ * is found with RTLD_NOLOAD / among the process's objects and used -- a process never holds two RCCLs), 0 = loaded afresh
+ * (librccl.so, librccl.so.1, /opt/rocm/lib/librccl.so, or $GAT_RCCL_LIB), -1 = none found. */
+int gat_comm_library_preloaded(void);
 
 /* queries */
 int gat_problem_info(const gat_problem* p, int64_t* n_units, int64_t* n_contigs, int64_t* n_tracks,

@@ -77,3 +77,28 @@ def test_final_line_of_an_n_gpu_report():
     assert "cpu_baseline" not in line
     assert line["distributed"] == {"backend": "nccl", "world_size": 8, "one_gpu_per_rank": True}
     assert line["allgather"]["avg_ms"] > 0 and line["strong_scaling"]["config2"]["n8"] > 0
+
+
+def test_headline_quotes_the_longer_measurement_when_the_k_steps_are_a_blink():
+    """20 steps of config 2 are 50 ms: where the same step repeated for a second says something else by more than 2 %, `value` is
+    the longer measurement; K steps that are themselves half a second, or agree within 2 %, stay the value."""
+    B = _bench()
+    sus = {"value": 3.84e6, "ms_per_step": 2.604, "seconds": 1.02, "steps": 392}
+    h = B.headline({"value": 4.02e6, "ms_per_step": 2.4876, "sustained": sus}, 20)
+    assert h["value"] == 3.84e6 and h["ms_per_step"] == 2.604 and h["k_steps_value"] == 4.02e6 and h["value_source"].startswith("sustained")
+    h = B.headline({"value": 3.90e6, "ms_per_step": 2.564, "sustained": sus}, 20)           # within 2 %
+    assert h["value"] == 3.90e6 and h["value_source"].startswith("the 20 timed steps")
+    h = B.headline({"value": 4.02e6, "ms_per_step": 2.4876, "sustained": sus}, 400)         # K steps of a second by themselves
+    assert h["value"] == 4.02e6
+    h = B.headline({"value": 4.02e6, "ms_per_step": 2.4876}, 20)                            # no sustained loop was run
+    assert h["value"] == 4.02e6 and "sustained_value" not in h
+
+
+def test_final_line_carries_the_target_shape_and_the_value_source():
+    B = _bench()
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_run.json")))
+    out.update(B.headline(out, out["steps"]))
+    line = json.loads(B.final_line(out, "bench_details.json"))
+    assert "value_source" in line and line["k_steps_value"] > 0
+    c3 = line["configs"]["config3"]
+    assert c3["kernel"].startswith("k_count_merged") and c3["cpu_baseline"]["kind"] == "port" and c3["cpu_baseline"]["cores"] >= 1

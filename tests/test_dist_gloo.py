@@ -89,3 +89,52 @@ def test_eight_ranks_ragged_shards(tmp_path):
             want[k, a] = (k * 3 + a) * 1000 + np.arange(S)
     for r in range(world):
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "ragged%d.npy" % r)), want), r
+
+
+def _worker_shard_and_gather(rank, world, path):
+    """distributed.shard_and_gather -- the arithmetic of gat_amd.run() under the nccl backend (_nccl_shard_and_gather): equal
+    shards of ceil(S / world), the ids at or beyond S never drawn, a rank past the end filling nothing, ONE all-gather, the
+    surplus cut off -- with a fill function that names every slot it writes; every rank must end up with the matrix one process
+    would have filled."""
+    import torch
+    from gat_amd import distributed
+    _init("gloo", rank, world, path)
+    K, A = 2, 3
+    out = {}
+    for S in (1, 7, 8, 9, 10000):
+        asked = []
+
+        def fill(lo, hi, block):
+            asked.append((lo, hi))
+            for k in range(K):
+                for a in range(A):
+                    block[k, a] = (k * A + a) * 100000 + torch.arange(lo, hi, dtype=torch.int64)
+        full = distributed.shard_and_gather(fill, K, A, S, torch.device("cpu"))
+        per = -(-S // world)
+        lo, hi = min(S, rank * per), min(S, (rank + 1) * per)
+        assert asked == ([(lo, hi)] if hi > lo else []), (S, rank, asked)       # never a sample id beyond the job
+        out[str(S)] = full.numpy()
+    np.savez(os.path.join(path, "sg%d.npz" % rank), **out)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _shard_and_gather_case(tmp_path, world):
+    mp.spawn(_worker_shard_and_gather, args=(world, str(tmp_path)), nprocs=world, join=True)
+    for S in (1, 7, 8, 9, 10000):
+        want = np.zeros((2, 3, S), dtype=np.int64)
+        for k in range(2):
+            for a in range(3):
+                want[k, a] = (k * 3 + a) * 100000 + np.arange(S)
+        for r in range(world):
+            got = np.load(os.path.join(str(tmp_path), "sg%d.npz" % r))[str(S)]
+            assert got.shape == want.shape and np.array_equal(got, want), (S, world, r)
+
+
+def test_shard_and_gather_two_ranks(tmp_path):
+    _shard_and_gather_case(tmp_path, 2)
+
+
+def test_shard_and_gather_eight_ranks(tmp_path):
+    _shard_and_gather_case(tmp_path, 8)

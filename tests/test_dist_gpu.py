@@ -85,9 +85,14 @@ def test_run_two_ranks_equals_single_process(tmp_path, seed):
 def test_c_abi_allgather_counts_single_rank():
     """gat_comm_* / gat_allgather_counts (RCCL loaded by the library itself, no torch): a communicator of one rank on this
     box's GPU gathers a count block onto itself."""
+    import torch  # noqa: F401  (torch brings its own RCCL: torch/lib/librccl.so)
     from gat_amd import _lib
     ctx = _lib.Context(0)
     comm = _lib.Comm(ctx, 1, 0, _lib.comm_unique_id())
+    # a process never holds two RCCLs: with torch's copy mapped, the library takes that one (RTLD_NOLOAD), it loads none
+    if any("librccl" in line for line in open("/proc/self/maps")):
+        assert _lib.lib().gat_comm_library_preloaded() == 1
+        assert len(set(line.split()[-1] for line in open("/proc/self/maps") if "librccl" in line)) == 1
     n = 3 * 5 * 7
     src = np.arange(n, dtype=np.int64) * 3 - 11
     a, b = ctx.alloc(n * 8), ctx.alloc(n * 8)

@@ -1060,6 +1060,22 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert line["sustained_value"] == pytest.approx(out["sustained_value"], rel=1e-5)
 
 
+def test_bench_leaves_a_line_when_a_rank_fails(tmp_path):
+    """a rank that dies behind the roll call takes the job down -- non-zero exit, no hang -- and rank 0 still leaves ONE JSON
+    line: value null, the error, and who was there (world size, backend, the ranks' devices, the collective's own count)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAT_BENCH_SHARE_GPU="1", GAT_BENCH_FAIL_RANK="1", GAT_BENCH_DIST_TIMEOUT="60")
+    r = _torchrun(2, [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--samples", "500", "--extra", "",
+                      "--no-strong", "--sustain-seconds", "0", "--details", str(tmp_path / "df.json")], env, root, 300)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["error"] and line["n_gpus"] == 2
+    d = line["distributed"]
+    assert d["world_size"] == 2 and d["ranks_in_collective"] == 2 and len(d["devices"]) == 2 and d["backend"] == "gloo"
+
+
 def test_bench_eight_ranks_on_one_gpu(tmp_path):
     """the launch the driver's scaling run makes -- eight ranks under torch.distributed.run -- on this box's one GPU (gloo
     instead of RCCL): every rank its own sample range, the gathered matrix of the last step against the oracle's columns"""
@@ -1073,6 +1089,7 @@ def test_bench_eight_ranks_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line, out = _bench_outputs(r, str(tmp_path / "d8.json"))
     assert line["n_gpus"] == 8 and line["distributed"]["world_size"] == 8 and line["value"] > 0
+    assert line["distributed"]["ranks_in_collective"] == 8
     assert line["allgather"]["avg_ms"] > 0
     # the metric's own job cut over the eight ranks: measured (every rank its 1 250 samples, the gather, the read-back)
     st = out["strong_scaling"]
