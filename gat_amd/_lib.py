@@ -32,7 +32,7 @@ SYMBOLS = [
     "gat_comm_unique_id", "gat_comm_create", "gat_comm_destroy", "gat_allgather_counts", "gat_null_stats",
     "gat_sample_and_count_serial", "gat_mt19937_seed", "gat_sample_and_count_enqueue", "gat_wait",
     "gat_annotations_create", "gat_annotations_destroy", "gat_annotations_wait", "gat_list_sums", "gat_problem_rng_rows",
-    "gat_isochore_split", "gat_comm_library_preloaded",
+    "gat_isochore_split", "gat_comm_library_preloaded", "gat_ctx_set_option", "gat_ctx_get_option",
 ]
 
 MT_STATE_WORDS = 625          # GAT_MT_STATE_WORDS: 624 state words + numpy's position
@@ -205,6 +205,10 @@ def lib():
     L.gat_comm_unique_id.argtypes = [vp]
     L.gat_comm_library_preloaded.restype = C.c_int
     L.gat_comm_library_preloaded.argtypes = []
+    L.gat_ctx_set_option.restype = C.c_int
+    L.gat_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.gat_ctx_get_option.restype = C.c_char_p
+    L.gat_ctx_get_option.argtypes = [vp, C.c_char_p]
     L.gat_comm_create.restype = C.c_int
     L.gat_comm_create.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, vp]
     L.gat_comm_destroy.restype = None
@@ -229,6 +233,46 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+class _Options(object):
+    """a context's tuning / testing knobs (gat_ctx_set_option) as a mapping: options["GAT_X"] = "1" sets, del / pop go back to
+    the process's value (the environment as the library first saw it), "" means "not set whatever the environment says".
+    pytest's monkeypatch.setitem(ctx.options, key, value) undoes itself."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self._mine = {}
+
+    def __setitem__(self, key, value):
+        _check(lib().gat_ctx_set_option(self._ctx._h, key.encode(), str(value).encode()), self._ctx._h)
+        self._mine[key] = str(value)
+
+    def __delitem__(self, key):
+        _check(lib().gat_ctx_set_option(self._ctx._h, key.encode(), None), self._ctx._h)
+        del self._mine[key]
+
+    def __getitem__(self, key):
+        return self._mine[key]                      # (KeyError: not set on this context -- what monkeypatch.setitem asks)
+
+    def __contains__(self, key):
+        return key in self._mine
+
+    def get(self, key, default=None):
+        """the value in force: this context's, else the process's; None: not set"""
+        v = lib().gat_ctx_get_option(self._ctx._h, key.encode())
+        return v.decode() if v is not None else default
+
+    def pop(self, key, default=None):
+        if key in self._mine:
+            v = self._mine[key]
+            del self[key]
+            return v
+        return default
+
+    def update(self, **kw):
+        for k, v in kw.items():
+            self[k] = v
+
+
 class Context(object):
     """one HIP device + stream (gat_ctx)."""
 
@@ -243,6 +287,7 @@ class Context(object):
             handle = C.c_void_p(int(stream) if int(stream) != 0 else 1)      # hipStreamLegacy == (hipStream_t)1
         _check(lib().gat_ctx_create(C.byref(self._h), int(device), handle))
         self.device = device
+        self.options = _Options(self)           # the knobs (GAT_*): ctx.options["GAT_NO_SPLIT"] = "1"
 
     def close(self):
         if self._h:

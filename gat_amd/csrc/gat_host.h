@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,7 +90,23 @@ struct gat_ctx {
   unsigned long long* h_stat = nullptr;         // pinned, 16 words: statistics and status word of a gat_sample batch
   std::string err;
   int max_lds = 65536;
+  // gat_ctx_set_option: the context's own values of the tuning / testing knobs (GAT_*), in front of the process's -- the
+  // environment as it was when the library was first asked (gat_opt); aux_ctx / build_ctx read their owner's
+  std::map<std::string, std::string> options;
+  mutable std::mutex options_mutex;
+  const gat_ctx* options_owner = nullptr;
 };
+
+// The knobs are no longer read from the environment where they act: gat_opt answers from the context's
+// options (gat_ctx_set_option), else from a snapshot of the process's GAT_* variables taken ONCE -- no getenv on a call's path,
+// and two host threads with a context each no longer share what a test sets.  nullptr: not set (or set to the empty string).
+const char* gat_opt(const gat_ctx* ctx, const char* key);
+
+// k_count_seg stages a track tile's lists in LDS: a list of max_m intervals takes max_m + 4 entries (one in front of its first
+// interval, three sentinels behind the last: segs_vs_pairs).  ONE condition for the launch (launch_count) and for the build
+// (build_annos: lists beyond it get the merged index) -- they had drifted apart by three entries
+inline int64_t count_lds_entries(const gat_ctx* ctx) { const char* e = gat_opt(ctx, "GAT_COUNT_LDS_ENTRIES"); return e ? atoll(e) : 1024; }
+inline bool count_lists_staged(const gat_ctx* ctx, int64_t max_m) { return max_m > 0 && max_m + 4 <= count_lds_entries(ctx); }
 
 void ctx_release(gat_ctx* ctx);     // gat_mi355.hip: drops one reference, frees the context with the last
 
@@ -277,7 +295,7 @@ int annotations_wait(gat_ctx* ctx, gat_annotations* a);   // joins the build; re
 struct PrepTimer {
   bool on;
   std::chrono::steady_clock::time_point t;
-  PrepTimer() : on(getenv("GAT_TIME_CREATE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  PrepTimer() : on(gat_opt(nullptr, "GAT_TIME_CREATE") != nullptr), t(std::chrono::steady_clock::now()) {}
   void lap(const char* what) {
     if (!on) return;
     const auto n = std::chrono::steady_clock::now();

@@ -179,7 +179,7 @@ extern "C" int gat_memcpy_h2d(gat_ctx* ctx, void* dst, const void* src, size_t b
 static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
   if (P->batch >= want) return GAT_OK;
   PrepTimer tm;
-  const char* env = getenv("GAT_SLAB_BYTES");
+  const char* env = gat_opt(ctx, "GAT_SLAB_BYTES");
   // a batch as large as a quarter of the 288 GB takes: the lane-per-stream kernels have a fixed floor per launch (the serial
   // chain of the longest unit's tile) and the wave-per-unit kernels of long-list problems fill the chip only with
   // thousands of samples in flight, so fewer, larger batches are faster (config 3, 10 000 samples: 9.7 ms in two batches
@@ -250,13 +250,16 @@ static int parse_counters(gat_ctx* ctx, const int32_t* ids, int n, Counters& C) 
 
 static_assert(gat::kMergedThreads / gat::kWave == kMergedWavesHost, "gat_host.h: kMergedWavesHost");
 // which kernel serves the segment-side counters (the choice launch_count makes)
-static int count_route(const gat_ctx* ctx, bool has_merged, const Counters& C, int n_contigs, int n_tracks, int swap_capx) {
+// merged_only: the tables were BUILT for that route alone (AnnoDev::per_track false -- decided from the knobs as they were then):
+// the route stands whatever the knobs say now (a knob flipped between the build and the call was GAT_ERR_ARG)
+static int count_route(const gat_ctx* ctx, bool has_merged, const Counters& C, int n_contigs, int n_tracks, int swap_capx,
+                       bool merged_only = false) {
   if (!C.any_seg || n_contigs <= 0) return GAT_COUNT_KERNEL_NONE;
   const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
   const size_t lds_merged = (size_t)n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-  if (only_overlap && has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_MERGED"))
+  if (only_overlap && has_merged && (int64_t)lds_merged + 1024 <= ctx->max_lds && (merged_only || !gat_opt(ctx, "GAT_COUNT_NO_MERGED")))
     return GAT_COUNT_KERNEL_MERGED;
-  if (swap_capx > 0 && only_overlap && !getenv("GAT_COUNT_NO_SWAP")) return GAT_COUNT_KERNEL_SWAP;
+  if (swap_capx > 0 && only_overlap && !gat_opt(ctx, "GAT_COUNT_NO_SWAP")) return GAT_COUNT_KERNEL_SWAP;
   return GAT_COUNT_KERNEL_SEG;
 }
 
@@ -280,13 +283,12 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
   A.a_start = annos.start.p; A.a_end = annos.end.p; A.a_cumx = annos.cumx.p; A.a_off = annos.off.p;
   A.a_grid = annos.grid.p; A.g_off = annos.goff.p; A.c_shift = annos.shift.p; A.c_cells = annos.cells.p;
   if (A.n_samples <= 0 || A.n_tracks <= 0) return GAT_OK;
-  if (!annos.per_track && (C.any_anno || (C.any_seg && count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx) != GAT_COUNT_KERNEL_MERGED)))
+  if (!annos.per_track && (C.any_anno || (C.any_seg && count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx, true) != GAT_COUNT_KERNEL_MERGED)))
     return set_err(ctx, GAT_ERR_ARG, "the annotation tables were made for the nucleotide counters only (GAT_ANNOTATIONS_NUCLEOTIDE_ONLY): "
                                      "no per-track tables for the counters asked for");
   if (C.any_seg) {
-    const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
-    const int E_max = env_e ? atoi(env_e) : 1024;
-    const char* env_sc = getenv("GAT_COUNT_SAMPLES_PER_BLOCK");
+    const int E_max = (int)count_lds_entries(ctx);
+    const char* env_sc = gat_opt(ctx, "GAT_COUNT_SAMPLES_PER_BLOCK");
     int SC = env_sc ? atoi(env_sc) : 32;
     if (!env_sc) {   // enough blocks to fill 256 CUs several times over, large enough to amortise the staging
       const int64_t tiles0 = (A.n_tracks + 0) , work = (int64_t)A.n_samples * tiles0 * std::max(1, A.n_contigs) / 8192;
@@ -294,12 +296,12 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
       while (SC < 128 && SC * 2 <= work) SC *= 2;
     }
     SC = std::max(1, std::min(SC, 256));
-    const char* env_tt = getenv("GAT_COUNT_TRACKS_PER_BLOCK");
+    const char* env_tt = gat_opt(ctx, "GAT_COUNT_TRACKS_PER_BLOCK");
     const int TT_max = env_tt ? atoi(env_tt) : 16;
     int TT;
-    const char* env_st = getenv("GAT_COUNT_STAGED");
+    const char* env_st = gat_opt(ctx, "GAT_COUNT_STAGED");
     // (+4: a staged list has an entry in front of its first interval and three sentinels behind the last: segs_vs_pairs)
-    bool staged = annos.max_m > 0 && annos.max_m + 4 <= E_max && !(env_st && atoi(env_st) == 0);
+    bool staged = count_lists_staged(ctx, annos.max_m) && !(env_st && atoi(env_st) == 0);
     if (staged) TT = (int)std::min<int64_t>(std::min<int64_t>(A.n_tracks, TT_max), E_max / (annos.max_m + 4));
     else TT = (int)std::min<int64_t>(A.n_tracks, TT_max);
     TT = std::max(1, TT);
@@ -318,13 +320,13 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     dim3 grid((unsigned)((A.n_samples + SC - 1) / SC), gpy, gpz);
     const unsigned gcy = (unsigned)std::min(std::max(1, A.n_contigs), 32768), gcz = ((unsigned)std::max(1, A.n_contigs) + gcy - 1) / gcy;
     const size_t lds_merged = (size_t)A.n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
-    const int route = count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx);
+    const int route = count_route(ctx, annos.has_merged, C, A.n_contigs, A.n_tracks, swap_capx, !annos.per_track);
     if (route == GAT_COUNT_KERNEL_MERGED) {
       // several tracks: one look-up per sample segment in the merged index of all tracks
       A.mz = annos.mz.p; A.mz_off = annos.mz_off.p; A.mfirst = annos.mfirst.p; A.mf_off = annos.mf_off.p;
       A.m_shift = annos.m_shift.p; A.m_cells = annos.m_cells.p;
       A.m_slot_off = annos.m_slot_off.p; A.m_slot_contigs = annos.m_slot_contigs.p;
-      const char* env_sg = getenv("GAT_MERGED_SAMPLES_PER_BLOCK");
+      const char* env_sg = gat_opt(ctx, "GAT_MERGED_SAMPLES_PER_BLOCK");
       // samples per workgroup: one per wave.  (Larger groups were meant to keep the contig's index hot; measured on config 3,
       // main kernel per 10 000 samples: 4 -> 1.60 ms, 8 -> 1.69, 16 -> 1.73, 32 -> 1.83, 64 -> 2.1: the finer deal wins.)
       int SG = env_sg ? atoi(env_sg) : 4;
@@ -424,7 +426,7 @@ static int launch_count(gat_ctx* ctx, const AnnoDev& annos, const Counters& C, g
     int lcells = 4;
     while ((1 << lcells) < list_cap + 1 && lcells < 13) ++lcells;
     const size_t lds_a = (size_t)2 * (list_cap + 1) * 4 + ((size_t)(1 << lcells) + 1) * 4;
-    if (list_cap > 0 && A.n_contigs > 0 && (int64_t)lds_a + 1024 <= ctx->max_lds && !getenv("GAT_COUNT_NO_SWAP")) {
+    if (list_cap > 0 && A.n_contigs > 0 && (int64_t)lds_a + 1024 <= ctx->max_lds && !gat_opt(ctx, "GAT_COUNT_NO_SWAP")) {
       gat::CountArgs B = A;
       B.lds_entries = list_cap + 1;
       B.lds_grid = lcells;
@@ -484,7 +486,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       A.ws = P->d_ws.p; A.ws_cdf = P->d_ws_cdf.p; A.rank_len = P->d_rank_len.p; A.ws_tree = P->d_ws_tree.p;
       A.ws_rec = P->d_ws_rec.p;
       A.seed = seed; A.sample_begin = begin; A.sampler_kind = P->sampler;
-      A.place_plain_step = getenv("GAT_PLACE_NO_CM") ? 1 : 0;
+      A.place_plain_step = gat_opt(ctx, "GAT_PLACE_NO_CM") ? 1 : 0;
       A.slab = P->d_slab.p; A.slab_stride = P->slab_stride;
       A.unit_n = P->d_unit_n.p; A.flags = P->flags_dev(); A.stat = P->d_stat.p; A.ws_stat = P->d_ws_stat.p;
 #if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
@@ -536,16 +538,16 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         //  eight GPUs -- take the wide kernel as well: its loop stores unconditionally and four tiles share a rank table; config 2,
         //  k_place at 1 250 / 2 500 / 5 000 samples: 0.46 / 0.47 / 0.56 ms against the lean kernel's 0.52 / 0.53 / 0.57, at 10 000
         //  1.05 against 0.92)
-        const bool small_call = (int64_t)nsb * (int64_t)n_act <= 1536 && !getenv("GAT_PLACE_NO_WIDE");
-        const int mode = P->all_simple ? ((getenv("GAT_PLACE_WIDE") || small_call) ? 3 : 1)
-                                       : (P->all_one_ws && !getenv("GAT_PLACE_NO_WIDE") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
+        const bool small_call = (int64_t)nsb * (int64_t)n_act <= 1536 && !gat_opt(ctx, "GAT_PLACE_NO_WIDE");
+        const int mode = P->all_simple ? ((gat_opt(ctx, "GAT_PLACE_WIDE") || small_call) ? 3 : 1)
+                                       : (P->all_one_ws && !gat_opt(ctx, "GAT_PLACE_NO_WIDE") ? 3 : (P->max_nws > gat::kPlaceWsLds ? 2 : 0));
         // (k_place_wide: kPlaceWide tiles per workgroup, the largest unit's rank table beside their rings)
         const dim3 gw((nsb + gat::kPlaceWide - 1) / gat::kPlaceWide, gy, gz);
         const size_t lds_wide = (size_t)P->max_hist * 4;
         // calls of a few hundred tiles of a problem of simple units: one stream walked by the 64 lanes of a wave (k_place_scan:
         // a stream's states as a prefix scan over its rows) instead of one lane walking it row by row -- the chain of the longest
         // unit's tile, 0.37 ms on config 2 whatever the sample count, is what such a call waited for
-        const char* env_scan = getenv("GAT_PLACE_SCAN_TILES");
+        const char* env_scan = gat_opt(ctx, "GAT_PLACE_SCAN_TILES");
         const int64_t scan_tiles = env_scan ? atoll(env_scan) : 768;      // (config 2: faster up to ~2 300 samples x 24 units per call)
         const bool scan = P->sampler == GAT_SAMPLER_ANNOTATOR && P->all_simple && P->all_cm_ok && A.place_plain_step == 0 &&
                           (int64_t)nsb * (int64_t)n_act <= scan_tiles;
@@ -553,7 +555,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           const int64_t n_tiles = (int64_t)nsb * n_act;
           const unsigned nblocks = (unsigned)(((n_tiles + 7) / 8) * 8 * 4);
           hipLaunchKernelGGL(gat::k_place_scan, dim3(nblocks), dim3(gat::kScanWaves * 64), 0, ctx->stream, A, (int)nsb,
-                             getenv("GAT_PLACE_SCAN_SEQ") ? 1 : 0);
+                             gat_opt(ctx, "GAT_PLACE_SCAN_SEQ") ? 1 : 0);
         } else
         if (P->sampler == GAT_SAMPLER_SEGMENTS) {
           if (mode == 3) {
@@ -564,7 +566,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           else hipLaunchKernelGGL((gat::k_place<1, 2>), gp, dim3(64), 0, ctx->stream, A);
         } else {
           // (k_place_pipe: the rows of the single-workspace-segment units prefetched by hand, see GAT_PLACE_LOOP_PIPE)
-          const bool pipe = P->pipe_pays && !getenv("GAT_PLACE_NO_PIPE");
+          const bool pipe = P->pipe_pays && !gat_opt(ctx, "GAT_PLACE_NO_PIPE");
           const bool rank_fits = P->max_hist < (uint32_t)gat::kPlaceRankLds;
           // fragmented workspaces: the cdf grids of the long workspaces in LDS, eight tiles of a unit per workgroup (k_place_grid);
           // static LDS: the workspace and rank tables (4 KB each) and an 8 KB ring per tile
@@ -594,7 +596,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       ctx->k_recorded = timed && smode;
       size_t lds = (size_t)(gat::kMtLdsWords + 2 * (size_t)P->max_unit_cap) * 4;
       // SamplerSegments never holds a list; a SamplerAnnotator list beyond LDS is worked on in the slab (HUGE variant)
-      const bool huge = P->sampler != GAT_SAMPLER_SEGMENTS && ((int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr);
+      const bool huge = P->sampler != GAT_SAMPLER_SEGMENTS && ((int64_t)lds > ctx->max_lds || gat_opt(ctx, "GAT_TEST_HUGE") != nullptr);
       if (huge || P->sampler == GAT_SAMPLER_SEGMENTS) lds = (size_t)gat::kMtLdsWords * 4;
       A.lds_cap = P->max_unit_cap;
       A.big_buckets = 0;
@@ -615,7 +617,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         unsigned n_long = 0;
         for (int32_t u : P->h_order) { const uint32_t w = P->h_units[u].hist_total; if (w + w / 8 > 1024) ++n_long; else break; }
         if (smode && P->sampler != GAT_SAMPLER_SEGMENTS && (int64_t)lds_m + 1024 <= ctx->max_lds && n_long > 0 &&
-            !getenv("GAT_NO_MERGE_BIG")) {
+            !gat_opt(ctx, "GAT_NO_MERGE_BIG")) {
           gat::SamplerArgs M = A;
           M.st2 = P->d_st2.p;
           M.big_buckets = nbk;
@@ -650,19 +652,19 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           }
           A.st2 = P->d_st2.p;                    // (k_sampler reads it for those units only: see n_long below)
           A.n_long = (int32_t)n_long;
-          if (!split && P->d_patch.p != nullptr && P->max_nws <= gat::kTailMaxWs && !getenv("GAT_NO_TAIL_BIG")) {
+          if (!split && P->d_patch.p != nullptr && P->max_nws <= gat::kTailMaxWs && !gat_opt(ctx, "GAT_NO_TAIL_BIG")) {
             // the placement rounds behind that consolidation, one stream per lane; k_sampler resumes at the trim
             gat::TailArgs TB;
             TB.S = A;
             TB.cum = nullptr; TB.patch = P->d_patch.p; TB.todo = nullptr; TB.todo_count = nullptr;
             // (counts alone, by k_count_merged -- or through k_contig, which merge(0)s the lists again: what a trim emptied may
             //  stay in the list as [0, 0))
-            TB.loose_ok = (loose_ok && !need_unit_lists && !getenv("GAT_RESUME_COMPACT")) ? 1 : 0;
+            TB.loose_ok = (loose_ok && !need_unit_lists && !gat_opt(ctx, "GAT_RESUME_COMPACT")) ? 1 : 0;
             const unsigned gby = std::min(n_long, 32768u);
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
                                ctx->stream, TB);
             HIPCHK(ctx, hipGetLastError());
-            if (!getenv("GAT_NO_RESUME_BIG")) {
+            if (!gat_opt(ctx, "GAT_NO_RESUME_BIG")) {
               // ... and the rest of the unit -- log inserted, trim, final filter -- with the list where it is
               hipLaunchKernelGGL(gat::k_resume_big, dim3((unsigned)nb, gby, (n_long + gby - 1) / gby), dim3(64), 0, ctx->stream, TB);
               HIPCHK(ctx, hipGetLastError());
@@ -701,7 +703,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         else HIPCHK(ctx, hipFuncSetAttribute((const void*)gat::k_consolidate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
         // (a call of a few hundred tiles does not fill the chip whatever the LDS of a workgroup: one launch for all classes,
         //  each launch less is a tail less -- config 2 at 1 250 samples: k_consolidate 0.121 -> 0.101 ms)
-        const bool one_class = (int64_t)((nb + 63) / 64) * (int64_t)n_act <= 1024 && !getenv("GAT_SIZE_CLASSES");
+        const bool one_class = (int64_t)((nb + 63) / 64) * (int64_t)n_act <= 1024 && !gat_opt(ctx, "GAT_SIZE_CLASSES");
         for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
           // one launch per size class, its LDS sized for the class's longest list
           if (one_class && c > 0) break;
@@ -709,7 +711,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           // (as for k_merge_big: LDS for what the class's longest unit is expected to have placed -- its segments +- a renewal
           //  count's spread -- not for its slab region; the rare list beyond it is k_sampler's.  GAT_CONSOLIDATE_SLAB_LDS: the old size)
           const int n0 = (int)P->h_units[(size_t)P->h_order[(size_t)a0]].hist_total;
-          const int tight = getenv("GAT_CONSOLIDATE_SLAB_LDS") ? INT32_MAX : (n0 + n0 / 12 + 64 + 31) / 32 * 32;
+          const int tight = gat_opt(ctx, "GAT_CONSOLIDATE_SLAB_LDS") ? INT32_MAX : (n0 + n0 / 12 + 64 + 31) / 32 * 32;
           const int ccap = std::min(std::min(P->h_units[(size_t)P->h_order[(size_t)a0]].slab_cap, T.S.lds_cap), tight);
           gat::TailArgs C = T;
           C.S.a_base = a0; C.S.a_end = a1; C.S.lds_cap = ccap;
@@ -727,7 +729,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream));
         // isochore problems: k_contig re-sorts the units of a contig anyway and takes (merged list, k_tail's record) as
         // it is -- no final unit lists unless somebody asked for them (gat_sample_units)
-        P->patched_contigs = P->merge_contigs && P->n_contigs > 0 && !need_unit_lists && !getenv("GAT_CONTIG_FINAL_LISTS");
+        P->patched_contigs = P->merge_contigs && P->n_contigs > 0 && !need_unit_lists && !gat_opt(ctx, "GAT_CONTIG_FINAL_LISTS");
         P->units_direct = units_direct && P->patched_contigs && P->units_direct_ok && serial_state == nullptr;
         P->patched_counts = !P->merge_contigs && records_ok && !need_unit_lists;
         if (!P->patched_contigs && !P->patched_counts) hipLaunchKernelGGL(gat::k_finalize, gu, dim3(64), 0, ctx->stream, T);
@@ -745,7 +747,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       int variant = P->sampler == GAT_SAMPLER_SEGMENTS ? (tree ? 5 : 4)
                   : huge ? (tree ? 7 : 6) : (long_lists ? 2 : 0) + (tree ? 1 : 0);
       // short lists only (20 waves of this kernel fit a CU's LDS): the instantiation with registers for 5 waves per SIMD
-      if (variant == 0 && (int64_t)lds * 20 <= ctx->max_lds && !getenv("GAT_NO_WPE5")) variant = 8;
+      if (variant == 0 && (int64_t)lds * 20 <= ctx->max_lds && !gat_opt(ctx, "GAT_NO_WPE5")) variant = 8;
       const void* ks = variant == 0 ? (const void*)gat::k_sampler<0, false, false, false>
                      : variant == 1 ? (const void*)gat::k_sampler<0, false, true, false>
                      : variant == 2 ? (const void*)gat::k_sampler<0, true, false, false>
@@ -830,7 +832,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
       }
       const int need_max = P->h_contig_order.empty() ? 64 : P->h_contig_need[(size_t)P->h_contig_order[0]];
       size_t lds = (size_t)std::max(64, need_max) * 8 + gat::kSortScratchWords * 4;
-      const bool huge_c = (int64_t)lds > ctx->max_lds || getenv("GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
+      const bool huge_c = (int64_t)lds > ctx->max_lds || gat_opt(ctx, "GAT_TEST_HUGE") != nullptr;   // list stays in the output slab
       if (huge_c) lds = gat::kSortScratchWords * 4;
       // (units_direct: the lists only concatenated, the candidates for k_units_overlap noted: k_contig<., true>)
       const bool nosort = P->units_direct;
@@ -911,7 +913,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       if (st && P->units_direct) { st->n_straddle_candidates += (int64_t)uw[2]; st->n_unit_overlaps += (int64_t)uw[1]; }
     }
 #if defined(GAT_DIAG) || defined(GAT_DIAG_CONS)
-    if (const char* fn = getenv("GAT_DIAG_OUT")) {
+    if (const char* fn = gat_opt(ctx, "GAT_DIAG_OUT")) {
       // shares of a k_sampler work unit's life per phase, summed over the batch (tools/diag_sampler.sh)
       const size_t nd = (size_t)nb * std::max(1, P->n_units) * 8;
       std::vector<unsigned long long> h(nd);
@@ -1138,12 +1140,12 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
     if (annotations_ready(P->anno)) {
       if ((rc = annotations_wait(ctx, P->anno))) return rc;
       decide_swap(P);
-      route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+      route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P), !P->anno->dev.per_track);
     } else {
       const bool only_overlap = C.slot[GAT_COUNTER_SEGMENT_OVERLAP] < 0 && C.slot[GAT_COUNTER_SEGMENT_MIDOVERLAP] < 0;
       const size_t lds_merged = (size_t)P->n_tracks * 4 * (gat::kMergedThreads / gat::kWave);
       if (C.any_seg && P->n_contigs > 0 && only_overlap && P->anno->will_merge && (int64_t)lds_merged + 1024 <= ctx->max_lds &&
-          !getenv("GAT_COUNT_NO_MERGED")) {
+          !gat_opt(ctx, "GAT_COUNT_NO_MERGED")) {
         route = GAT_COUNT_KERNEL_MERGED;                       // (whatever the swap decision would be)
       } else if (P->anno->shape_known && P->anno->total_known >= 0) {
         decide_swap(P);                                        // (from the sizes announced before the build)
@@ -1151,7 +1153,7 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
       } else {
         if ((rc = annotations_wait(ctx, P->anno))) return rc;
         decide_swap(P);
-        route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P));
+        route = count_route(ctx, P->anno->dev.has_merged, C, P->n_contigs, P->n_tracks, call_swap_capx(ctx, P), !P->anno->dev.per_track);
       }
     }
     // the scratch is sized while nothing of this problem is in flight; batches behind the first fit by construction
@@ -1161,12 +1163,12 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
     if (d_state != nullptr)
       HIPCHK(ctx, hipMemcpyAsync(d_state + GAT_MT_STATE_WORDS, d_state, GAT_MT_STATE_WORDS * 4, hipMemcpyDeviceToDevice, ctx->stream));
     // counts alone, all of them k_count_seg's: it reads the units as k_tail left them (no final lists are written)
-    const bool records_ok = !C.any_anno && !getenv("GAT_COUNT_FINAL_LISTS") &&
+    const bool records_ok = !C.any_anno && !gat_opt(ctx, "GAT_COUNT_FINAL_LISTS") &&
                             (route == GAT_COUNT_KERNEL_SEG || route == GAT_COUNT_KERNEL_MERGED);
     // (k_count_merged skips empty segments: long lists may keep what a trim emptied, no compaction pass in k_resume_big)
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
     // isochore problems: the merged index takes the units' lists as they are, no k_contig (round 6)
-    const bool units_direct = loose_ok && P->merge_contigs && P->units_direct_ok && !getenv("GAT_COUNT_VIA_CONTIGS");
+    const bool units_direct = loose_ok && P->merge_contigs && P->units_direct_ok && !gat_opt(ctx, "GAT_COUNT_VIA_CONTIGS");
     if (units_direct && P->d_cand.n == 0) {
       // candidates: segments with a workspace boundary in their cells, of units that have a segment reaching out of their workspace
       // -- a fraction of a per cent of a batch's segments on isochore blocks much longer than the segments --, dealt to kCandSlots
@@ -1221,7 +1223,7 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   K.done = K.enq = 0; K.n_flight = 0;
   memset(&K.local, 0, sizeof(K.local));
   // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
-  K.timed = (ctx->kernel_times || getenv("GAT_KERNEL_TIMES") != nullptr) && ctx->timed_owner == nullptr;
+  K.timed = (ctx->kernel_times || gat_opt(ctx, "GAT_KERNEL_TIMES") != nullptr) && ctx->timed_owner == nullptr;
   if (K.timed) ctx->timed_owner = (const void*)P;
   K.mstat_on = false;                              // (set with the first count kernels: it takes the tables)
   K.count_pending = false;
@@ -1414,6 +1416,7 @@ static int count_lists_impl(gat_ctx* ctx, const int32_t* counter_ids, int n_coun
   HIPCHK(ctx, hipSetDevice(ctx->device));
   if (ctx->aux_ctx == nullptr) {
     int rc = gat_ctx_create(&ctx->aux_ctx, ctx->device, nullptr);
+    if (rc == GAT_OK) ctx->aux_ctx->options_owner = ctx;              // (the knobs are its owner's)
     if (rc) return rc;
   }
   gat_ctx* x = ctx->aux_ctx;
@@ -1458,7 +1461,7 @@ static int count_lists_body(gat_ctx* ctx, const int32_t* counter_ids, int n_coun
   AnnoDev& A = B.A;
   // (the merged index pays when many lists are counted against it; for a handful -- the observed counts of a run's
   //  segment tracks -- building it costs more than the per-track kernel's extra look-ups)
-  const bool want_merged = n_lists >= 16 || getenv("GAT_COUNT_LISTS_MERGED") != nullptr;
+  const bool want_merged = n_lists >= 16 || gat_opt(ctx, "GAT_COUNT_LISTS_MERGED") != nullptr;
   if ((rc = build_annos(ctx, A, annos, anno_begin, anno_end, (int64_t)n_tracks * n_groups, n_groups, want_merged, false))) return rc;
   for (int64_t l = 0; l < n_lists * n_groups; ++l)
     if ((rc = check_list(ctx, lists + list_off[l], list_off[l + 1] - list_off[l], "segment", l))) return rc;
@@ -1547,7 +1550,7 @@ static RcclApi* rccl_api() {
     // RTLD_NOLOAD returns a handle only for a library that is loaded, by soname or by the path it was loaded from.  Failing
     // that, any object of the process that exports the entry points (RTLD_DEFAULT: a host that linked RCCL itself); only then
     // is a library loaded afresh.  GAT_RCCL_LIB names one explicitly.
-    const char* env_lib = getenv("GAT_RCCL_LIB");
+    const char* env_lib = gat_opt(nullptr, "GAT_RCCL_LIB");
     if (env_lib && *env_lib) api.handle = dlopen(env_lib, RTLD_NOW | RTLD_LOCAL);
     if (!api.handle)
       for (const char* name : {"librccl.so", "librccl.so.1"}) {

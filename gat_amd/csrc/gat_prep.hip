@@ -26,7 +26,7 @@ std::map<int, DevPool> g_pools;
 constexpr size_t kPoolMinBytes = (size_t)1 << 20;
 size_t pool_limit() {
   static const size_t limit = [] {
-    const char* env = getenv("GAT_POOL_BYTES");
+    const char* env = gat_opt(nullptr, "GAT_POOL_BYTES");
     return env ? (size_t)atof(env) : (size_t)96 << 30;
   }();
   return limit;
@@ -38,6 +38,42 @@ size_t pool_limit() {
 // changes the device's page tables, and the first operation on the device after such a change was seen to wait 25-30 ms
 // when gigabytes are mapped (gat_amd.run() on config 3: the memsets behind gat_problem_create, the read-back behind
 // gat_null_stats)
+// ---- the knobs (GAT_*): a context's own values, else the process's environment as it was when first asked ------------------
+extern char** environ;
+static const std::map<std::string, std::string>& env_snapshot() {
+  static const std::map<std::string, std::string> snap = [] {
+    std::map<std::string, std::string> m;
+    for (char** e = environ; e && *e; ++e) {
+      if (strncmp(*e, "GAT_", 4) != 0) continue;
+      const char* eq = strchr(*e, '=');
+      if (eq) m[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+    }
+    return m;
+  }();
+  return snap;
+}
+const char* gat_opt(const gat_ctx* ctx, const char* key) {
+  if (ctx != nullptr) {
+    const gat_ctx* own = ctx->options_owner ? ctx->options_owner : ctx;
+    std::lock_guard<std::mutex> lock(own->options_mutex);
+    auto it = own->options.find(key);
+    if (it != own->options.end()) return it->second.empty() ? nullptr : it->second.c_str();   // (values live as long as the entry:
+  }                                                                                             //  set_option between calls only)
+  const auto& snap = env_snapshot();
+  auto it = snap.find(key);
+  return it != snap.end() && !it->second.empty() ? it->second.c_str() : nullptr;
+}
+extern "C" int gat_ctx_set_option(gat_ctx* ctx, const char* key, const char* value) {
+  if (!ctx || !key || strncmp(key, "GAT_", 4) != 0) return set_err(ctx, GAT_ERR_ARG, "gat_ctx_set_option: a context and a key GAT_* are needed");
+  std::lock_guard<std::mutex> lock(ctx->options_mutex);
+  if (value == nullptr) ctx->options.erase(key);      // back to the process's value
+  else ctx->options[key] = value;                     // ("" : not set, whatever the environment says)
+  return GAT_OK;
+}
+extern "C" const char* gat_ctx_get_option(const gat_ctx* ctx, const char* key) {
+  return key ? gat_opt(ctx, key) : nullptr;
+}
+
 static size_t pool_class(size_t bytes) {
   if (bytes >= kPoolMinBytes) return bytes;
   size_t c = 512;
@@ -196,11 +232,11 @@ void run_with_own_threads(int64_t n, void (*fn)(void*, int64_t), void* arg, unsi
 void host_pool_select(int pool) { t_pool = pool == 1 ? 1 : 0; }
 
 void host_pool_run(int64_t n, void (*fn)(void*, int64_t), void* arg) {
-  const char* env_t = getenv("GAT_HOST_THREADS");
+  const char* env_t = gat_opt(nullptr, "GAT_HOST_THREADS");
   unsigned nthreads = env_t ? (unsigned)std::max(1, atoi(env_t)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   nthreads = (unsigned)std::min<int64_t>(nthreads, std::max<int64_t>(1, n));
   if (nthreads <= 1 || t_in_pool_job) { for (int64_t i = 0; i < n; ++i) fn(arg, i); return; }
-  const char* env_p = getenv("GAT_HOST_POOL");
+  const char* env_p = gat_opt(nullptr, "GAT_HOST_POOL");
   if (env_p && atoi(env_p) == 0) { run_with_own_threads(n, fn, arg, nthreads); return; }
   HostPool* P;
   {
@@ -302,7 +338,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
   std::vector<std::vector<uint32_t>> cf((size_t)n_groups);
   std::vector<int> c_err((size_t)n_groups, 0);
   std::vector<double> c_scan((size_t)n_groups, 0.0);                 // entries a scan is expected to pass, x the contig's entries
-  const char* env_bf = getenv("GAT_MERGED_BOUND");
+  const char* env_bf = gat_opt(ctx, "GAT_MERGED_BOUND");
   const uint64_t bfac = env_bf ? (uint64_t)std::max(1, atoi(env_bf)) : 2;
   auto build_one = [&](int c) {
     std::vector<uint64_t>& e = ck[(size_t)c];
@@ -423,7 +459,7 @@ static int build_merged(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, cons
     // entries per step of a scan (k_count_merged<.., BLK>): blocks of eight where a scan passes six or more on average
     double num = 0, den = 0;
     for (int c = 0; c < n_groups; ++c) { num += c_scan[(size_t)c]; den += (double)(hz_off[(size_t)c + 1] - hz_off[(size_t)c]); }
-    const char* env_b = getenv("GAT_MERGED_BLOCK");
+    const char* env_b = gat_opt(ctx, "GAT_MERGED_BLOCK");
     // short scans: the first two entries ride in the grid cell's own record (32 bytes per cell: where the cells are few
     // enough -- the records of the config-4 shape would be 160 MB, but its scans are long and take the blocks anyway)
     const int by_length = den > 0 && num / den >= 6.0 ? 8 : (n_hf <= ((size_t)64 << 20) / 32 ? 1 : 2);
@@ -490,15 +526,16 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   // would read them from global memory with four look-ups per sample segment; the index needs two: config-5 shape,
   // one track of a million intervals, count 2.86 -> 1.74 ms per 16 384 samples)
   const int64_t n_tracks = n_groups > 0 ? n_lists / n_groups : 0;
-  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
-  const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
-  const bool unstaged = A.max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+  const char* env_mm = gat_opt(ctx, "GAT_MERGED_MIN_TRACKS");
+  const char* env_e = gat_opt(ctx, "GAT_COUNT_LDS_ENTRIES");
+  (void)env_e;
+  const bool unstaged = !count_lists_staged(ctx, A.max_m) && A.max_m > 0 && !env_mm;
   const bool do_merged = want_merged && n_groups > 0 && (n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged);
   // GAT_ANNOTATIONS_NUCLEOTIDE_ONLY: the per-track tables are k_count_seg's / k_count_anno's; a caller that will only ask for the
   // nucleotide counters never reaches them once the merged index exists (config 3: 2.0 of the build's 5.3 ms)
   // (... and the count launch would take it: count_route's conditions, gat_mi355.hip)
   A.per_track = !(nucleotide_only && do_merged && n_tracks * 4 * kMergedWavesHost + 1024 <= (int64_t)ctx->max_lds &&
-                  !getenv("GAT_COUNT_NO_MERGED"));
+                  !gat_opt(ctx, "GAT_COUNT_NO_MERGED"));
   if (A.per_track) {
   {
     // starts / ends / running lengths: one pass over the lists, written straight into the pinned staging buffer (three
@@ -546,7 +583,7 @@ int build_annos(gat_ctx* ctx, AnnoDev& A, const gat_segment* annos, const int64_
   std::vector<int32_t> h_shift((size_t)std::max(1, n_groups), 0), h_cells((size_t)std::max(1, n_groups), 1);
   std::vector<int64_t> h_goff((size_t)n_lists + 1, 0);
   A.max_cells = 1;
-  const char* env_g = getenv("GAT_GRID_FACTOR");
+  const char* env_g = gat_opt(ctx, "GAT_GRID_FACTOR");
   const int gfac = env_g ? atoi(env_g) : 2;                        // about one start per two cells (measured best of 1, 2, 4, 8)
   for (int c = 0; c < n_groups; ++c) {
     uint32_t max_start = 0;
@@ -709,9 +746,9 @@ static uint32_t host_overlap(const gat_segment* w, int64_t nw, uint32_t s, uint3
   return ov;
 }
 
-static int32_t cap_for(int64_t n) {
+static int32_t cap_for(const gat_ctx* ctx, int64_t n) {
   int64_t c = n + n / 4 + 96;
-  if (getenv("GAT_TEST_SMALL_CAPS")) c = n / 2 + 8;      // tests: force the overflow / retry path
+  if (gat_opt(ctx, "GAT_TEST_SMALL_CAPS")) c = n / 2 + 8;      // tests: force the overflow / retry path
   c = (c + 63) / 64 * 64;
   return (int32_t)c;
 }
@@ -759,7 +796,7 @@ int layout_slab(gat_problem* P) {
         ccap += P->h_units[u].slab_cap;
       }
       need = (need + 64 + 63) / 64 * 64;
-      if (getenv("GAT_TEST_SMALL_CAPS")) need = std::max<int64_t>(64, need / 4 / 64 * 64);      // tests: force the repeat
+      if (gat_opt(P->ctx, "GAT_TEST_SMALL_CAPS")) need = std::max<int64_t>(64, need / 4 / 64 * 64);      // tests: force the repeat
       P->h_contig_need[c] = (int32_t)std::min<int64_t>(P->contig_tight ? need : ccap, std::max<int64_t>(64, ccap));
     }
     P->h_contig_order.resize((size_t)P->n_contigs);
@@ -798,7 +835,7 @@ int upload_layout(gat_ctx* ctx, gat_problem* P) {
     P->h_class_start.clear();
     const int N = (int)P->h_order.size();
     int32_t first_cap = 0;
-    const char* env_c = getenv("GAT_SIZE_CLASSES");
+    const char* env_c = gat_opt(ctx, "GAT_SIZE_CLASSES");
     const int max_classes = env_c ? std::max(1, atoi(env_c)) : 6;
     for (int i = 0; i < N; ++i) {
       const int32_t cap = P->h_units[(size_t)P->h_order[(size_t)i]].slab_cap;
@@ -907,7 +944,7 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
   A->merge_groups = d->merge_contigs ? 1 : 0;
   // whether the merged index will exist is known from the shape alone when there are enough tracks (build_annos): only then
   // may a problem sample before the tables are there (the sampler's last steps depend on the count kernel that follows)
-  const char* env_mm = getenv("GAT_MERGED_MIN_TRACKS");
+  const char* env_mm = gat_opt(ctx, "GAT_MERGED_MIN_TRACKS");
   const int64_t n_groups_all = (int64_t)d->n_tracks * d->n_contigs;
   A->will_merge = d->n_contigs > 0 && d->n_tracks >= (env_mm ? atoi(env_mm) : 4) && d->n_tracks <= 65535;
   A->shape_known = A->will_merge;
@@ -928,15 +965,16 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
       int64_t total = 0, max_m = 0;
       for (int64_t g = 0; g < n_groups_all; ++g) { if (len[(size_t)g] < 0) ok = false; total += len[(size_t)g]; max_m = std::max(max_m, len[(size_t)g]); }
       if (ok) {
-        const char* env_e = getenv("GAT_COUNT_LDS_ENTRIES");
-        const bool unstaged = max_m + 1 > (env_e ? atoi(env_e) : 1024) && !env_mm;
+        const char* env_e = gat_opt(ctx, "GAT_COUNT_LDS_ENTRIES");
+        (void)env_e;
+        const bool unstaged = !count_lists_staged(ctx, max_m) && max_m > 0 && !env_mm;
         A->will_merge = d->n_contigs > 0 && d->n_tracks <= 65535 && (d->n_tracks >= (env_mm ? atoi(env_mm) : 4) || unstaged);
         A->total_known = total;
         A->shape_known = true;
       }
     }
   }
-  const char* env_a = getenv("GAT_ANNOTATIONS_SYNC");
+  const char* env_a = gat_opt(ctx, "GAT_ANNOTATIONS_SYNC");
   const bool async = (d->flags & GAT_ANNOTATIONS_ASYNC) != 0 && A->shape_known && !(env_a && atoi(env_a) != 0);
   if (!async) {
     int rc = annotations_build(ctx, A.get(), d);
@@ -945,6 +983,7 @@ extern "C" int gat_annotations_create(gat_ctx* ctx, const gat_annotations_desc* 
     if (ctx->building != nullptr) (void)annotations_wait(ctx, ctx->building);     // (one build at a time has the build context)
     if (ctx->build_ctx == nullptr) {
       int rc = gat_ctx_create(&ctx->build_ctx, ctx->device, nullptr);
+      if (rc == GAT_OK) ctx->build_ctx->options_owner = ctx;          // (the knobs are its owner's)
       if (rc) return rc;
     }
     ctx->build_ctx->err.clear();
@@ -1167,7 +1206,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
         const uint32_t topc = tot - 1u;                             // the largest p
         // (one cell per two segments -- GAT_GRID_CELL_SEGS -- to begin with; refdata, k_place_grid with eight tiles: 2.2 ms at
         //  two, 2.6 at eight: the halving search over a cell's span is LDS round trips on the lane's chain)
-        const char* env_cs = getenv("GAT_GRID_CELL_SEGS");
+        const char* env_cs = gat_opt(ctx, "GAT_GRID_CELL_SEGS");
         const int64_t cell_segs = env_cs ? std::max<int64_t>(1, atoll(env_cs)) : 2;
         int shift = 16;
         while (shift > 0 && ((int64_t)topc >> shift) + 1 < nuw / cell_segs) --shift;
@@ -1236,7 +1275,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     if (!R.pgrid.empty()) U.pgrid_off = append16(R.pgrid);
     if (!R.cgrid.empty()) U.cgrid_off = append16(R.cgrid);
     len_cv2[(size_t)u] = R.cv2;
-    P->h_base_cap[u] = cap_for(d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(R.nwork, d->seg_off[u + 1] - d->seg_off[u]) : R.nwork);
+    P->h_base_cap[u] = cap_for(ctx, d->sampler == GAT_SAMPLER_SEGMENTS ? std::max<int64_t>(R.nwork, d->seg_off[u + 1] - d->seg_off[u]) : R.nwork);
     work.push_back(std::make_pair(R.nwork, (int32_t)u));
   }
   // contig -> units (reference order)
@@ -1291,7 +1330,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       if (U.cgrid_off < 0) { all = false; break; }
       words = std::max(words, (int32_t)h_ws_tree[(size_t)U.cgrid_off + 3]);
     }
-    P->grid_place = any && all && !getenv("GAT_PLACE_NO_GRID");
+    P->grid_place = any && all && !gat_opt(ctx, "GAT_PLACE_NO_GRID");
     P->grid_lds_words = words;
   }
   P->pipe_pays = 2 * work_simple >= work_all;
@@ -1304,18 +1343,18 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     size_t small_ws = 0;
     // (round 6: k_tail takes the longer workspaces too -- their position draw through the tree over the cumulated lengths, their
     //  overlaps through the position grid; GAT_TAIL_NO_LONG_WS: as before, such units are k_sampler's)
-    P->tail_long_ws = !getenv("GAT_TAIL_NO_LONG_WS");
+    P->tail_long_ws = !gat_opt(ctx, "GAT_TAIL_NO_LONG_WS");
     for (int32_t u : P->h_order) if (P->h_units[(size_t)u].n_ws <= gat::kTailMaxWs || P->tail_long_ws) ++small_ws;
     // (long lists: their tail places dozens of segments, not the handful k_tail keeps aside -- 0.2 % finished there on the
     //  config-4 shape -- so those problems stay with k_merge_big + k_sampler)
     P->split_path = P->sampler == GAT_SAMPLER_ANNOTATOR && !P->h_order.empty() && 2 * small_ws >= P->h_order.size() &&
-                    max_hist + max_hist / 8 <= 1024 && !getenv("GAT_NO_SPLIT");
+                    max_hist + max_hist / 8 <= 1024 && !gat_opt(ctx, "GAT_NO_SPLIT");
   }
   // expected raw MT19937 outputs per placement under masked rejection (mask+1)/(range+1) per draw;
   // rows = that x working segments + slack, in whole 624-word blocks.  Streams that still run out
   // are redone by k_sampler from their seed.
   {
-    const char* env = getenv("GAT_SAMPLER_MODE");
+    const char* env = gat_opt(ctx, "GAT_SAMPLER_MODE");
     if (env && !strcmp(env, "wave")) P->sampler_mode = 0;
     auto expect = [](uint64_t range) {
       if (range == 0) return 0.0;
@@ -1340,7 +1379,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       if (U.hist_total > 2) { const double x = expect((uint64_t)U.hist_total - 2); e += x; addvar(x); }
       if (U.bucket > 1) { const double x = expect((uint64_t)U.bucket - 1); e += x; addvar(x); }
       if (U.ws_total > 1) { const double x = expect((uint64_t)U.ws_total - 1); e += x; addvar(x); }
-      const char* env_sl = getenv("GAT_RNG_SLACK");
+      const char* env_sl = gat_opt(ctx, "GAT_RNG_SLACK");
       const double slack = env_sl ? atof(env_sl) : 1.0;
       // Spread of the raw-output count of a stream: the NUMBER of placements until the unit's bases are reproduced varies
       // by cv(length) x sqrt(n) (a renewal count) and every placement costs e outputs -- that term dominates (measured on
@@ -1356,9 +1395,9 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
       // out; round 3's 5-7.5 sigma + 96, sized for a redo of every placement from the seed at 0.5 ms, generated 1.4x the rows
       // that were consumed: k_rng 0.48 -> 0.43 ms on config 2, 1.07 -> 0.92 on config 3).  A long list that runs out behind
       // k_tail_big's in-place unions is still redone from its seed -- milliseconds for thousands of placements: 7.5 sigma + 96.
-      const char* env_s0 = getenv("GAT_RNG_SIGMA_MIN");
-      const char* env_s1 = getenv("GAT_RNG_SIGMA_MAX");
-      const char* env_tr = getenv("GAT_RNG_TAIL_ROWS");
+      const char* env_s0 = gat_opt(ctx, "GAT_RNG_SIGMA_MIN");
+      const char* env_s1 = gat_opt(ctx, "GAT_RNG_SIGMA_MAX");
+      const char* env_tr = gat_opt(ctx, "GAT_RNG_TAIL_ROWS");
       const double s_min = env_s0 ? atof(env_s0) : 3.5, s_max = env_s1 ? atof(env_s1) : 7.5;
       const bool long_list = U.hist_total + U.hist_total / 8 > 1024 || P->sampler == GAT_SAMPLER_SEGMENTS;
       // (a resumed unit goes through k_sampler's wave-per-unit consolidation and tail: tens of microseconds for hundreds of
@@ -1403,7 +1442,7 @@ extern "C" int gat_problem_create(gat_ctx* ctx, const gat_problem_desc* d, gat_p
     HIPCHK(ctx, P->d_ws_rec.upload(rec, ctx));
   }
   P->units_direct_ok = false;
-  if (P->merge_contigs && P->n_contigs > 0 && P->split_path && !getenv("GAT_COUNT_VIA_CONTIGS")) {
+  if (P->merge_contigs && P->n_contigs > 0 && P->split_path && !gat_opt(ctx, "GAT_COUNT_VIA_CONTIGS")) {
     // counting an isochore problem from the units' lists: where a segment could reach over the end of its workspace piece.
     // One bit per cell of 2^bshift bases (about two mean segment lengths): a boundary of some unit's workspace piece lies in the
     // cell -- a segment whose cells hold no boundary lies inside one piece (k_count_merged<2, .> tests the bits from its first

@@ -175,6 +175,13 @@ void gat_ctx_destroy(gat_ctx* ctx);
 const char* gat_last_error(const gat_ctx* ctx);      /* ctx may be NULL: last error of the thread */
 const char* gat_version(void);
 int gat_ctx_synchronize(gat_ctx* ctx);
+/* The tuning / testing knobs (GAT_*) of a context.  None is needed for normal use.  A knob's value is the
+ * context's own (set here: value "" = not set, whatever the environment says; NULL = back to the process's), else the process's
+ * environment variable of that name AS IT WAS when the library first looked (one snapshot: nothing reads the environment on a
+ * call's path, and two host threads with a context each do not see each other's settings).  Values are read where they act:
+ * a knob that shapes a problem or the annotation tables at their creation, one that picks a kernel at the call. */
+int gat_ctx_set_option(gat_ctx* ctx, const char* key, const char* value);
+const char* gat_ctx_get_option(const gat_ctx* ctx, const char* key);   /* NULL: not set */
 /* the hipStream_t the context's work is enqueued on (the one given to gat_ctx_create, or its private stream): a host that
  * runs other work on the device -- a collective over the count matrix, a copy -- orders it against the library's with
  * events on this stream instead of synchronising the device */

@@ -63,7 +63,7 @@ def test_more_batches_than_one_flight_holds(ctx, monkeypatch):
     counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
     S = 150
     want, _ = O.run_samples(flat, counters, 31, 1, 2, 2 + S)
-    monkeypatch.setenv("GAT_SLAB_BYTES", "400000")
+    monkeypatch.setitem(ctx.options, "GAT_SLAB_BYTES", "400000")
     P = _lib.Problem(ctx, flat)
     got, st = _enqueue_wait(ctx, P, counters, 31, 2, 2 + S)
     assert st["n_batches"] > 8, st
@@ -80,8 +80,8 @@ def test_overflow_in_flight_repeats_the_batch_and_what_was_behind_it(ctx, monkey
     counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
     S = 90
     want, wsamples = O.run_samples(flat, counters, 32, 1, 0, S, want_samples=True)
-    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
-    monkeypatch.setenv("GAT_SLAB_BYTES", "300000")
+    monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
+    monkeypatch.setitem(ctx.options, "GAT_SLAB_BYTES", "300000")
     P = _lib.Problem(ctx, flat)
     got, st = _enqueue_wait(ctx, P, counters, 32, 0, S)
     assert st["n_retried"] > 0 and st["n_batches"] > 2, st
@@ -125,8 +125,8 @@ def test_steps_taking_turns_on_two_problems_over_the_same_inputs(ctx, monkeypatc
     S, steps = 64, 6
     wants = [O.run_samples(flat, counters, 77, 1, i * S, (i + 1) * S)[0] for i in range(steps)]
     A = _lib.Annotations(ctx, flat)
-    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
-    monkeypatch.setenv("GAT_SLAB_BYTES", "300000")            # (tiny slabs: a call is several batches, some overflow)
+    monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
+    monkeypatch.setitem(ctx.options, "GAT_SLAB_BYTES", "300000")            # (tiny slabs: a call is several batches, some overflow)
     Ps = [_lib.Problem(ctx, flat, annotations=A) for _ in range(2)]
     small = _lib.Problem(ctx, flat, annotations=A)
     devs = [ctx.alloc(len(counters) * flat["n_tracks"] * S * 8) for _ in range(2)]
@@ -147,8 +147,8 @@ def test_steps_taking_turns_on_two_problems_over_the_same_inputs(ctx, monkeypatc
     retried += order[steps - 1].wait()["n_retried"]
     check(steps - 1)
     assert retried > 0
-    monkeypatch.delenv("GAT_TEST_SMALL_CAPS")
-    monkeypatch.delenv("GAT_SLAB_BYTES")
+    monkeypatch.delitem(ctx.options, "GAT_TEST_SMALL_CAPS")
+    monkeypatch.delitem(ctx.options, "GAT_SLAB_BYTES")
     for P in Ps:
         P.close()
     Ps = [_lib.Problem(ctx, flat, annotations=A) for _ in range(2)]

@@ -67,7 +67,7 @@ def test_final_line_of_an_n_gpu_report():
     del out["cpu_baseline"], out["api"]
     out["n_gpus"] = 8
     out["distributed"] = {"backend": "nccl", "world_size": 8, "devices": [["host", i, "uuid-%032d" % i] for i in range(8)],
-                          "one_gpu_per_rank": True}
+                          "one_gpu_per_rank": True, "ranks_in_collective": 8}
     out["allgather"] = {"avg_ms": 0.123456789, "bytes_per_rank": 80000, "collective": "RCCL all_gather_into_tensor",
                         "backend": "nccl", "world_size": 8}
     out["strong_scaling"] = {"samples_total": 10000, "measured_on": "8 GPU(s)",
@@ -75,7 +75,7 @@ def test_final_line_of_an_n_gpu_report():
                              "config3": {"n8": out["strong_scaling"]["config3"]["n8"]}}
     line = json.loads(B.final_line(out, "bench_details.json"))
     assert "cpu_baseline" not in line
-    assert line["distributed"] == {"backend": "nccl", "world_size": 8, "one_gpu_per_rank": True}
+    assert line["distributed"] == {"backend": "nccl", "world_size": 8, "one_gpu_per_rank": True, "ranks_in_collective": 8}
     assert line["allgather"]["avg_ms"] > 0 and line["strong_scaling"]["config2"]["n8"] > 0
 
 

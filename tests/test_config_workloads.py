@@ -64,11 +64,11 @@ def test_config_workloads_vs_oracle(ctx, name):
         # on the long lists of the config-4 shape k_sampler running the placement rounds itself (instead of k_tail_big) / finishing
         # the units itself (instead of k_resume_big)
         for knob in ("GAT_PLACE_NO_PIPE", "GAT_NO_TAIL_BIG", "GAT_NO_RESUME_BIG"):
-            os.environ[knob] = "1"
+            ctx.options[knob] = "1"
             try:
                 again = P.sample_and_count(counters, seed, begin, begin + S)
             finally:
-                os.environ.pop(knob)
+                ctx.options.pop(knob)
             for k, c in enumerate(counters):
                 assert np.array_equal(again[k], want[k]), (name, c, knob)
     finally:
@@ -91,14 +91,14 @@ def test_config_workloads_full_size_properties(ctx, name):
             # counts alone: no final unit lists are written, k_count_seg (config 2, 5) / k_contig (config 3) take the
             # merged lists and k_tail's records; the same matrix must come from the final lists
             assert P.last_stats["lists_from_records"] > 0, name
-            os.environ["GAT_COUNT_FINAL_LISTS"] = "1"
-            os.environ["GAT_CONTIG_FINAL_LISTS"] = "1"
+            ctx.options["GAT_COUNT_FINAL_LISTS"] = "1"
+            ctx.options["GAT_CONTIG_FINAL_LISTS"] = "1"
             try:
                 again = P.sample_and_count(counters, seed, 0, S)[0]
                 assert P.last_stats["lists_from_records"] == 0
             finally:
-                os.environ.pop("GAT_COUNT_FINAL_LISTS")
-                os.environ.pop("GAT_CONTIG_FINAL_LISTS")
+                ctx.options.pop("GAT_COUNT_FINAL_LISTS", None)
+                ctx.options.pop("GAT_CONTIG_FINAL_LISTS", None)
             assert np.array_equal(again, full), name
         cols = sorted(set([0, S - 1] + [int(x) for x in np.random.RandomState(1).randint(0, S, ncheck)]))[:max(2, ncheck)]
         for s in cols:
@@ -158,12 +158,12 @@ def test_config4_shard_across_batches(ctx):
         stride = P.info()["slab_segments_per_sample"]
     finally:
         P.close()
-    os.environ["GAT_SLAB_BYTES"] = str(stride * 8 * 40)      # (the slab alone: rows, records and partials make a sample larger)
+    ctx.options["GAT_SLAB_BYTES"] = str(stride * 8 * 40)      # (the slab alone: rows, records and partials make a sample larger)
     Q = _lib.Problem(ctx, flat)
     try:
         cut = Q.sample_and_count(counters, seed, 0, S)[0]
     finally:
-        os.environ.pop("GAT_SLAB_BYTES")
+        ctx.options.pop("GAT_SLAB_BYTES", None)
         Q.close()
     assert np.array_equal(cut, one)
     assert Q.last_stats["n_batches"] >= 3 and P.last_stats["n_batches"] == 1

@@ -136,11 +136,11 @@ def _check_counts_alone(P, counters, want, seed, lo, hi):
         got = P.sample_and_count(sub, seed, lo, hi)
         for k, c in enumerate(sub):
             assert np.array_equal(got[k], want[counters.index(c)]), ("counts alone", c, P.last_stats["lists_from_records"])
-    os.environ["GAT_COUNT_FINAL_LISTS"] = "1"
+    P.ctx.options["GAT_COUNT_FINAL_LISTS"] = "1"
     try:
         got = P.sample_and_count(SEGMENT_SIDE, seed, lo, hi)
     finally:
-        os.environ.pop("GAT_COUNT_FINAL_LISTS", None)
+        P.ctx.options.pop("GAT_COUNT_FINAL_LISTS", None)
     for k, c in enumerate(SEGMENT_SIDE):
         assert np.array_equal(got[k], want[counters.index(c)]), ("final lists", c)
 
@@ -308,16 +308,16 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     elif case in ("large_units", "large_units_swapped_count"):
         flat = _big_problem(rs, 6000, 3)
     elif case == "rows_run_out":
-        monkeypatch.setenv("GAT_RNG_SLACK", "0.6")
+        monkeypatch.setitem(ctx.options, "GAT_RNG_SLACK", "0.6")
         flat = _big_problem(rs, 700, 5)
     elif case == "slab_overflow_retry_batches_shrink":
         # a scratch budget of about 15 samples: the 24 samples run in batches, and after the overflow the doubled regions
         # make the batch that fits the budget smaller -- the remaining samples must be re-batched, not refused
-        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
-        monkeypatch.setenv("GAT_SLAB_BYTES", "300000")
+        monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
+        monkeypatch.setitem(ctx.options, "GAT_SLAB_BYTES", "300000")
         flat = _big_problem(rs, 700, 5)
     else:
-        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+        monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
         flat = _big_problem(rs, 700, 5)
     counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
     if case == "large_units_swapped_count":        # overlap counters only: sample lists indexed, tracks streamed
@@ -338,20 +338,20 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     if case in ("large_units", "large_units_one_workspace_segment"):
         # long lists: k_merge_big, then k_tail_big carries the units through their placement rounds
         assert st["n_tail_units"] > 0.5 * S * flat["n_units"], st["n_tail_units"]
-        os.environ["GAT_NO_TAIL_BIG"] = "1"
+        ctx.options["GAT_NO_TAIL_BIG"] = "1"
         try:
             other = P.sample_and_count(counters, 99, 3, 3 + S)
             assert P.last_stats["n_tail_units"] == 0
         finally:
-            os.environ.pop("GAT_NO_TAIL_BIG")
+            ctx.options.pop("GAT_NO_TAIL_BIG", None)
         for k in range(len(counters)):
             assert np.array_equal(other[k], want[k])
-        os.environ["GAT_NO_RESUME_BIG"] = "1"            # ... and k_sampler, not k_resume_big, finishing them
+        ctx.options["GAT_NO_RESUME_BIG"] = "1"            # ... and k_sampler, not k_resume_big, finishing them
         try:
             other = P.sample_and_count(counters, 99, 3, 3 + S)
             seg2, off2 = P.sample(99, 3, 3 + S)
         finally:
-            os.environ.pop("GAT_NO_RESUME_BIG")
+            ctx.options.pop("GAT_NO_RESUME_BIG", None)
         for k in range(len(counters)):
             assert np.array_equal(other[k], want[k])
         assert np.array_equal(off2, wsamples[1]) and np.array_equal(seg2, wsamples[0])
@@ -381,12 +381,12 @@ def _long_list_case(ctx, seed):
     S = 5
     want, wsamples = O.run_samples(flat, counters, seed, 1, 0, S, want_samples=True)
     if loose:
-        os.environ["GAT_MERGED_MIN_TRACKS"] = "1"
+        ctx.options["GAT_MERGED_MIN_TRACKS"] = "1"
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
     finally:
-        os.environ.pop("GAT_MERGED_MIN_TRACKS", None)
+        ctx.options.pop("GAT_MERGED_MIN_TRACKS", None)
     if loose:
         assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
     handed = P.last_stats["n_tail_units"]
@@ -459,7 +459,7 @@ def _frag_ws_case(ctx, seed, setenv=None):
             _lib.Problem(ctx, flat)
         return 0
     for k, v in knobs.items():
-        os.environ[k] = v
+        ctx.options[k] = v
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
@@ -471,7 +471,7 @@ def _frag_ws_case(ctx, seed, setenv=None):
         P.close()
     finally:
         for k in knobs:
-            os.environ.pop(k, None)
+            ctx.options.pop(k, None)
     return st["n_tail_units"]
 
 
@@ -504,7 +504,7 @@ def _units_direct_case(ctx, seed):
         want, _ = O.run_samples(flat, counters, seed, 1, 0, S)
     except ValueError:
         return 0, 0, 0
-    os.environ["GAT_MERGED_MIN_TRACKS"] = "1"
+    ctx.options["GAT_MERGED_MIN_TRACKS"] = "1"
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
@@ -513,17 +513,17 @@ def _units_direct_case(ctx, seed):
         for k, c in enumerate(counters):
             assert np.array_equal(got[k], want[k]), (seed, c, block, nclasses, n_segs, mean_len)
         # ... and once more through the contig lists (k_contig), which must agree
-        os.environ["GAT_COUNT_VIA_CONTIGS"] = "1"
+        ctx.options["GAT_COUNT_VIA_CONTIGS"] = "1"
         try:
             other = P.sample_and_count(counters, seed, 0, S)
             assert P.last_stats["n_straddle_candidates"] == 0
         finally:
-            os.environ.pop("GAT_COUNT_VIA_CONTIGS")
+            ctx.options.pop("GAT_COUNT_VIA_CONTIGS", None)
         for k in range(len(counters)):
             assert np.array_equal(other[k], want[k])
         P.close()
     finally:
-        os.environ.pop("GAT_MERGED_MIN_TRACKS", None)
+        ctx.options.pop("GAT_MERGED_MIN_TRACKS", None)
     return st["n_straddle_candidates"], st["n_unit_overlaps"], st["n_retried"]
 
 
@@ -614,7 +614,7 @@ def test_reference_stream_random_problems_vs_oracle(ctx, seed, monkeypatch):
     to the reference -- and a run cut into three calls against the same run in one"""
     rs = np.random.RandomState(seed)
     if seed % 4 == 3:
-        monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+        monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
     if seed % 6 == 5:
         flat = _big_problem(rs, 1500, 3, n_contigs=1)
     else:
@@ -640,7 +640,7 @@ def test_contig_lists_longer_than_expected(ctx, monkeypatch):
     """k_contig's LDS is sized for the lists a contig is expected to have, not for every unit at its capacity; a batch in
     which a contig's lists do not fit is repeated with the full size (forced here by shrinking the expectation; the same
     switch shrinks the slab regions, so the slab-overflow repeat runs in front of it)"""
-    monkeypatch.setenv("GAT_TEST_SMALL_CAPS", "1")
+    monkeypatch.setitem(ctx.options, "GAT_TEST_SMALL_CAPS", "1")
     rs = np.random.RandomState(4242)
     flat = _random_problem(rs, n_contigs=3, n_segs=500, n_tracks=2, isochores=True, dense=False)
     counters = ["nucleotide-overlap", "segment-overlap", "annotation-overlap"]
@@ -701,7 +701,7 @@ def _scan_case(ctx, seed, setenv):
 def test_place_scan_vs_oracle(ctx, seed, monkeypatch):
     """k_place_scan (one stream walked by the 64 lanes of a wave, the states as a prefix scan) on random problems of simple
     units: bit-exact with the oracle, with the scan's fixed-point loop forced on odd seeds"""
-    _scan_case(ctx, seed, monkeypatch.setenv)
+    _scan_case(ctx, seed, lambda k, v: monkeypatch.setitem(ctx.options, k, v))
 
 
 @pytest.mark.parametrize("seed", list(range(100, 164)))
@@ -712,14 +712,14 @@ def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
     import collections
     from gat_amd import problem
     if seed % 6 == 0:
-        monkeypatch.setenv("GAT_TEST_HUGE", "1")          # ... and the list-in-global-memory variants
+        monkeypatch.setitem(ctx.options, "GAT_TEST_HUGE", "1")          # ... and the list-in-global-memory variants
     if seed % 2 == 1:
         # (a call of a few samples of simple units takes k_place_wide by itself: every other seed keeps the lean kernels)
-        monkeypatch.setenv("GAT_PLACE_NO_WIDE", "1")
+        monkeypatch.setitem(ctx.options, "GAT_PLACE_NO_WIDE", "1")
     if seed % 4 >= 2:
         # (k_place's written-out steps take every unit they can: half the seeds keep the compiler's form of the same steps,
         #  which is what units with a bucket draw, SamplerSegments and offset masks that depend on the length still run)
-        monkeypatch.setenv("GAT_PLACE_NO_CM", "1")
+        monkeypatch.setitem(ctx.options, "GAT_PLACE_NO_CM", "1")
     rs = np.random.RandomState(seed)
     n_contigs = int(rs.randint(1, 4))
     contigs = collections.OrderedDict(("f%d" % i, int(rs.randint(200000, 3000000))) for i in range(n_contigs))
@@ -761,7 +761,7 @@ def test_fuzz_shapes_vs_oracle(ctx, seed, monkeypatch):
 def test_lists_in_global_memory_vs_oracle(ctx, seed, monkeypatch):
     """the HUGE kernel variants (lists worked on in the slab instead of LDS) forced onto ordinary problems,
     with and without isochores: same counts and sampled lists as the oracle."""
-    monkeypatch.setenv("GAT_TEST_HUGE", "1")
+    monkeypatch.setitem(ctx.options, "GAT_TEST_HUGE", "1")
     rs = np.random.RandomState(seed)
     flat = _random_problem(rs, n_contigs=3, n_segs=int(rs.randint(200, 700)), n_tracks=2, isochores=bool(seed % 2))
     counters = ["nucleotide-overlap", "segment-overlap"]
@@ -906,7 +906,7 @@ def test_sampler_segments_vs_oracle(ctx, monkeypatch):
             with pytest.raises(AssertionError):
                 P.sample_and_count(["nucleotide-overlap"], 77, 2, 34)
         P.close()
-    monkeypatch.setenv("GAT_RNG_SLACK", "0.5")
+    monkeypatch.setitem(ctx.options, "GAT_RNG_SLACK", "0.5")
     flat = _random_problem(rs, n_contigs=2, n_segs=300, n_tracks=1, isochores=False)
     flat["sampler"] = 1
     _, wsamples = O.run_samples(flat, [], 5, 1, 0, 20, want_samples=True)
@@ -977,10 +977,51 @@ def test_host_classes_on_device(ctx):
     assert r.asList() == O.aslist(want)
 
 
+def test_knobs_are_options_of_a_context_not_the_environment(ctx):
+    """gat_ctx_set_option: a knob's value is the context's own, else the process's environment AS THE LIBRARY FIRST SAW IT --
+    nothing reads the environment on a call's path, and a second context does not see what the first one set"""
+    key = "GAT_COUNT_FINAL_LISTS"
+    assert ctx.options.get(key) is None
+    os.environ[key] = "1"                                   # (behind the snapshot: not seen)
+    try:
+        assert ctx.options.get(key) is None
+    finally:
+        del os.environ[key]
+    other = _lib.Context(0)
+    try:
+        ctx.options[key] = "1"
+        assert ctx.options.get(key) == "1" and other.options.get(key) is None
+        ctx.options[key] = ""                               # "not set", whatever the environment says
+        assert ctx.options.get(key) is None
+        del ctx.options[key]
+        assert key not in ctx.options and ctx.options.get(key) is None
+        with pytest.raises(_lib.GatError):
+            other.options["NOT_A_GAT_KEY"] = "1"
+    finally:
+        other.close()
+    # ... and it acts: the same problem with and without the final lists (a knob read at the call)
+    _, cfg = synthetic.small_genome()
+    from gat_amd import problem
+    flat = problem.flatten_arrays(cfg["segments"], cfg["annotations"], cfg["workspace"], None)
+    P = _lib.Problem(ctx, flat)
+    try:
+        a = P.sample_and_count(["nucleotide-overlap"], 5, 0, 16)
+        rec = P.last_stats["lists_from_records"]
+        ctx.options[key] = "1"
+        try:
+            b = P.sample_and_count(["nucleotide-overlap"], 5, 0, 16)
+            assert P.last_stats["lists_from_records"] == 0 and rec > 0
+        finally:
+            ctx.options.pop(key)
+        assert np.array_equal(a[0], b[0])
+    finally:
+        P.close()
+
+
 def test_wave_only_sampler_mode(ctx, monkeypatch):
     """GAT_SAMPLER_MODE=wave: the stand-alone wave-per-unit sampler (own MT19937 in LDS, no k_rng / k_place),
     which is also the fallback path of the default pipeline, gives the same bits."""
-    monkeypatch.setenv("GAT_SAMPLER_MODE", "wave")
+    monkeypatch.setitem(ctx.options, "GAT_SAMPLER_MODE", "wave")
     z = np.load(os.path.join(G, "run_small_isochores.npz"))
     counters = [str(c) for c in z["counters"]]
     P = _lib.Problem(ctx, _flat(z))
@@ -1314,10 +1355,10 @@ def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
     oracle, and against the per-track kernel on the same problem."""
     import collections
     from gat_amd import problem, intervals as iv
-    monkeypatch.setenv("GAT_MERGED_MIN_TRACKS", "1")
+    monkeypatch.setitem(ctx.options, "GAT_MERGED_MIN_TRACKS", "1")
     # the three forms of the scan: index entries fetched in 64-byte blocks of eight / in pairs / the first two out of the
     # grid cell's record (the host picks by the expected length of a scan; here the seed does)
-    monkeypatch.setenv("GAT_MERGED_BLOCK", ("8", "2", "1")[seed % 3])
+    monkeypatch.setitem(ctx.options, "GAT_MERGED_BLOCK", ("8", "2", "1")[seed % 3])
     rs = np.random.RandomState(seed)
     contigs = collections.OrderedDict(("m%d" % i, int(rs.randint(100000, 2000000))) for i in range(int(rs.randint(1, 4))))
     segs = synthetic.random_segments(contigs, int(rs.choice([40, 400, 3000])), int(rs.choice([30, 300, 2000])), int(rs.randint(1 << 30)))
@@ -1348,14 +1389,14 @@ def test_merged_track_index_vs_oracle(ctx, seed, monkeypatch):
     assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
     for k, c in enumerate(counters):
         assert np.array_equal(got[k], want[k]), (c, n_tracks)
-    monkeypatch.setenv("GAT_COUNT_NO_MERGED", "1")
+    monkeypatch.setitem(ctx.options, "GAT_COUNT_NO_MERGED", "1")
     other = P.sample_and_count(counters, 400 + seed, 0, S)
     assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] != "k_count_merged"
     for k in range(2):
         assert np.array_equal(other[k], want[k])
     P.close()
     # observed counts (gat_count_lists) take the same kernel
-    monkeypatch.delenv("GAT_COUNT_NO_MERGED")
+    monkeypatch.delitem(ctx.options, "GAT_COUNT_NO_MERGED")
     C = flat["n_contigs"]
     lists = [flat["segs"][flat["seg_off"][u]:flat["seg_off"][u + 1]] for u in range(flat["n_units"])]
     if iso is None and C == flat["n_units"]:

@@ -9,12 +9,18 @@ spec.loader.exec_module(m)
 from gat_amd import _lib
 
 
-class MP(object):                      # minimal monkeypatch stand-in
+class MP(object):                      # minimal monkeypatch stand-in: the knobs go through the context's options
     def setenv(self, k, v):
-        os.environ[k] = v
+        ctx.options[k] = v
+
+    def setitem(self, d, k, v):
+        d[k] = v
 
     def delenv(self, k):
-        os.environ.pop(k, None)
+        ctx.options.pop(k, None)
+
+    def delitem(self, d, k):
+        d.pop(k, None)
 
 
 ctx = _lib.Context(0)
@@ -33,9 +39,9 @@ t0 = time.time()
 for seed in range(first, first + n):
     for k in ("GAT_TEST_HUGE", "GAT_PLACE_NO_WIDE", "GAT_PLACE_NO_CM", "GAT_PLACE_SCAN_SEQ", "GAT_PLACE_SCAN_TILES", "GAT_GRID_CELL_SEGS",
               "GAT_PLACE_NO_GRID", "GAT_TAIL_NO_LONG_WS", "GAT_COUNT_VIA_CONTIGS", "GAT_MERGED_MIN_TRACKS"):       # (what a seed's test sets stays set here: MP does not undo)
-        os.environ.pop(k, None)
+        ctx.options.pop(k, None)
     if (merged or long_lists or edge) and seed % 4 >= 2:
-        os.environ["GAT_PLACE_NO_CM"] = "1"           # k_place's steps as the compiler writes them (the shapes test picks by itself)
+        ctx.options["GAT_PLACE_NO_CM"] = "1"           # k_place's steps as the compiler writes them (the shapes test picks by itself)
     try:
         if units:
             r = m._units_direct_case(ctx, seed)
@@ -46,7 +52,7 @@ for seed in range(first, first + n):
             m._scan_case(ctx, seed, MP().setenv)
         elif merged:
             for k in ("GAT_MERGED_MIN_TRACKS", "GAT_COUNT_NO_MERGED", "GAT_MERGED_BLOCK"):
-                os.environ.pop(k, None)
+                ctx.options.pop(k, None)
             m.test_merged_track_index_vs_oracle(ctx, seed, MP())
         elif long_lists:
             handed += m._long_list_case(ctx, seed)
