@@ -54,6 +54,7 @@ struct CallState {
   int count_kernel[kMaxInflight] = {};
   bool main_rec[kMaxInflight] = {};
   bool timed = false, mstat_on = false;
+  int times_state = 0;             // gat_stats::kernel_times of the call
   bool end_recorded = false;                  // ev_end is on the stream behind the call's last batch (gat_wait waits for IT)
   bool count_pending = false;                 // the newest batch's sampler kernels are enqueued, its count kernels wait for the
                                               // annotation tables (an asynchronous build)

@@ -541,6 +541,9 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
         const uint2 e0 = l_out[w0 + 2 * w][lane], e1 = l_out[w0 + 2 * w + 1][lane];
+#ifdef GAT_EXP_NO_STORES
+        if (e0.x == 0xfffffff1u && e1.y == 0xfffffff2u)            // (never: the reads stay, the stores go)
+#endif
         dst[w] = make_uint4(e0.x, e0.y, e1.x, e1.y);
       }
       nF += 8;
@@ -812,10 +815,18 @@ __device__ __forceinline__ void place_body(const SamplerArgs& A) {
 #ifndef GAT_ROW_NT
 #define GAT_ROW_NT " nt"              /* the rows are read once: streamed past the L2's lines (the ring's half-written ones stay) */
 #endif
+// (timing-only builds, tools/exp_place_bound.sh: GAT_EXP_SAME_ROWS -- every tile of the launch reads the same 64 rows, 16 KB that
+//  stay in the caches: the kernel without its row traffic; GAT_EXP_NO_STORES -- the flush's stores left out.  Results are wrong.)
+#ifdef GAT_EXP_SAME_ROWS
+#define GAT_EXP_ROWPTR(ROW0) (A.rng_out + lane + (int64_t)((int)(ROW0) & 56) * kWave)
+#else
+#define GAT_EXP_ROWPTR(ROW0) (rp + (int64_t)r0_ * kWave)
+#endif
 #define GAT_PIN_LOAD(R0, R1, R2, R3, R4, R5, R6, R7, ROW0)                                                     \
   {                                                                                                            \
     const int r0_ = (int)(ROW0) < rows - kPlaceChunk ? (int)(ROW0) : rows - kPlaceChunk;                       \
-    const uint32_t* p_ = rp + (int64_t)r0_ * kWave;                                                            \
+    (void)r0_;                                                                                                 \
+    const uint32_t* p_ = GAT_EXP_ROWPTR(ROW0);                                                                 \
     asm volatile("global_load_dword v" #R0 ", %0, off" GAT_ROW_NT "\n\tglobal_load_dword v" #R1 ", %0, off offset:256" GAT_ROW_NT "\n\t" \
                  "global_load_dword v" #R2 ", %0, off offset:512" GAT_ROW_NT "\n\tglobal_load_dword v" #R3 ", %0, off offset:768" GAT_ROW_NT "\n\t" \
                  "global_load_dword v" #R4 ", %0, off offset:1024" GAT_ROW_NT "\n\tglobal_load_dword v" #R5 ", %0, off offset:1280" GAT_ROW_NT "\n\t" \

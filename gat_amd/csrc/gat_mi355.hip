@@ -1223,8 +1223,12 @@ static int call_begin(gat_ctx* ctx, gat_problem* P, const int32_t* counter_ids, 
   K.done = K.enq = 0; K.n_flight = 0;
   memset(&K.local, 0, sizeof(K.local));
   // (an event behind every kernel of the sampler costs 50-60 us of a call: 2 % at 10 000 samples of config 2, 6 % at 1 250)
-  K.timed = (ctx->kernel_times || gat_opt(ctx, "GAT_KERNEL_TIMES") != nullptr) && ctx->timed_owner == nullptr;
+  const bool times_wanted = ctx->kernel_times || gat_opt(ctx, "GAT_KERNEL_TIMES") != nullptr;
+  K.timed = times_wanted && ctx->timed_owner == nullptr;
   if (K.timed) ctx->timed_owner = (const void*)P;
+  // (the per-kernel events exist once per context: a call enqueued while another problem's timed call is in flight runs
+  //  untimed -- its ms_* split reads 0 -- and says so: gat_stats::kernel_times)
+  K.times_state = !times_wanted ? 0 : (K.timed ? 1 : -1);
   K.mstat_on = false;                              // (set with the first count kernels: it takes the tables)
   K.count_pending = false;
   K.end_recorded = false;
@@ -1300,6 +1304,7 @@ static int call_wait(gat_ctx* ctx, gat_problem* P, gat_stats* stats) {
     for (int i = 0; i < 256; ++i) { K.local.n_index_entries += (int64_t)K.blk->h_mstat[2 * i]; K.local.n_index_lookups += (int64_t)K.blk->h_mstat[2 * i + 1]; }
   float ms = 0;
   if (hipEventElapsedTime(&ms, K.blk->ev_begin, K.blk->ev_end) == hipSuccess) K.local.ms_total = ms; else (void)hipGetLastError();
+  K.local.kernel_times = K.times_state;
   if (stats) *stats = K.local;
   call_end(ctx, P);
   return GAT_OK;

@@ -461,6 +461,12 @@ class _LazyLists(collections.defaultdict):
     def all_normalized(self):
         return all(p.isNormalized for p in self._protos) and all(dict.__getitem__(self, k).isNormalized for k, _ in self._made)
 
+    def __iter__(self):
+        # A Python-level __iter__ takes dict(d) / OrderedDict(d) / {**d} / other.update(d) off CPython's fast path for dict
+        # subclasses, which copies the RAW values -- the None placeholders -- without asking anybody: with it they go through
+        # keys() and [], and get the lists.  Iterating makes nothing by itself.
+        return dict.__iter__(self)
+
     def __getitem__(self, key):
         v = dict.get(self, key, _MISSING)
         if v is None:

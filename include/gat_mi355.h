@@ -156,10 +156,14 @@ typedef struct {
                                 /* 1 the grid cell's record (its first two entries) + pairs; 0: the kernel did not run     */
   int64_t n_resumed_units;      /* work units whose pre-generated random rows ran out and whose stream went on from the     */
                                 /* generator moved up to its position (instead of a run in full: n_full_units)              */
-  int64_t n_straddle_candidates; /* isochore problems counted from the units' lists (no k_contig): segments beginning within a  */
-                                /* cell of a workspace boundary, looked at by k_units_overlap; 0: the contig lists were made    */
+  int64_t n_straddle_candidates; /* isochore problems whose contig lists were only concatenated (nucleotide counters; k_contig<., true>):  */
+                                /* segments with a workspace boundary in their cells, of units that have a segment reaching out of   */
+                                /* their workspace -- what k_units_overlap looked at; 0: the sorted, merged contig lists were made   */
   int64_t n_unit_overlaps;      /* ... and the overlaps between different units' segments it took off the sums again -- what      */
                                 /* IntervalDictionary.fromIsochores' merge(0) unites (gat/Engine.pyx:2857-2876)                   */
+  int64_t kernel_times;         /* the ms_* split of the sampler's kernels: 1 recorded, 0 not asked for (gat_ctx_set_kernel_times),   */
+                                /* -1 asked for but NOT recorded -- the events exist once per context and another problem's timed  */
+                                /* call was in flight (gat_amd.run() keeps two segment tracks' calls in flight): the fields read 0 */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0

@@ -547,6 +547,17 @@ def test_lists_made_on_demand_behave_like_a_dictionary():
     e = pickle.loads(pickle.dumps(d.intervals))                               # (travels as the plain dictionary it stands for)
     assert type(e) is collections.defaultdict and list(e.keys()) == list(d.keys()) and e["c1.b"].asList() == [(100, 500)]
     assert copy.copy(d.intervals)["c0.b"].asList() == [(120, 180), (300, 320)] and d._flat() is f
+    # the copies CPython makes of a dict subclass without asking it -- dict(d), OrderedDict(d), {**d}, update(d) -- hold the lists
+    B = _coll(seg)
+    B.toIsochores(_coll(iso), True)
+    lazy = B["t"].intervals
+    assert dict.__getitem__(lazy, "c1.b") is None
+    for cp in (dict(lazy), collections.OrderedDict(lazy), {**lazy}):
+        assert all(v is not None for v in cp.values()) and cp["c1.b"].asList() == [(100, 500)] and list(cp) == list(d.keys())
+    other = {}
+    other.update(lazy)
+    assert other["c0.b"].asList() == [(120, 180), (300, 320)]
+    assert copy.deepcopy(lazy)["c1.a"].asList() == [(5, 100)]
     c = d.clone()                                                             # (goes through items(): everything is made)
     assert [k for k, _ in c.items()] == list(d.keys()) and c["c1.b"].asList() == [(100, 500)]
     assert d._flat() is f

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 TAG=$1; shift
-SHAPES=${@:-"config2:10000 config3:10000 config5:125000 config4:12500"}
+SHAPES=${@:-"config2:10000 config3:10000 config5:125000 config4:12500 refdata:10000"}
 for SH in $SHAPES; do
   CFG=${SH%%:*}; S=${SH##*:}
   OUT=$R/gpurun_out/prof_${TAG}/${CFG}; rm -rf $OUT; mkdir -p $OUT
