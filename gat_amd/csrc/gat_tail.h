@@ -382,8 +382,22 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   if (true_remaining == remaining) nuns++; else true_remaining = remaining;           // :601-605
   bool done = !(true_remaining != 0 && nuns < 20);
   bool bail = false;
-  uint32_t trim = 0, trim_part = 0, drop_len = 0;
-  int trim_v0 = 0, trim_full = 0;
+  // The overshoot trims.  One in a workspace that is a contig: the trim takes exactly the overshoot off the coverage.  In a
+  // fragmented workspace (LONGWS) trim_ends takes `size` bases off SEGMENTS wherever they lie (gat/SegmentList.pyx:545-597), the
+  // ones in gaps do not lower the coverage, and the loop trims again -- smaller amounts each time, only trims behind a trim (the
+  // coverage never falls below the target).  Up to kMaxTrims of them are kept as records and applied at the end: a trim's touched
+  // elements are a contiguous range [t_lo, t_hi] of the list (full ones emptied, one partly), a later position draw maps through
+  // the earlier ranges (t_before: the running length in front of a range, t_s: the bases it lost, t_rem: what is left of its
+  // partly trimmed element), and a later trim that would start in or walk into an earlier range -- or any that wraps round the
+  // list's end -- leaves the unit to k_sampler.
+  constexpr int kMaxTrims = LONGWS ? 3 : 1;
+  uint32_t t_flags[kMaxTrims], t_part[kMaxTrims], t_before[kMaxTrims], t_s[kMaxTrims], t_rem[kMaxTrims];
+  int t_v0[kMaxTrims], t_full[kMaxTrims], t_lo[kMaxTrims], t_hi[kMaxTrims];
+#pragma unroll
+  for (int t = 0; t < kMaxTrims; ++t) { t_flags[t] = 0u; t_part[t] = 0u; t_before[t] = 0u; t_s[t] = 0u; t_rem[t] = 0u; t_v0[t] = 0; t_full[t] = 0; t_lo[t] = 0; t_hi[t] = -1; }
+  int nT = 0;
+  bool wrapped = false;
+  uint32_t drop_len = 0;
   bool strad_extra = false;    // a new segment that is not wholly inside the unit's workspace (TailPatch::pad, bit 16)
 
   // element v of the list with the extras in place
@@ -405,17 +419,43 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
   for (int step = 0; step < 48 && !done && !bail; ++step) {
     // ---- overshoot: trim (:608-626) -- only as the last thing that happens to the unit
     if (true_remaining < 0) {
-      if (trim) { bail = true; break; }                              // a second trim: k_sampler's
+      if (nT >= kMaxTrims || wrapped) { bail = true; break; }        // one trim more than is kept: k_sampler's
       const uint32_t p = tail_range(rng, total - 1u);
-      // leftmost element whose inclusive running length exceeds p (searchsorted over cdf = incl - 1)
-      // ((int32_t)(c - 1 - p) >= 0 is c > p: running lengths stay below 2^31)
+      // p counts bases of the list AS IT IS NOW; the running lengths at hand are the list's before any trim.  Earlier trims in
+      // list order: in front of a range nothing has changed; inside it only the partly trimmed element is left (t_rem bases);
+      // behind it everything has moved down by the range's t_s
+      uint32_t key = p;
+      bool direct = false;
+      if constexpr (kMaxTrims > 1) {
+        int o0 = 0, o1 = 1;
+        if (nT == 2 && t_lo[1] < t_lo[0]) { o0 = 1; o1 = 0; }
+        uint32_t offset = 0;
+        bool stop = false;                                             // (p lies in front of the range at hand: nothing behind it matters)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int t = q == 0 ? o0 : o1;
+          if (q < nT && !direct && !stop) {
+            uint32_t tb = 0, tr = 0, ts = 0;
+#pragma unroll
+            for (int u = 0; u < kMaxTrims; ++u) if (u == t) { tb = t_before[u]; tr = t_rem[u]; ts = t_s[u]; }
+            const uint32_t rb = tb - offset;
+            if (p < rb) stop = true;
+            else if (p < rb + tr) direct = true;
+            else offset += ts;
+          }
+        }
+        key = p + offset;
+      }
+      if (direct) { bail = true; break; }                              // it starts in what an earlier trim left of a segment
+      // leftmost element whose inclusive running length exceeds key (searchsorted over cdf = incl - 1)
+      // ((int32_t)(c - 1 - key) >= 0 is c > key: running lengths stay below 2^31)
       // The running lengths are kept per BLOCK of eight merged segments (cum[b] = through element 8 b + 7, the last entry through
       // the last element): an eighth of what k_consolidate used to write, and the search below touches the two lines that hold
       // a list's block sums instead of a line per probe; the block found, its eight segments -- one 64-byte piece of the list
       // -- are walked.  val(i) = merged running length through i + the extras in front of or at i, non-decreasing in i, so the
-      // first block whose last element exceeds p holds the answer.
+      // first block whose last element exceeds key holds the answer.
       const int nB = (nU + 7) >> 3;
-      const int bl = interp_upper_bound(nB, p, [&](int b) -> uint32_t {
+      const int bl = interp_upper_bound(nB, key, [&](int b) -> uint32_t {
         const int last = b * 8 + 7 < nU - 1 ? b * 8 + 7 : nU - 1;
         uint32_t c = cum[b];
 #pragma unroll
@@ -437,7 +477,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
             uint32_t c = runm + (blk[q].y - blk[q].x);
 #pragma unroll
             for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] <= i) c += ex[j].y - ex[j].x;
-            if (c > p) { hit = true; lo = i; before = runm; }
+            if (c > key) { hit = true; lo = i; before = runm; }
             else runm += blk[q].y - blk[q].x;
           }
         }
@@ -449,15 +489,22 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       for (int j = 0; j < kTailMaxExtra; ++j) if (j < nE && epos[j] < lo) { before += ex[j].y - ex[j].x; nbefore++; }
       int v = lo + nbefore;                                          // (every extra in front of it counted)
       bool found = false;
+      uint32_t before_v = before;                                    // the running length in front of element v (before any trim)
 #pragma unroll
       for (int j = 0; j < kTailMaxExtra; ++j) {
         if (j < nE && epos[j] == lo && !found) {
+          before_v = before;
           before += ex[j].y - ex[j].x;
-          if ((int32_t)(before - 1u - p) >= 0) found = true; else v++;
+          if ((int32_t)(before - 1u - key) >= 0) found = true; else { v++; before_v = before; }
         }
       }
       const int nV = nU + nE;
       if (v >= nV) { bail = true; break; }                           // (cannot happen: p < total)
+      if constexpr (kMaxTrims > 1) {
+#pragma unroll
+        for (int t = 0; t < kMaxTrims; ++t) if (t < nT && v >= t_lo[t] && v <= t_hi[t]) bail = true;   // (cannot happen either)
+        if (bail) break;
+      }
       const uint2 chosen = vget(v);
       (void)tail_range(rng, chosen.y - 1u - chosen.x);               // position inside the segment: only its index matters
       const uint32_t forward = tail_range(rng, 1u);                  // numpy.random.randint(0, 2)
@@ -467,32 +514,56 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       // trim_ends(pos, s, forward) (gat/SegmentList.pyx:545-597)
       uint32_t removed = 0;
       int idx = v, full = 0;
-      uint32_t part = 0;
+      uint32_t part = 0, part_len = 0, walked_behind = 0;            // (walked_behind: the lengths of the elements walked behind the first)
+      bool wraps = false;
       for (int w = 0; s > 0; ++w) {
         if (w >= (longws ? kTailMaxWalkLong : kTailMaxWalk)) { bail = true; break; }
+        if constexpr (kMaxTrims > 1) {
+#pragma unroll
+          for (int t = 0; t < kMaxTrims; ++t) if (t < nT && idx >= t_lo[t] && idx <= t_hi[t]) bail = true;   // into an earlier trim's range
+          if (bail) break;
+        }
         const uint2 x = vget(idx);
         const int32_t l = (int32_t)x.y - (int32_t)x.x;
+        if (w > 0) walked_behind += (uint32_t)l;
         uint32_t ra, rb;
         if (l < s) { s -= l; ra = x.x; rb = x.y; full++; }
         else {
-          part = (uint32_t)s;
+          part = (uint32_t)s; part_len = (uint32_t)l;
           if (forward) { ra = x.x; rb = x.x + (uint32_t)s; } else { ra = (uint32_t)((int32_t)x.y - s); rb = x.y; }
           s = 0;
         }
         if (rb > ra) removed += ws_overlap(ra, rb);
-        if (forward) { idx++; if (idx == nV) idx = 0; } else { idx--; if (idx < 0) idx = nV - 1; }
+        if (forward) { idx++; if (idx == nV) { idx = 0; wraps = s > 0; } } else { idx--; if (idx < 0) { idx = nV - 1; wraps = s > 0; } }
       }
       if (bail) break;
-      trim = 1u | (forward ? 2u : 0u);
-      trim_v0 = v; trim_full = full; trim_part = part;
+      if (wraps) { if (nT > 0) { bail = true; break; } wrapped = true; }   // (a walk round the list's end: kept only as the one trim)
+      const int touched = full + (part > 0 ? 1 : 0);
+#pragma unroll
+      for (int t = 0; t < kMaxTrims; ++t) {
+        if (t == nT) {
+          t_flags[t] = 1u | (forward ? 2u : 0u);
+          t_v0[t] = v; t_full[t] = full; t_part[t] = part;
+          t_lo[t] = forward ? v : v - touched + 1;
+          t_hi[t] = forward ? v + touched - 1 : v;
+          t_s[t] = (uint32_t)(-true_remaining);
+          t_rem[t] = part > 0 ? part_len - part : 0u;
+          t_before[t] = forward ? before_v : before_v - walked_behind;
+        }
+      }
       if (part > 0) {
         // the final filter(workspace) (:644) can only drop what this trim leaves of the partly trimmed segment: every
         // other segment is a union of placed segments, each of which overlaps its workspace segment (:331-343)
         const int last = forward ? (idx == 0 ? nV - 1 : idx - 1) : (idx == nV - 1 ? 0 : idx + 1);
         const uint2 x = vget(last);
         const uint32_t ks = forward ? x.x + part : x.x, ke = forward ? x.y : x.y - part;
-        if (!(ke > ks && ws_overlap(ks, ke) > 0)) { trim |= 4u; drop_len = ke > ks ? ke - ks : 0u; }
+        if (!(ke > ks && ws_overlap(ks, ke) > 0)) {
+#pragma unroll
+          for (int t = 0; t < kMaxTrims; ++t) if (t == nT) t_flags[t] |= 4u;
+          drop_len += ke > ks ? ke - ks : 0u;
+        }
       }
+      nT++;
       cov -= removed;
       total -= (uint32_t)(-true_remaining);
       true_remaining = 1;
@@ -596,7 +667,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
     T.todo[atomicAdd(T.todo_count, 1u)] = qe;
     return;
   }
-  if (trim & 1u) {
+#pragma unroll
+  for (int t = 0; t < kMaxTrims; ++t) {
+    if (t >= nT) continue;
+    const uint32_t trim = t_flags[t], trim_part = t_part[t];
+    const int trim_v0 = t_v0[t], trim_full = t_full[t];
+   {
     // the unit is finished here, the trim was the last thing that happened to its list (a placement behind a trim cannot
     // be: the trim leaves remaining <= 0): apply it where the segments are -- trim_ends walked from v0
     // (gat/SegmentList.pyx:567-596): `full` segments emptied, `part` bases off the next, which is dropped altogether
@@ -623,6 +699,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
       } else U[v - c] = y;
       if (trim & 2u) { v++; if (v == nV) v = 0; } else { v--; if (v < 0) v = nV - 1; }
     }
+  }
   }
   TailPatch* P = T.patch + sa;
   P->n_extra = nE;
