@@ -894,7 +894,10 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       return kRelayout;
     }
     if (flags & gat::kStatusOverflow) {
-      if (P->cap_scale >= 64) return set_err(ctx, GAT_ERR_CAPACITY, "sampler slab overflow even at 64x capacity");
+      // (doubled until the lists fit: a unit whose segments are longer than its whole workspace beside one of a few bases places
+      //  thousands of the small one between the large one's trims -- two of 200 000 edge-case seeds needed more than 64 x 128 slots,
+      //  which the reference's lists simply grow to (round 6); the per-sample slab's 2^31 segments and the device's memory end it)
+      if (P->cap_scale >= (1 << 20)) return set_err(ctx, GAT_ERR_CAPACITY, "sampler slab overflow even at 2^20 x capacity");
       P->cap_scale *= 2;
       if (layout_slab(P)) return set_err(ctx, GAT_ERR_CAPACITY, "per-sample slab exceeds 2^31 segments after growth");
       if ((rc = upload_layout(ctx, P))) return rc;

@@ -1341,6 +1341,14 @@ def _edge_case(ctx, seed):
     return "compared"
 
 
+@pytest.mark.parametrize("seed", [2614126, 2764763])
+def test_lists_that_outgrow_64_times_their_region(ctx, seed):
+    """a unit of one 70 000-base segment and one of two bases in a workspace of 40 pieces of 32 000 bases in all: the small one is
+    placed tens of thousands of times between the large one's trims, the list grows to 100 times the unit's region -- the library
+    doubles the regions until it fits (round 5 gave up at 64 x: two of 200 000 edge-case seeds of round 6's sweep)"""
+    assert _edge_case(ctx, seed) == "compared"
+
+
 @pytest.mark.parametrize("seed", list(range(1, 49)))
 def test_fuzz_edge_cases_vs_oracle(ctx, seed):
     """the corners (see _edge_case): equal to the oracle, or the same exception on both sides"""
