@@ -405,6 +405,7 @@ struct gat_problem {
   int32_t bshift = 12;
   DevBuf<uint4> d_cand;                  // the candidates k_count_merged notes for k_units_overlap (kCandSlots regions)
   DevBuf<uint32_t> d_cand_count;         // ... their numbers per region, and k_units_overlap's words behind them
+  int cand_scale = 1;                    // ... the buffer's size against the estimate (x 4 when a region overflowed, up to 64)
   bool small_tables = false;             // every active unit: <= 64 workspace segments, < 256 working segments
   bool all_one_ws = false;               // every active unit: one workspace segment, bucket 1, and most of the working segments in units
                                          // whose rank table is beyond k_place's LDS table but within k_place_wide's (k_place MODE 3)

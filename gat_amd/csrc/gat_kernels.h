@@ -2384,7 +2384,7 @@ __global__ __launch_bounds__(64) void k_contig(ContigArgs A) {
             if (cand) {
               const uint32_t at = base + (uint32_t)__popcll(m & lanemask_lt(lane));
               if (at < A.cand_cap) A.cand[(size_t)slot_c * A.cand_cap + at] = make_uint4((uint32_t)sidx, (uint32_t)(ub + k), xv.x, xv.y);
-              else A.cand_count[kCandSlots] = 1u;
+              else atomicOr(&A.cand_count[kCandSlots], 2u);      // (the region is full: the host makes the buffer larger and repeats the batch)
             }
           }
         }
@@ -2480,8 +2480,8 @@ struct CountArgs {
   const uint2* seg_units_merged;
   uint4* cand;                // {sample, entry of cu_rec, start, end}: kCandSlots regions of cand_cap entries, a workgroup appends to
                               // region blockIdx % kCandSlots (one counter for the chip's appends would be most of the time)
-  uint32_t* cand_count;       // [0, kCandSlots) candidates appended per region; [kCandSlots] set when a region was too small / the overlaps
-                              // were not pairwise, [kCandSlots + 1] overlaps taken off, [kCandSlots + 2] candidates in all (k_units_overlap adds them up)
+  uint32_t* cand_count;       // [0, kCandSlots) candidates appended per region; [kCandSlots]: bit 0 the overlaps were not pairwise, bit 1 a
+                              // region was too small; [kCandSlots + 1] overlaps taken off, [kCandSlots + 2] candidates in all (k_units_overlap adds them up)
   uint32_t cand_cap;
 };
 
@@ -3202,7 +3202,7 @@ __global__ __launch_bounds__(256) void k_units_overlap(UnitsOverlapArgs B, int m
       if (k3 == cu || k3 == k) continue;
       unit_overlapping(A, s, k3, is_[a], ie_[a], [&](const uint2) { bad = true; });
     }
-  if (bad) { A.cand_count[kCandSlots] = 1u; return; }
+  if (bad) { atomicOr(&A.cand_count[kCandSlots], 1u); return; }     // (not pairwise: the host repeats the batch through the sorted lists)
   const uint2* __restrict__ Z = A.mz + A.mz_off[c];
   const uint32_t* __restrict__ F = A.mfirst + A.mf_off[c];
   const int shift = A.m_shift[c];

@@ -909,7 +909,8 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       // the batch is repeated through k_contig, and the problem keeps to that
       const uint32_t* uw = reinterpret_cast<const uint32_t*>(h_stat + 10);
       if (P->units_direct && P->units_direct_ok && uw[0] != 0u) {
-        P->units_direct_ok = false;
+        if ((uw[0] & 1u) != 0u || P->cand_scale >= 64) P->units_direct_ok = false;   // not pairwise (or a buffer that will not do)
+        else P->cand_scale *= 4;                                                       // a candidate region was too small
         if (st) st->n_retried += nb * (int64_t)P->h_order.size();
         return kRelayout;
       }
@@ -1172,14 +1173,23 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
     const bool loose_ok = records_ok && route == GAT_COUNT_KERNEL_MERGED;
     // isochore problems: the merged index takes the units' lists as they are, no k_contig (round 6)
     const bool units_direct = loose_ok && P->merge_contigs && P->units_direct_ok && !gat_opt(ctx, "GAT_COUNT_VIA_CONTIGS");
-    if (units_direct && P->d_cand.n == 0) {
+    if (units_direct) {
       // candidates: segments with a workspace boundary in their cells, of units that have a segment reaching out of their workspace
       // -- a fraction of a per cent of a batch's segments on isochore blocks much longer than the segments --, dealt to kCandSlots
-      // regions by (sample, contig); a region that overflows sends the batch through the sorted contig lists
-      const double est = 0.006 * (double)nb * (double)std::max<int64_t>(1, P->n_seg_total) / gat::kCandSlots + 512.0;
-      HIPCHK(ctx, P->d_cand.alloc((size_t)std::min(est, 64.0 * 1024) * gat::kCandSlots));
-      HIPCHK(ctx, P->d_cand_count.alloc(gat::kCandSlots + 4));
-      HIPCHK(ctx, hipMemsetAsync(P->d_cand_count.p, 0, (gat::kCandSlots + 4) * 4, ctx->stream));
+      // regions by (sample, contig).  Sized for THIS batch (a call's first batch is its largest; a later, larger call makes it
+      // anew while nothing of the problem is in flight); a region that overflows anyway has the batch repeated with four
+      // times the buffer (cand_scale), and beyond 64 times through the sorted contig lists
+      double est = 0.006 * (double)nb * (double)std::max<int64_t>(1, P->n_seg_total) / gat::kCandSlots + 512.0;
+      if (gat_opt(ctx, "GAT_TEST_SMALL_CAPS")) est = 1.0;        // (tests: regions that overflow, the batch repeated with larger ones)
+      const size_t want = (size_t)std::min(est * P->cand_scale, 1024.0 * 1024) * gat::kCandSlots;
+      if (P->d_cand.n < want && K.n_flight == 0) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // (an earlier call's kernels may still read the old buffer)
+        HIPCHK(ctx, P->d_cand.alloc(want));
+      }
+      if (P->d_cand_count.n == 0) {
+        HIPCHK(ctx, P->d_cand_count.alloc(gat::kCandSlots + 4));
+        HIPCHK(ctx, hipMemsetAsync(P->d_cand_count.p, 0, (gat::kCandSlots + 4) * 4, ctx->stream));
+      }
     }
     if ((rc = run_sampler_batch(ctx, P, K.seed, K.begin + K.enq, nb, &K.local, K.timed, false, true, records_ok, d_state, loose_ok,
                                 K.blk->h_stat + (size_t)slot * 16, units_direct))) return rc;   // (enqueued only)

@@ -542,6 +542,42 @@ def test_isochore_units_counted_directly_takes_overlaps_off(ctx):
     assert cands > 0 and ovl > 0 and retried > 0, (cands, ovl, retried)
 
 
+def test_isochore_units_counted_directly_candidate_buffer_follows_the_call(ctx):
+    """the candidate buffer of the concatenated-lists path is sized for a call's batch: a small call first, a large one behind it
+    -- the second must not fall back to the sorted lists for want of room (it makes the buffer anew), and a region that
+    overflows anyway has the batch repeated with a larger buffer, not the path given up"""
+    import collections
+    from gat_amd import problem
+    contigs = collections.OrderedDict([("k0", 300000), ("k1", 200000)])
+    segs = synthetic.random_segments(contigs, 600, 60, 5)
+    annos = [("t%d" % i, synthetic.random_segments(contigs, 200, 700, 50 + i)) for i in range(4)]
+    ws = synthetic.workspace_ungapped(contigs, pieces=2, gap=500)
+    iso = synthetic.isochores_blocks(contigs, nclasses=4, block=20000)
+    flat = problem.flatten_arrays(segs, annos, ws, iso, bucket_size=1, nbuckets=100000)
+    counters = ["nucleotide-overlap"]
+    P = _lib.Problem(ctx, flat)
+    try:
+        a = P.sample_and_count(counters, 3, 0, 4)
+        assert P.last_stats["n_straddle_candidates"] > 0
+        b = P.sample_and_count(counters, 3, 0, 700)
+        st = P.last_stats
+        assert st["n_straddle_candidates"] > 0 and st["n_unit_overlaps"] > 0, st      # still the concatenated lists
+        want, _ = O.run_samples(flat, counters, 3, 1, 0, 700)
+        assert np.array_equal(b[0], want[0]) and np.array_equal(a[0], want[0][:, :4])
+    finally:
+        P.close()
+    # regions of one entry: they overflow, the batch is repeated with four times the buffer until it holds -- still this path
+    ctx.options["GAT_TEST_SMALL_CAPS"] = "1"
+    try:
+        P = _lib.Problem(ctx, flat)
+        c = P.sample_and_count(counters, 3, 0, 700)
+        st = P.last_stats
+        assert st["n_retried"] > 0 and st["n_straddle_candidates"] > 0 and np.array_equal(c[0], want[0]), st
+        P.close()
+    finally:
+        ctx.options.pop("GAT_TEST_SMALL_CAPS")
+
+
 @pytest.mark.parametrize("seed", list(range(700, 732)))
 def test_fragmented_workspaces_vs_oracle(ctx, seed):
     _frag_ws_case(ctx, seed)
