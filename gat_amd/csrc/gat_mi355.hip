@@ -666,7 +666,13 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             HIPCHK(ctx, hipGetLastError());
             if (!gat_opt(ctx, "GAT_NO_RESUME_BIG")) {
               // ... and the rest of the unit -- log inserted, trim, final filter -- with the list where it is
-              hipLaunchKernelGGL(gat::k_resume_big, dim3((unsigned)nb, gby, (n_long + gby - 1) / gby), dim3(64), 0, ctx->stream, TB);
+              // (a reader that takes the segments one by one in any order -- k_count_merged on the units' lists, no contig lists
+              //  in between --: the log stays behind the merged list, the trim works on virtual indices)
+              const dim3 gr((unsigned)nb, gby, (n_long + gby - 1) / gby);
+              if (TB.loose_ok && !P->merge_contigs && !gat_opt(ctx, "GAT_RESUME_INSERT"))
+                hipLaunchKernelGGL(gat::k_resume_big<true>, gr, dim3(64), 0, ctx->stream, TB);
+              else
+                hipLaunchKernelGGL(gat::k_resume_big<false>, gr, dim3(64), 0, ctx->stream, TB);
               HIPCHK(ctx, hipGetLastError());
             }
             A.tb = reinterpret_cast<const int32_t*>(P->d_patch.p);

@@ -893,6 +893,14 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
 // time and the occupancy is what registers allow.  Whatever does not fit (segments k_tail_big could not apply, a log
 // beyond 128 entries, workspaces beyond the register loop, rows running out) is left to k_sampler as before (record state
 // 2), or handed to it for a redo from the seed (state 3).  A finished unit is marked state 1.
+//
+// VIRT (round 6; the lists' only reader takes its segments one by one, in any order: k_count_merged without contig lists): the
+// log is NOT inserted.  Its entries touch nothing, so the list as a set is already what merge(0) of everything gives; only the
+// trim cares for the order (a position in the running lengths of the sorted list, then a walk over neighbours).  The sorted log
+// goes right behind the merged list, out[nU .. nU + nE), and the trim works on VIRTUAL indices: v -> the log entry r where
+// vpos[r] = (merged elements with start <= its start) + r equals v, the merged element v - #{r: vpos[r] < v} otherwise
+// (vpos sorted, in LDS).  The insertion was a read and a write of the whole list -- 20 of this kernel's 25 GB on the config-4 shape.
+template <bool VIRT>
 __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   __shared__ int32_t l_cs[2 * kWave];
   const SamplerArgs& A = T.S;
@@ -927,6 +935,7 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
 
   // ---- the log (nE <= 128 segments that touch nothing, unsorted) into the merged list, in place from the back
+  int vp0 = 0x7fffffff, vp1 = 0x7fffffff, nL = 0;         // VIRT: virtual positions of the sorted log entries lane, 64 + lane; their number
   if (nE > 0) {
     uint2 e[2];
     int cu[2], rk[2];
@@ -956,8 +965,17 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     }
     wave_sync<true>();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) l_cs[rk[h]] = cu[h];
+    for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) l_cs[rk[h]] = VIRT ? cu[h] + rk[h] : cu[h];
     wave_sync<true>();
+    if constexpr (VIRT) {
+      // (every entry is in a register by now -- the searches above compared it --: the sorted run may overlap the log's slots)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) out[nU + rk[h]] = e[h];
+      vp0 = lane < nE ? l_cs[lane] : 0x7fffffff;
+      vp1 = kWave + lane < nE ? l_cs[kWave + lane] : 0x7fffffff;
+      nL = nE;
+      wave_sync<true>();
+    } else {
     const int cs0 = lane < nE ? l_cs[lane] : 0x7fffffff, cs1 = kWave + lane < nE ? l_cs[kWave + lane] : 0x7fffffff;
     constexpr int kB = 8;
     for (int top = ((nU - 1) >> 6) << 6; top >= 0; top -= kB * kWave) {
@@ -985,7 +1003,26 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     for (int h = 0; h < 2; ++h) if (h * kWave + lane < nE) out[cu[h] + rk[h]] = e[h];
     nU += nE;
     wave_sync<true>();                                                    // (the list is read again below: stores done)
+    }
   }
+  const int nV = nU + nL;                                  // elements of the (virtual) sorted list
+  // VIRT: where the 64 virtual indices [base, base + 64) stand in the slab (all lanes call it together)
+  auto phys_block = [&](int base) -> int {
+    const int v = base + lane;
+    if (!VIRT || nL == 0) return v;
+    const int below = __popcll(__ballot(vp0 < base)) + __popcll(__ballot(vp1 < base));
+    const int upto = __popcll(__ballot(vp0 < base + kWave)) + __popcll(__ballot(vp1 < base + kWave));
+    int c = below, r = -1;
+    for (int j = below; j < upto; ++j) { const int vp = l_cs[j]; c += vp < v ? 1 : 0; if (vp == v) r = j; }
+    return r >= 0 ? nU + r : v - c;
+  };
+  // ... and one virtual index (a single lane's walk)
+  auto phys_one = [&](int v) -> int {
+    if (!VIRT || nL == 0) return v;
+    int lo = 0, hi = nL;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (l_cs[mid] < v) lo = mid + 1; else hi = mid; }
+    return (lo < nL && l_cs[lo] == v) ? nU + lo : v - lo;
+  };
 
   WaveRng rng;
   rng.mt = nullptr;
@@ -1008,23 +1045,27 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
       uint32_t run = 0;
       bool found = false;
       constexpr int kB = 8;
-      for (int base0 = 0; base0 < nU && !found; base0 += kB * kWave) {
+      for (int base0 = 0; base0 < nV && !found; base0 += kB * kWave) {
         uint2 v[kB];
 #pragma unroll
-        for (int q = 0; q < kB; ++q) { const int i = base0 + q * kWave + lane; v[q] = i < nU ? out[i] : make_uint2(0u, 0u); }
+        for (int q = 0; q < kB; ++q) {
+          const int i = base0 + q * kWave + lane;
+          const int ph = phys_block(base0 + q * kWave);
+          v[q] = i < nV ? out[ph] : make_uint2(0u, 0u);
+        }
 #pragma unroll
         for (int q = 0; q < kB; ++q) {
           if (found) continue;
           const int i = base0 + q * kWave + lane;
           const uint32_t incl = run + wave_incl_sum_u32(v[q].y - v[q].x, lane);
-          const bool ge = i < nU && (int32_t)(incl - 1u - p) >= 0;  // cdf[i] = incl - 1; leftmost i with (int)(cdf[i] - p) >= 0
+          const bool ge = i < nV && (int32_t)(incl - 1u - p) >= 0;  // cdf[i] = incl - 1; leftmost i with (int)(cdf[i] - p) >= 0
           const uint64_t b = __ballot(ge);
           if (b != 0) { k = base0 + q * kWave + (int)__builtin_ctzll(b); found = true; }
           run = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
         }
       }
     }
-    const uint2 chosen = out[k];
+    const uint2 chosen = out[phys_one(k)];
     (void)rng_range(rng, chosen.y - 1u - chosen.x, lane);           // position inside the segment: only its index matters
     const uint32_t forward = rng_range(rng, 1u, lane);              // numpy.random.randint(0, 2)
     int32_t s = -true_remaining;
@@ -1035,19 +1076,20 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     if (lane == 0) {
       int idx = k;
       while (s > 0) {
-        const uint2 v = out[idx];
+        const int at = phys_one(idx);
+        const uint2 v = out[at];
         const int32_t l = (int32_t)v.y - (int32_t)v.x;
         uint32_t ra, rb;
-        if (l < s) { out[idx] = make_uint2(0u, 0u); s -= l; ra = v.x; rb = v.y; }
+        if (l < s) { out[at] = make_uint2(0u, 0u); s -= l; ra = v.x; rb = v.y; }
         else {
-          if (forward) { out[idx] = make_uint2(v.x + (uint32_t)s, v.y); ra = v.x; rb = v.x + (uint32_t)s; }
-          else { out[idx] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
+          if (forward) { out[at] = make_uint2(v.x + (uint32_t)s, v.y); ra = v.x; rb = v.x + (uint32_t)s; }
+          else { out[at] = make_uint2(v.x, (uint32_t)((int32_t)v.y - s)); ra = (uint32_t)((int32_t)v.y - s); rb = v.y; }
           s = 0;
-          partial = idx;
+          partial = at;
         }
         if (rb > ra) removed += ws_overlap_regs(W, ra, rb);
-        if (forward) { idx++; if (idx == nU) idx = 0; }
-        else { idx--; if (idx < 0) idx = nU - 1; }
+        if (forward) { idx++; if (idx == nV) idx = 0; }
+        else { idx--; if (idx < 0) idx = nV - 1; }
       }
     }
     partial = __builtin_amdgcn_readfirstlane(partial);
@@ -1096,17 +1138,18 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
         }
       }
     }
-    nout = nU;
+    nout = nV;
     tsum = total - (uint32_t)__builtin_amdgcn_readfirstlane((int)gone);
   } else {
+    // (VIRT: the slab's order -- the merged list, then the sorted log -- is as good as any for this list's reader)
     constexpr int kB = 8;
-    for (int base0 = 0; base0 < nU; base0 += kB * kWave) {
+    for (int base0 = 0; base0 < nV; base0 += kB * kWave) {
       uint2 v[kB];
       bool keep[kB];
 #pragma unroll
-      for (int q = 0; q < kB; ++q) { const int i = base0 + q * kWave + lane; v[q] = i < nU ? out[i] : make_uint2(0u, 0u); }
+      for (int q = 0; q < kB; ++q) { const int i = base0 + q * kWave + lane; v[q] = i < nV ? out[i] : make_uint2(0u, 0u); }
 #pragma unroll
-      for (int q = 0; q < kB; ++q) keep[q] = base0 + q * kWave + lane < nU && ws_overlap_regs(W, v[q].x, v[q].y) > 0;
+      for (int q = 0; q < kB; ++q) keep[q] = base0 + q * kWave + lane < nV && ws_overlap_regs(W, v[q].x, v[q].y) > 0;
 #pragma unroll
       for (int q = 0; q < kB; ++q) {
         const uint64_t b = __ballot(keep[q]);

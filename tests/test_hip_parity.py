@@ -382,11 +382,14 @@ def _long_list_case(ctx, seed):
     want, wsamples = O.run_samples(flat, counters, seed, 1, 0, S, want_samples=True)
     if loose:
         ctx.options["GAT_MERGED_MIN_TRACKS"] = "1"
+        if seed % 4 == 3:                 # ... with the log inserted into the list (round 3's form) instead of left behind it
+            ctx.options["GAT_RESUME_INSERT"] = "1"
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
     finally:
         ctx.options.pop("GAT_MERGED_MIN_TRACKS", None)
+        ctx.options.pop("GAT_RESUME_INSERT", None)
     if loose:
         assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
     handed = P.last_stats["n_tail_units"]
