@@ -1391,6 +1391,8 @@ constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 w
 #endif
 constexpr int kMergeThreads = GAT_MERGE_THREADS;
 constexpr int kMergeWaves = kMergeThreads / kWave;
+constexpr int kMergeRank = 4;            // ... and look-ups of the order inside the buckets it keeps in flight
+constexpr int kMergeRegs = 24;           // list elements a thread of k_merge_big<., REGS> keeps in registers at most (lists of up to 12 288)
 
 __device__ __forceinline__ uint32_t block_reduce_u32(uint32_t v, uint32_t* red, int tid, bool want_max, bool want_min) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -1406,11 +1408,13 @@ __device__ __forceinline__ uint32_t block_reduce_u32(uint32_t v, uint32_t* red, 
   return r;
 }
 
-template <bool TREE>
+template <bool TREE, int REGS>
 __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   __shared__ uint32_t red[kMergeWaves];
   __shared__ int32_t redi[kMergeWaves];
+  __shared__ uint32_t red2[kMergeWaves];
+  __shared__ int32_t redi2[kMergeWaves];
   __shared__ uint32_t wsl[2 * kWsTreeMin];                       // short workspaces: starts, ends
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sidx = blockIdx.x, a = A.a_base + (int)(blockIdx.y + blockIdx.z * gridDim.y);
@@ -1433,7 +1437,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
 #define GAT_MPHASE(K)
 #endif
   uint2* seg = reinterpret_cast<uint2*>(lds);                     // lds_cap entries
-  uint32_t* hist = lds + 2 * (size_t)A.lds_cap;                  // big_buckets + 1
+  // REGS: the sort works on the starts alone (4 bytes an element: the lower half of the list's LDS), the histogram lives in the
+  // upper half -- as many buckets as elements for nothing -- and the elements come in from the registers when both are done with
+  uint32_t* hist = REGS > 0 ? lds + (size_t)A.lds_cap : lds + 2 * (size_t)A.lds_cap;     // big_buckets + 1
   uint2* out = A.slab + (int64_t)sidx * A.slab_stride + Up->slab_off;
   const int nws = Up->n_ws;
   const uint2* __restrict__ ws = A.ws + Up->ws_off;
@@ -1459,128 +1465,337 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   while (nb < n && nb < A.big_buckets) nb <<= 1;
   const bool direct = span < (uint32_t)nb;
   const uint32_t scale = direct ? 0u : (uint32_t)(((uint64_t)nb << 32) / ((uint64_t)span + 1u));
-  for (int i = tid; i <= nb; i += kMergeThreads) hist[i] = 0;
+  // (REGS: a word of padding behind every thread's buckets -- the prefix pass below reads them thread by thread, and a stride of
+  //  16 words put a whole wave on two LDS banks)
+  const int per_b = nb / kMergeThreads;
+  const int per_shift = __builtin_ctz((unsigned)per_b);
+  auto hidx = [&](uint32_t b) -> uint32_t { return REGS > 0 ? b + (b >> per_shift) : b; };
+  for (int i = tid; i <= (REGS > 0 ? nb + kMergeThreads : nb); i += kMergeThreads) hist[i] = 0;
   __syncthreads();
   GAT_MPHASE(0)
-  for (int base = 0; base < n; base += kB * kMergeThreads) {
-    uint32_t x[kB];
-#pragma unroll
-    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; x[q] = i < n ? out[i].x : 0u; }
-#pragma unroll
-    for (int q = 0; q < kB; ++q)
-      if (base + q * kMergeThreads + tid < n) { const uint32_t d = x[q] - lo; atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u); }
-  }
-  __syncthreads();
-  GAT_MPHASE(1)
-  {
-    // exclusive prefix over the buckets: thread owns nb/256 consecutive ones
-    const int per = nb / kMergeThreads;
-    uint32_t sum = 0, maxc = 0;
-    for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
-    const uint32_t incl = wave_incl_sum_u32(sum, lane);
-    maxc = block_reduce_u32(maxc, red, tid, true, false);         // (two barriers: red is free again below)
-    if (maxc > 48u) return;                                       // clustered: not worth sorting buckets thread by thread
-    __syncthreads();                                              // everybody has read red
-    if (lane == 63) red[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (int k = 0; k < wave; ++k) run += red[k];
-    for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
-  }
-  __syncthreads();
-  GAT_MPHASE(2)
-  for (int base = 0; base < n; base += kB * kMergeThreads) {
-    uint2 v[kB];
-#pragma unroll
-    for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < n ? out[i] : make_uint2(0u, 0u); }
-#pragma unroll
-    for (int q = 0; q < kB; ++q)
-      if (base + q * kMergeThreads + tid < n) {
-        const uint32_t d = v[q].x - lo;
-        seg[atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u)] = v[q];
-      }
-  }
-  __syncthreads();
-  GAT_MPHASE(3)
-  for (int b = tid; b < nb; b += kMergeThreads) {                // hist[b] is now the END of bucket b
-    const int e = (int)hist[b], s0 = b ? (int)hist[b - 1] : 0;
-    for (int i = s0 + 1; i < e; ++i) {
-      const uint2 v = seg[i];
-      int j = i - 1;
-      while (j >= s0 && seg[j].x > v.x) { seg[j + 1] = seg[j]; --j; }
-      seg[j + 1] = v;
-    }
-  }
-  __syncthreads();
-  GAT_MPHASE(4)
-
-  // ---- merge(0) (gat/SegmentList.pyx:756-816): head = first non-empty, or int32(start) > running max end
   int count = 0;
-  int32_t carry = INT32_MIN;
-  bool any = false;
-  for (int base = 0; base < n; base += kMergeThreads) {
-    const int i = base + tid;
-    uint32_t s0 = 0, e0 = 0;
-    bool valid = false;
-    if (i < n) { const uint2 v = seg[i]; s0 = v.x; e0 = v.y; valid = s0 != e0; }
-    const int32_t m = wave_incl_max_i32(valid ? (int32_t)e0 : INT32_MIN, lane);
-    const uint64_t vb = __ballot(valid);
-    if (lane == 63) { redi[wave] = m; }
-    if (lane == 0) red[wave] = vb != 0 ? 1u : 0u;
-    __syncthreads();
-    int32_t before = carry;                                       // running max of everything before this wave
-    bool any_before = any;
-    for (int k = 0; k < wave; ++k) { const int32_t x = redi[k]; before = x > before ? x : before; any_before = any_before || red[k] != 0; }
-    int32_t total = carry;
-    bool any_now = any;
-    for (int k = 0; k < kMergeWaves; ++k) { const int32_t x = redi[k]; total = x > total ? x : total; any_now = any_now || red[k] != 0; }
-    const int32_t incl = m > before ? m : before;
-    const int32_t excl = __builtin_amdgcn_update_dpp(before, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps `before`
-    const bool prev_valid = any_before || (vb & lanemask_lt(lane)) != 0;
-    const bool head = valid && (!prev_valid || (int32_t)s0 > excl);
-    const uint64_t hb = __ballot(head);
-    __syncthreads();                                              // red / redi are reused for the head counts
-    if (lane == 0) red[wave] = (uint32_t)__popcll(hb);
-    __syncthreads();
-    int pos = count + __popcll(hb & lanemask_lt(lane));
-    int heads = 0;
-    for (int k = 0; k < kMergeWaves; ++k) { if (k < wave) pos += (int)red[k]; heads += (int)red[k]; }
-    if (head) {
-      out[pos].x = s0;
-      if (pos > 0) out[pos - 1].y = (uint32_t)excl;
-    }
-    count += heads;
-    carry = total;
-    any = any_now;
-    __syncthreads();
-  }
-  if (count > 0 && tid == 0) out[count - 1].y = (uint32_t)carry;
-  __syncthreads();                                                // the merged list in the slab, visible to the block
-  GAT_MPHASE(5)
-
-  // ---- coverage of the merged list inside the workspace, and its total length
   uint32_t cov = 0, tot = 0;
-  if (nws <= kWsTreeMin) {
-    for (int base = 0; base < count; base += kB * kMergeThreads) {
-      uint2 v[kB];
+  auto bucket_of = [&](uint32_t x) -> uint32_t { const uint32_t d = x - lo; return direct ? d : __umulhi(d, scale); };
+  if constexpr (REGS > 0) {
+    if (n > REGS * kMergeThreads) return;                          // (the host picks REGS for the class's longest list)
+    // (round 6) The list is read ONCE, into registers (a thread keeps elements tid, tid + 512, ...), and stays there through
+    // histogram, scatter and the order inside the buckets: every ELEMENT counts the starts of its bucket in front of it (four
+    // look-ups side by side; a thread per BUCKET running an insertion sort was 36 % of the kernel: sixteen dependent rounds, each
+    // as long as its wave's fullest bucket).  The histogram's atomic hands every element its place of arrival in its bucket, so
+    // the scatter needs no second one.  merge(0) then runs wave by wave on contiguous eighths of the list, four elements a lane
+    // -- its running maximum handed from wave to wave through two barriers in all (a barrier four times per 512 elements was
+    // another 35 %) --, compacts in LDS, and the copy to the slab adds up coverage and total length on its way.
+    // (every store into the register arrays is unconditional: a conditional one makes the compiler carry the whole array as one
+    //  value through the branch -- hundreds of spilled registers)
+    uint2 v[REGS];
+    int at[REGS];
 #pragma unroll
-      for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < count ? out[i] : make_uint2(0u, 0u); }
+    for (int q = 0; q < REGS; ++q) {
+      const int i = q * kMergeThreads + tid;
+      v[q] = out[i < n ? i : n - 1];
+    }
 #pragma unroll
-      for (int q = 0; q < kB; ++q) {
-        tot += v[q].y - v[q].x;
-        for (int k = 0; k < nws; ++k) {
-          const uint32_t l2 = v[q].x > wsl[k] ? v[q].x : wsl[k], h2 = v[q].y < wsl[kWsTreeMin + k] ? v[q].y : wsl[kWsTreeMin + k];
-          cov += h2 > l2 ? h2 - l2 : 0u;
+    for (int q = 0; q < REGS; ++q) {
+      int c_ = 0;
+      if (q * kMergeThreads + tid < n) c_ = (int)atomicAdd(&hist[hidx(bucket_of(v[q].x))], 1u);
+      at[q] = c_;                                                  // place of arrival in its bucket
+    }
+    __syncthreads();
+    GAT_MPHASE(1)
+    {
+      uint32_t sum = 0, maxc = 0;
+      uint32_t* hb_ = hist + tid * (per_b + 1);                    // this thread's buckets (per_b of them, then the padding)
+      for (int q = 0; q < per_b; ++q) { const uint32_t c = hb_[q]; sum += c; maxc = c > maxc ? c : maxc; }
+      const uint32_t incl = wave_incl_sum_u32(sum, lane);
+      maxc = block_reduce_u32(maxc, red, tid, true, false);
+      if (maxc > 48u) return;                                     // clustered: left to k_sampler's own sort
+      __syncthreads();
+      if (lane == 63) red[wave] = incl;
+      __syncthreads();
+      uint32_t run = incl - sum;
+      for (int k = 0; k < wave; ++k) run += red[k];
+      for (int q = 0; q < per_b; ++q) { const uint32_t c = hb_[q]; hb_[q] = run; run += c; }
+      if (tid == kMergeThreads - 1) hist[hidx((uint32_t)nb)] = run;       // (= n: the end of the last bucket)
+    }
+    __syncthreads();
+    GAT_MPHASE(2)
+    // hist[b] is the START of bucket b.  The starts go to where they arrived; an element remembers its bucket's first slot (14
+    // bits), length (6) and its own place of arrival (6)
+#pragma unroll
+    for (int q = 0; q < REGS; ++q) {
+      int w_ = 0;
+      if (q * kMergeThreads + tid < n) {
+        const uint32_t b = bucket_of(v[q].x);
+        const int s0 = (int)hist[hidx(b)], e = (int)hist[hidx(b + 1u)];
+        lds[s0 + at[q]] = v[q].x;
+        w_ = s0 | ((e - s0) << 14) | (at[q] << 20);
+      }
+      at[q] = w_;
+    }
+    __syncthreads();
+    GAT_MPHASE(3)
+    // place of an element among its bucket's: by start, then by arrival
+#pragma unroll
+    for (int q0 = 0; q0 < REGS; q0 += kMergeRank) {
+      int rk[kMergeRank];
+      int mx = 0;
+#pragma unroll
+      for (int r = 0; r < kMergeRank; ++r) { const int len = (at[q0 + r] >> 14) & 63; rk[r] = 0; mx = len > mx ? len : mx; }
+      if (mx > 1) {
+#pragma unroll 1
+        for (int k = 0; k < mx; ++k) {
+#pragma unroll
+          for (int r = 0; r < kMergeRank; ++r) {
+            const int s0 = at[q0 + r] & 0x3fff, len = (at[q0 + r] >> 14) & 63, c = at[q0 + r] >> 20;
+            const uint32_t x = lds[s0 + (k < len ? k : 0)];
+            rk[r] += (k < len && (x < v[q0 + r].x || (x == v[q0 + r].x && k < c))) ? 1 : 0;
+          }
         }
       }
+#pragma unroll
+      for (int r = 0; r < kMergeRank; ++r) at[q0 + r] = (at[q0 + r] & 0x3fff) + rk[r];
     }
-  } else if constexpr (TREE) {
-    const uint32_t* __restrict__ pg = A.ws_tree + Up->pgrid_off;          // (round 6: the position grid, not two tree searches)
-    const uint32_t pshift = pg[0], pcells = pg[1];
-    for (int i = tid; i < count; i += kMergeThreads) {
-      const uint2 v = out[i];
-      tot += v.y - v.x;
-      cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y);
+    __syncthreads();                                               // every look-up done before the elements come in (over starts and histogram)
+#pragma unroll
+    for (int q = 0; q < REGS; ++q)
+      if (q * kMergeThreads + tid < n) seg[at[q]] = v[q];
+    __syncthreads();
+    GAT_MPHASE(4)
+
+    // ---- merge(0) (gat/SegmentList.pyx:756-816): head = first non-empty, or int32(start) > running max end
+    constexpr int kE = 4;                                          // consecutive elements a lane takes per round
+    const int chunk = ((n + kMergeWaves * kWave * kE - 1) / (kMergeWaves * kWave * kE)) * kWave * kE;   // a wave's elements: [w0, w1)
+    const int w0 = wave * chunk < n ? wave * chunk : n, w1 = w0 + chunk < n ? w0 + chunk : n;
+    auto load4 = [&](int base, uint2* x) {
+#pragma unroll
+      for (int t = 0; t < kE; ++t) { const int i = base + lane * kE + t; x[t] = i < w1 ? seg[i] : make_uint2(0u, 0u); }
+    };
+    {
+      int32_t wm = INT32_MIN;
+      for (int base = w0; base < w1; base += kWave * kE) {
+        uint2 x[kE];
+        load4(base, x);
+#pragma unroll
+        for (int t = 0; t < kE; ++t) if (x[t].x != x[t].y) wm = (int32_t)x[t].y > wm ? (int32_t)x[t].y : wm;
+      }
+      const uint64_t wany = __ballot(wm != INT32_MIN);             // (a valid end is a coordinate: never INT32_MIN)
+      wm = (int32_t)wave_max_u32((uint32_t)wm ^ 0x80000000u) ^ (int32_t)0x80000000;
+      if (lane == 0) { redi[wave] = wm; red[wave] = wany != 0 ? 1u : 0u; }
+    }
+    __syncthreads();
+    int32_t carry = INT32_MIN, total = INT32_MIN;
+    bool any = false;
+    for (int k = 0; k < kMergeWaves; ++k) {
+      const int32_t x = redi[k];
+      if (k < wave) { carry = x > carry ? x : carry; any = any || red[k] != 0; }
+      total = x > total ? x : total;
+    }
+    int cnt = 0;
+    int32_t first_excl = 0;
+    uint32_t* sw = reinterpret_cast<uint32_t*>(seg);
+    uint2 nx[kE];
+    load4(w0, nx);
+    for (int base = w0; base < w1; base += kWave * kE) {
+      uint2 x[kE];
+#pragma unroll
+      for (int t = 0; t < kE; ++t) x[t] = nx[t];
+      load4(base + kWave * kE, nx);        // (the next round, ahead of this one's stores: they land at or before this round's slots)
+      // the running maximum of the ends inside the lane, then over the lanes in front of it
+      int32_t lm[kE];
+      bool lv[kE];                                                 // a valid (non-empty) element at or before t in this lane
+#pragma unroll
+      for (int t = 0; t < kE; ++t) {
+        const bool valid = x[t].x != x[t].y;                       // (beyond the chunk: [0, 0))
+        const int32_t e = valid ? (int32_t)x[t].y : INT32_MIN;
+        lm[t] = t == 0 ? e : (e > lm[t - 1] ? e : lm[t - 1]);
+        lv[t] = t == 0 ? valid : (valid || lv[t - 1]);
+      }
+      const int32_t sc = wave_incl_max_i32(lm[kE - 1], lane);
+      int32_t ex = __builtin_amdgcn_update_dpp(INT32_MIN, sc, 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0: nothing in front
+      ex = ex > carry ? ex : carry;
+      const uint64_t vb = __ballot(lv[kE - 1]);
+      const bool pv = any || (vb & lanemask_lt(lane)) != 0;        // a valid element in front of this lane
+      bool head[kE];
+      int32_t excl[kE];
+      int h = 0;
+      int32_t fe = 0;
+#pragma unroll
+      for (int t = 0; t < kE; ++t) {
+        excl[t] = t == 0 ? ex : (lm[t - 1] > ex ? lm[t - 1] : ex);
+        const bool prev_valid = pv || (t > 0 && lv[t - 1]);
+        head[t] = x[t].x != x[t].y && (!prev_valid || (int32_t)x[t].x > excl[t]);
+        if (head[t] && h == 0) fe = excl[t];
+        h += head[t] ? 1 : 0;
+      }
+      const uint32_t ps = wave_incl_sum_u32((uint32_t)h, lane);
+      const uint64_t hb = __ballot(h > 0);
+      if (cnt == 0 && hb != 0) first_excl = __builtin_amdgcn_readlane(fe, (int)__builtin_ctzll(hb));
+      // (compacted where the wave's elements stand: a head's slot is at or before its element, and the round is in registers)
+      int p_ = w0 + cnt + (int)ps - h;
+#pragma unroll
+      for (int t = 0; t < kE; ++t) {
+        if (head[t]) {
+          sw[2 * p_] = x[t].x;
+          if (p_ > w0) sw[2 * (p_ - 1) + 1] = (uint32_t)excl[t];
+          p_++;
+        }
+      }
+      cnt += __builtin_amdgcn_readlane((int)ps, kWave - 1);
+      const int32_t top = __builtin_amdgcn_readlane(sc, kWave - 1);
+      carry = top > carry ? top : carry;
+      any = any || vb != 0;
+      wave_fence();
+    }
+    if (lane == 0) { red2[wave] = (uint32_t)cnt; redi2[wave] = first_excl; }
+    __syncthreads();
+    int offset = 0;
+    int32_t last_end = total;                                      // end of the wave's last merged segment: up to the next head
+    bool next_seen = false;
+    for (int k = 0; k < kMergeWaves; ++k) {
+      const int c = (int)red2[k];
+      if (k < wave) offset += c;
+      if (k > wave && c > 0 && !next_seen) { last_end = redi2[k]; next_seen = true; }
+      count += c;
+    }
+    if (cnt > 0 && lane == 0) sw[2 * (w0 + cnt - 1) + 1] = (uint32_t)last_end;
+    wave_fence();
+    GAT_MPHASE(5)
+    // ---- the merged list to the slab; its coverage inside the workspace and its total length on the way
+    const uint32_t* __restrict__ pg = A.ws_tree + (TREE && Up->pgrid_off >= 0 ? Up->pgrid_off : 0);
+    const uint32_t pshift = TREE && nws > kWsTreeMin ? pg[0] : 0u, pcells = TREE && nws > kWsTreeMin ? pg[1] : 0u;
+    for (int j = lane; j < cnt; j += kWave) {
+      const uint2 x = seg[w0 + j];
+      out[offset + j] = x;
+      tot += x.y - x.x;
+      if (nws <= kWsTreeMin) {
+        for (int k = 0; k < nws; ++k) {
+          const uint32_t l2 = x.x > wsl[k] ? x.x : wsl[k], h2 = x.y < wsl[kWsTreeMin + k] ? x.y : wsl[kWsTreeMin + k];
+          cov += h2 > l2 ? h2 - l2 : 0u;
+        }
+      } else if constexpr (TREE) {
+        cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, x.x, x.y);
+      }
+    }
+    __syncthreads();                                                // the merged list in the slab, visible to the block
+  } else {
+    for (int base = 0; base < n; base += kB * kMergeThreads) {
+      uint32_t x[kB];
+  #pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; x[q] = i < n ? out[i].x : 0u; }
+  #pragma unroll
+      for (int q = 0; q < kB; ++q)
+        if (base + q * kMergeThreads + tid < n) { const uint32_t d = x[q] - lo; atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u); }
+    }
+    __syncthreads();
+    GAT_MPHASE(1)
+    {
+      // exclusive prefix over the buckets: thread owns nb/256 consecutive ones
+      const int per = nb / kMergeThreads;
+      uint32_t sum = 0, maxc = 0;
+      for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; sum += c; maxc = c > maxc ? c : maxc; }
+      const uint32_t incl = wave_incl_sum_u32(sum, lane);
+      maxc = block_reduce_u32(maxc, red, tid, true, false);         // (two barriers: red is free again below)
+      if (maxc > 48u) return;                                       // clustered: not worth sorting buckets thread by thread
+      __syncthreads();                                              // everybody has read red
+      if (lane == 63) red[wave] = incl;
+      __syncthreads();
+      uint32_t run = incl - sum;
+      for (int k = 0; k < wave; ++k) run += red[k];
+      for (int q = 0; q < per; ++q) { const uint32_t c = hist[tid * per + q]; hist[tid * per + q] = run; run += c; }
+    }
+    __syncthreads();
+    GAT_MPHASE(2)
+    for (int base = 0; base < n; base += kB * kMergeThreads) {
+      uint2 v[kB];
+  #pragma unroll
+      for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < n ? out[i] : make_uint2(0u, 0u); }
+  #pragma unroll
+      for (int q = 0; q < kB; ++q)
+        if (base + q * kMergeThreads + tid < n) {
+          const uint32_t d = v[q].x - lo;
+          seg[atomicAdd(&hist[direct ? d : __umulhi(d, scale)], 1u)] = v[q];
+        }
+    }
+    __syncthreads();
+    GAT_MPHASE(3)
+    for (int b = tid; b < nb; b += kMergeThreads) {                // hist[b] is now the END of bucket b
+      const int e = (int)hist[b], s0 = b ? (int)hist[b - 1] : 0;
+      for (int i = s0 + 1; i < e; ++i) {
+        const uint2 v = seg[i];
+        int j = i - 1;
+        while (j >= s0 && seg[j].x > v.x) { seg[j + 1] = seg[j]; --j; }
+        seg[j + 1] = v;
+      }
+    }
+    __syncthreads();
+    GAT_MPHASE(4)
+
+    // ---- merge(0) (gat/SegmentList.pyx:756-816): head = first non-empty, or int32(start) > running max end
+    int32_t carry = INT32_MIN;
+    bool any = false;
+    for (int base = 0; base < n; base += kMergeThreads) {
+      const int i = base + tid;
+      uint32_t s0 = 0, e0 = 0;
+      bool valid = false;
+      if (i < n) { const uint2 v = seg[i]; s0 = v.x; e0 = v.y; valid = s0 != e0; }
+      const int32_t m = wave_incl_max_i32(valid ? (int32_t)e0 : INT32_MIN, lane);
+      const uint64_t vb = __ballot(valid);
+      if (lane == 63) { redi[wave] = m; }
+      if (lane == 0) red[wave] = vb != 0 ? 1u : 0u;
+      __syncthreads();
+      int32_t before = carry;                                       // running max of everything before this wave
+      bool any_before = any;
+      for (int k = 0; k < wave; ++k) { const int32_t x = redi[k]; before = x > before ? x : before; any_before = any_before || red[k] != 0; }
+      int32_t total = carry;
+      bool any_now = any;
+      for (int k = 0; k < kMergeWaves; ++k) { const int32_t x = redi[k]; total = x > total ? x : total; any_now = any_now || red[k] != 0; }
+      const int32_t incl = m > before ? m : before;
+      const int32_t excl = __builtin_amdgcn_update_dpp(before, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps `before`
+      const bool prev_valid = any_before || (vb & lanemask_lt(lane)) != 0;
+      const bool head = valid && (!prev_valid || (int32_t)s0 > excl);
+      const uint64_t hb = __ballot(head);
+      __syncthreads();                                              // red / redi are reused for the head counts
+      if (lane == 0) red[wave] = (uint32_t)__popcll(hb);
+      __syncthreads();
+      int pos = count + __popcll(hb & lanemask_lt(lane));
+      int heads = 0;
+      for (int k = 0; k < kMergeWaves; ++k) { if (k < wave) pos += (int)red[k]; heads += (int)red[k]; }
+      if (head) {
+        out[pos].x = s0;
+        if (pos > 0) out[pos - 1].y = (uint32_t)excl;
+      }
+      count += heads;
+      carry = total;
+      any = any_now;
+      __syncthreads();
+    }
+    if (count > 0 && tid == 0) out[count - 1].y = (uint32_t)carry;
+    __syncthreads();                                                // the merged list in the slab, visible to the block
+    GAT_MPHASE(5)
+
+    // ---- coverage of the merged list inside the workspace, and its total length
+    if (nws <= kWsTreeMin) {
+      for (int base = 0; base < count; base += kB * kMergeThreads) {
+        uint2 v[kB];
+  #pragma unroll
+        for (int q = 0; q < kB; ++q) { const int i = base + q * kMergeThreads + tid; v[q] = i < count ? out[i] : make_uint2(0u, 0u); }
+  #pragma unroll
+        for (int q = 0; q < kB; ++q) {
+          tot += v[q].y - v[q].x;
+          for (int k = 0; k < nws; ++k) {
+            const uint32_t l2 = v[q].x > wsl[k] ? v[q].x : wsl[k], h2 = v[q].y < wsl[kWsTreeMin + k] ? v[q].y : wsl[kWsTreeMin + k];
+            cov += h2 > l2 ? h2 - l2 : 0u;
+          }
+        }
+      }
+    } else if constexpr (TREE) {
+      const uint32_t* __restrict__ pg = A.ws_tree + Up->pgrid_off;          // (round 6: the position grid, not two tree searches)
+      const uint32_t pshift = pg[0], pcells = pg[1];
+      for (int i = tid; i < count; i += kMergeThreads) {
+        const uint2 v = out[i];
+        tot += v.y - v.x;
+        cov += ws_overlap_pgrid(ws, nws, pg + kGridHeader, pshift, pcells, v.x, v.y);
+      }
     }
   }
   cov = block_reduce_u32(cov, red, tid, false, false);

@@ -624,8 +624,15 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           M.cum = split ? P->d_cum.p : nullptr;
           n_long_big = n_long;
           const bool tree_m = P->max_nws > gat::kWsTreeMin;
-          const void* km = tree_m ? (const void*)gat::k_merge_big<true> : (const void*)gat::k_merge_big<false>;
-          HIPCHK(ctx, hipFuncSetAttribute(km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+          // (the form by the class's longest list: 8, 16 or 24 elements of it in every thread's registers; 0 = round 3's form,
+          //  the list read twice and sorted bucket by bucket)
+          typedef void (*merge_fn)(gat::SamplerArgs);
+          static const merge_fn kMergeFns[2][4] = {
+              {gat::k_merge_big<false, 0>, gat::k_merge_big<false, 8>, gat::k_merge_big<false, 16>, gat::k_merge_big<false, gat::kMergeRegs>},
+              {gat::k_merge_big<true, 0>, gat::k_merge_big<true, 8>, gat::k_merge_big<true, 16>, gat::k_merge_big<true, gat::kMergeRegs>}};
+          const bool merge_old = gat_opt(ctx, "GAT_MERGE_OLD") != nullptr;
+          for (int f = 0; f < 4; ++f)
+            HIPCHK(ctx, hipFuncSetAttribute((const void*)kMergeFns[tree_m ? 1 : 0][f], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
           M.n_long = (int32_t)n_long;
           for (size_t c = 0; c + 1 < P->h_class_start.size() && (unsigned)P->h_class_start[c] < n_long; ++c) {
             // one launch per size class: LDS for the class's longest list and its histogram
@@ -643,11 +650,21 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             int cnbk = 8192;
             while (cnbk > 1024 && (cnbk / 2 >= ccap || wgs_at(cnbk) < wgs_at(1024))) cnbk >>= 1;
             const size_t lds_c = (size_t)2 * ccap * 4 + (size_t)(cnbk + 1) * 4;
+            const int per = (ccap + gat::kMergeThreads - 1) / gat::kMergeThreads;
+            const int form = merge_old || per > gat::kMergeRegs ? 0 : (per <= 8 ? 1 : (per <= 16 ? 2 : 3));
+            size_t lds_k = lds_c;
+            if (form > 0) {
+              // (the register forms: the histogram shares the list's LDS -- up to about a bucket per element)
+              int maxb = 8192;
+              if (const char* e = gat_opt(ctx, "GAT_MERGE_BUCKETS")) maxb = std::max(1024, atoi(e));
+              cnbk = 1024;
+              while (2 * cnbk + gat::kMergeThreads + 1 <= ccap && 2 * cnbk <= maxb) cnbk <<= 1;     // (+ a word of padding per thread)
+              lds_k = ((size_t)ccap + (size_t)std::max(ccap, cnbk + gat::kMergeThreads + 1)) * 4;   // (short lists: the 1 024 buckets and their padding need their own words)
+            }
             M.a_base = a0; M.a_end = a1; M.lds_cap = ccap; M.big_buckets = cnbk;
             const unsigned cnt = (unsigned)(a1 - a0), gmy = std::min(cnt, 32768u);
             const dim3 gm((unsigned)nb, gmy, (cnt + gmy - 1) / gmy);
-            if (tree_m) hipLaunchKernelGGL(gat::k_merge_big<true>, gm, dim3(gat::kMergeThreads), lds_c, ctx->stream, M);
-            else hipLaunchKernelGGL(gat::k_merge_big<false>, gm, dim3(gat::kMergeThreads), lds_c, ctx->stream, M);
+            hipLaunchKernelGGL(kMergeFns[tree_m ? 1 : 0][form], gm, dim3(gat::kMergeThreads), lds_k, ctx->stream, M);
             HIPCHK(ctx, hipGetLastError());
           }
           A.st2 = P->d_st2.p;                    // (k_sampler reads it for those units only: see n_long below)
