@@ -1470,9 +1470,11 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
   const int per_b = nb / kMergeThreads;
   const int per_shift = __builtin_ctz((unsigned)per_b);
   auto hidx = [&](uint32_t b) -> uint32_t { return REGS > 0 ? b + (b >> per_shift) : b; };
-  for (int i = tid; i <= (REGS > 0 ? nb + kMergeThreads : nb); i += kMergeThreads) hist[i] = 0;
-  __syncthreads();
-  GAT_MPHASE(0)
+  if constexpr (REGS == 0) {
+    for (int i = tid; i <= nb; i += kMergeThreads) hist[i] = 0;
+    __syncthreads();
+    GAT_MPHASE(0)
+  }
   int count = 0;
   uint32_t cov = 0, tot = 0;
   auto bucket_of = [&](uint32_t x) -> uint32_t { const uint32_t d = x - lo; return direct ? d : __umulhi(d, scale); };
@@ -1494,6 +1496,9 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       const int i = q * kMergeThreads + tid;
       v[q] = out[i < n ? i : n - 1];
     }
+    for (int i = tid; i <= nb + kMergeThreads; i += kMergeThreads) hist[i] = 0;       // (while the list is on its way)
+    __syncthreads();
+    GAT_MPHASE(0)
 #pragma unroll
     for (int q = 0; q < REGS; ++q) {
       int c_ = 0;
@@ -1798,8 +1803,15 @@ __global__ __launch_bounds__(kMergeThreads) void k_merge_big(SamplerArgs A) {
       }
     }
   }
-  cov = block_reduce_u32(cov, red, tid, false, false);
-  tot = block_reduce_u32(tot, red, tid, false, false);
+  {
+    // (both sums through one pair of barriers)
+    const uint32_t wc = wave_total_u32(cov), wt = wave_total_u32(tot);
+    __syncthreads();
+    if (lane == 0) { red[wave] = wc; red2[wave] = wt; }
+    __syncthreads();
+    cov = 0; tot = 0;
+    for (int k = 0; k < kMergeWaves; ++k) { cov += red[k]; tot += red2[k]; }
+  }
   GAT_MPHASE(6)
   if (A.cum != nullptr) {
     // split path: the running lengths k_tail's position draw searches (block-wide inclusive scan, 256 elements a round)
@@ -2356,7 +2368,9 @@ __global__ __launch_bounds__(64, WPE) void k_sampler(SamplerArgs A) {
     const uint32_t count = *A.todo_count;
     for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
       const uint32_t e = A.todo[w];
-      sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)(e / (uint32_t)A.n_active), (int)(e % (uint32_t)A.n_active), lds, lane);
+      const int qa = (int)(e % (uint32_t)A.n_active);
+      if (A.a_end > 0 && (qa < A.a_base || qa >= A.a_end)) continue;       // (long lists: a launch per size class, each takes its own)
+      sampler_unit<KIND, BIG, TREE, HUGE>(A, (int)(e / (uint32_t)A.n_active), qa, lds, lane);
       wave_sync<HUGE>();
     }
     return;

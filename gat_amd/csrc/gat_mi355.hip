@@ -219,6 +219,7 @@ static int ensure_scratch(gat_ctx* ctx, gat_problem* P, int64_t want) {
     if (!P->split_path && P->long_lists) {                                      // k_tail_big's hand-over records
       HIPCHK(ctx, P->d_patch.alloc(ns));
       HIPCHK(ctx, hipMemsetAsync(P->d_patch.p, 0, ns * sizeof(gat::TailPatch), ctx->stream));
+      HIPCHK(ctx, P->d_todo.alloc(ns));                                         // ... and the queue of what k_resume_big leaves
     }
     if (P->split_path) {
       HIPCHK(ctx, P->d_cum.alloc((size_t)(b * P->slab_stride / 8 + 8)));      // (slab regions are multiples of 64 entries: cap_for)
@@ -694,6 +695,16 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             }
             A.tb = reinterpret_cast<const int32_t*>(P->d_patch.p);
             A.skip_stride = (int32_t)(sizeof(gat::TailPatch) / 4);
+            if (!gat_opt(ctx, "GAT_NO_RESUME_BIG") && !gat_opt(ctx, "GAT_NO_LONG_QUEUE")) {
+              // k_sampler behind them works off a queue: launched over every (sample, unit) -- one or two waves a CU with such
+              // lists in LDS -- it took 3.1 ms per 12 500 samples of the config-4 shape to find every unit finished
+              TB.todo = P->d_todo.p; TB.todo_count = P->todo_count_dev();
+              const int64_t tot = (int64_t)nb * n_act;
+              hipLaunchKernelGGL(gat::k_queue_rest, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, TB, (int)n_act);
+              HIPCHK(ctx, hipGetLastError());
+              A.todo = P->d_todo.p;
+              A.todo_count = P->todo_count_dev();
+            }
           }
         } else {
           // no workgroup pass: the wave's own counting sort, scratch behind the segment buffer if it fits
@@ -826,8 +837,12 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
           gat::SamplerArgs K = A;
           K.a_base = a0; K.a_end = a1;
           const unsigned cnt = (unsigned)(a1 - a0), cy = std::min(cnt, 32768u);
-          launch_sampler(dim3((unsigned)nb, cy, (cnt + cy - 1) / cy), (size_t)(gat::kMtLdsWords + 2 * (size_t)ccap) * 4, K);
+          // (off the queue -- long lists behind k_resume_big --: a one-dimensional launch, every class takes its own entries)
+          const dim3 gc = A.todo_count != nullptr ? dim3((unsigned)std::min<int64_t>((int64_t)nb * cnt, 8192)) : dim3((unsigned)nb, cy, (cnt + cy - 1) / cy);   // (8 192: what is left is a few long units, one to a workgroup)
+          launch_sampler(gc, (size_t)(gat::kMtLdsWords + 2 * (size_t)ccap) * 4, K);
         }
+      } else if (A.todo_count != nullptr) {
+        launch_sampler(dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)), lds, A);      // off the queue
       } else {
         launch_sampler(dim3((unsigned)nb, gy, gz), lds, A);
       }

@@ -813,19 +813,32 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
     bool applied = false;
     if (!broken && x.x != x.y) {
       // merged-list elements with start <= x.start
+#ifdef GAT_EXP_TB_NOSEARCH
+      const int lo = (int)(((uint64_t)x.x * (uint64_t)nU) >> 32) % (nU > 0 ? nU : 1);      // (timing experiment: wrong results)
+#else
       const int lo = interp_upper_bound(nU, x.x, [&](int i) -> uint32_t { return U[i].x; });
+#endif
       const uint2 pv = lo > 0 ? U[lo - 1] : make_uint2(0u, 0u), nv = lo < nU ? U[lo] : make_uint2(0u, 0u);
       const uint2 nn = lo + 1 < nU ? U[lo + 1] : make_uint2(0xffffffffu, 0xffffffffu);
       const bool tl = lo > 0 && (int32_t)x.x <= (int32_t)pv.y;
       const bool tr = lo < nU && (int32_t)nv.x <= (int32_t)x.y;
       const bool tr2 = tr && lo + 1 < nU && (int32_t)nn.x <= (int32_t)x.y;
       int nt = 0, tj = 0;                                            // logged segments it touches
-      for (int j0 = 0; j0 < nE; j0 += 4) {
-        uint2 e[4];
+#ifndef GAT_TB_LOGCHUNK
+#define GAT_TB_LOGCHUNK 4
+#endif
+      constexpr int kLC = GAT_TB_LOGCHUNK;                           // logged segments looked at per round trip
+#ifdef GAT_EXP_TB_NOLOGSCAN
+      const int nE_scan = 0;                                         // (timing experiment: wrong results)
+#else
+      const int nE_scan = nE;
+#endif
+      for (int j0 = 0; j0 < nE_scan; j0 += kLC) {
+        uint2 e[kLC];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e[r] = j0 + r < nE ? U[cap - 1 - (j0 + r)] : make_uint2(0xffffffffu, 0xffffffffu);
+        for (int r = 0; r < kLC; ++r) e[r] = j0 + r < nE ? U[cap - 1 - (j0 + r)] : make_uint2(0xffffffffu, 0xffffffffu);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (j0 + r < nE && touches(e[r], x)) { nt++; tj = j0 + r; }
+        for (int r = 0; r < kLC; ++r) if (j0 + r < nE && touches(e[r], x)) { nt++; tj = j0 + r; }
       }
       if (!(tl && tr) && !tr2 && nt <= 1 && !(nt == 1 && (tl || tr))) {
         if (tl || tr || nt == 1) {
@@ -1165,6 +1178,28 @@ __global__ __launch_bounds__(64) void k_resume_big(TailArgs T) {
     *reinterpret_cast<uint4*>(A.ws_stat + GAT_REC(A, sidx, u) * 4) = make_uint4((uint32_t)R[kPatchPlaced], rng.ndraws, (uint32_t)nuns, 0u);
     R[kPatchState] = 1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_queue_rest: long lists -- every (sample, launch position) k_resume_big did not finish (and the units k_merge_big was not
+// given) into k_sampler's queue, entries sidx * n_active + launch position as k_tail's
+__global__ __launch_bounds__(256) void k_queue_rest(TailArgs T, int n_act) {
+  const SamplerArgs& A = T.S;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, tot = (int64_t)A.batch * n_act;
+  bool push = false;
+  uint32_t e = 0;
+  if (i < tot) {
+    const int sidx = (int)(i % A.batch), a = (int)(i / A.batch);
+    push = a >= A.n_long || T.patch[GAT_REC(A, sidx, a)].state != 1;
+    e = (uint32_t)sidx * (uint32_t)n_act + (uint32_t)a;
+  }
+  const uint64_t b = __ballot(push);
+  if (b == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(T.todo_count, (uint32_t)__popcll(b));
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (push) T.todo[base + (uint32_t)__popcll(b & lanemask_lt(lane))] = e;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
