@@ -121,6 +121,7 @@ class Stats(C.Structure):
         ("n_straddle_candidates", C.c_int64),
         ("n_unit_overlaps", C.c_int64),
         ("kernel_times", C.c_int64),
+        ("n_queued_units", C.c_int64),
     ]
 
     def asdict(self):

@@ -678,6 +678,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             // (counts alone, by k_count_merged -- or through k_contig, which merge(0)s the lists again: what a trim emptied may
             //  stay in the list as [0, 0))
             TB.loose_ok = (loose_ok && !need_unit_lists && !gat_opt(ctx, "GAT_RESUME_COMPACT")) ? 1 : 0;
+            TB.no_bridge = gat_opt(ctx, "GAT_TB_NO_BRIDGE") ? 1 : 0;
             const unsigned gby = std::min(n_long, 32768u);
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
                                ctx->stream, TB);
@@ -722,7 +723,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
         gat::TailArgs T;
         T.S = A;
-        T.loose_ok = 0;
+        T.loose_ok = 0; T.no_bridge = 0;
         T.S.st2 = P->d_st2.p;
         T.S.n_long = (int32_t)n_long_big;                           // (whose verdict k_consolidate respects)
         T.S.lds_cap = std::min(P->max_unit_cap, 1280);              // k_consolidate: the lists the wave bucket sorts take
@@ -829,7 +830,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         }
       } else if (split) {
         launch_sampler(dim3((unsigned)std::min<int64_t>((int64_t)nb * n_act, 8192)), lds, A);      // off the queue
-      } else if (list_in_lds && A.big_buckets == 0 && P->h_class_start.size() > 2) {
+      } else if (list_in_lds && A.big_buckets == 0 && P->h_class_start.size() > 2 &&
+                 !(A.todo_count != nullptr && P->max_nws <= gat::kWsTreeMin && !gat_opt(ctx, "GAT_SIZE_CLASSES"))) {
+        // (not behind k_resume_big where it takes every unit -- workspaces of up to 32 segments --: the queue then holds the
+        //  per cent of units it declined, and one launch runs them side by side where five ran them class after class)
         // one launch per size class: LDS for the class's longest list
         for (size_t c = 0; c + 1 < P->h_class_start.size(); ++c) {
           const int a0 = P->h_class_start[c], a1 = P->h_class_start[c + 1];
@@ -906,7 +910,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                          (int64_t)nb, (int64_t)P->n_units, (int64_t)P->batch, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
-    HIPCHK(ctx, hipMemcpyAsync(h_stat, P->d_stat.p, 9 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_stat, P->d_stat.p, 10 * 8, hipMemcpyDeviceToHost, ctx->stream));   // (word 9: the queue's length)
     if (defer) return GAT_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return finish_sampler_batch(ctx, P, nb, st, timed, h_stat);
@@ -1037,6 +1041,7 @@ static int finish_sampler_batch(gat_ctx* ctx, gat_problem* P, int64_t nb, gat_st
       if (P->split_ran && (P->patched_contigs || P->patched_counts)) st->lists_from_records += 1;
       st->n_full_units += (int64_t)stat[4];
       st->n_resumed_units += (int64_t)stat[5];
+      st->n_queued_units += (int64_t)(stat[9] & 0xffffffffull);
       if (timed) {
         // (a timing query that fails leaves its figure at 0: it must not turn a call that computed its counts into an error)
         auto lap = [](hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); ms = 0; } return ms; };

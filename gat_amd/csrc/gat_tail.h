@@ -63,6 +63,7 @@ struct TailArgs {
   TailPatch* patch;       // [launch position][rec_stride] (GAT_REC)
   uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
+  int32_t no_bridge;      // k_tail_big: a segment that joins its two neighbours ends the lane's round (round 3's form; GAT_TB_NO_BRIDGE)
   int32_t loose_ok;       // k_resume_big: the lists' only readers are the segment-side count kernels (or k_contig, which
                           // merge(0)s them again): what a trim emptied may stay in the list as [0, 0) -- no compaction pass
 };
@@ -840,7 +841,21 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
 #pragma unroll
         for (int r = 0; r < kLC; ++r) if (j0 + r < nE && touches(e[r], x)) { nt++; tj = j0 + r; }
       }
-      if (!(tl && tr) && !tr2 && nt <= 1 && !(nt == 1 && (tl || tr))) {
+      // (a neighbour that is the placeholder of an earlier bridge says nothing about what stands there: left to the round's end)
+      const bool gone = (lo > 0 && pv.x == pv.y) || (lo < nU && nv.x == nv.y);
+      if (!gone && tl && tr && !tr2 && nt == 0 && !T.no_bridge) {
+        // a bridge (round 6): it touches both neighbours and nothing else -- the three are one segment where the left one stands,
+        // and the right one stays as an EMPTY segment at its own start: the list keeps its order and its length, merge(0), the
+        // trim's running lengths, the final filter and the count kernels all pass over an empty segment (these were 0.9 % of
+        // the config-4 shape's units, each a wave of k_sampler's with the list in LDS: 1.4 ms of the step)
+        const uint32_t ye = (int32_t)pv.y > (int32_t)x.y ? pv.y : x.y;
+        const uint2 u = make_uint2(pv.x, (int32_t)nv.y > (int32_t)ye ? nv.y : ye);
+        U[lo - 1] = u;
+        U[lo] = make_uint2(nv.x, nv.x);
+        cov += ws_overlap(u.x, u.y) - ws_overlap(pv.x, pv.y) - ws_overlap(nv.x, nv.y);
+        total += (u.y - u.x) - (pv.y - pv.x) - (nv.y - nv.x);
+        applied = true;
+      } else if (!gone && !(tl && tr) && !tr2 && nt <= 1 && !(nt == 1 && (tl || tr))) {
         if (tl || tr || nt == 1) {
           const int at = tl ? lo - 1 : (tr ? lo : cap - 1 - tj);
           const uint2 o = U[at];

@@ -164,6 +164,8 @@ typedef struct {
   int64_t kernel_times;         /* the ms_* split of the sampler's kernels: 1 recorded, 0 not asked for (gat_ctx_set_kernel_times),   */
                                 /* -1 asked for but NOT recorded -- the events exist once per context and another problem's timed  */
                                 /* call was in flight (gat_amd.run() keeps two segment tracks' calls in flight): the fields read 0 */
+  int64_t n_queued_units;       /* work units k_tail (lists of up to 1 024 segments) or k_resume_big (longer ones) left to     */
+                                /* k_sampler's queue: a wave each, the slow way (0 when neither ran: k_sampler took every unit)  */
 } gat_stats;
 
 #define GAT_COUNT_KERNEL_NONE 0

@@ -384,18 +384,22 @@ def _long_list_case(ctx, seed):
         ctx.options["GAT_MERGED_MIN_TRACKS"] = "1"
         if seed % 4 == 3:                 # ... with the log inserted into the list (round 3's form) instead of left behind it
             ctx.options["GAT_RESUME_INSERT"] = "1"
+    if seed % 8 >= 6:                     # ... and a segment that joins two neighbours ending its lane's round, as before round 6
+        ctx.options["GAT_TB_NO_BRIDGE"] = "1"
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
+        stats = P.last_stats
+        seg, off = P.sample(seed, 0, S)
     finally:
         ctx.options.pop("GAT_MERGED_MIN_TRACKS", None)
         ctx.options.pop("GAT_RESUME_INSERT", None)
+        ctx.options.pop("GAT_TB_NO_BRIDGE", None)
     if loose:
-        assert _lib.COUNT_KERNELS[P.last_stats["count_kernel"]] == "k_count_merged"
-    handed = P.last_stats["n_tail_units"]
+        assert _lib.COUNT_KERNELS[stats["count_kernel"]] == "k_count_merged"
+    handed = stats["n_tail_units"]
     for k, c in enumerate(counters):
         assert np.array_equal(got[k], want[k]), (c, n_segs, mean_len)
-    seg, off = P.sample(seed, 0, S)
     assert np.array_equal(off, wsamples[1]) and np.array_equal(seg, wsamples[0])
     P.close()
     return handed
