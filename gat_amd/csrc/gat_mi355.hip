@@ -473,7 +473,11 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
     if (P->batch < nb) return set_err(ctx, GAT_ERR_MEMORY, "internal: batch %lld > scratch %lld", (long long)nb, (long long)P->batch);
     // (unit_n, contig_n and ws_stat are zeroed once when allocated: the kernels rewrite every entry of the active units
     //  in every batch and never touch the others)
-    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 10 * 8, ctx->stream));         // (statistics, status word, k_tail's queue length)
+#ifdef GAT_DBG_QUEUE
+    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 16 * 8, ctx->stream));
+#else
+    HIPCHK(ctx, hipMemsetAsync(P->d_stat.p, 0, 10 * 8, ctx->stream));
+#endif         // (statistics, status word, k_tail's queue length)
     if (units_direct && P->d_cand_count.n) HIPCHK(ctx, hipMemsetAsync(P->d_cand_count.p, 0, P->d_cand_count.n * 4, ctx->stream));
     if (timed) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     const int32_t* skip_ptr = nullptr;
@@ -910,6 +914,10 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
                          (int64_t)nb, (int64_t)P->n_units, (int64_t)P->batch, P->d_stat.p, skip_ptr, skip_stride);
       HIPCHK(ctx, hipGetLastError());
     }
+#ifdef GAT_DBG_QUEUE
+    { unsigned long long w[16]; hipStreamSynchronize(ctx->stream); hipMemcpy(w, P->d_stat.p, 16 * 8, hipMemcpyDeviceToHost);
+      fprintf(stderr, "round broken by: empty segment %llu, placeholder neighbour %llu, both neighbours and more %llu, two on the right %llu, two logged %llu, logged + neighbour %llu\n", w[10], w[11], w[12], w[13], w[14], w[15]); }
+#endif
     HIPCHK(ctx, hipMemcpyAsync(h_stat, P->d_stat.p, 10 * 8, hipMemcpyDeviceToHost, ctx->stream));   // (word 9: the queue's length)
     if (defer) return GAT_OK;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

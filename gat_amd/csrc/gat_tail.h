@@ -812,6 +812,9 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
     // The segment goes into the structure at once (every lane does the same work in every step; at the consolidation
     // only the bookkeeping is left): where it stands in the merged list, what it touches there and in the log
     bool applied = false;
+#ifdef GAT_DBG_QUEUE
+    int dbg_why = 10;
+#endif
     if (!broken && x.x != x.y) {
       // merged-list elements with start <= x.start
 #ifdef GAT_EXP_TB_NOSEARCH
@@ -843,6 +846,9 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
       }
       // (a neighbour that is the placeholder of an earlier bridge says nothing about what stands there: left to the round's end)
       const bool gone = (lo > 0 && pv.x == pv.y) || (lo < nU && nv.x == nv.y);
+#ifdef GAT_DBG_QUEUE
+      dbg_why = gone ? 11 : (tl && tr) ? 12 : tr2 ? 13 : nt >= 2 ? 14 : 15;
+#endif
       if (!gone && tl && tr && !tr2 && nt == 0 && !T.no_bridge) {
         // a bridge (round 6): it touches both neighbours and nothing else -- the three are one segment where the left one stands,
         // and the right one stays as an EMPTY segment at its own start: the list keeps its order and its length, merge(0), the
@@ -855,6 +861,19 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
         cov += ws_overlap(u.x, u.y) - ws_overlap(pv.x, pv.y) - ws_overlap(nv.x, nv.y);
         total += (u.y - u.x) - (pv.y - pv.x) - (nv.y - nv.x);
         applied = true;
+      } else if (!gone && !tl && tr2 && nt == 0 && !T.no_bridge && nn.x != nn.y) {
+        // ... and the same on the right: it starts in front of the next segment, covers it and reaches the one behind (as
+        // frequent as the bridge where short segments are common) -- unless it reaches a third
+        const uint2 n3 = lo + 2 < nU ? U[lo + 2] : make_uint2(0xffffffffu, 0xffffffffu);
+        const uint32_t ye = (int32_t)nv.y > (int32_t)x.y ? nv.y : x.y;
+        const uint2 u = make_uint2(x.x, (int32_t)nn.y > (int32_t)ye ? nn.y : ye);
+        if (!(lo + 2 < nU && (int32_t)n3.x <= (int32_t)u.y)) {
+          U[lo] = u;
+          U[lo + 1] = make_uint2(nn.x, nn.x);
+          cov += ws_overlap(u.x, u.y) - ws_overlap(nv.x, nv.y) - ws_overlap(nn.x, nn.y);
+          total += (u.y - u.x) - (nv.y - nv.x) - (nn.y - nn.x);
+          applied = true;
+        }
       } else if (!gone && !(tl && tr) && !tr2 && nt <= 1 && !(nt == 1 && (tl || tr))) {
         if (tl || tr || nt == 1) {
           const int at = tl ? lo - 1 : (tr ? lo : cap - 1 - tj);
@@ -872,6 +891,9 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
         applied = true;
       }
     }
+#ifdef GAT_DBG_QUEUE
+    if (!applied && !broken) atomicAdd(reinterpret_cast<unsigned long long*>(A.stat) + dbg_why, 1ull);
+#endif
     if (!applied) { broken = true; U[nU + nP] = x; nP++; }
     // ---- hs.sample() (:413-435)
     {
@@ -1208,6 +1230,20 @@ __global__ __launch_bounds__(256) void k_queue_rest(TailArgs T, int n_act) {
     const int sidx = (int)(i % A.batch), a = (int)(i / A.batch);
     push = a >= A.n_long || T.patch[GAT_REC(A, sidx, a)].state != 1;
     e = (uint32_t)sidx * (uint32_t)n_act + (uint32_t)a;
+#ifdef GAT_DBG_QUEUE
+    // (why a unit is queued: words 10..15 of the statistics -- 10 k_merge_big declined, 11 k_tail_big left at the first
+    //  consolidation, 12 a round broken, 13 a log beyond 128, 14 another hand-over k_resume_big left, 15 rows ran out)
+    if (push && a < A.n_long) {
+      const int32_t* R = reinterpret_cast<const int32_t*>(T.patch + GAT_REC(A, sidx, a));
+      const int st = R[kPatchState];
+      int why = 14;
+      if (st == 0) why = (A.st2[GAT_REC(A, sidx, a)].w & 1) != 1 ? 10 : 11;
+      else if (st == 3) why = 15;
+      else if (R[kTbNSampled] > 0) why = 12;
+      else if (R[kPatchNExtra] > 2 * kWave) why = 13;
+      (void)why;   // (the histogram is k_tail_big's, of what broke the round)
+    }
+#endif
   }
   const uint64_t b = __ballot(push);
   if (b == 0) return;
