@@ -2083,7 +2083,10 @@ __device__ __forceinline__ void sampler_unit(const SamplerArgs& A, const int sid
           const uint2 pv = seg[pcount > 0 ? pcount - 1 : 0], nv = seg[pcount < nU ? pcount : nU - 1];
           const bool touch_prev = pcount > 0 && (int32_t)xs <= (int32_t)rfl(pv.y);
           const bool touch_next = pcount < nU && (int32_t)rfl(nv.x) <= (int32_t)xe;
-          if (xs != xe && !touch_prev && !touch_next) {
+          // (an EMPTY neighbour -- what a trim emptied, or the placeholder one of k_tail_big's bridges left at its start -- says
+          //  nothing about what stands there: the full merge below)
+          const bool hole = (pcount > 0 && rfl(pv.x) == rfl(pv.y)) || (pcount < nU && rfl(nv.x) == rfl(nv.y));
+          if (xs != xe && !touch_prev && !touch_next && !hole) {
             wave_insert_sorted<HUGE>(seg, nU, 1, lane);
             nU += 1;
             nS = 0;

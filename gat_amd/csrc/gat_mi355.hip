@@ -682,7 +682,8 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             // (counts alone, by k_count_merged -- or through k_contig, which merge(0)s the lists again: what a trim emptied may
             //  stay in the list as [0, 0))
             TB.loose_ok = (loose_ok && !need_unit_lists && !gat_opt(ctx, "GAT_RESUME_COMPACT")) ? 1 : 0;
-            TB.no_bridge = gat_opt(ctx, "GAT_TB_NO_BRIDGE") ? 1 : 0;
+            TB.no_bridge = gat_opt(ctx, "GAT_TB_NO_BRIDGE") ? std::max(1, atoi(gat_opt(ctx, "GAT_TB_NO_BRIDGE"))) | (atoi(gat_opt(ctx, "GAT_TB_NO_BRIDGE")) == 1 ? 3 : 0) : 0;   // (1: both forms off; 2: the right-hand form; 5: the bridge)
+            TB.no_log_map = gat_opt(ctx, "GAT_TB_NO_LOG_MAP") ? 1 : 0;
             const unsigned gby = std::min(n_long, 32768u);
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
                                ctx->stream, TB);
@@ -727,7 +728,7 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
         // unit); k_sampler below then only resumes -- from the merged list -- the units k_tail left alone
         gat::TailArgs T;
         T.S = A;
-        T.loose_ok = 0; T.no_bridge = 0;
+        T.loose_ok = 0; T.no_bridge = 0; T.no_log_map = 0;
         T.S.st2 = P->d_st2.p;
         T.S.n_long = (int32_t)n_long_big;                           // (whose verdict k_consolidate respects)
         T.S.lds_cap = std::min(P->max_unit_cap, 1280);              // k_consolidate: the lists the wave bucket sorts take

@@ -63,6 +63,7 @@ struct TailArgs {
   TailPatch* patch;       // [launch position][rec_stride] (GAT_REC)
   uint32_t* todo_count;   // units left to k_sampler: k_tail queues them
   uint32_t* todo;
+  int32_t no_log_map;     // k_tail_big: every step scans the lane's log (round 3's form; GAT_TB_NO_LOG_MAP)
   int32_t no_bridge;      // k_tail_big: a segment that joins its two neighbours ends the lane's round (round 3's form; GAT_TB_NO_BRIDGE)
   int32_t loose_ok;       // k_resume_big: the lists' only readers are the segment-side count kernels (or k_contig, which
                           // merge(0)s them again): what a trim emptied may stay in the list as [0, 0) -- no compaction pass
@@ -727,8 +728,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs T) {
 //     not yet applied are handed on as "sampled since the last consolidation", which is what they are.
 // The lane stops at the consolidation after which the loop would trim or end (:601-626) -- with that consolidation's
 // bookkeeping still to do -- and k_sampler resumes there: merged list + log (inserted in one pass per 64) + loop state.
+constexpr int kLogMapWords = 16;     // k_tail_big: a lane's map of where its logged segments stand, 512 cells over the unit's span
 __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
   __shared__ uint32_t l_ws[3 * kTailMaxWs];
+  __shared__ uint32_t l_map[kLogMapWords * kWave];
   const SamplerArgs& A = T.S;
   const int lane = threadIdx.x;
   const int sb = blockIdx.x, a = (int)(blockIdx.y + blockIdx.z * gridDim.y);
@@ -780,6 +783,39 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
     return (int32_t)g.x <= (int32_t)f.y;
   };
 
+  // Where the lane's logged segments stand (round 6): a bit per cell of 1/512 of the unit's span, set for the cells a logged
+  // segment covers.  A new segment whose cells are all clear touches none of them and skips the scan of the log -- the kernel is
+  // bound by the rate of its gathers (a lane's 8-byte loads are requests of their own), and the scan was 30 of a step's ~50; with
+  // ~30 segments logged one step in twelve still scans.  Cells are monotone in the position, so two closed intervals that share
+  // a point share a cell; a segment over more than four cells (or a log entry that long) scans as before.
+  uint32_t map_lo, map_shift;
+  {
+    const uint32_t max_len = rank_len[hist_total] * bucket + bucket;
+    const uint32_t w0 = l_ws[0], w1 = l_ws[kTailMaxWs + nws - 1];
+    map_lo = w0 > max_len ? w0 - max_len : 0u;
+    const uint32_t span = w1 + max_len - map_lo;
+    const int bits = 32 - __builtin_clz(span | 1u);
+    map_shift = bits > 9 ? (uint32_t)(bits - 9) : 0u;
+  }
+#pragma unroll
+  for (int w = 0; w < kLogMapWords; ++w) l_map[w * kWave + lane] = 0u;
+  bool map_all = T.no_log_map != 0;                                 // a logged segment too long for the map: every step scans
+  auto map_cell = [&](uint32_t p) -> uint32_t {
+    const uint32_t c = (p > map_lo ? p - map_lo : 0u) >> map_shift;
+    return c < (uint32_t)(kLogMapWords * 32 - 1) ? c : (uint32_t)(kLogMapWords * 32 - 1);
+  };
+  auto map_mark = [&](uint32_t a, uint32_t b) {
+    const uint32_t c0 = map_cell(a), c1 = map_cell(b);
+    if (c1 - c0 >= 4u) { map_all = true; return; }
+    for (uint32_t c = c0; c <= c1; ++c) l_map[(c >> 5) * kWave + lane] |= 1u << (c & 31u);
+  };
+  auto map_maybe = [&](uint32_t a, uint32_t b) -> bool {
+    const uint32_t c0 = map_cell(a), c1 = map_cell(b);
+    if (map_all || c1 - c0 >= 4u) return true;
+    bool any = false;
+    for (uint32_t c = c0; c <= c1; ++c) any = any || ((l_map[(c >> 5) * kWave + lane] >> (c & 31u)) & 1u) != 0u;
+    return any;
+  };
   int nE = 0, nP = 0;          // logged segments U[cap - 1 - j]; placements of this round NOT applied: U[nU + j]
   bool broken = false;         // a placement of this round could not be applied: the rest of the round is only recorded
   uint32_t placed = (uint32_t)pre.x;
@@ -835,7 +871,7 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
 #ifdef GAT_EXP_TB_NOLOGSCAN
       const int nE_scan = 0;                                         // (timing experiment: wrong results)
 #else
-      const int nE_scan = nE;
+      const int nE_scan = map_maybe(x.x, x.y) ? nE : 0;
 #endif
       for (int j0 = 0; j0 < nE_scan; j0 += kLC) {
         uint2 e[kLC];
@@ -849,7 +885,7 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
 #ifdef GAT_DBG_QUEUE
       dbg_why = gone ? 11 : (tl && tr) ? 12 : tr2 ? 13 : nt >= 2 ? 14 : 15;
 #endif
-      if (!gone && tl && tr && !tr2 && nt == 0 && !T.no_bridge) {
+      if (!gone && tl && tr && !tr2 && nt == 0 && !(T.no_bridge & 1)) {
         // a bridge (round 6): it touches both neighbours and nothing else -- the three are one segment where the left one stands,
         // and the right one stays as an EMPTY segment at its own start: the list keeps its order and its length, merge(0), the
         // trim's running lengths, the final filter and the count kernels all pass over an empty segment (these were 0.9 % of
@@ -861,7 +897,7 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
         cov += ws_overlap(u.x, u.y) - ws_overlap(pv.x, pv.y) - ws_overlap(nv.x, nv.y);
         total += (u.y - u.x) - (pv.y - pv.x) - (nv.y - nv.x);
         applied = true;
-      } else if (!gone && !tl && tr2 && nt == 0 && !T.no_bridge && nn.x != nn.y) {
+      } else if (!gone && !tl && tr2 && nt == 0 && !(T.no_bridge & 2) && nn.x != nn.y) {
         // ... and the same on the right: it starts in front of the next segment, covers it and reaches the one behind (as
         // frequent as the bridge where short segments are common) -- unless it reaches a third
         const uint2 n3 = lo + 2 < nU ? U[lo + 2] : make_uint2(0xffffffffu, 0xffffffffu);
@@ -880,11 +916,13 @@ __global__ __launch_bounds__(64) void k_tail_big(TailArgs T) {
           const uint2 o = U[at];
           const uint2 u = make_uint2(o.x < x.x ? o.x : x.x, (int32_t)o.y > (int32_t)x.y ? o.y : x.y);
           U[at] = u;
+          if (!tl && !tr) map_mark(u.x, u.y);                         // (a logged segment grew)
           cov += ws_overlap(u.x, u.y) - ws_overlap(o.x, o.y);
           total += (u.y - u.x) - (o.y - o.x);
         } else {
           U[cap - 1 - nE] = x;
           nE++;
+          map_mark(x.x, x.y);
           cov += ws_overlap(x.x, x.y);
           total += x.y - x.x;
         }
