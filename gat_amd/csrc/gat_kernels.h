@@ -1391,7 +1391,10 @@ constexpr int kSortScratchWords = 528;   // bucket-sort scratch of a wave (513 w
 #endif
 constexpr int kMergeThreads = GAT_MERGE_THREADS;
 constexpr int kMergeWaves = kMergeThreads / kWave;
-constexpr int kMergeRank = 4;            // ... and look-ups of the order inside the buckets it keeps in flight
+#ifndef GAT_MERGE_RANK
+#define GAT_MERGE_RANK 4
+#endif
+constexpr int kMergeRank = GAT_MERGE_RANK;            // ... and look-ups of the order inside the buckets it keeps in flight
 constexpr int kMergeRegs = 24;           // list elements a thread of k_merge_big<., REGS> keeps in registers at most (lists of up to 12 288)
 
 __device__ __forceinline__ uint32_t block_reduce_u32(uint32_t v, uint32_t* red, int tid, bool want_max, bool want_min) {
