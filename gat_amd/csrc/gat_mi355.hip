@@ -1235,7 +1235,7 @@ static int call_enqueue_more(gat_ctx* ctx, gat_problem* P, bool block) {
       if (gat_opt(ctx, "GAT_TEST_SMALL_CAPS")) est = 1.0;        // (tests: regions that overflow, the batch repeated with larger ones)
       const size_t want = (size_t)std::min(est * P->cand_scale, 1024.0 * 1024) * gat::kCandSlots;
       if (P->d_cand.n < want && K.n_flight == 0) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));          // (an earlier call's kernels may still read the old buffer)
+        if (P->d_cand.n > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // (an earlier call's kernels may still read the old buffer)
         HIPCHK(ctx, P->d_cand.alloc(want));
       }
       if (P->d_cand_count.n == 0) {
