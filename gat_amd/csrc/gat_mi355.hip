@@ -682,7 +682,9 @@ static int run_sampler_batch(gat_ctx* ctx, gat_problem* P, uint32_t seed, int64_
             // (counts alone, by k_count_merged -- or through k_contig, which merge(0)s the lists again: what a trim emptied may
             //  stay in the list as [0, 0))
             TB.loose_ok = (loose_ok && !need_unit_lists && !gat_opt(ctx, "GAT_RESUME_COMPACT")) ? 1 : 0;
-            TB.no_bridge = gat_opt(ctx, "GAT_TB_NO_BRIDGE") ? std::max(1, atoi(gat_opt(ctx, "GAT_TB_NO_BRIDGE"))) | (atoi(gat_opt(ctx, "GAT_TB_NO_BRIDGE")) == 1 ? 3 : 0) : 0;   // (1: both forms off; 2: the right-hand form; 5: the bridge)
+            // (bit 0: no bridge between two neighbours, bit 1: none over two segments on the right; "1" or anything else: both off)
+            TB.no_bridge = 0;
+            if (const char* e = gat_opt(ctx, "GAT_TB_NO_BRIDGE")) { const int v = atoi(e); TB.no_bridge = (v == 2 || v == 5) ? (v == 2 ? 2 : 1) : 3; }
             TB.no_log_map = gat_opt(ctx, "GAT_TB_NO_LOG_MAP") ? 1 : 0;
             const unsigned gby = std::min(n_long, 32768u);
             hipLaunchKernelGGL(gat::k_tail_big, dim3((unsigned)((nb + 63) / 64), gby, (n_long + gby - 1) / gby), dim3(64), 0,
