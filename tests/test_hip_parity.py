@@ -290,7 +290,7 @@ def _big_problem(rs, n_segs, ws_pieces, n_contigs=2, mean_len=80):
 
 @pytest.mark.parametrize("case", ["many_workspace_segments", "large_units", "large_units_swapped_count", "rows_run_out",
                                   "slab_overflow_retry", "slab_overflow_retry_batches_shrink", "large_units_many_workspace_segments",
-                                  "large_units_one_workspace_segment", "mid_workspace_table"])
+                                  "large_units_one_workspace_segment", "mid_workspace_table", "very_large_unit"])
 def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
     """code paths the BASELINE shapes do not reach: workspace lists beyond the register / LDS tables,
     units beyond the register sort, streams that run out of pre-generated rows (redone from the seed),
@@ -307,6 +307,8 @@ def test_robustness_paths_vs_oracle(ctx, case, monkeypatch):
         flat = _big_problem(rs, 900, 150)
     elif case in ("large_units", "large_units_swapped_count"):
         flat = _big_problem(rs, 6000, 3)
+    elif case == "very_large_unit":                       # one list of 13 500: beyond k_merge_big's registers (its round-3 form), within LDS
+        flat = _big_problem(rs, 13500, 1, n_contigs=1, mean_len=30)
     elif case == "rows_run_out":
         monkeypatch.setitem(ctx.options, "GAT_RNG_SLACK", "0.6")
         flat = _big_problem(rs, 700, 5)
@@ -391,6 +393,10 @@ def _long_list_case(ctx, seed):
         ctx.options["GAT_TB_NO_BRIDGE"] = "1"
     if seed % 16 >= 12:                   # ... and every step scanning the lane's log
         ctx.options["GAT_TB_NO_LOG_MAP"] = "1"
+    if seed % 16 in (2, 3, 10):           # ... and k_merge_big<., 0>: the list read twice, its buckets sorted thread by thread (what lists
+        ctx.options["GAT_MERGE_OLD"] = "1"   #     beyond 12 288 segments still take)
+    if seed % 32 == 5:                    # ... and k_sampler launched over every unit, not off k_queue_rest's queue
+        ctx.options["GAT_NO_LONG_QUEUE"] = "1"
     try:
         P = _lib.Problem(ctx, flat)
         got = P.sample_and_count(counters, seed, 0, S)
@@ -401,6 +407,8 @@ def _long_list_case(ctx, seed):
         ctx.options.pop("GAT_RESUME_INSERT", None)
         ctx.options.pop("GAT_TB_NO_BRIDGE", None)
         ctx.options.pop("GAT_TB_NO_LOG_MAP", None)
+        ctx.options.pop("GAT_MERGE_OLD", None)
+        ctx.options.pop("GAT_NO_LONG_QUEUE", None)
     if loose:
         assert _lib.COUNT_KERNELS[stats["count_kernel"]] == "k_count_merged"
     handed = stats["n_tail_units"]
